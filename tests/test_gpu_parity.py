@@ -1,0 +1,397 @@
+"""GPU parity tests: the HIP engine, called through the C ABI (libvs_hnsw.so), against the CPU
+oracle on the same inputs and against the reference's known-answer tests.
+
+Bar (integer / index work): identical ids.  Floating point: |d_gpu - d_cpu| <= 1e-5 * max(1, |d|)
+(f32 re-association of a <=1536-term sum).  Where two candidates are
+closer than that tolerance their order is unspecified (usearch leaves tie order unspecified too).
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import OracleIndex
+from tests import kat_runner as K
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def vs():
+    import vector_store_amd as v
+    return v
+
+
+def gpu_factory(metric, dim, **kw):
+    v = vs()
+    return v.HipUsearchIndex(dim, v.METRICS[metric], **kw)
+
+
+def close(a, b):
+    return abs(float(a) - float(b)) <= TOL * max(1.0, abs(float(b)))
+
+
+# ------------------------------------------------------------------ reference known-answer tests
+@pytest.mark.parametrize("name", ["B2_l2sq_3d_http", "B3_l2sq_1d_scores", "B4_empty", "B5_cos_winners",
+                                  "B6_ip_winner", "B7_l2_winner", "B8_quant_f32", "B10_self_zero_f32"])
+def test_kat_simple(name):
+    v = vs()
+    keys, d = K.run_simple(gpu_factory, name)
+    t = K.KAT[name]
+    for x in d:
+        assert v.distance_valid(float(x), v.METRICS[t["metric"]], t["dim"])
+    if "expect_similarity" in t:
+        for x, want in zip(d, t["expect_similarity"]):
+            assert abs(v.similarity_score(float(x), v.METRICS[t["metric"]], t["dim"]) - want) <= 1e-5
+
+
+def test_kat_b1_add_remove_readd():
+    K.run_b1(gpu_factory)
+
+
+def test_kat_b11_filtered_30():
+    K.run_b11(gpu_factory)
+
+
+def test_kat_b12_fine_order():
+    first, _ = K.run_b12(gpu_factory)
+    assert first == sorted(first)
+    assert first == list(range(100))
+
+
+def test_kat_b13_zero_query():
+    K.run_b13(gpu_factory)
+
+
+def test_kat_b17_concurrency():
+    """usearch.rs:1526-1607: 2 x cores tasks x 50 adds and as many searches, no error, final count."""
+    v = vs()
+    t = K.KAT["B17_concurrency"]
+    tasks, per = 16, t["adds_per_worker"]
+    ix = v.HipUsearchIndex(t["dim"], v.L2SQ)
+    ix.reserve(tasks * per)
+    z = np.zeros(t["dim"], dtype=np.float32)
+    errs = []
+
+    def adder(tid):
+        try:
+            for i in range(per):
+                ix.add(tid * per + i, z)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    def searcher():
+        try:
+            for _ in range(per):
+                keys, d = ix.search(z, t["search_k"])
+                assert len(keys) <= t["search_k"] and all(float(x) == 0.0 for x in d)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    # the reference's actor alternates families: adds || adds, then searches || searches (usearch.rs:590-612)
+    th = [threading.Thread(target=adder, args=(i,)) for i in range(tasks)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    th = [threading.Thread(target=searcher) for _ in range(tasks)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    assert ix.size() == tasks * per
+    keys, d = ix.search(z, t["search_k"])
+    assert len(keys) == t["search_k"]
+
+
+# ------------------------------------------------------------------ same graph, same queries: ids identical
+def _dataset(n, dim, seed, kind="lowrank"):
+    rng = np.random.default_rng(seed)
+    if kind == "gauss" or dim <= 8:
+        return rng.standard_normal((n, dim)).astype(np.float32)
+    r = min(16, dim)
+    w = rng.standard_normal((r, dim)).astype(np.float32) / np.sqrt(r)
+    return (rng.standard_normal((n, r)).astype(np.float32) @ w + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+
+
+@pytest.mark.parametrize("metric", ["cos", "l2sq", "ip"])
+@pytest.mark.parametrize("dim,n", [(3, 500), (24, 3000), (100, 3000), (128, 4000), (768, 3000), (1536, 1500)])
+def test_search_matches_oracle_on_same_graph(metric, dim, n):
+    v = vs()
+    m = oracle.METRICS[metric]
+    data = _dataset(n + 64, dim, 11 + dim)
+    base, q = data[:n], data[n:]
+    if metric == "ip":
+        base = base / np.linalg.norm(base, axis=1, keepdims=True)
+    o = OracleIndex(dim, m)
+    o.reserve(n)
+    o.add_batch(np.arange(n, dtype=np.uint64) * 3 + 7, base, threads=4)
+    g = o.export_graph()
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric])
+    ix.import_graph(g)
+    assert ix.size() == n
+    for ef, k in ((64, 10), (128, 10), (200, 100)):
+        o.set_expansion_search(ef)
+        ix.set_expansion_search(ef)
+        gk, gd, gf = ix.search_batch(q, k)
+        same_rows = 0
+        for i in range(len(q)):
+            ok_, od_ = o.search(q[i], k)
+            assert gf[i] == len(ok_)
+            for j in range(len(ok_)):
+                assert close(gd[i, j], od_[j]), (metric, dim, i, j, gd[i, j], od_[j])
+            same_rows += gk[i, : len(ok_)].tolist() == ok_.tolist()
+            assert all(gd[i, j] <= gd[i, j + 1] for j in range(gf[i] - 1))
+        # identical traversal => identical ids, except where f32 rounding flips a near-tie
+        assert same_rows >= 0.9 * len(q), (metric, dim, ef, same_rows)
+        st = ix.stats(reset=True)
+        assert st["visited_overflow"] == 0
+    # single-query entry point == batch entry point
+    k1, d1 = ix.search(q[0], 10)
+    kb, db, _ = ix.search_batch(q[:1], 10)
+    assert k1.tolist() == kb[0, : len(k1)].tolist()
+
+
+def test_evals_and_hops_match_oracle_counters():
+    """The engine counts E_q / H_q exactly as the CPU restatement does."""
+    v = vs()
+    n, dim = 5000, 64
+    data = _dataset(n + 100, dim, 5)
+    o = OracleIndex(dim, oracle.L2SQ)
+    o.reserve(n)
+    o.add_batch(np.arange(n, dtype=np.uint64), data[:n], threads=1)
+    ix = v.HipUsearchIndex(dim, v.L2SQ)
+    ix.import_graph(o.export_graph())
+    o.stats(reset=True)
+    ix.stats(reset=True)
+    for i in range(100):
+        o.search(data[n + i], 10)
+    ix.search_batch(data[n:], 10)
+    so, sg = o.stats(), ix.stats()
+    assert sg["queries"] == 100
+    assert abs(sg["search_evals"] - so["computed_distances"]) <= 0.01 * so["computed_distances"]
+    assert abs(sg["search_hops"] - so["node_expansions"]) <= 0.01 * so["node_expansions"]
+
+
+# ------------------------------------------------------------------ exact search == numpy brute force
+@pytest.mark.parametrize("metric", ["cos", "l2sq", "ip"])
+def test_exact_search_matches_numpy(metric):
+    v = vs()
+    n, dim, k = 70000, 96, 10  # crosses the 65536-row chunk boundary
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((37, dim)).astype(np.float32)
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric])
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64) + 100, base)
+    keys, d, found = ix.exact_search_batch(q, k)
+    b64, q64 = base.astype(np.float64), q.astype(np.float64)
+    if metric == "l2sq":
+        D = (q64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None, :] - 2 * q64 @ b64.T
+    elif metric == "ip":
+        D = 1.0 - q64 @ b64.T
+    else:
+        D = 1.0 - (q64 / np.linalg.norm(q64, axis=1, keepdims=True)) @ (b64 / np.linalg.norm(b64, axis=1, keepdims=True)).T
+    truth = np.argsort(D, axis=1, kind="stable")[:, :k]
+    assert (found == k).all()
+    for i in range(len(q)):
+        assert set((keys[i] - 100).tolist()) == set(truth[i].tolist()), (metric, i)
+        for j in range(k):
+            assert close(d[i, j], D[i, int(keys[i, j]) - 100])
+        assert all(d[i, j] <= d[i, j + 1] for j in range(k - 1))
+
+
+# ------------------------------------------------------------------ GPU build
+def _graph_invariants(g, M, M0):
+    n = len(g["levels"])
+    adj0 = g["adj0"]
+    valid = adj0 != 0xFFFFFFFF
+    assert adj0.shape == (n, M0)
+    assert (adj0[valid] < n).all()
+    for s in range(n):
+        row = adj0[s][valid[s]]
+        assert len(set(row.tolist())) == len(row), "duplicate link"
+        assert s not in row, "self loop"
+        # packed at the front
+        assert valid[s][: len(row)].all()
+    for s in np.nonzero(g["levels"] > 0)[0]:
+        for l in range(1, g["levels"][s] + 1):
+            blk = g["upper"][g["upper_off"][s] + l - 1]
+            nb = blk[blk != 0xFFFFFFFF]
+            assert (nb < n).all() and s not in nb and len(set(nb.tolist())) == len(nb)
+            assert (g["levels"][nb] >= l).all(), "link to a node missing on that level"
+    assert g["levels"][g["entry_slot"]] == g["max_level"] == g["levels"].max()
+
+
+@pytest.mark.parametrize("metric,dim,n", [("cos", 128, 20000), ("l2sq", 24, 20000), ("ip", 768, 6000)])
+def test_gpu_build_recall_and_invariants(metric, dim, n):
+    v = vs()
+    data = _dataset(n + 200, dim, 21)
+    base, q = data[:n], data[n:]
+    if metric == "ip":
+        base = base / np.linalg.norm(base, axis=1, keepdims=True)
+    keys = np.arange(n, dtype=np.uint64) + (1 << 48)  # epoch bits set, like the reference's PrimaryId
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric])
+    ix.reserve(n)
+    ix.add_batch(keys[: n // 2], base[: n // 2])
+    ix.add_batch(keys[n // 2:], base[n // 2:])
+    assert ix.size() == n
+    g = ix.export_graph()
+    _graph_invariants(g, 16, 32)
+    assert np.array_equal(g["vectors"], base)
+    assert (g["levels"] == oracle.level_stream(16, n)).all(), "level stream == single-thread usearch context"
+    st = ix.stats(reset=True)
+    assert st["added"] == n - 1 and st["visited_overflow"] == 0
+    tk, td, _ = ix.exact_search_batch(q, 10)
+    ix.set_expansion_search(128)
+    gk, gd, gf = ix.search_batch(q, 10)
+    rec_gpu = np.mean([len(set(tk[i].tolist()) & set(gk[i].tolist())) / 10.0 for i in range(len(q))])
+    # the CPU restatement on the same data, same parameters
+    o = OracleIndex(dim, oracle.METRICS[metric])
+    o.reserve(n)
+    o.add_batch(keys, base, threads=8)
+    o.set_expansion_search(128)
+    ok_, _, _ = o.search_batch(q, 10, threads=8)
+    rec_cpu = np.mean([len(set(tk[i].tolist()) & set(ok_[i].tolist())) / 10.0 for i in range(len(q))])
+    assert rec_gpu >= rec_cpu - 0.03, (rec_gpu, rec_cpu)
+    assert rec_gpu >= 0.9, rec_gpu
+    # the GPU-built graph searched by the CPU algorithm gives the same answers as the GPU search
+    o2 = OracleIndex(dim, oracle.METRICS[metric])
+    o2.import_graph(g)
+    o2.set_expansion_search(128)
+    same = 0
+    for i in range(50):
+        k2, d2 = o2.search(q[i], 10)
+        same += k2.tolist() == gk[i].tolist()
+        for j in range(10):
+            assert close(gd[i, j], d2[j])
+    assert same >= 45
+
+
+def test_sequential_adds_build_the_oracle_graph():
+    """One add per call (sub-batch of 1) is the sequential usearch algorithm: adjacency rows match
+    the single-threaded CPU restatement except where an f32 near-tie flips a heuristic decision."""
+    v = vs()
+    n, dim = 1500, 16
+    base = np.random.default_rng(9).standard_normal((n, dim)).astype(np.float32)
+    o = OracleIndex(dim, oracle.L2SQ)
+    o.reserve(n)
+    ix = v.HipUsearchIndex(dim, v.L2SQ)
+    ix.reserve(n)
+    for i in range(n):
+        o.add(i, base[i])
+        ix.add(i, base[i])
+    go, gg = o.export_graph(), ix.export_graph()
+    assert (go["levels"] == gg["levels"]).all()
+    assert go["entry_slot"] == gg["entry_slot"] and go["max_level"] == gg["max_level"]
+    same = sum(set(go["adj0"][s].tolist()) == set(gg["adj0"][s].tolist()) for s in range(n))
+    assert same >= 0.97 * n, same
+
+
+def test_remove_update_and_errors():
+    v = vs()
+    dim = 8
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((300, dim)).astype(np.float32)
+    ix = v.HipUsearchIndex(dim, v.L2SQ)
+    with pytest.raises(v.VsError, match="Reserve capacity"):
+        ix.add(1, base[0])
+    ix.reserve(300)
+    assert ix.capacity() == 300
+    ix.add_batch(np.arange(300, dtype=np.uint64), base)
+    with pytest.raises(v.VsError, match="Duplicate"):
+        ix.add(5, base[5])
+    with pytest.raises(v.VsError) as e:
+        ix.add(1000, base[0][:4])
+    assert e.value.code == -2  # VS_ERR_DIMENSION -> HTTP 400 in the reference (validator.rs:12-26)
+    with pytest.raises(v.VsError) as e:
+        ix.search(base[0][:4], 3)
+    assert e.value.code == -2
+    with pytest.raises(v.VsError, match="Reserve capacity"):
+        ix.add(1000, base[0])
+    # removed members are never returned, the slot is reused by the next add (update path)
+    assert ix.remove(17) and not ix.remove(17)
+    assert ix.size() == 299
+    keys, d = ix.search(base[17], 5)
+    assert 17 not in keys.tolist()
+    newv = base[17] + 0.001
+    ix.add((3 << 48) | 17, newv)  # same row index, next epoch: how the reference re-keys an update
+    assert ix.size() == 300
+    keys, d = ix.search(newv, 1)
+    assert keys.tolist() == [(3 << 48) | 17] and float(d[0]) == 0.0
+    keys, _ = ix.search(base[17], 300)
+    assert len(keys) == 300 and 17 not in keys.tolist()
+    # growing keeps everything
+    ix.reserve(1000)
+    assert ix.capacity() == 1000
+    keys, d = ix.search(base[3], 1)
+    assert keys.tolist() == [3] and float(d[0]) == 0.0
+    ix.add(2000, base[0] * 2)
+    assert ix.size() == 301
+
+
+def test_large_k_uses_exhaustive_path():
+    v = vs()
+    dim, n = 12, 1200
+    base = np.random.default_rng(2).standard_normal((n, dim)).astype(np.float32)
+    ix = v.HipUsearchIndex(dim, v.L2SQ)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    keys, d = ix.search(base[0], 1000)  # the reference allows any limit (httproutes.rs:842-847)
+    assert len(keys) == 1000 and keys[0] == 0
+    want = np.sort(((base - base[0]) ** 2).sum(1))[:1000]
+    assert np.allclose(d, want, rtol=1e-5, atol=1e-5)
+
+
+def test_topk_merge_matches_numpy():
+    import torch
+    v = vs()
+    parts, nq, k = 8, 300, 10
+    rng = np.random.default_rng(4)
+    d = np.sort(rng.random((parts, nq, k)).astype(np.float32), axis=2)
+    keys = rng.integers(0, 1 << 60, size=(parts, nq, k), dtype=np.uint64)
+    d[3, :, 7:] = np.inf
+    keys[3, :, 7:] = 0xFFFFFFFFFFFFFFFF
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    dd = torch.from_numpy(d).cuda()
+    ok_ = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    od = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    of = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    v.topk_merge_device(dk.data_ptr(), dd.data_ptr(), parts, nq, k, ok_.data_ptr(), od.data_ptr(), of.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got_k = ok_.cpu().numpy().view(np.uint64)
+    got_d = od.cpu().numpy()
+    for qi in range(nq):
+        flat_d = d[:, qi, :].reshape(-1)
+        flat_k = keys[:, qi, :].reshape(-1)
+        order = np.argsort(flat_d, kind="stable")[:k]
+        assert np.array_equal(got_d[qi], flat_d[order])
+        assert np.array_equal(got_k[qi], flat_k[order])
+
+
+def test_device_entry_points_with_torch_buffers():
+    import torch
+    v = vs()
+    n, dim, k = 8000, 768, 10
+    data = _dataset(n + 256, dim, 31)
+    ix = v.HipUsearchIndex(dim, v.COS)
+    ix.reserve(n)
+    dv = torch.from_numpy(data[:n]).cuda()
+    ix.add_batch_device(np.arange(n, dtype=np.uint64), dv.data_ptr(), n, dim)
+    dq = torch.from_numpy(data[n:]).cuda()
+    ok_ = torch.empty((256, k), dtype=torch.int64, device="cuda")
+    od = torch.empty((256, k), dtype=torch.float32, device="cuda")
+    of = torch.empty((256,), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ix.search_batch_device(dq.data_ptr(), 256, k, ok_.data_ptr(), od.data_ptr(), of.data_ptr(), s)
+    torch.cuda.synchronize()
+    hk, hd, hf = ix.search_batch(data[n:], k)
+    assert np.array_equal(ok_.cpu().numpy().view(np.uint64), hk)
+    assert np.array_equal(od.cpu().numpy(), hd)
+    ek = torch.empty((256, k), dtype=torch.int64, device="cuda")
+    ed = torch.empty((256, k), dtype=torch.float32, device="cuda")
+    ix.exact_search_batch_device(dq.data_ptr(), 256, k, ek.data_ptr(), ed.data_ptr(), of.data_ptr(), s)
+    torch.cuda.synchronize()
+    truth = ek.cpu().numpy().view(np.uint64)
+    rec = np.mean([len(set(truth[i].tolist()) & set(hk[i].tolist())) / k for i in range(256)])
+    assert rec >= 0.9, rec

@@ -1,0 +1,11 @@
+"""vector_store_amd -- MI355X-native HNSW engine behind the usearch boundary of scylladb/vector-store.
+
+The product is `libvs_hnsw.so` (HIP/gfx950, C ABI in include/vs_hnsw.h).  This package is the
+thin host-side binding used by tests and bench.py; it mirrors the reference's private
+`trait UsearchIndex` (crates/vector-store/src/vs_index/usearch.rs:142-160).  It never falls
+back to a CPU path: if the library or a GPU is missing, it raises.
+"""
+from .index import (  # noqa: F401
+    COS, HAMMING, IP, L2SQ, METRICS, HipUsearchIndex, VsError, distance_valid, f32_to_b1x8, lib, lib_path,
+    similarity_score, topk_merge_device, version,
+)

@@ -1,0 +1,1087 @@
+// engine.hip -- host side of the MI355X HNSW engine and its C ABI (include/vs_hnsw.h).
+//
+// Mirrors what `ThreadedUsearchIndex` expects of `usearch::Index`
+// (reference crates/vector-store/src/vs_index/usearch.rs:162-251): reserve / capacity /
+// add / remove / search / filtered_search on u64 keys and f32 vectors, blocking calls,
+// errors as status codes.  Everything that touches vectors or the graph runs on the GPU
+// (kernels_*.hip); the host keeps only the key->slot map, the free-slot ring, the level
+// RNG and the batching of concurrent single-vector callers.  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/vs_hnsw.h"
+#include "kernels.hpp"
+
+#define VS_VERSION "0.1.0"
+
+namespace vs {
+
+thread_local std::string g_err;
+
+struct Fail {
+    int code;
+    std::string msg;
+};
+[[noreturn]] static void fail(int code, std::string msg) { throw Fail{code, std::move(msg)}; }
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) ::vs::fail(VS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+struct DeviceBuf {  // grow-only device scratch
+    void* p = nullptr;
+    size_t bytes = 0;
+    void* ensure(size_t n) {
+        if (n > bytes) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            bytes = 0;
+            size_t want = n + n / 4 + 256;
+            HIP_OK(hipMalloc(&p, want));
+            bytes = want;
+        }
+        return p;
+    }
+    ~DeviceBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+// Stream + scratch leased per host call.  Shared by every index on the device, so thousands
+// of per-partition handles (reference usearch.rs:704-705,766-778) do not each own a stream.
+struct WorkCtx {
+    hipStream_t stream = nullptr;
+    DeviceBuf a, b, c, d, e, f;
+};
+
+struct DevicePool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<WorkCtx>> idle;
+};
+static DevicePool& pool(int dev) {
+    static std::mutex mu;
+    static std::unordered_map<int, std::unique_ptr<DevicePool>> pools;
+    std::lock_guard<std::mutex> g(mu);
+    auto& p = pools[dev];
+    if (!p) p.reset(new DevicePool());
+    return *p;
+}
+struct Lease {
+    DevicePool& pl;
+    std::unique_ptr<WorkCtx> ctx;
+    explicit Lease(int dev) : pl(pool(dev)) {
+        {
+            std::lock_guard<std::mutex> g(pl.mu);
+            if (!pl.idle.empty()) {
+                ctx = std::move(pl.idle.back());
+                pl.idle.pop_back();
+            }
+        }
+        if (!ctx) {
+            ctx.reset(new WorkCtx());
+            HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        }
+    }
+    ~Lease() {
+        std::lock_guard<std::mutex> g(pl.mu);
+        pl.idle.push_back(std::move(ctx));
+    }
+    WorkCtx* operator->() { return ctx.get(); }
+};
+
+static uint32_t pow2_ceil(uint32_t x) {
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// Sub-batches stay below 1/16 of the graph they are inserted into (nodes of one sub-batch do
+// not see each other during their search phase); capped so one sub-batch fills the chip
+// (256 CUs x ~6 resident waves) a few times over.
+constexpr uint32_t kMaxSubBatch = 8192;
+constexpr uint32_t kSubBatchRatio = 16;
+constexpr uint32_t kChunk = 32768;  // vectors staged per host->device copy
+
+struct Engine {
+    // configuration (reference usearch.rs:74-82)
+    uint32_t dim = 0, M = 16, M0 = 32, ef_add = 128;
+    std::atomic<uint32_t> ef_search{64};
+    int metric = VS_METRIC_COS;
+    int device = 0;
+    uint32_t lanes = 64, lanes_log2 = 6, iters = 1, stride4 = 64;
+
+    // HBM arenas
+    float* d_vectors = nullptr;
+    float* d_inv_norm = nullptr;
+    uint32_t* d_adj0 = nullptr;
+    uint32_t* d_upper = nullptr;
+    uint32_t* d_upper_off = nullptr;
+    uint64_t* d_keys = nullptr;
+    int32_t* d_levels = nullptr;
+    unsigned long long* d_stats = nullptr;
+    size_t capacity = 0, upper_cap = 0;
+
+    // host bookkeeping (guarded by mod_mu)
+    std::mutex mod_mu;
+    size_t slots = 0, upper_blocks = 0;
+    std::atomic<size_t> live{0};
+    size_t linked = 0;  // nodes present in the graph
+    std::unordered_map<uint64_t, uint32_t> lookup;
+    std::deque<uint32_t> free_slots;  // usearch ring_gt: FIFO
+    std::vector<uint8_t> h_levels;
+    std::vector<uint32_t> h_upper_off;
+    std::default_random_engine level_rng;  // same stream as a 1-thread usearch context (oracle orc_level_stream)
+    double inv_log_m = 0;
+    std::atomic<uint32_t> entry_slot{0};
+    std::atomic<int32_t> max_level{-1};
+
+    // batching of concurrent single-vector callers
+    struct PendingSearch {
+        const float* q;
+        size_t k;
+        uint64_t* keys;
+        float* dist;
+        size_t* found;
+        int status = 0;
+        std::string err;
+        bool done = false;
+    };
+    struct PendingAdd {
+        uint64_t key;
+        const float* v;
+        int status = 0;
+        std::string err;
+        bool done = false;
+    };
+    std::mutex sq_mu, aq_mu;
+    std::condition_variable sq_cv, aq_cv;
+    std::vector<PendingSearch*> sq;
+    std::vector<PendingAdd*> aq;
+    bool s_leader = false, a_leader = false;
+
+    void use_device() const { HIP_OK(hipSetDevice(device)); }
+
+    IndexView view() const {
+        IndexView v;
+        v.vectors = reinterpret_cast<const float4*>(d_vectors);
+        v.inv_norm = d_inv_norm;
+        v.adj0 = d_adj0;
+        v.upper = d_upper;
+        v.upper_off = d_upper_off;
+        v.keys = d_keys;
+        v.dim = dim;
+        v.stride4 = stride4;
+        v.lanes = lanes;
+        v.lanes_log2 = lanes_log2;
+        v.M = M;
+        v.M0 = M0;
+        v.metric = metric;
+        v.entry_slot = entry_slot.load();
+        v.max_level = max_level.load();
+        return v;
+    }
+
+    ~Engine() {
+        (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        for (void* p : {(void*)d_vectors, (void*)d_inv_norm, (void*)d_adj0, (void*)d_upper, (void*)d_upper_off,
+                        (void*)d_keys, (void*)d_levels, (void*)d_stats})
+            if (p) (void)hipFree(p);
+    }
+
+    void init(const vs_hnsw_options& o) {
+        if (!o.dimensions) fail(VS_ERR_INVALID_ARGUMENT, "dimensions must be > 0");
+        if (o.quantization != VS_SCALAR_F32)
+            fail(VS_ERR_UNSUPPORTED, "only f32 storage is implemented (quantization f16/bf16/i8/b1: not yet)");
+        if (o.metric != VS_METRIC_COS && o.metric != VS_METRIC_L2SQ && o.metric != VS_METRIC_IP)
+            fail(VS_ERR_UNSUPPORTED, "metric must be cos, l2sq or ip (hamming/b1: not yet)");
+        dim = (uint32_t)o.dimensions;
+        metric = o.metric;
+        M = o.connectivity ? (uint32_t)o.connectivity : 16;  // usearch default_connectivity
+        if (M < 2 || M > 32) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 32]");
+        M0 = 2 * M;
+        ef_add = o.expansion_add ? (uint32_t)o.expansion_add : 128;
+        ef_search = o.expansion_search ? (uint32_t)o.expansion_search : 64;
+        if (ef_add > 256) fail(VS_ERR_UNSUPPORTED, "expansion_add > 256 is not supported");
+        inv_log_m = 1.0 / std::log((double)M);
+        uint32_t dim4 = (dim + 3) / 4;
+        lanes = std::min<uint32_t>(64, pow2_ceil(dim4));
+        lanes_log2 = 0;
+        while ((1u << lanes_log2) < lanes) ++lanes_log2;
+        uint32_t need = (dim4 + lanes - 1) / lanes;
+        static const uint32_t ok_iters[] = {1, 2, 3, 4, 6, 8};
+        iters = 0;
+        for (uint32_t it : ok_iters)
+            if (it >= need) {
+                iters = it;
+                break;
+            }
+        if (!iters) fail(VS_ERR_UNSUPPORTED, "dimensions > 2048 are not supported");
+        stride4 = iters * lanes;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0) fail(VS_ERR_DEVICE, "no HIP device available");
+        if (o.device >= 0) {
+            if (o.device >= count) fail(VS_ERR_DEVICE, "device ordinal out of range");
+            device = o.device;
+        } else {
+            HIP_OK(hipGetDevice(&device));
+        }
+        use_device();
+        HIP_OK(hipMalloc(&d_stats, sizeof(unsigned long long) * ST_COUNT));
+        HIP_OK(hipMemset(d_stats, 0, sizeof(unsigned long long) * ST_COUNT));
+    }
+
+    template <class T>
+    static void regrow(T*& ptr, size_t old_n, size_t new_n, int fill_byte) {
+        T* np = nullptr;
+        HIP_OK(hipMalloc(&np, std::max<size_t>(new_n, 1) * sizeof(T)));
+        if (fill_byte >= 0 && new_n > old_n) HIP_OK(hipMemset(np + old_n, fill_byte, (new_n - old_n) * sizeof(T)));
+        if (ptr && old_n) HIP_OK(hipMemcpy(np, ptr, std::min(old_n, new_n) * sizeof(T), hipMemcpyDeviceToDevice));
+        if (ptr) HIP_OK(hipFree(ptr));
+        ptr = np;
+    }
+
+    // usearch reserve_capacity_and_threads (reference usearch.rs:181-185); exclusive by contract.
+    void reserve(size_t cap) {
+        std::lock_guard<std::mutex> g(mod_mu);
+        use_device();
+        if (cap < slots) fail(VS_ERR_INVALID_ARGUMENT, "can't reserve less than the current size");
+        if (cap >= (1ull << 31)) fail(VS_ERR_UNSUPPORTED, "capacity must be below 2^31 slots per index");
+        if (cap == capacity) return;
+        HIP_OK(hipDeviceSynchronize());
+        // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
+        // coexist with the old ones while rows are copied across.
+        const size_t row_bytes = (size_t)stride4 * 16 + 4 + (size_t)M0 * 4 + 4 + 8 + 4 + (size_t)M * 4 / 8;
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        if (cap > capacity && cap * row_bytes > free_b)
+            fail(VS_ERR_OUT_OF_MEMORY, "not enough HBM to reserve " + std::to_string(cap) + " vectors");
+        const size_t sf = (size_t)stride4 * 4;
+        regrow(d_vectors, slots * sf, cap * sf, -1);
+        regrow(d_inv_norm, slots, cap, 0);
+        regrow(d_adj0, capacity * M0, cap * M0, 0xFF);
+        regrow(d_upper_off, capacity, cap, 0xFF);
+        regrow(d_keys, capacity, cap, 0xFF);
+        regrow(d_levels, capacity, cap, 0);
+        h_levels.resize(cap, 0);
+        h_upper_off.resize(cap, kInvalid);
+        capacity = cap;
+        ensure_upper(cap / 8 + 64);
+    }
+
+    void ensure_upper(size_t blocks) {
+        if (blocks <= upper_cap) return;
+        HIP_OK(hipDeviceSynchronize());
+        size_t ncap = std::max(blocks, upper_cap * 2);
+        regrow(d_upper, upper_cap * M, ncap * M, 0xFF);
+        upper_cap = ncap;
+    }
+
+    int32_t draw_level() {  // usearch choose_random_level_
+        std::uniform_real_distribution<double> distribution(0.0, 1.0);
+        double r = -std::log(distribution(level_rng)) * inv_log_m;
+        return (int32_t)(int16_t)r;
+    }
+
+    // ------------------------------------------------------------------ add
+    // Returns per-item status (VS_OK / VS_ERR_*), all items attempted.
+    void add_batch(const uint64_t* keys, const float* vecs, bool on_device, size_t n, std::vector<int>& status,
+                   std::string& first_err) {
+        status.assign(n, VS_OK);
+        if (!n) return;
+        std::lock_guard<std::mutex> g(mod_mu);
+        use_device();
+        Lease w(device);
+        hipStream_t st = w->stream;
+        for (size_t c0 = 0; c0 < n; c0 += kChunk) {
+            const size_t cn = std::min<size_t>(kChunk, n - c0);
+            // 1. validate, assign slots and levels
+            std::vector<uint32_t> slot_v, src_row, reuse_rows, reuse_upper;
+            std::vector<int32_t> level_v;
+            std::vector<uint64_t> key_v;
+            std::vector<uint8_t> reused_v;
+            std::unordered_set<uint64_t> in_chunk;
+            slot_v.reserve(cn);
+            bool contiguous = true;
+            for (size_t i = 0; i < cn; ++i) {
+                const uint64_t key = keys[c0 + i];
+                auto bad = [&](int code, const char* m) {
+                    status[c0 + i] = code;
+                    if (first_err.empty()) first_err = m;
+                };
+                if (key == kFreeKey) {
+                    bad(VS_ERR_INVALID_ARGUMENT, "Key is reserved for internal use");
+                    continue;
+                }
+                if (lookup.count(key) || !in_chunk.insert(key).second) {
+                    bad(VS_ERR_DUPLICATE_KEY, "Duplicate keys not allowed in high-level wrappers");
+                    continue;
+                }
+                uint32_t slot;
+                int32_t level;
+                bool reused = false;
+                if (!free_slots.empty()) {  // usearch index_dense: reuse a removed node in place (update path)
+                    slot = free_slots.front();
+                    free_slots.pop_front();
+                    level = h_levels[slot];
+                    reused = true;
+                    reuse_rows.push_back(slot);
+                    for (int l = 0; l < level; ++l) reuse_upper.push_back(h_upper_off[slot] + l);
+                } else {
+                    if (slots >= capacity) {
+                        in_chunk.erase(key);
+                        bad(VS_ERR_CAPACITY, "Reserve capacity ahead of insertions!");
+                        continue;
+                    }
+                    slot = (uint32_t)slots++;
+                    level = draw_level();
+                    h_levels[slot] = (uint8_t)std::min(level, 255);
+                    if (level > 0) {
+                        h_upper_off[slot] = (uint32_t)upper_blocks;
+                        upper_blocks += (size_t)level;
+                    }
+                }
+                if (!slot_v.empty() && (slot != slot_v.back() + 1 || i != src_row.back() + 1)) contiguous = false;
+                if (reused) contiguous = false;
+                slot_v.push_back(slot);
+                level_v.push_back(level);
+                key_v.push_back(key);
+                src_row.push_back((uint32_t)i);
+                reused_v.push_back(reused);
+            }
+            const uint32_t m = (uint32_t)slot_v.size();
+            if (!m) continue;
+            ensure_upper(upper_blocks);
+            IndexView ix = view();
+
+            // 2. stage: slots / levels / keys / upper offsets, vectors into padded rows, norms
+            std::vector<uint32_t> uoff(m);
+            for (uint32_t i = 0; i < m; ++i) uoff[i] = h_upper_off[slot_v[i]];
+            // request offsets: (min(level, max_level at its turn) + 1) * M per node
+            std::vector<uint32_t> req_off(m + 1, 0);
+            {
+                int32_t ml = max_level.load();
+                size_t lk = linked;
+                for (uint32_t i = 0; i < m; ++i) {
+                    uint32_t cnt = 0;
+                    if (ml < 0) {
+                        ml = level_v[i];  // becomes the entry point, no requests
+                    } else {
+                        cnt = (uint32_t)(std::min(level_v[i], ml) + 1) * M;
+                        if (level_v[i] > ml) ml = level_v[i];
+                    }
+                    (void)lk;
+                    req_off[i + 1] = req_off[i] + cnt;
+                }
+            }
+            uint32_t* d_slots = (uint32_t*)w->a.ensure((size_t)m * 4 * 4 + 64);
+            int32_t* d_lv = (int32_t*)(d_slots + m);
+            uint32_t* d_uoff = (uint32_t*)(d_lv + m);
+            uint32_t* d_reqoff = d_uoff + m;
+            uint64_t* d_keyv = (uint64_t*)w->b.ensure((size_t)m * 8);
+            HIP_OK(hipMemcpyAsync(d_slots, slot_v.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(d_lv, level_v.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(d_uoff, uoff.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(d_reqoff, req_off.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(d_keyv, key_v.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
+            const float* src = nullptr;
+            const uint32_t* d_src_slots = d_slots;
+            if (on_device) {
+                if (m == cn) {
+                    src = vecs + c0 * dim;
+                } else {  // some rows were rejected: compact on the host side list of source rows
+                    float* stg = (float*)w->c.ensure((size_t)m * dim * 4);
+                    for (uint32_t i = 0; i < m; ++i)
+                        HIP_OK(hipMemcpyAsync(stg + (size_t)i * dim, vecs + (c0 + src_row[i]) * dim, (size_t)dim * 4,
+                                              hipMemcpyDeviceToDevice, st));
+                    src = stg;
+                }
+            } else {
+                float* stg = (float*)w->c.ensure((size_t)m * dim * 4);
+                if (m == cn) {
+                    HIP_OK(hipMemcpyAsync(stg, vecs + c0 * dim, (size_t)m * dim * 4, hipMemcpyHostToDevice, st));
+                } else {
+                    for (uint32_t i = 0; i < m; ++i)
+                        HIP_OK(hipMemcpyAsync(stg + (size_t)i * dim, vecs + (c0 + src_row[i]) * dim, (size_t)dim * 4,
+                                              hipMemcpyHostToDevice, st));
+                }
+                src = stg;
+            }
+            (void)contiguous;
+            HIP_OK(launch_scatter_rows(d_vectors, stride4 * 4, src, dim, dim, d_src_slots, 0, m, st));
+            if (metric == VS_METRIC_COS) HIP_OK(launch_inv_norms(ix, d_inv_norm, d_slots, 0, m, st));
+            HIP_OK(launch_scatter_u64(d_keys, d_slots, d_keyv, m, st));
+            HIP_OK(launch_scatter_u32((uint32_t*)d_levels, d_slots, (const uint32_t*)d_lv, m, st));
+            HIP_OK(launch_scatter_u32(d_upper_off, d_slots, d_uoff, m, st));
+            if (!reuse_rows.empty()) {  // usearch update(): the reused node's links are zeroed first
+                uint32_t* d_rr = (uint32_t*)w->d.ensure((reuse_rows.size() + reuse_upper.size()) * 4 + 64);
+                HIP_OK(hipMemcpyAsync(d_rr, reuse_rows.data(), reuse_rows.size() * 4, hipMemcpyHostToDevice, st));
+                HIP_OK(launch_fill_rows_u32(d_adj0, M0, d_rr, (uint32_t)reuse_rows.size(), kInvalid, st));
+                if (!reuse_upper.empty()) {
+                    uint32_t* d_ru = d_rr + reuse_rows.size();
+                    HIP_OK(hipMemcpyAsync(d_ru, reuse_upper.data(), reuse_upper.size() * 4, hipMemcpyHostToDevice, st));
+                    HIP_OK(launch_fill_rows_u32(d_upper, M, d_ru, (uint32_t)reuse_upper.size(), kInvalid, st));
+                }
+            }
+
+            // 3. sub-batches against the frozen graph
+            size_t max_req = 0;
+            {
+                // upper bound of requests in one sub-batch
+                size_t acc = 0, cntb = 0;
+                for (uint32_t i = 0; i < m; ++i) {
+                    acc += req_off[i + 1] - req_off[i];
+                    if (++cntb == kMaxSubBatch) {
+                        max_req = std::max(max_req, acc);
+                        acc = 0;
+                        cntb = 0;
+                    }
+                }
+                max_req = std::max(max_req, acc);
+            }
+            uint64_t* rk_in = (uint64_t*)w->e.ensure(std::max<size_t>(max_req, 1) * 8 * 4);
+            uint64_t* rv_in = rk_in + max_req;
+            uint64_t* rk_out = rv_in + max_req;
+            uint64_t* rv_out = rk_out + max_req;
+            size_t temp_bytes = sort_temp_bytes(std::max<size_t>(max_req, 1));
+            void* temp = w->f.ensure(temp_bytes);
+
+            uint32_t pos = 0;
+            while (pos < m) {
+                if (max_level.load() < 0) {  // first member: entry point, no links (usearch add(), `!new_slot`)
+                    entry_slot = slot_v[pos];
+                    max_level = level_v[pos];
+                    ++pos;
+                    ++linked;
+                    continue;
+                }
+                const int32_t ml = max_level.load();
+                uint32_t limit = (uint32_t)std::min<size_t>(kMaxSubBatch, std::max<size_t>(1, linked / kSubBatchRatio));
+                uint32_t take = 0;
+                while (take < limit && pos + take < m && level_v[pos + take] <= ml) ++take;
+                bool promote = false;
+                if (take == 0) {  // a node above the current top level is inserted alone, then becomes the entry
+                    take = 1;
+                    promote = true;
+                }
+                const uint32_t total_req = req_off[pos + take] - req_off[pos];
+                InsertArgs ia;
+                ia.ix = view();
+                ia.slots = d_slots + pos;
+                ia.levels = d_lv + pos;
+                ia.req_off = d_reqoff + pos;
+                ia.n = take;
+                ia.ef_add = ef_add;
+                ia.req_base = req_off[pos];
+                ia.req_key = rk_in;
+                ia.req_val = rv_in;
+                ia.stats = d_stats;
+                HIP_OK(launch_insert(ia, iters, st));
+                if (total_req) {
+                    HIP_OK(sort_pairs(temp, temp_bytes, rk_in, rk_out, rv_in, rv_out, total_req, 40, st));
+                    LinkArgs la;
+                    la.ix = ia.ix;
+                    la.req_key = rk_out;
+                    la.req_val = rv_out;
+                    la.total = total_req;
+                    la.stats = d_stats;
+                    HIP_OK(launch_link(la, iters, st));
+                }
+                if (promote) {
+                    entry_slot = slot_v[pos];
+                    max_level = level_v[pos];
+                }
+                pos += take;
+                linked += take;
+            }
+            HIP_OK(hipStreamSynchronize(st));
+            for (uint32_t i = 0; i < m; ++i) lookup.emplace(key_v[i], slot_v[i]);
+            live += m;
+        }
+    }
+
+    // Single-vector callers (one add per FFI call from <= num_workers()+1 threads, reference
+    // worker.rs:44-118) are combined: whoever finds no batch in flight becomes the leader and
+    // inserts everything queued so far.
+    int add_one(uint64_t key, const float* v) {
+        PendingAdd me;
+        me.key = key;
+        me.v = v;
+        std::unique_lock<std::mutex> lk(aq_mu);
+        aq.push_back(&me);
+        while (!me.done) {
+            if (!a_leader) {
+                a_leader = true;
+                std::vector<PendingAdd*> batch;
+                batch.swap(aq);
+                lk.unlock();
+                std::vector<uint64_t> keys(batch.size());
+                std::vector<float> vecs(batch.size() * (size_t)dim);
+                for (size_t i = 0; i < batch.size(); ++i) {
+                    keys[i] = batch[i]->key;
+                    std::memcpy(&vecs[i * dim], batch[i]->v, (size_t)dim * 4);
+                }
+                std::vector<int> status;
+                std::string err;
+                int hard = VS_OK;
+                std::string hard_msg;
+                try {
+                    add_batch(keys.data(), vecs.data(), false, batch.size(), status, err);
+                } catch (const Fail& f) {
+                    hard = f.code;
+                    hard_msg = f.msg;
+                }
+                lk.lock();
+                for (size_t i = 0; i < batch.size(); ++i) {
+                    batch[i]->status = hard != VS_OK ? hard : status[i];
+                    if (batch[i]->status != VS_OK) batch[i]->err = hard != VS_OK ? hard_msg : error_text(batch[i]->status);
+                    batch[i]->done = true;
+                }
+                a_leader = false;
+                aq_cv.notify_all();
+            } else {
+                aq_cv.wait(lk);
+            }
+        }
+        if (me.status != VS_OK) g_err = me.err;
+        return me.status;
+    }
+
+    static const char* error_text(int code) {
+        switch (code) {
+            case VS_ERR_DUPLICATE_KEY: return "Duplicate keys not allowed in high-level wrappers";
+            case VS_ERR_CAPACITY: return "Reserve capacity ahead of insertions!";
+            case VS_ERR_INVALID_ARGUMENT: return "Key is reserved for internal use";
+            default: return "add failed";
+        }
+    }
+
+    // ------------------------------------------------------------------ remove (usearch index_dense::remove)
+    bool remove(uint64_t key) {
+        std::lock_guard<std::mutex> g(mod_mu);
+        use_device();
+        auto it = lookup.find(key);
+        if (it == lookup.end()) return false;
+        uint32_t slot = it->second;
+        lookup.erase(it);
+        const uint64_t free_key = kFreeKey;
+        HIP_OK(hipMemcpy(d_keys + slot, &free_key, 8, hipMemcpyHostToDevice));
+        free_slots.push_back(slot);
+        --live;
+        return true;
+    }
+
+    // ------------------------------------------------------------------ search
+    void check_search(size_t k, uint32_t& ef) const {
+        if (k == 0) fail(VS_ERR_INVALID_ARGUMENT, "k must be > 0");
+        ef = (uint32_t)std::max<size_t>(ef_search.load(), k);  // usearch: expansion = max(expansion_search, wanted)
+        if (ef > 256)
+            fail(VS_ERR_UNSUPPORTED, "k / expansion_search above 256 needs the exhaustive path (use exact search)");
+        if (slots > (1ull << visited_domain_bits(ef)))
+            fail(VS_ERR_UNSUPPORTED, "index too large for the LDS visited table of this beam width");
+    }
+
+    void search_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
+                       hipStream_t st) {
+        uint32_t ef;
+        check_search(k, ef);
+        SearchArgs a;
+        a.ix = view();
+        a.queries = d_q;
+        a.q_stride = dim;
+        a.nq = (uint32_t)nq;
+        a.k = (uint32_t)k;
+        a.ef = ef;
+        a.out_keys = d_keys_out;
+        a.out_dist = d_dist_out;
+        a.out_found = d_found;
+        a.stats = d_stats;
+        HIP_OK(launch_search(a, iters, st));
+    }
+
+    void exact_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
+                      hipStream_t st, WorkCtx& w) {
+        if (k == 0 || k > 256) fail(VS_ERR_UNSUPPORTED, "exact search supports 1 <= k <= 256");
+        ExactArgs a;
+        a.ix = view();
+        a.queries = d_q;
+        a.q_stride = dim;
+        a.nq = (uint32_t)nq;
+        a.k = (uint32_t)k;
+        a.slots = (uint32_t)slots;
+        a.out_keys = d_keys_out;
+        a.out_dist = d_dist_out;
+        a.out_found = d_found;
+        void* scratch = w.f.ensure(exact_scratch_bytes((uint32_t)nq, (uint32_t)k));
+        HIP_OK(launch_exact(a, scratch, st));
+    }
+
+    void search_host(const float* q, size_t nq, size_t k, uint64_t* keys, float* dist, size_t* found, bool exact) {
+        if (!nq) return;
+        use_device();
+        Lease w(device);
+        hipStream_t st = w->stream;
+        float* d_q = (float*)w->a.ensure(nq * dim * 4);
+        uint64_t* d_k = (uint64_t*)w->b.ensure(nq * k * 8);
+        float* d_d = (float*)w->c.ensure(nq * k * 4);
+        uint32_t* d_f = (uint32_t*)w->d.ensure(nq * 4);
+        HIP_OK(hipMemcpyAsync(d_q, q, nq * dim * 4, hipMemcpyHostToDevice, st));
+        if (exact)
+            exact_device(d_q, nq, k, d_k, d_d, d_f, st, *w.ctx);
+        else
+            search_device(d_q, nq, k, d_k, d_d, d_f, st);
+        std::vector<uint32_t> f32(nq);
+        HIP_OK(hipMemcpyAsync(keys, d_k, nq * k * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(dist, d_d, nq * k * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(f32.data(), d_f, nq * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        for (size_t i = 0; i < nq; ++i) found[i] = f32[i];
+    }
+
+    // One query per FFI call (reference usearch.rs:212): concurrent callers are coalesced into
+    // one kernel launch; no timer -- a batch is whatever queued while the previous one ran.
+    int search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
+        PendingSearch me;
+        me.q = q;
+        me.k = k;
+        me.keys = keys;
+        me.dist = dist;
+        me.found = found;
+        std::unique_lock<std::mutex> lk(sq_mu);
+        sq.push_back(&me);
+        while (!me.done) {
+            if (!s_leader) {
+                s_leader = true;
+                std::vector<PendingSearch*> batch, rest;
+                for (PendingSearch* p : sq) (p->k == sq.front()->k ? batch : rest).push_back(p);
+                sq.swap(rest);
+                lk.unlock();
+                const size_t nb = batch.size(), kk = batch[0]->k;
+                int hard = VS_OK;
+                std::string msg;
+                std::vector<uint64_t> bk(nb * kk);
+                std::vector<float> bd(nb * kk), bq(nb * (size_t)dim);
+                std::vector<size_t> bf(nb);
+                try {
+                    for (size_t i = 0; i < nb; ++i) std::memcpy(&bq[i * dim], batch[i]->q, (size_t)dim * 4);
+                    search_host(bq.data(), nb, kk, bk.data(), bd.data(), bf.data(), false);
+                } catch (const Fail& f) {
+                    hard = f.code;
+                    msg = f.msg;
+                }
+                lk.lock();
+                for (size_t i = 0; i < nb; ++i) {
+                    PendingSearch* p = batch[i];
+                    p->status = hard;
+                    if (hard == VS_OK) {
+                        std::memcpy(p->keys, &bk[i * kk], bf[i] * 8);
+                        std::memcpy(p->dist, &bd[i * kk], bf[i] * 4);
+                        *p->found = bf[i];
+                    } else {
+                        p->err = msg;
+                    }
+                    p->done = true;
+                }
+                s_leader = false;
+                sq_cv.notify_all();
+            } else {
+                sq_cv.wait(lk);
+            }
+        }
+        if (me.status != VS_OK) g_err = me.err;
+        return me.status;
+    }
+
+    // All distances from one query to every slot (exhaustive path for filtered search with
+    // selective predicates and for k beyond the LDS beam).  Host gets (distance, key) pairs.
+    void all_distances(const float* q, std::vector<float>& dist, std::vector<uint64_t>& keys) {
+        use_device();
+        Lease w(device);
+        hipStream_t st = w->stream;
+        const size_t n = slots;
+        dist.assign(n, 0.f);
+        keys.assign(n, kFreeKey);
+        if (!n) return;
+        float* d_q = (float*)w->a.ensure((size_t)dim * 4);
+        HIP_OK(hipMemcpyAsync(d_q, q, (size_t)dim * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(launch_distance_row(view(), d_q, (uint32_t)n, (float*)w->f.ensure(n * 4 + 64), st, dist.data()));
+        HIP_OK(hipMemcpyAsync(keys.data(), d_keys, n * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+
+    // usearch filtered_search (reference usearch.rs:224-248): the predicate is host state
+    // (a table read-lock + restriction evaluation, usearch.rs:1118-1124), so it cannot run in
+    // the kernel.  Over-fetch with a doubling beam; when even the widest LDS beam does not
+    // yield k admitted keys, rank every member exhaustively -- all matches are then found,
+    // as the reference tests require (vs_index.rs:1119-1158: 9 of 30 with limit 100).
+    size_t filtered(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist) {
+        const size_t n_live = live.load();
+        if (!n_live) return 0;
+        size_t fetch = std::max<size_t>(k, ef_search.load());
+        for (;;) {
+            if (fetch > 256 || fetch >= n_live) break;
+            std::vector<uint64_t> kk(fetch);
+            std::vector<float> dd(fetch);
+            size_t f = 0;
+            search_host(q, 1, fetch, kk.data(), dd.data(), &f, false);
+            size_t out = 0;
+            for (size_t i = 0; i < f && out < k; ++i)
+                if (pred(kk[i], pctx)) {
+                    keys[out] = kk[i];
+                    dist[out] = dd[i];
+                    ++out;
+                }
+            if (out == k) return out;
+            fetch *= 2;
+        }
+        std::vector<float> dd;
+        std::vector<uint64_t> kk;
+        all_distances(q, dd, kk);
+        std::vector<uint32_t> order;
+        order.reserve(dd.size());
+        for (uint32_t s = 0; s < dd.size(); ++s)
+            if (kk[s] != kFreeKey && pred(kk[s], pctx)) order.push_back(s);
+        size_t out = std::min(k, order.size());
+        std::partial_sort(order.begin(), order.begin() + out, order.end(),
+                          [&](uint32_t a, uint32_t b) { return dd[a] < dd[b] || (dd[a] == dd[b] && a < b); });
+        for (size_t i = 0; i < out; ++i) {
+            keys[i] = kk[order[i]];
+            dist[i] = dd[order[i]];
+        }
+        return out;
+    }
+};
+
+}  // namespace vs
+
+// =============================================================================== C ABI
+using vs::Engine;
+using vs::Fail;
+
+struct vs_hnsw {
+    Engine e;
+};
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return VS_OK;
+    } catch (const Fail& x) {
+        vs::g_err = x.msg;
+        return x.code;
+    } catch (const std::bad_alloc&) {
+        vs::g_err = "host out of memory";
+        return VS_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& x) {
+        vs::g_err = x.what();
+        return VS_ERR_DEVICE;
+    } catch (...) {
+        vs::g_err = "unknown error";
+        return VS_ERR_DEVICE;
+    }
+}
+
+static void need(bool cond, const char* what) {
+    if (!cond) vs::fail(VS_ERR_INVALID_ARGUMENT, what);
+}
+static void check_dim(const vs_hnsw* h, size_t dim) {
+    if (dim != h->e.dim)
+        vs::fail(VS_ERR_DIMENSION, "wrong embedding dimension: got " + std::to_string(dim) + ", index has " +
+                                       std::to_string(h->e.dim));
+}
+
+extern "C" {
+
+const char* vs_hnsw_version(void) { return VS_VERSION; }
+const char* vs_hnsw_last_error(void) { return vs::g_err.c_str(); }
+
+int vs_hnsw_create(const vs_hnsw_options* o, vs_hnsw** out) {
+    return guarded([&] {
+        need(o && out, "null argument");
+        std::unique_ptr<vs_hnsw> h(new vs_hnsw());
+        h->e.init(*o);
+        *out = h.release();
+    });
+}
+void vs_hnsw_free(vs_hnsw* h) {
+    try {
+        delete h;
+    } catch (...) {
+    }
+}
+int vs_hnsw_reserve(vs_hnsw* h, size_t capacity, size_t /*threads*/) {
+    return guarded([&] {
+        need(h, "null index");
+        h->e.reserve(capacity);
+    });
+}
+size_t vs_hnsw_capacity(const vs_hnsw* h) { return h ? h->e.capacity : 0; }
+size_t vs_hnsw_size(const vs_hnsw* h) { return h ? h->e.live.load() : 0; }
+
+int vs_hnsw_add(vs_hnsw* h, uint64_t key, const float* v, size_t dim) {
+    int rc = VS_OK;
+    int g = guarded([&] {
+        need(h && v, "null argument");
+        check_dim(h, dim);
+        rc = h->e.add_one(key, v);
+    });
+    return g != VS_OK ? g : rc;
+}
+
+static int add_many(vs_hnsw* h, const uint64_t* keys, const float* vecs, size_t n, size_t dim, bool on_device) {
+    return guarded([&] {
+        need(h && (n == 0 || (keys && vecs)), "null argument");
+        check_dim(h, dim);
+        std::vector<int> status;
+        std::string err;
+        h->e.add_batch(keys, vecs, on_device, n, status, err);
+        size_t bad = 0;
+        int code = VS_OK;
+        for (int s : status)
+            if (s != VS_OK) {
+                if (!bad) code = s;
+                ++bad;
+            }
+        if (bad) vs::fail(code, err + " (" + std::to_string(bad) + " of " + std::to_string(n) + " vectors rejected)");
+    });
+}
+int vs_hnsw_add_batch(vs_hnsw* h, const uint64_t* keys, const float* vecs, size_t n, size_t dim) {
+    return add_many(h, keys, vecs, n, dim, false);
+}
+int vs_hnsw_add_batch_device(vs_hnsw* h, const uint64_t* keys, const float* d_vecs, size_t n, size_t dim) {
+    return add_many(h, keys, d_vecs, n, dim, true);
+}
+
+int vs_hnsw_remove(vs_hnsw* h, uint64_t key, int* removed) {
+    return guarded([&] {
+        need(h, "null index");
+        bool r = h->e.remove(key);
+        if (removed) *removed = r ? 1 : 0;
+    });
+}
+
+int vs_hnsw_search(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* keys, float* dist, size_t* found) {
+    int rc = VS_OK;
+    int g = guarded([&] {
+        need(h && q && keys && dist && found, "null argument");
+        check_dim(h, dim);
+        uint32_t ef;
+        *found = 0;
+        if (k > 256 || std::max<size_t>(k, h->e.ef_search.load()) > 256) {
+            // beyond the LDS beam: exhaustive ranking (exact, superset of what the beam would find)
+            struct All {
+                static int yes(uint64_t, void*) { return 1; }
+            };
+            need(k > 0, "k must be > 0");
+            *found = h->e.filtered(q, k, &All::yes, nullptr, keys, dist);
+            return;
+        }
+        h->e.check_search(k, ef);
+        rc = h->e.search_one(q, k, keys, dist, found);
+    });
+    return g != VS_OK ? g : rc;
+}
+
+int vs_hnsw_filtered_search(vs_hnsw* h, const float* q, size_t dim, size_t k, vs_hnsw_predicate pred, void* ctx,
+                            uint64_t* keys, float* dist, size_t* found) {
+    return guarded([&] {
+        need(h && q && keys && dist && found && pred, "null argument");
+        need(k > 0, "k must be > 0");
+        check_dim(h, dim);
+        *found = h->e.filtered(q, k, pred, ctx, keys, dist);
+    });
+}
+
+int vs_hnsw_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim, size_t k, uint64_t* keys, float* dist,
+                         size_t* found) {
+    return guarded([&] {
+        need(h && (nq == 0 || (q && keys && dist && found)), "null argument");
+        check_dim(h, dim);
+        h->e.search_host(q, nq, k, keys, dist, found, false);
+    });
+}
+int vs_hnsw_exact_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim, size_t k, uint64_t* keys, float* dist,
+                               size_t* found) {
+    return guarded([&] {
+        need(h && (nq == 0 || (q && keys && dist && found)), "null argument");
+        check_dim(h, dim);
+        h->e.search_host(q, nq, k, keys, dist, found, true);
+    });
+}
+int vs_hnsw_search_batch_device(vs_hnsw* h, const float* d_q, size_t nq, size_t dim, size_t k, uint64_t* d_keys,
+                                float* d_dist, uint32_t* d_found, void* stream) {
+    return guarded([&] {
+        need(h && (nq == 0 || (d_q && d_keys && d_dist && d_found)), "null argument");
+        check_dim(h, dim);
+        h->e.use_device();
+        h->e.search_device(d_q, nq, k, d_keys, d_dist, d_found, (hipStream_t)stream);
+    });
+}
+int vs_hnsw_exact_search_batch_device(vs_hnsw* h, const float* d_q, size_t nq, size_t dim, size_t k, uint64_t* d_keys,
+                                      float* d_dist, uint32_t* d_found, void* stream) {
+    return guarded([&] {
+        need(h && (nq == 0 || (d_q && d_keys && d_dist && d_found)), "null argument");
+        check_dim(h, dim);
+        h->e.use_device();
+        vs::Lease w(h->e.device);
+        h->e.exact_device(d_q, nq, k, d_keys, d_dist, d_found, (hipStream_t)stream, *w.ctx);
+        HIP_OK(hipStreamSynchronize((hipStream_t)stream));  // scratch returns to the pool with the lease
+    });
+}
+
+int vs_hnsw_set_expansion_search(vs_hnsw* h, size_t ef) {
+    return guarded([&] {
+        need(h && ef > 0, "invalid argument");
+        h->e.ef_search = (uint32_t)ef;
+    });
+}
+
+int vs_hnsw_stats(vs_hnsw* h, uint64_t out[8], int reset) {
+    return guarded([&] {
+        need(h && out, "null argument");
+        h->e.use_device();
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(out, h->e.d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (reset) HIP_OK(hipMemset(h->e.d_stats, 0, 8 * sizeof(uint64_t)));
+    });
+}
+
+int vs_hnsw_graph_info_get(vs_hnsw* h, vs_hnsw_graph_info* info) {
+    return guarded([&] {
+        need(h && info, "null argument");
+        std::lock_guard<std::mutex> g(h->e.mod_mu);
+        info->slots = h->e.slots;
+        info->upper_blocks = h->e.upper_blocks;
+        info->max_level = h->e.max_level.load();
+        info->entry_slot = h->e.entry_slot.load();
+        info->connectivity = h->e.M;
+        info->connectivity_base = h->e.M0;
+    });
+}
+
+int vs_hnsw_export_graph(vs_hnsw* h, float* vectors, int32_t* levels, uint64_t* keys, uint32_t* adj0, uint32_t* upper_off,
+                         uint32_t* upper) {
+    return guarded([&] {
+        need(h, "null index");
+        Engine& e = h->e;
+        std::lock_guard<std::mutex> g(e.mod_mu);
+        e.use_device();
+        HIP_OK(hipDeviceSynchronize());
+        const size_t n = e.slots;
+        if (!n) return;
+        if (vectors) {
+            vs::Lease w(e.device);
+            float* tmp = (float*)w->a.ensure(n * e.dim * 4);
+            HIP_OK(vs::launch_gather_rows(e.d_vectors, e.stride4 * 4, tmp, e.dim, (uint32_t)n, w->stream));
+            HIP_OK(hipMemcpyAsync(vectors, tmp, n * e.dim * 4, hipMemcpyDeviceToHost, w->stream));
+            HIP_OK(hipStreamSynchronize(w->stream));
+        }
+        if (levels) HIP_OK(hipMemcpy(levels, e.d_levels, n * 4, hipMemcpyDeviceToHost));
+        if (keys) HIP_OK(hipMemcpy(keys, e.d_keys, n * 8, hipMemcpyDeviceToHost));
+        if (adj0) HIP_OK(hipMemcpy(adj0, e.d_adj0, n * e.M0 * 4, hipMemcpyDeviceToHost));
+        if (upper_off) HIP_OK(hipMemcpy(upper_off, e.d_upper_off, n * 4, hipMemcpyDeviceToHost));
+        if (upper && e.upper_blocks) HIP_OK(hipMemcpy(upper, e.d_upper, e.upper_blocks * e.M * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const float* vectors, const int32_t* levels, const uint64_t* keys,
+                         const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* upper, size_t upper_blocks,
+                         int32_t max_level, uint32_t entry_slot) {
+    return guarded([&] {
+        need(h && (n == 0 || (vectors && levels && keys && adj0 && upper_off)), "null argument");
+        Engine& e = h->e;
+        need(e.slots == 0, "import needs an empty index");
+        if (n > e.capacity) e.reserve(n);
+        std::lock_guard<std::mutex> g(e.mod_mu);
+        e.use_device();
+        if (!n) return;
+        e.ensure_upper(upper_blocks);
+        vs::Lease w(e.device);
+        float* tmp = (float*)w->a.ensure(n * e.dim * 4);
+        HIP_OK(hipMemcpyAsync(tmp, vectors, n * e.dim * 4, hipMemcpyHostToDevice, w->stream));
+        HIP_OK(vs::launch_scatter_rows(e.d_vectors, e.stride4 * 4, tmp, e.dim, e.dim, nullptr, 0, (uint32_t)n, w->stream));
+        vs::IndexView ix = e.view();
+        if (e.metric == VS_METRIC_COS) HIP_OK(vs::launch_inv_norms(ix, e.d_inv_norm, nullptr, 0, (uint32_t)n, w->stream));
+        HIP_OK(hipStreamSynchronize(w->stream));
+        HIP_OK(hipMemcpy(e.d_levels, levels, n * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(e.d_keys, keys, n * 8, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(e.d_adj0, adj0, n * e.M0 * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(e.d_upper_off, upper_off, n * 4, hipMemcpyHostToDevice));
+        if (upper_blocks) HIP_OK(hipMemcpy(e.d_upper, upper, upper_blocks * e.M * 4, hipMemcpyHostToDevice));
+        e.slots = n;
+        e.linked = n;
+        e.upper_blocks = upper_blocks;
+        size_t live = 0;
+        for (size_t s = 0; s < n; ++s) {
+            e.h_levels[s] = (uint8_t)levels[s];
+            e.h_upper_off[s] = upper_off[s];
+            if (keys[s] != vs::kFreeKey) {
+                e.lookup.emplace(keys[s], (uint32_t)s);
+                ++live;
+            } else {
+                e.free_slots.push_back((uint32_t)s);
+            }
+        }
+        e.live = live;
+        e.max_level = max_level;
+        e.entry_slot = entry_slot;
+    });
+}
+
+int vs_topk_merge_device(const uint64_t* d_part_keys, const float* d_part_dists, size_t parts, size_t nq, size_t k,
+                         uint64_t* d_keys, float* d_dists, uint32_t* d_found, void* stream) {
+    return guarded([&] {
+        need(d_part_keys && d_part_dists && d_keys && d_dists, "null argument");
+        HIP_OK(vs::launch_topk_merge(d_part_keys, d_part_dists, (uint32_t)parts, (uint32_t)nq, (uint32_t)k, d_keys, d_dists,
+                                     d_found, (hipStream_t)stream));
+    });
+}
+
+// reference vs_index/usearch.rs:1179-1205
+void vs_f32_to_b1x8(const float* v, size_t n, uint8_t* out) {
+    const size_t nb = (n + 7) / 8;
+    for (size_t j = 0; j < nb; ++j) {
+        uint8_t byte = 0;
+        for (size_t i = 0; i < 8 && j * 8 + i < n; ++i)
+            if (v[j * 8 + i] > 0.0f) byte |= (uint8_t)(1u << i);
+        out[j] = byte;
+    }
+}
+
+// reference distance.rs:58-105
+int vs_distance_valid(float v, int metric, size_t dim) {
+    switch (metric) {
+        case VS_METRIC_COS: return v >= 0.0f && v <= 2.0f;
+        case VS_METRIC_L2SQ: return v >= 0.0f;
+        case VS_METRIC_IP: return !std::isnan(v);
+        case VS_METRIC_HAMMING: return v >= 0.0f && std::isfinite(v) && v == std::trunc(v) && v <= (float)dim;
+        default: return 0;
+    }
+}
+
+// reference similarity.rs:28-35
+float vs_similarity_score(float d, int metric, size_t dim) {
+    switch (metric) {
+        case VS_METRIC_COS:
+        case VS_METRIC_IP: return (2.0f - d) / 2.0f;
+        case VS_METRIC_L2SQ: return 1.0f / (1.0f + d);
+        default: return 1.0f - d / (float)dim;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,486 @@
+// hnsw_device.hpp -- device-side building blocks of the MI355X HNSW engine (gfx950, wave64).
+//
+// One 64-lane wavefront owns one query (or one node being inserted).  All control flow
+// is wave-uniform; per-lane work is (a) one neighbour id per lane for the visited test,
+// (b) 16 B of a vector row per lane per load for distances.
+//
+// Replaces what the reference delegates to usearch::Index::{search,add}
+// (reference crates/vector-store/src/vs_index/usearch.rs:196,212); the algorithm is the
+// one restated in oracle/cpu_hnsw.cpp (search_for_one / search_to_insert /
+// search_to_find_in_base / refine / reconnect_neighbor_nodes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vs {
+
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+constexpr uint32_t kExpanded = 0x80000000u;  // MSB of a list entry's slot: already expanded
+constexpr uint32_t kSlotMask = 0x7FFFFFFFu;
+constexpr uint64_t kFreeKey = ~0ull;
+constexpr int kWave = 64;
+
+enum : int { COS = 0, L2SQ = 1, IP = 2 };  // vs_metric_kind
+enum : int { KDOT = 0, KL2 = 1 };            // arithmetic kind: cos and ip share the dot product
+
+// HBM layout (see DESIGN.md "Data layout"):
+//  vectors  [capacity][stride4] float4, row = iters*lanes float4, zero padded
+//  inv_norm [capacity] f32 (cosine only; 0 marks the zero vector)
+//  adj0     [capacity][M0] u32 slots, kInvalid padded (128 B at M0=32: one cache line/expansion)
+//  upper    [blocks][M] u32; node s, level l>=1 lives in block upper_off[s]+l-1
+//  keys     [capacity] u64, kFreeKey = removed / never used
+struct IndexView {
+    const float4* vectors;
+    const float* inv_norm;
+    uint32_t* adj0;
+    uint32_t* upper;
+    const uint32_t* upper_off;
+    const uint64_t* keys;
+    uint32_t dim;
+    uint32_t stride4;     // float4 per row = iters * lanes
+    uint32_t lanes;       // lanes cooperating on one vector (power of two <= 64)
+    uint32_t lanes_log2;
+    uint32_t M, M0;
+    int32_t metric;       // COS / L2SQ / IP
+    uint32_t entry_slot;
+    int32_t max_level;    // -1: empty index
+};
+
+struct Counters {
+    unsigned long long evals;
+    unsigned long long hops;
+    unsigned long long overflow;
+};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// (distance, slot) strict total order; slot compared without the expanded flag.
+__device__ __forceinline__ bool key_less(float ad, uint32_t as, float bd, uint32_t bs) {
+    return ad < bd || (ad == bd && (as & kSlotMask) < (bs & kSlotMask));
+}
+
+template <int KIND>
+__device__ __forceinline__ float accumulate(float acc, const float4 a, const float4 b) {
+    if (KIND == KL2) {
+        float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+        acc = fmaf(dx, dx, acc);
+        acc = fmaf(dy, dy, acc);
+        acc = fmaf(dz, dz, acc);
+        acc = fmaf(dw, dw, acc);
+    } else {
+        acc = fmaf(a.x, b.x, acc);
+        acc = fmaf(a.y, b.y, acc);
+        acc = fmaf(a.z, b.z, acc);
+        acc = fmaf(a.w, b.w, acc);
+    }
+    return acc;
+}
+
+// usearch metric_cos_gt / l2sq / ip with the SimSIMD zero rules (oracle dist_cos):
+// both zero -> 0, one zero or ab == 0 -> 1, clamp to [0, 2] so Distance::try_from
+// (reference distance.rs:65-70) never rejects a result.
+__device__ __forceinline__ float finalize(int metric, float acc, float a_inv, float b_inv) {
+    if (metric == L2SQ) return acc;
+    if (metric == IP) return 1.0f - acc;
+    if (a_inv == 0.f && b_inv == 0.f) return 0.f;
+    if (a_inv == 0.f || b_inv == 0.f || acc == 0.f) return 1.f;
+    float r = 1.0f - acc * (a_inv * b_inv);
+    return fminf(fmaxf(r, 0.f), 2.f);
+}
+
+// Row -> registers: lane li of a `lanes`-wide group holds float4 li, li+lanes, ...
+template <int I>
+__device__ __forceinline__ void load_row(const IndexView& ix, uint32_t slot, float4 (&r)[I], int lane) {
+    const uint32_t li = lane & (ix.lanes - 1);
+    const float4* row = ix.vectors + (size_t)slot * ix.stride4 + li;
+#pragma unroll
+    for (int i = 0; i < I; ++i) r[i] = row[(size_t)i * ix.lanes];
+}
+
+// A caller-provided (unpadded, possibly unaligned) f32 vector -> registers, zero padded.
+template <int I>
+__device__ __forceinline__ void load_query(const IndexView& ix, const float* q, float4 (&r)[I], int lane) {
+    const uint32_t li = lane & (ix.lanes - 1);
+#pragma unroll
+    for (int i = 0; i < I; ++i) {
+        uint32_t e = ((uint32_t)i * ix.lanes + li) * 4u;
+        r[i].x = e + 0 < ix.dim ? q[e + 0] : 0.f;
+        r[i].y = e + 1 < ix.dim ? q[e + 1] : 0.f;
+        r[i].z = e + 2 < ix.dim ? q[e + 2] : 0.f;
+        r[i].w = e + 3 < ix.dim ? q[e + 3] : 0.f;
+    }
+}
+
+// 1/|q| over one lane group (every group holds a replica of q); 0 for the zero vector.
+template <int I>
+__device__ __forceinline__ float inv_norm_of(const IndexView& ix, const float4 (&q)[I]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < I; ++i) s = accumulate<KDOT>(s, q[i], q[i]);
+    for (uint32_t o = ix.lanes >> 1; o; o >>= 1) s += __shfl_xor(s, (int)o);
+    return s > 0.f ? 1.0f / sqrtf(s) : 0.f;
+}
+
+// Distances from q to u_slot[0..m): 64/lanes vectors per wave-load, U loads deep so that
+// U*I 16-byte loads per lane are in flight before the first FMA (memory-level parallelism
+// is what bounds this kernel: MI355X_MICROARCH "Indexed rows", ~72 KiB in flight per CU).
+template <int KIND, int I>
+__device__ __forceinline__ void eval_batch(const IndexView& ix, const float4 (&q)[I], float q_inv,
+                                           const uint32_t* u_slot, float* u_dist, uint32_t m, int lane) {
+    constexpr int U = I >= 6 ? 2 : (I >= 2 ? 4 : 8);
+    const uint32_t L = ix.lanes, lg = ix.lanes_log2;
+    const uint32_t V = 64u >> lg;
+    const uint32_t g = (uint32_t)lane >> lg, li = (uint32_t)lane & (L - 1);
+    for (uint32_t t = 0; t < m; t += V * U) {
+        float4 buf[U][I];
+        uint32_t slot[U];
+        float inv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t idx = t + (uint32_t)u * V + g;
+            slot[u] = idx < m ? u_slot[idx] : kInvalid;
+            inv[u] = 0.f;
+            if (slot[u] != kInvalid) {
+                const float4* row = ix.vectors + (size_t)slot[u] * ix.stride4 + li;
+#pragma unroll
+                for (int i = 0; i < I; ++i) buf[u][i] = row[(size_t)i * L];
+                if (ix.metric == COS) inv[u] = ix.inv_norm[slot[u]];
+            } else {
+#pragma unroll
+                for (int i = 0; i < I; ++i) buf[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < I; ++i) acc = accumulate<KIND>(acc, q[i], buf[u][i]);
+            for (uint32_t o = L >> 1; o; o >>= 1) acc += __shfl_xor(acc, (int)o);
+            if (slot[u] != kInvalid && li == 0) u_dist[t + (uint32_t)u * V + g] = finalize(ix.metric, acc, q_inv, inv[u]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-wave LDS state of one beam search.
+//   list     : the `top` buffer of usearch (ascending, <= ef entries) fused with `next`:
+//              an entry's MSB says whether it has been expanded.  Entries that fall out
+//              of the top-ef can never be expanded (their distance exceeds the radius and
+//              the radius only shrinks), so dropping them is equivalent to the CPU heaps.
+//   visited  : exact set of slots, NB buckets x 8 x 16-bit tags.  (slot * odd) mod
+//              2^(16+log2 NB) is a bijection, so (bucket, tag) identifies the slot as long
+//              as capacity <= 2^(16+log2 NB) (enforced by the host).
+// ---------------------------------------------------------------------------------------
+constexpr int kOvf = 256;
+
+template <int EFCAP, int NB>
+struct BeamShared {
+    float lst_d[2][EFCAP];
+    uint32_t lst_s[2][EFCAP];
+    alignas(16) uint16_t vis_tag[NB * 8];
+    uint32_t vis_cnt[NB];
+    uint32_t vis_ovf[kOvf];
+    uint32_t ovf_cnt;
+    uint32_t overflowed;
+    uint32_t u_slot[64];
+    float u_dist[64];
+    uint32_t sel_s[64];
+    float sel_d[64];
+};
+
+template <int NB>
+struct VisitedCfg {
+    static constexpr int log2nb = NB == 256 ? 8 : NB == 512 ? 9 : NB == 1024 ? 10 : NB == 2048 ? 11 : 12;
+    static constexpr uint32_t domain_bits = 16 + log2nb;
+    static constexpr uint32_t domain_mask = (1u << domain_bits) - 1u;
+};
+
+template <int EFCAP, int NB>
+__device__ __forceinline__ void visited_clear(BeamShared<EFCAP, NB>& sh, int lane) {
+    for (int i = lane; i < NB; i += kWave) sh.vis_cnt[i] = 0;
+    if (lane == 0) {
+        sh.ovf_cnt = 0;
+        sh.overflowed = 0;
+    }
+}
+
+// Per-lane test-and-set; returns true when `slot` was already in the set.
+template <int EFCAP, int NB>
+__device__ __forceinline__ bool visited_test_and_set(BeamShared<EFCAP, NB>& sh, uint32_t slot) {
+    using C = VisitedCfg<NB>;
+    const uint32_t m = (slot * 0x9E3779B1u) & C::domain_mask;
+    const uint32_t b = m >> 16;
+    const uint32_t tag = m & 0xFFFFu;
+    const uint32_t cnt = sh.vis_cnt[b];
+    const uint4 t4 = *reinterpret_cast<const uint4*>(&sh.vis_tag[b * 8]);
+    const uint32_t w[4] = {t4.x, t4.y, t4.z, t4.w};
+    const uint32_t n = cnt < 8u ? cnt : 8u;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t tj = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+        found |= ((uint32_t)j < n) && tj == tag;
+    }
+    if (!found && cnt > 8u) {
+        uint32_t oc = sh.ovf_cnt < (uint32_t)kOvf ? sh.ovf_cnt : (uint32_t)kOvf;
+        for (uint32_t j = 0; j < oc; ++j) found |= sh.vis_ovf[j] == slot;
+    }
+    if (found) return true;
+    uint32_t pos = atomicAdd(&sh.vis_cnt[b], 1u);
+    if (pos < 8u) {
+        sh.vis_tag[b * 8 + pos] = (uint16_t)tag;
+        return false;
+    }
+    uint32_t o = atomicAdd(&sh.ovf_cnt, 1u);
+    if (o < (uint32_t)kOvf) {
+        sh.vis_ovf[o] = slot;
+        return false;
+    }
+    sh.overflowed = 1;  // counted in stats[6]; the node is skipped (never a duplicate result)
+    return true;
+}
+
+__device__ __forceinline__ const uint32_t* adjacency(const IndexView& ix, uint32_t slot, int level, uint32_t& cap) {
+    if (level == 0) {
+        cap = ix.M0;
+        return ix.adj0 + (size_t)slot * ix.M0;
+    }
+    cap = ix.M;
+    return ix.upper + ((size_t)ix.upper_off[slot] + (uint32_t)(level - 1)) * ix.M;
+}
+
+// usearch search_for_one_: greedy walk on levels (from_level .. to_level+1].
+template <int KIND, int I, int EFCAP, int NB>
+__device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB>& sh, const float4 (&q)[I], float q_inv,
+                                   uint32_t start, int from_level, int to_level, Counters& cnt, int lane) {
+    uint32_t cur = start;
+    if (lane == 0) sh.u_slot[0] = cur;
+    __syncthreads();
+    eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, 1, lane);
+    __syncthreads();
+    float cur_d = sh.u_dist[0];
+    cnt.evals += 1;
+    for (int level = from_level; level > to_level; --level) {
+        for (;;) {
+            uint32_t cap;
+            const uint32_t* row = adjacency(ix, cur, level, cap);
+            uint32_t n = (uint32_t)lane < cap ? row[lane] : kInvalid;
+            uint64_t mask = __ballot(n != kInvalid);
+            uint32_t m = (uint32_t)__popcll(mask);
+            __syncthreads();
+            if (n != kInvalid) sh.u_slot[mbcnt(mask)] = n;
+            __syncthreads();
+            eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, m, lane);
+            __syncthreads();
+            cnt.evals += m;
+            cnt.hops += 1;
+            float d = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
+            uint32_t idx = (uint32_t)lane;
+            // argmin over (d, position): first minimum in adjacency order, as the CPU's strict '<' scan.
+            for (int o = 32; o; o >>= 1) {
+                float od = __shfl_xor(d, o);
+                uint32_t oi = (uint32_t)__shfl_xor((int)idx, o);
+                if (od < d || (od == d && oi < idx)) {
+                    d = od;
+                    idx = oi;
+                }
+            }
+            if (m && d < cur_d) {
+                cur_d = d;
+                cur = sh.u_slot[idx];
+            } else {
+                break;
+            }
+        }
+    }
+    return cur;
+}
+
+// Merge m new (distance, slot) pairs held by lanes 0..m-1 into the sorted list `cur`
+// (size sz), writing the ef best into the other buffer.  Rank-based merge: O(m + log sz)
+// per lane, no data-dependent divergence.  Returns the new size.
+template <int EFCAP, int NB>
+__device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB>& sh, int cur, uint32_t sz, uint32_t ef,
+                                               float nd, uint32_t ns, uint32_t m, int lane) {
+    const int nxt = cur ^ 1;
+    const float* od = sh.lst_d[cur];
+    const uint32_t* os = sh.lst_s[cur];
+    // rank of each new element among the old ones (binary search) ...
+    uint32_t r_old = 0;
+    if ((uint32_t)lane < m) {
+        uint32_t lo = 0, hi = sz;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (key_less(od[mid], os[mid], nd, ns)) lo = mid + 1; else hi = mid;
+        }
+        r_old = lo;
+    }
+    // ... and among the new ones.
+    uint32_t r_new = 0;
+    for (uint32_t i = 0; i < m; ++i) {
+        float di = __shfl(nd, (int)i);
+        uint32_t si = (uint32_t)__shfl((int)ns, (int)i);
+        r_new += ((uint32_t)lane < m && key_less(di, si, nd, ns)) ? 1u : 0u;
+    }
+    if ((uint32_t)lane < m) {
+        uint32_t pos = r_old + r_new;
+        if (pos < ef) {
+            sh.lst_d[nxt][pos] = nd;
+            sh.lst_s[nxt][pos] = ns;
+        }
+    }
+    // old entries shift right by the number of new elements ranked at or before them
+#pragma unroll
+    for (int r = 0; r < EFCAP / kWave; ++r) {
+        uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+        uint32_t shift = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+            uint32_t rj = (uint32_t)__shfl((int)r_old, (int)j);
+            shift += rj <= p ? 1u : 0u;
+        }
+        if (p < sz) {
+            uint32_t np = p + shift;
+            if (np < ef) {
+                sh.lst_d[nxt][np] = od[p];
+                sh.lst_s[nxt][np] = os[p];
+            }
+        }
+    }
+    uint32_t nsz = sz + m;
+    return nsz < ef ? nsz : ef;
+}
+
+// usearch search_to_insert_ / search_to_find_in_base_ (unfiltered): beam search on one level.
+// On return the sorted candidates are in sh.lst_*[cur] (cur returned through `out_cur`).
+// `self` (or kInvalid): slot that is never evaluated, expanded nor returned.
+template <int KIND, int I, int EFCAP, int NB>
+__device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB>& sh, const float4 (&q)[I], float q_inv,
+                                uint32_t start, int level, uint32_t ef, uint32_t self, Counters& cnt, int lane,
+                                int& out_cur) {
+    visited_clear(sh, lane);
+    __syncthreads();
+    int cur = 0;
+    uint32_t sz = 0;
+    if (lane == 0) {
+        if (self != kInvalid) visited_test_and_set(sh, self);
+        if (start != self) visited_test_and_set(sh, start);
+        sh.u_slot[0] = start;
+    }
+    __syncthreads();
+    if (start != self) {
+        eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, 1, lane);
+        __syncthreads();
+        cnt.evals += 1;
+        if (lane == 0) {
+            sh.lst_d[0][0] = sh.u_dist[0];
+            sh.lst_s[0][0] = start;
+        }
+        sz = 1;
+    }
+    __syncthreads();
+    for (;;) {
+        // closest unexpanded entry
+        int pick = -1;
+#pragma unroll
+        for (int r = 0; r < EFCAP / kWave; ++r) {
+            uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+            bool un = p < sz && !(sh.lst_s[cur][p] & kExpanded);
+            uint64_t mask = __ballot(un);
+            if (pick < 0 && mask) pick = r * kWave + (int)__builtin_ctzll(mask);
+        }
+        if (pick < 0) break;
+        uint32_t c_slot = sh.lst_s[cur][pick];
+        __syncthreads();
+        if (lane == 0) sh.lst_s[cur][pick] = c_slot | kExpanded;
+        cnt.hops += 1;
+        // neighbours: one id per lane, exact visited test-and-set, compaction
+        uint32_t cap;
+        const uint32_t* row = adjacency(ix, c_slot, level, cap);
+        uint32_t n = (uint32_t)lane < cap ? row[lane] : kInvalid;
+        bool fresh = n != kInvalid && !visited_test_and_set(sh, n);
+        uint64_t fmask = __ballot(fresh);
+        uint32_t m = (uint32_t)__popcll(fmask);
+        if (fresh) sh.u_slot[mbcnt(fmask)] = n;
+        __syncthreads();
+        if (m == 0) continue;
+        eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, m, lane);
+        __syncthreads();
+        cnt.evals += m;
+        // admission: top not full, or closer than the current radius (usearch: `top.size() < top_limit || d < radius`)
+        float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
+        uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
+        bool admit = (uint32_t)lane < m;
+        if (sz + m > ef) {
+            // only elements that can land inside the top-ef matter; prune against the radius when full
+            if (sz == ef) admit = admit && nd < sh.lst_d[cur][ef - 1];
+        }
+        uint64_t amask = __ballot(admit);
+        uint32_t ma = (uint32_t)__popcll(amask);
+        if (ma == 0) continue;
+        __syncthreads();
+        if (admit) {
+            uint32_t r = mbcnt(amask);
+            sh.u_dist[r] = nd;
+            sh.u_slot[r] = ns;
+        }
+        __syncthreads();
+        nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
+        ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
+        sz = list_merge(sh, cur, sz, ef, nd, ns, ma, lane);
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (sh.overflowed) cnt.overflow += 1;
+    out_cur = cur;
+    return sz;
+}
+
+// usearch refine_: neighbour-selection heuristic over the sorted candidates in
+// sh.lst_*[cur][0..sz).  Accept c iff for every already accepted a: d(c, a) >= d(c, centre).
+// Result in sh.sel_s / sh.sel_d (ascending); returns the number selected (<= needed).
+template <int KIND, int I, class Sh>
+__device__ uint32_t refine(const IndexView& ix, Sh& sh, int cur, uint32_t sz, uint32_t needed,
+                           Counters& cnt, int lane) {
+    if (sz < needed || sz == 0) {
+        __syncthreads();
+        if ((uint32_t)lane < sz) {
+            sh.sel_s[lane] = sh.lst_s[cur][lane] & kSlotMask;
+            sh.sel_d[lane] = sh.lst_d[cur][lane];
+        }
+        __syncthreads();
+        return sz;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        sh.sel_s[0] = sh.lst_s[cur][0] & kSlotMask;
+        sh.sel_d[0] = sh.lst_d[cur][0];
+    }
+    __syncthreads();
+    uint32_t nsel = 1;
+    for (uint32_t c = 1; c < sz && nsel < needed; ++c) {
+        const uint32_t cs = sh.lst_s[cur][c] & kSlotMask;
+        const float cd = sh.lst_d[cur][c];
+        float4 cv[I];
+        load_row<I>(ix, cs, cv, lane);
+        const float c_inv = ix.metric == COS ? ix.inv_norm[cs] : 0.f;
+        eval_batch<KIND, I>(ix, cv, c_inv, sh.sel_s, sh.u_dist, nsel, lane);
+        __syncthreads();
+        cnt.evals += nsel;
+        bool bad = (uint32_t)lane < nsel && sh.u_dist[lane] < cd;
+        bool reject = __ballot(bad) != 0ull;
+        __syncthreads();
+        if (!reject) {
+            if (lane == 0) {
+                sh.sel_s[nsel] = cs;
+                sh.sel_d[nsel] = cd;
+            }
+            ++nsel;
+            __syncthreads();
+        }
+    }
+    return nsel;
+}
+
+}  // namespace vs

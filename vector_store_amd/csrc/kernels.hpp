@@ -1,0 +1,91 @@
+// kernels.hpp -- host-callable launchers of the HIP kernels (implemented in kernels_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "hnsw_device.hpp"
+
+namespace vs {
+
+// stats layout == vs_hnsw_stats() (include/vs_hnsw.h)
+enum : int { ST_SEARCH_EVALS = 0, ST_SEARCH_HOPS, ST_QUERIES, ST_ADD_EVALS, ST_ADD_HOPS, ST_ADDED, ST_OVERFLOW, ST_RESERVED, ST_COUNT };
+
+struct SearchArgs {
+    IndexView ix;
+    const float* queries;  // nq x q_stride floats (unpadded rows)
+    uint32_t q_stride;
+    uint32_t nq, k, ef;
+    uint64_t* out_keys;    // nq x k, padded with kFreeKey
+    float* out_dist;       // nq x k, padded with +inf
+    uint32_t* out_found;   // nq
+    unsigned long long* stats;
+};
+
+struct InsertArgs {
+    IndexView ix;
+    const uint32_t* slots;    // n
+    const int32_t* levels;    // n
+    const uint32_t* req_off;  // n: first request index of node b (levels*(M) requests, one block per level)
+    uint32_t n, ef_add;
+    uint32_t req_base;        // req_off[first node of this sub-batch]
+    uint64_t* req_key;        // (level << 32) | target, ~0 = unused
+    uint64_t* req_val;        // (float bits of d(source,target) << 32) | source
+    unsigned long long* stats;
+};
+
+struct LinkArgs {
+    IndexView ix;
+    const uint64_t* req_key;  // sorted
+    const uint64_t* req_val;
+    uint32_t total;
+    unsigned long long* stats;
+};
+
+// iters = stride4 / lanes must be one of {1,2,3,4,6,8}; ef <= 256.
+bool search_supported(uint32_t iters, uint32_t ef);
+hipError_t launch_search(const SearchArgs& a, uint32_t iters, hipStream_t s);
+hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s);
+hipError_t launch_link(const LinkArgs& a, uint32_t iters, hipStream_t s);
+// bits of slot ids the visited table of the kernel chosen for `ef` can distinguish
+uint32_t visited_domain_bits(uint32_t ef);
+
+// inv_norm[slot] = 1/|row| (0 for the zero row) for slots[0..n) (slots == nullptr: first + i)
+hipError_t launch_inv_norms(const IndexView& ix, float* inv_norm, const uint32_t* slots, uint32_t first, uint32_t n,
+                            hipStream_t s);
+// dst rows (padded stride) <- src rows (dim floats, src_stride floats apart), rows given by slots or first+i
+hipError_t launch_scatter_rows(float* vectors, uint32_t stride_f, const float* src, uint32_t src_stride, uint32_t dim,
+                               const uint32_t* slots, uint32_t first, uint32_t n, hipStream_t s);
+hipError_t launch_gather_rows(const float* vectors, uint32_t stride_f, float* dst, uint32_t dim, uint32_t n, hipStream_t s);
+hipError_t launch_fill_u32(uint32_t* p, uint32_t value, size_t n, hipStream_t s);
+hipError_t launch_fill_rows_u32(uint32_t* base, uint32_t row_words, const uint32_t* rows, uint32_t nrows, uint32_t value,
+                                hipStream_t s);
+hipError_t launch_scatter_u64(uint64_t* dst, const uint32_t* idx, const uint64_t* src, uint32_t n, hipStream_t s);
+hipError_t launch_scatter_u32(uint32_t* dst, const uint32_t* idx, const uint32_t* src, uint32_t n, hipStream_t s);
+
+// Exact (brute-force) top-k, k <= 256.  scratch: see exact_scratch_bytes().
+struct ExactArgs {
+    IndexView ix;
+    const float* queries;
+    uint32_t q_stride, nq, k;
+    uint32_t slots;  // rows [0, slots) are scanned; removed rows skipped
+    uint64_t* out_keys;
+    float* out_dist;
+    uint32_t* out_found;
+};
+size_t exact_scratch_bytes(uint32_t nq, uint32_t k);
+hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s);
+
+// out[s] = distance(query, row s) for s in [0, n): one wave per row; result copied to host_out
+hipError_t launch_distance_row(const IndexView& ix, const float* d_query, uint32_t n, float* d_scratch, hipStream_t s,
+                               float* host_out);
+
+hipError_t launch_topk_merge(const uint64_t* part_keys, const float* part_dist, uint32_t parts, uint32_t nq, uint32_t k,
+                             uint64_t* out_keys, float* out_dist, uint32_t* out_found, hipStream_t s);
+
+// radix sort of (key, value) pairs by key bits [0, end_bit); temp sized by sort_temp_bytes()
+size_t sort_temp_bytes(size_t n);
+hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in,
+                      uint64_t* vals_out, size_t n, unsigned end_bit, hipStream_t s);
+
+}  // namespace vs

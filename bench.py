@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""bench.py -- QPS at recall@10 >= 0.95 of the HNSW search hot path on MI355X (driver contract).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (hnsw_search, one wavefront per query) over one batch of
+`--nq` synthetic queries that are already resident in HBM.  Workload at N=1 = BASELINE.json
+configs[1]: 1M x 768 cosine, top-10 (ef_search chosen as the smallest of {64,128,256} reaching
+recall@10 >= 0.95 against the exact brute-force ground truth computed on the GPU).
+
+Multi-GPU (`--mode replica`, default): the reference scales by replication -- every vector-store
+process holds the whole index -- so each rank builds a full replica and
+serves its own query stream; no data-path collective; scaling "weak"; value = all ranks' queries
+per second.  With N>1 a sharded leg (key-range shards, per-shard top-k all-gathered over RCCL and
+merged by vs_topk_merge_device) is also run and reported under "sharded" (`--mode shard` makes it
+the timed path).
+
+Synthetic data: `--dist lowrank` (default) = 24-d Gaussian latent mapped by a fixed random 24 x dim
+matrix plus 0.05 isotropic noise: embedding-like local intrinsic dimension, on which HNSW reaches
+the recall target at the reference's beam widths.  `--dist gaussian` is the i.i.d. generator of
+SURVEY.md section 8d, on which no graph index reaches useful recall at dim 768.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+ADJ_BYTES = 132        # level-0 adjacency record, 4 + 32*4
+
+
+def make_data(n, dim, kind, seed, device, rank=24):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if kind == "gaussian":
+        return torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+    gw = torch.Generator(device=device)
+    gw.manual_seed(99)
+    w = torch.randn((rank, dim), generator=gw, device=device, dtype=torch.float32) / rank ** 0.5
+    out = torch.randn((n, rank), generator=g, device=device, dtype=torch.float32) @ w
+    chunk = 1 << 18
+    for i in range(0, n, chunk):  # noise in slices: keeps the generator's transient footprint small
+        m = min(chunk, n - i)
+        out[i:i + m] += 0.05 * torch.randn((m, dim), generator=g, device=device, dtype=torch.float32)
+    return out
+
+
+def recall_at_k(truth: np.ndarray, got: np.ndarray) -> float:
+    # crates/benchmark/src/db.rs:308: |neighbors ∩ found| / |neighbors|
+    k = truth.shape[1]
+    return float(np.mean([len(set(truth[i].tolist()) & set(got[i].tolist())) / k for i in range(truth.shape[0])]))
+
+
+class Searcher:
+    """Device-resident query batch + output buffers; one call = one step of the hot path."""
+
+    def __init__(self, ix, queries, k):
+        self.ix, self.q, self.k = ix, queries, k
+        nq = queries.shape[0]
+        dev = queries.device
+        self.keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        self.dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        self.found = torch.empty((nq,), dtype=torch.int32, device=dev)
+
+    def step(self):
+        s = torch.cuda.current_stream().cuda_stream
+        self.ix.search_batch_device(self.q.data_ptr(), self.q.shape[0], self.k, self.keys.data_ptr(),
+                                    self.dist.data_ptr(), self.found.data_ptr(), s)
+
+    def exact(self):
+        s = torch.cuda.current_stream().cuda_stream
+        self.ix.exact_search_batch_device(self.q.data_ptr(), self.q.shape[0], self.k, self.keys.data_ptr(),
+                                          self.dist.data_ptr(), self.found.data_ptr(), s)
+        torch.cuda.synchronize()
+        return self.keys.cpu().numpy().copy(), self.dist.cpu().numpy().copy()
+
+
+def build_index(vs, base, keys, metric, ef_add=128):
+    n, dim = base.shape
+    ix = vs.HipUsearchIndex(dim, vs.METRICS[metric], 16, ef_add, 64)
+    ix.reserve(n)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    ix.add_batch_device(keys, base.data_ptr(), n, dim)
+    torch.cuda.synchronize()
+    return ix, time.perf_counter() - t
+
+
+def cpu_baseline(ix, queries_host, k, ef, seconds):
+    """The CPU restatement of the usearch algorithm (oracle/, kind "port") searching the SAME graph on
+    the host cores of this box: one query per call from T threads (reference usearch.rs:212)."""
+    import oracle
+    g = ix.export_graph()
+    o = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef)
+    o.import_graph(g)
+    del g
+    o.set_expansion_search(ef)
+    threads = os.cpu_count() or 1
+    nq = queries_host.shape[0]
+    o.search_batch(queries_host[: min(nq, 4 * threads)], k, threads=threads)  # page in, create contexts
+    done, t0 = 0, time.perf_counter()
+    while True:
+        keys, _, _ = o.search_batch(queries_host, k, threads=threads)
+        done += nq
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": done / el, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{done} queries ({done // nq} passes over the bench batch) in {el:.1f}s on the GPU-built graph, "
+                      f"ef_search={ef}, usearch-algorithm CPU restatement (not the usearch binary)"}, keys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000, help="vectors per GPU")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--nq", type=int, default=10_000, help="queries per step per GPU")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", default="cos", choices=["cos", "l2sq", "ip"])
+    ap.add_argument("--dist", default="lowrank", choices=["lowrank", "gaussian"])
+    ap.add_argument("--rank", type=int, default=24, help="latent dimension of the lowrank generator")
+    ap.add_argument("--ef", type=int, default=0, help="expansion_search; 0 = smallest of 64/128/256 with recall >= target")
+    ap.add_argument("--target-recall", type=float, default=0.95)
+    ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall seconds of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-sharded-leg", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    import vector_store_amd as vs  # after torch: one HIP runtime per process
+    from vector_store_amd import sharded
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    n, dim, nq, k = a.n, a.dim, a.nq, a.k
+    shard_mode = a.mode == "shard" and world > 1
+    # replica: same base on every rank, own queries; shard: own base (key range r*n..), same queries
+    base = make_data(n, dim, a.dist, 1234 + (rank if shard_mode else 0), dev, a.rank)
+    queries = make_data(nq, dim, a.dist, 4321 + (0 if shard_mode else rank), dev, a.rank)
+    keys = np.arange(n, dtype=np.uint64) + (np.uint64(rank * n) if shard_mode else np.uint64(0))
+    ix, build_s = build_index(vs, base, keys, a.metric)
+    st = ix.stats(reset=True)
+    build_info = {"vectors_per_s": n / build_s, "seconds": build_s, "vectors": n,
+                  "evals_per_add": st["add_evals"] / max(st["added"], 1)}
+    se = Searcher(ix, queries, k)
+    if shard_mode:
+        gs = sharded.ShardedSearcher(ix, queries, k, dist, vs)
+        truth = gs.exact()
+        step = gs.step
+        result_keys = lambda: gs.keys.cpu().numpy()
+    else:
+        truth, _ = se.exact()
+        step = se.step
+        result_keys = lambda: se.keys.cpu().numpy()
+
+    # ---- beam width: smallest of {64,128,256} reaching the recall target
+    sweep = []
+    chosen = None
+    for ef in ([a.ef] if a.ef else [64, 128, 256]):
+        ix.set_expansion_search(ef)
+        step()
+        torch.cuda.synchronize()
+        r = recall_at_k(truth, result_keys())
+        if dist is not None:
+            t = torch.tensor([r], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            r = float(t.item())
+        sweep.append({"ef": ef, "recall": round(r, 4)})
+        if chosen is None and r >= a.target_recall:
+            chosen = (ef, r)
+            break
+    if chosen is None:
+        chosen = (sweep[-1]["ef"], sweep[-1]["recall"])
+    ef, recall = chosen
+    ix.set_expansion_search(ef)
+
+    # ---- timed region: W warmup steps, then exactly K steps between barrier + synchronize
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    ix.stats(reset=True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = ix.stats(reset=True)
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))  # HIP events on the launch stream
+    e_q = st["search_evals"] / max(st["queries"], 1)
+    h_q = st["search_hops"] / max(st["queries"], 1)
+    b_q = e_q * dim * 4 + h_q * ADJ_BYTES + dim * 4  # algorithmic bytes per query
+    achieved = b_q * nq / (kernel_ms * 1e-3) / 1e9
+    total_q = nq * a.steps * (1 if shard_mode else world)
+    value = total_q / elapsed
+
+    out = {
+        "metric": "QPS at recall@10>=0.95 (hnsw_search, inputs resident in HBM)",
+        "value": value, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{n}x{dim} {a.metric} top-{k} per GPU, {nq} queries/step, M=16 ef_add=128 ef_search={ef}",
+                   "distribution": a.dist + (f"{a.rank}" if a.dist == "lowrank" else ""), "mode": a.mode if world > 1 else "single",
+                   "index_vectors_total": n * (world if shard_mode else 1)},
+        "recall_at_10": round(recall, 4), "ef_search": ef, "ef_sweep": sweep,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "hnsw_search_kernel",
+                     "kernel_ms": kernel_ms, "bytes_per_query": b_q, "evals_per_query": e_q, "hops_per_query": h_q,
+                     "visited_overflow": st["visited_overflow"]},
+        "build": build_info,
+    }
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):  # PMC-measured HBM bytes per launch for this exact workload (see profiles/README.md)
+        try:
+            rec = json.load(open(tr))
+            if rec.get("workload") == out["config"]["workload"]:
+                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+
+    # ---- sharded leg at N>1 (RCCL all-gather + merge), reported beside the replica number
+    if world > 1 and not shard_mode and not a.no_sharded_leg:
+        try:
+            sbase = make_data(n, dim, a.dist, 777 + rank, dev, a.rank)
+            skeys = np.arange(n, dtype=np.uint64) + np.uint64(rank * n)
+            six, sbuild = build_index(vs, sbase, skeys, a.metric)
+            six.set_expansion_search(ef)
+            sq = make_data(nq, dim, a.dist, 4321, dev, a.rank)
+            gs = sharded.ShardedSearcher(six, sq, k, dist, vs)
+            struth = gs.exact()
+            gs.step()
+            torch.cuda.synchronize()
+            srec = recall_at_k(struth, gs.keys.cpu().numpy())
+            barrier()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(max(a.steps // 2, 1)):
+                gs.step()
+            torch.cuda.synchronize()
+            barrier()
+            tel = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
+            dist.all_reduce(tel, op=dist.ReduceOp.MAX)
+            out["sharded"] = {"index_vectors_total": n * world, "queries_per_s": nq * max(a.steps // 2, 1) / float(tel.item()),
+                              "recall_at_10": round(srec, 4), "collective": "RCCL all_gather of per-shard top-k + vs_topk_merge_device",
+                              "build_vectors_per_s_per_gpu": n / sbuild}
+            del six, sbase
+        except Exception as e:  # the replica number stands on its own
+            out["sharded"] = {"error": repr(e)}
+
+    # ---- CPU baseline: rank 0, N=1 only, bounded
+    if world == 1 and a.cpu_seconds > 0:
+        try:
+            cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds)
+            cb["recall_at_10"] = round(recall_at_k(truth, ckeys), 4)
+            out["cpu_baseline"] = cb
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -599,7 +599,10 @@ struct Index {
     // --- usearch index_gt::search [UPSTREAM] ---
     size_t search(const void* q, size_t wanted, pred_fn pred, void* pctx, uint64_t* out_keys, float* out_d,
                   size_t thread, uint32_t* out_slots) {
-        Context& c = ctx(thread);
+        return search(q, wanted, pred, pctx, out_keys, out_d, ctx(thread), out_slots);
+    }
+    size_t search(const void* q, size_t wanted, pred_fn pred, void* pctx, uint64_t* out_keys, float* out_d,
+                  Context& c, uint32_t* out_slots) {
         if (nodes_count.load() == 0 || max_level < 0) return 0;
         size_t expansion = std::max(ef_search, wanted);
         uint32_t closest = search_for_one(q, entry_slot, max_level, 0, c);
@@ -718,12 +721,14 @@ int orc_search_batch(void* h, const void* Q, size_t nq, size_t k, uint64_t* keys
     Index* ix = (Index*)h;
     if (threads < 1) threads = 1;
     std::atomic<size_t> next{0};
+    for (size_t t = 0; t < threads; ++t) ix->ctx(t);  // contexts exist before the workers start
     auto work = [&](size_t t) {
+        Context& c = ix->ctx(t);
         for (;;) {
             size_t i = next.fetch_add(1);
             if (i >= nq) break;
             found[i] = ix->search((const uint8_t*)Q + i * ix->bytes_per_vector, k, nullptr, nullptr, keys + i * k,
-                                  d + i * k, t, nullptr);
+                                  d + i * k, c, nullptr);
         }
     };
     std::vector<std::thread> th;

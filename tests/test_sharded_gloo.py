@@ -1,0 +1,86 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharded search plumbing (local top-k -> all-gather ->
+merge).  The local search and the merge are numpy stand-ins here (the product's are HIP kernels,
+covered by the -m gpu tests); what is under test is the key-range partition, the collective
+exchange and the merge order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vector_store_amd import sharded
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, dim, nq, k, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        base = rng.standard_normal((total, dim)).astype(np.float32)
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        lo, hi = sharded.key_range(rank, world, total)
+        mine = base[lo:hi]
+
+        def local_search(exact):
+            d = ((q[:, None, :] - mine[None, :, :]) ** 2).sum(-1)
+            order = np.argsort(d, axis=1, kind="stable")[:, :k]
+            keys = torch.from_numpy((order + lo).astype(np.int64))
+            dd = torch.from_numpy(np.take_along_axis(d, order, axis=1).astype(np.float32))
+            return keys, dd
+
+        def merge(gk, gd, out_k, out_d):
+            mk, md = sharded.merge_topk_reference(gk.numpy().view(np.uint64), gd.numpy(), k)
+            out_k.copy_(torch.from_numpy(mk.view(np.int64)))
+            out_d.copy_(torch.from_numpy(md))
+
+        s = sharded.ShardedSearcher(None, torch.from_numpy(q), k, dist, None, local_search, merge)
+        s.step()
+        d_all = ((q[:, None, :] - base[None, :, :]) ** 2).sum(-1)
+        truth = np.argsort(d_all, axis=1, kind="stable")[:, :k]
+        ok = np.array_equal(s.keys.numpy(), truth.astype(np.int64))
+        ok = ok and np.allclose(s.dists.numpy(), np.take_along_axis(d_all, truth, axis=1), rtol=1e-6)
+        # every rank holds the same merged answer
+        t = s.keys.clone()
+        dist.broadcast(t, src=0)
+        ok = ok and bool((t == s.keys).all())
+        out[rank] = 1 if ok else 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_key_ranges_partition_the_index():
+    for total, world in ((10, 2), (1000, 8), (7, 3), (12_500_000 * 8, 8)):
+        spans = [sharded.key_range(r, world, total) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        for key in (0, total // 2, total - 1):
+            r = sharded.owner_of(key | (5 << 48), world, total)  # epoch bits do not affect ownership
+            assert spans[r][0] <= key < spans[r][1]
+
+
+def test_merge_reference_handles_padding():
+    inf, free = np.float32(np.inf), np.uint64(0xFFFFFFFFFFFFFFFF)
+    pk = np.array([[[1, 2, free]], [[7, free, free]]], dtype=np.uint64)
+    pd = np.array([[[0.1, 0.5, inf]], [[0.3, inf, inf]]], dtype=np.float32)
+    k, d = sharded.merge_topk_reference(pk, pd, 3)
+    assert k[0].tolist() == [1, 7, 2] and np.allclose(d[0], [0.1, 0.3, 0.5])
+    k, d = sharded.merge_topk_reference(pk[:, :, 2:], pd[:, :, 2:], 3)
+    assert (k == free).all() and np.isinf(d).all()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_search_world2_gloo():
+    world = 2
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), 600, 8, 9, 5, out), nprocs=world, join=True)
+    assert dict(out) == {0: 1, 1: 1}

@@ -19,7 +19,7 @@ namespace vs {
 
 template <int KIND, int I, int EFCAP, int NB>
 __global__ __launch_bounds__(64) void hnsw_insert_kernel(InsertArgs a) {
-    __shared__ BeamShared<EFCAP, NB> sh;
+    __shared__ BeamShared<EFCAP, NB, true> sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
     const uint32_t b = blockIdx.x;

@@ -95,6 +95,28 @@ def build_index(vs, base, keys, metric, ef_add=128):
     return ix, time.perf_counter() - t
 
 
+def effective_cores() -> int:
+    """Host cores this process may actually use: affinity mask and cgroup CPU quota included."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(ix, queries_host, k, ef, seconds):
     """The CPU restatement of the usearch algorithm (oracle/, kind "port") searching the SAME graph on
     the host cores of this box: one query per call from T threads (reference usearch.rs:212)."""
@@ -104,7 +126,7 @@ def cpu_baseline(ix, queries_host, k, ef, seconds):
     o.import_graph(g)
     del g
     o.set_expansion_search(ef)
-    threads = os.cpu_count() or 1
+    threads = effective_cores()
     nq = queries_host.shape[0]
     o.search_batch(queries_host[: min(nq, 4 * threads)], k, threads=threads)  # page in, create contexts
     done, t0 = 0, time.perf_counter()

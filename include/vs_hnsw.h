@@ -64,7 +64,7 @@ typedef struct vs_hnsw_options {
     int metric;       /* vs_metric_kind */
     int quantization; /* vs_scalar_kind */
     int device;       /* HIP device ordinal; -1 = current device */
-    int reserved;
+    int reserved;     /* 0; bit 0 = test hook: tiny visited table in search (forces the overflow path) */
 } vs_hnsw_options;
 
 /* -- lifecycle: usearch::Index::new (usearch.rs:172), drop ------------------------------- */

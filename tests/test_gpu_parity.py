@@ -395,3 +395,34 @@ def test_device_entry_points_with_torch_buffers():
     truth = ek.cpu().numpy().view(np.uint64)
     rec = np.mean([len(set(truth[i].tolist()) & set(hk[i].tolist())) / k for i in range(256)])
     assert rec >= 0.9, rec
+
+
+def test_visited_table_overflow_is_graceful():
+    """When the LDS visited table overflows, only evaluations are repeated: results stay
+    duplicate-free and identical to the CPU algorithm on the same graph.  The test hook
+    (options.reserved bit 0) swaps in a 256-bucket table so that every query overflows."""
+    v = vs()
+    n, dim, k = 60000, 128, 100
+    data = _dataset(n + 64, dim, 77)
+    base, q = data[:n], data[n:]
+    ix = v.HipUsearchIndex(dim, v.L2SQ, _stress=1)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    ix.set_expansion_search(128)
+    ix.stats(reset=True)
+    gk, gd, gf = ix.search_batch(q, k)
+    st = ix.stats()
+    assert st["visited_overflow"] > 0, "test no longer reaches the overflow path"
+    assert (gf == k).all()
+    for i in range(len(q)):
+        assert len(set(gk[i].tolist())) == k, "duplicate result"
+        assert all(gd[i, j] <= gd[i, j + 1] for j in range(k - 1))
+    o = OracleIndex(dim, oracle.L2SQ)
+    o.import_graph(ix.export_graph())
+    o.set_expansion_search(128)
+    same = 0
+    for i in range(len(q)):
+        ok_, od_ = o.search(q[i], k)
+        same += ok_.tolist() == gk[i].tolist()
+        assert np.allclose(gd[i], od_, rtol=1e-5, atol=1e-5)
+    assert same >= 58, same

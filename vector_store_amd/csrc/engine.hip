@@ -122,6 +122,7 @@ struct Engine {
     std::atomic<uint32_t> ef_search{64};
     int metric = VS_METRIC_COS;
     int device = 0;
+    bool stress_small_table = false;  // vs_hnsw_options.reserved bit 0 (tests only)
     uint32_t lanes = 64, lanes_log2 = 6, iters = 1, stride4 = 64;
 
     // HBM arenas
@@ -211,6 +212,7 @@ struct Engine {
             fail(VS_ERR_UNSUPPORTED, "metric must be cos, l2sq or ip (hamming/b1: not yet)");
         dim = (uint32_t)o.dimensions;
         metric = o.metric;
+        stress_small_table = (o.reserved & 1) != 0;
         M = o.connectivity ? (uint32_t)o.connectivity : 16;  // usearch default_connectivity
         if (M < 2 || M > 32) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 32]");
         M0 = 2 * M;
@@ -606,6 +608,7 @@ struct Engine {
         a.nq = (uint32_t)nq;
         a.k = (uint32_t)k;
         a.ef = ef;
+        a.stress_small_table = stress_small_table ? 1u : 0u;
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;

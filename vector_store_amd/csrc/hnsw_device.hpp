@@ -213,8 +213,9 @@ template <>
 struct SelArrays<false> {};
 
 // EFCAP=128, NB=1024, no SelArrays: 20,480 B -> 8 single-wave workgroups per CU (160 KiB LDS).
-template <int EFCAP, int NB, bool SEL = false>
+template <int EFCAP, int NB, bool SEL = false, int CH = 1>
 struct BeamShared : SelArrays<SEL> {
+    static constexpr int kChoices = CH;
     float lst_d[2][EFCAP];
     uint32_t lst_s[2][EFCAP];
     alignas(16) uint16_t vis_tag[NB * 8];
@@ -226,15 +227,16 @@ struct BeamShared : SelArrays<SEL> {
     float u_dist[64];
 };
 
-template <int NB>
+template <int NB, int CH = 1>
 struct VisitedCfg {
     static constexpr int log2nb = NB == 256 ? 8 : NB == 512 ? 9 : NB == 1024 ? 10 : NB == 2048 ? 11 : 12;
-    static constexpr uint32_t domain_bits = 16 + log2nb;
+    static constexpr uint32_t tag_bits = CH == 2 ? 15 : 16;  // two-choice: bit 15 marks "stored in its alternate bucket"
+    static constexpr uint32_t domain_bits = tag_bits + log2nb;
     static constexpr uint32_t domain_mask = (1u << domain_bits) - 1u;
 };
 
-template <int EFCAP, int NB, bool SEL>
-__device__ __forceinline__ void visited_clear(BeamShared<EFCAP, NB, SEL>& sh, int lane) {
+template <int EFCAP, int NB, bool SEL, int CH>
+__device__ __forceinline__ void visited_clear(BeamShared<EFCAP, NB, SEL, CH>& sh, int lane) {
     for (int i = lane; i < NB / 4; i += kWave) sh.vis_cnt[i] = 0;
     if (lane == 0) {
         sh.ovf_cnt = 0;
@@ -242,15 +244,9 @@ __device__ __forceinline__ void visited_clear(BeamShared<EFCAP, NB, SEL>& sh, in
     }
 }
 
-// Per-lane test-and-set; returns true when `slot` was already in the set.
-template <int EFCAP, int NB, bool SEL>
-__device__ __forceinline__ bool visited_test_and_set(BeamShared<EFCAP, NB, SEL>& sh, uint32_t slot) {
-    using C = VisitedCfg<NB>;
-    const uint32_t m = (slot * 0x9E3779B1u) & C::domain_mask;
-    const uint32_t b = m >> 16;
-    const uint32_t tag = m & 0xFFFFu;
-    const uint32_t sh8 = (b & 3u) * 8u;
-    const uint32_t cnt = (sh.vis_cnt[b >> 2] >> sh8) & 0xFFu;
+// Tags of one bucket that match `want` among its first min(cnt, 8) entries.
+template <class Sh>
+__device__ __forceinline__ bool bucket_has(const Sh& sh, uint32_t b, uint32_t cnt, uint32_t want) {
     const uint4 t4 = *reinterpret_cast<const uint4*>(&sh.vis_tag[b * 8]);
     const uint32_t w[4] = {t4.x, t4.y, t4.z, t4.w};
     const uint32_t n = cnt < 8u ? cnt : 8u;
@@ -258,18 +254,52 @@ __device__ __forceinline__ bool visited_test_and_set(BeamShared<EFCAP, NB, SEL>&
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         uint32_t tj = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-        found |= ((uint32_t)j < n) && tj == tag;
+        found |= ((uint32_t)j < n) && tj == want;
+    }
+    return found;
+}
+
+// Per-lane test-and-set; returns true when `slot` was already in the set.
+// CH == 2 (two-choice): a slot may live in bucket b1 (tag as is) or in b2 = b1 ^ alt(tag) (tag | 0x8000);
+// it goes to the emptier one, which keeps 8-entry buckets overflow-free up to ~85 % load.
+// (bucket, stored tag) still identifies the slot: b1 is recovered from b2 and the tag.
+template <int EFCAP, int NB, bool SEL, int CH>
+__device__ __forceinline__ bool visited_test_and_set(BeamShared<EFCAP, NB, SEL, CH>& sh, uint32_t slot) {
+    using C = VisitedCfg<NB, CH>;
+    const uint32_t m = (slot * 0x9E3779B1u) & C::domain_mask;
+    const uint32_t b1 = m >> C::tag_bits;
+    const uint32_t tag = m & ((1u << C::tag_bits) - 1u);
+    const uint32_t s1 = (b1 & 3u) * 8u;
+    const uint32_t c1 = (sh.vis_cnt[b1 >> 2] >> s1) & 0xFFu;
+    bool found = bucket_has(sh, b1, c1, tag);
+    uint32_t b = b1, sb = s1, cb = c1, stored = tag;
+    bool full = c1 >= 8u;
+    if (CH == 2) {
+        const uint32_t alt = ((tag * 0x5BD1u) >> 3) & (uint32_t)(NB - 1);
+        const uint32_t b2 = b1 ^ alt;
+        if (b2 != b1) {
+            const uint32_t s2 = (b2 & 3u) * 8u;
+            const uint32_t c2 = (sh.vis_cnt[b2 >> 2] >> s2) & 0xFFu;
+            found |= bucket_has(sh, b2, c2, tag | 0x8000u);
+            full = full && c2 >= 8u;
+            if (c2 < c1) {
+                b = b2;
+                sb = s2;
+                cb = c2;
+                stored = tag | 0x8000u;
+            }
+        }
     }
     constexpr uint32_t ovf_cap = (uint32_t)kOvf - 2u;
-    if (!found && cnt >= 8u) {  // full bucket: later members of it live in the overflow list
+    if (!found && full) {  // every candidate bucket is full: later members live in the overflow list
         uint32_t oc = sh.ovf_cnt < ovf_cap ? sh.ovf_cnt : ovf_cap;
         for (uint32_t j = 0; j < oc; ++j) found |= sh.vis_ovf[j] == slot;
     }
     if (found) return true;
     // a full bucket is not incremented further: the byte counter can never wrap
-    uint32_t pos = cnt >= 8u ? 8u : (atomicAdd(&sh.vis_cnt[b >> 2], 1u << sh8) >> sh8) & 0xFFu;
+    uint32_t pos = cb >= 8u ? 8u : (atomicAdd(&sh.vis_cnt[b >> 2], 1u << sb) >> sb) & 0xFFu;
     if (pos < 8u) {
-        sh.vis_tag[b * 8 + pos] = (uint16_t)tag;
+        sh.vis_tag[b * 8 + pos] = (uint16_t)stored;
         return false;
     }
     uint32_t o = atomicAdd(&sh.ovf_cnt, 1u);
@@ -277,8 +307,11 @@ __device__ __forceinline__ bool visited_test_and_set(BeamShared<EFCAP, NB, SEL>&
         sh.vis_ovf[o] = slot;
         return false;
     }
-    sh.overflowed = 1;  // counted in stats[6]; the node is skipped (never a duplicate result)
-    return true;
+    // Table exhausted (counted in stats[6]): report "fresh".  The node may then be evaluated a second
+    // time; beam_search drops it again by an exact (distance, slot) lookup in the sorted list, so
+    // results never contain duplicates and no node is ever lost -- only evaluations are repeated.
+    sh.overflowed = 1;
+    return false;
 }
 
 __device__ __forceinline__ const uint32_t* adjacency(const IndexView& ix, uint32_t slot, int level, uint32_t& cap) {
@@ -291,8 +324,8 @@ __device__ __forceinline__ const uint32_t* adjacency(const IndexView& ix, uint32
 }
 
 // usearch search_for_one_: greedy walk on levels (from_level .. to_level+1].
-template <int KIND, int I, int EFCAP, int NB, bool SEL>
-__device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SEL>& sh, const float4 (&q)[I], float q_inv,
+template <int KIND, int I, int EFCAP, int NB, bool SEL, int CH>
+__device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const float4 (&q)[I], float q_inv,
                                    uint32_t start, int from_level, int to_level, Counters& cnt, int lane) {
     uint32_t cur = start;
     if (lane == 0) sh.u_slot[0] = cur;
@@ -340,8 +373,8 @@ __device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SE
 // Merge m new (distance, slot) pairs held by lanes 0..m-1 into the sorted list `cur`
 // (size sz), writing the ef best into the other buffer.  Rank-based merge: O(m + log sz)
 // per lane, no data-dependent divergence.  Returns the new size.
-template <int EFCAP, int NB, bool SEL>
-__device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL>& sh, int cur, uint32_t sz, uint32_t ef,
+template <int EFCAP, int NB, bool SEL, int CH>
+__device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& sh, int cur, uint32_t sz, uint32_t ef,
                                                float nd, uint32_t ns, uint32_t m, int lane) {
     const int nxt = cur ^ 1;
     const float* od = sh.lst_d[cur];
@@ -394,8 +427,8 @@ __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL>& sh, i
 // usearch search_to_insert_ / search_to_find_in_base_ (unfiltered): beam search on one level.
 // On return the sorted candidates are in sh.lst_*[cur] (cur returned through `out_cur`).
 // `self` (or kInvalid): slot that is never evaluated, expanded nor returned.
-template <int KIND, int I, int EFCAP, int NB, bool SEL>
-__device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL>& sh, const float4 (&q)[I], float q_inv,
+template <int KIND, int I, int EFCAP, int NB, bool SEL, int CH>
+__device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const float4 (&q)[I], float q_inv,
                                 uint32_t start, int level, uint32_t ef, uint32_t self, Counters& cnt, int lane,
                                 int& out_cur) {
     visited_clear(sh, lane);
@@ -473,6 +506,14 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL>&
         if (sz + m > ef) {
             // only elements that can land inside the top-ef matter; prune against the radius when full
             if (sz == ef) admit = admit && nd < sh.lst_d[cur][ef - 1];
+        }
+        if (sh.overflowed) {  // wave-uniform; see visited_test_and_set: re-evaluated nodes are dropped here
+            uint32_t lo = 0, hi = admit ? sz : 0;
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (key_less(sh.lst_d[cur][mid], sh.lst_s[cur][mid], nd, ns)) lo = mid + 1; else hi = mid;
+            }
+            if (admit && lo < sz && (sh.lst_s[cur][lo] & kSlotMask) == ns && sh.lst_d[cur][lo] == nd) admit = false;
         }
         uint64_t amask = __ballot(admit);
         uint32_t ma = (uint32_t)__popcll(amask);

@@ -17,9 +17,9 @@
 
 namespace vs {
 
-template <int KIND, int I, int EFCAP, int NB>
+template <int KIND, int I, int EFCAP, int NB, int CH>
 __global__ __launch_bounds__(64) void hnsw_insert_kernel(InsertArgs a) {
-    __shared__ BeamShared<EFCAP, NB, true> sh;
+    __shared__ BeamShared<EFCAP, NB, true, CH> sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
     const uint32_t b = blockIdx.x;
@@ -151,9 +151,9 @@ template <int KIND, int I>
 static hipError_t insert_ef(const InsertArgs& a, hipStream_t s) {
     dim3 grid(a.n), block(64);
     if (a.ef_add <= 128)
-        hipLaunchKernelGGL((hnsw_insert_kernel<KIND, I, 128, 1024>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((hnsw_insert_kernel<KIND, I, 128, 1024, 1>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((hnsw_insert_kernel<KIND, I, 256, 2048>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((hnsw_insert_kernel<KIND, I, 256, 1024, 2>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

@@ -4,9 +4,9 @@
 
 namespace vs {
 
-template <int KIND, int I, int EFCAP, int NB>
+template <int KIND, int I, int EFCAP, int NB, int CH>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
-    __shared__ BeamShared<EFCAP, NB> sh;
+    __shared__ BeamShared<EFCAP, NB, false, CH> sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
     const uint32_t qi = blockIdx.x;
@@ -63,10 +63,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
 template <int KIND, int I>
 static hipError_t launch_ef(const SearchArgs& a, hipStream_t s) {
     dim3 grid(a.nq), block(64);
-    if (a.ef <= 128)
-        hipLaunchKernelGGL((hnsw_search_kernel<KIND, I, 128, 1024>), grid, block, 0, s, a);
+    if (I == 1 && a.stress_small_table && a.ef <= 128)
+        hipLaunchKernelGGL((hnsw_search_kernel<KIND, 1, 128, 256, 1>), grid, block, 0, s, a);
+    else if (a.ef <= 128)
+        hipLaunchKernelGGL((hnsw_search_kernel<KIND, I, 128, 1024, 1>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((hnsw_search_kernel<KIND, I, 256, 2048>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((hnsw_search_kernel<KIND, I, 256, 1024, 2>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -87,7 +89,7 @@ bool search_supported(uint32_t iters, uint32_t ef) {
     return (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8) && ef >= 1 && ef <= 256;
 }
 
-uint32_t visited_domain_bits(uint32_t ef) { return ef <= 128 ? VisitedCfg<1024>::domain_bits : VisitedCfg<2048>::domain_bits; }
+uint32_t visited_domain_bits(uint32_t ef) { return ef <= 128 ? VisitedCfg<1024, 1>::domain_bits : VisitedCfg<1024, 2>::domain_bits; }
 
 hipError_t launch_search(const SearchArgs& a, uint32_t iters, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;

@@ -135,12 +135,12 @@ class HipUsearchIndex:
     """`impl UsearchIndex` over the HIP engine (what ThreadedUsearchIndex is over usearch)."""
 
     def __init__(self, dimensions: int, metric: int = COS, connectivity: int = 16, expansion_add: int = 128,
-                 expansion_search: int = 64, quantization: int = F32, device: int = -1):
+                 expansion_search: int = 64, quantization: int = F32, device: int = -1, _stress: int = 0):
         self.L = lib()
         self.dim, self.metric = int(dimensions), int(metric)
         self.M = connectivity or 16
         self.M0 = 2 * self.M
-        o = _Options(dimensions, connectivity, expansion_add, expansion_search, metric, quantization, device, 0)
+        o = _Options(dimensions, connectivity, expansion_add, expansion_search, metric, quantization, device, _stress)
         h = C.c_void_p()
         _check(self.L.vs_hnsw_create(C.byref(o), C.byref(h)))
         self.h = h

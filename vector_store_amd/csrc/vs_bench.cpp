@@ -1,0 +1,278 @@
+// vs_bench -- native benchmark driver over the C ABI (include/vs_hnsw.h): the counterpart of the
+// reference's `vector-search-benchmark` (crates/benchmark/src/main.rs) for the engine alone.
+//
+//   vs_bench selftest
+//   vs_bench gen          --data-dir D --n N --dim D [--queries Q] [--neighbors K] [--dist lowrank|gaussian]
+//                         [--rank R] [--metric cos|l2sq|ip] [--seed S]
+//   vs_bench build-index  --data-dir D [--metric M] [--connectivity C] [--expansion-add E]
+//   vs_bench search       --data-dir D --limit K --duration SEC --concurrency C [--expansion-search E]
+//                         [--metric M] [--connectivity C] [--expansion-add E]
+//
+// `search` is the reference's search-http / search-cql loop (main.rs:435-525): `concurrency` workers
+// each pick a random query and issue ONE query per call (vs_hnsw_search, as client.ann does), recording
+// latency into a 10,000-bucket histogram and recall against query.ibin.  The reference measures a
+// running service; here the index is built in-process first (its wall time is what `build-index`
+// reports: main.rs:285-306 times CREATE INDEX until SERVING).
+#include <atomic>
+#include <chrono>
+#include <cinttypes>
+#include <cstdlib>
+#include <iostream>
+#include <random>
+#include <thread>
+
+#include "../../include/vs_hnsw.h"
+#include "bench_util.hpp"
+
+using Clock = std::chrono::steady_clock;
+using namespace vsb;
+
+struct Args {
+    std::map<std::string, std::string> kv;
+    std::string get(const std::string& k, const std::string& d = "") const {
+        auto it = kv.find(k);
+        return it == kv.end() ? d : it->second;
+    }
+    long num(const std::string& k, long d) const { return kv.count(k) ? std::atol(kv.at(k).c_str()) : d; }
+    double real(const std::string& k, double d) const { return kv.count(k) ? std::atof(kv.at(k).c_str()) : d; }
+};
+
+static int metric_code(const std::string& m) {
+    if (m == "cos") return VS_METRIC_COS;
+    if (m == "l2sq" || m == "euclidean") return VS_METRIC_L2SQ;
+    if (m == "ip" || m == "dot") return VS_METRIC_IP;
+    throw std::runtime_error("unknown metric " + m);
+}
+
+static void ok(int rc, const char* what) {
+    if (rc != VS_OK) throw std::runtime_error(std::string(what) + ": " + vs_hnsw_last_error());
+}
+
+static vs_hnsw* make_index(const Args& a, size_t dim, size_t capacity) {
+    vs_hnsw_options o{};
+    o.dimensions = dim;
+    o.connectivity = (size_t)a.num("connectivity", 16);
+    o.expansion_add = (size_t)a.num("expansion-add", 128);
+    o.expansion_search = (size_t)a.num("expansion-search", 64);
+    o.metric = metric_code(a.get("metric", "cos"));
+    o.quantization = VS_SCALAR_F32;
+    o.device = -1;
+    vs_hnsw* h = nullptr;
+    ok(vs_hnsw_create(&o, &h), "create");
+    ok(vs_hnsw_reserve(h, capacity, 0), "reserve");
+    return h;
+}
+
+// Synthetic rows: i.i.d. Gaussian, or a `rank`-d Gaussian latent through a fixed random map + noise.
+static void synth(float* out, size_t rows, size_t dim, const std::string& dist, size_t rank, uint64_t seed) {
+    std::vector<float> w;
+    if (dist == "lowrank") {
+        std::mt19937_64 g(99);
+        std::normal_distribution<float> nd;
+        w.resize(rank * dim);
+        for (auto& x : w) x = nd(g) / std::sqrt((float)rank);
+    }
+    unsigned T = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            std::vector<float> z(rank);
+            for (size_t r = t; r < rows; r += T) {
+                std::mt19937_64 g(seed * 0x9E3779B97F4A7C15ull + r);
+                std::normal_distribution<float> nd;
+                float* row = out + r * dim;
+                if (dist == "lowrank") {
+                    for (auto& x : z) x = nd(g);
+                    for (size_t c = 0; c < dim; ++c) {
+                        float s = 0.05f * nd(g);
+                        for (size_t j = 0; j < rank; ++j) s += z[j] * w[j * dim + c];
+                        row[c] = s;
+                    }
+                } else {
+                    for (size_t c = 0; c < dim; ++c) row[c] = nd(g);
+                }
+            }
+        });
+    for (auto& x : th) x.join();
+}
+
+static int cmd_selftest() {
+    // fbin / ibin round trip
+    const char* dir = std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp";
+    std::string base = std::string(dir) + "/vs_bench_selftest";
+    std::string mk = "mkdir -p " + base;
+    if (std::system(mk.c_str())) return 1;
+    std::vector<float> f = {1.5f, -2.f, 3.f, 4.f, 5.f, 6.f};
+    std::vector<int32_t> t = {5, 1, 9, 2, 0, 7};
+    write_fbin(base + "/query.fbin", f.data(), 2, 3);
+    write_ibin(base + "/query.ibin", t.data(), 2, 3);
+    write_dataset_toml(base, DatasetConfig{});
+    auto cfg = read_dataset_toml(base);
+    auto q = load_queries(base, cfg, 2);
+    bool good = q.size() == 2 && q[1].query == std::vector<float>({4.f, 5.f, 6.f}) && q[0].neighbors.count(5) &&
+                q[0].neighbors.count(1) && !q[0].neighbors.count(9) && q[1].neighbors.size() == 2;
+    std::ifstream raw(base + "/query.fbin", std::ios::binary);
+    unsigned char hdr[8];
+    raw.read((char*)hdr, 8);
+    good = good && hdr[0] == 2 && hdr[1] == 0 && hdr[4] == 3 && hdr[7] == 0;  // little-endian u32 count, dim
+    // recall
+    uint64_t found[3] = {5, 42, 1};
+    good = good && recall(q[0].neighbors, found, 3) == 1.0 && recall(q[1].neighbors, found, 3) == 0.0;
+    // histogram: 1..100 ms, 10,000 buckets, percentiles as the reference computes them
+    Histogram h;
+    for (int i = 1; i <= 100; ++i) h.record((int64_t)i * 1000000);  // 1ms .. 100ms
+    good = good && h.percentile(50) == 1000000 + Histogram::kStepNs * (int64_t)std::llround(49e6 / Histogram::kStepNs + 1);
+    good = good && h.percentile(1) == Histogram::kMinNs + Histogram::kStepNs;  // first sample sits in bucket 1
+    h.record(500);          // below the window -> bucket 0
+    h.record(200000000);    // above the window -> overflow bucket
+    // exactly 100 ms rounds into the last index as well (same arithmetic as the reference, main.rs:569-577)
+    good = good && h.buckets.front() == 1 && h.buckets.back() == 2 && h.count == 102;
+    Histogram over;
+    for (int i = 0; i < 100; ++i) over.record(200000000);
+    good = good && over.percentile(99) == INT64_MAX;  // Duration::MAX in the reference
+    SearchMeasure a, b;
+    a.record(2000000, 0.5);
+    b.record(4000000, 1.0);
+    a.append(b);
+    good = good && a.count == 2 && a.latency_min == 2000000 && a.latency_max == 4000000 && a.recall_min == 0.5 &&
+           a.recall_sum == 1.5;
+    std::cout << (good ? "selftest ok" : "selftest FAILED") << std::endl;
+    return good ? 0 : 1;
+}
+
+static int cmd_gen(const Args& a) {
+    const std::string dir = a.get("data-dir");
+    const size_t n = (size_t)a.num("n", 100000), dim = (size_t)a.num("dim", 768), nq = (size_t)a.num("queries", 1000);
+    const size_t k = (size_t)a.num("neighbors", 100), rank = (size_t)a.num("rank", 24);
+    const std::string dist = a.get("dist", "lowrank");
+    const uint64_t seed = (uint64_t)a.num("seed", 1234);
+    if (dir.empty()) throw std::runtime_error("--data-dir is required");
+    if (std::system(("mkdir -p " + dir).c_str())) return 1;
+    std::vector<float> base(n * dim), q(nq * dim);
+    synth(base.data(), n, dim, dist, rank, seed);
+    synth(q.data(), nq, dim, dist, rank, seed + 3087);
+    DatasetConfig cfg;
+    write_fbin(dir + "/" + cfg.data_fbin, base.data(), (uint32_t)n, (uint32_t)dim);
+    write_fbin(dir + "/" + cfg.query_fbin, q.data(), (uint32_t)nq, (uint32_t)dim);
+    // ground truth: exact search of the engine (ids are row indices, fbin.rs:86)
+    vs_hnsw* h = make_index(a, dim, n);
+    std::vector<uint64_t> keys(n);
+    for (size_t i = 0; i < n; ++i) keys[i] = i;
+    ok(vs_hnsw_add_batch(h, keys.data(), base.data(), n, dim), "add_batch");
+    std::vector<int32_t> truth(nq * k, -1);
+    const size_t kk = std::min<size_t>(k, 256);
+    std::vector<uint64_t> tk(nq * kk);
+    std::vector<float> td(nq * kk);
+    std::vector<size_t> tf(nq);
+    ok(vs_hnsw_exact_search_batch(h, q.data(), nq, dim, kk, tk.data(), td.data(), tf.data()), "exact");
+    for (size_t i = 0; i < nq; ++i)
+        for (size_t j = 0; j < std::min(kk, tf[i]); ++j) truth[i * k + j] = (int32_t)tk[i * kk + j];
+    write_ibin(dir + "/" + cfg.query_ibin, truth.data(), (uint32_t)nq, (uint32_t)k);
+    write_dataset_toml(dir, cfg);
+    vs_hnsw_free(h);
+    std::cout << "wrote " << n << " x " << dim << " vectors, " << nq << " queries, " << k << " neighbours to " << dir << std::endl;
+    return 0;
+}
+
+static vs_hnsw* build(const Args& a, const std::string& dir, const DatasetConfig& cfg, size_t& dim_out, double& secs) {
+    Matrix d = read_bin(dir + "/" + cfg.data_fbin, false);
+    vs_hnsw* h = make_index(a, d.dim, d.count);
+    std::vector<uint64_t> keys(d.count);
+    for (size_t i = 0; i < d.count; ++i) keys[i] = i;
+    auto t0 = Clock::now();
+    ok(vs_hnsw_add_batch(h, keys.data(), d.f.data(), d.count, d.dim), "add_batch");
+    secs = std::chrono::duration<double>(Clock::now() - t0).count();
+    dim_out = d.dim;
+    std::cout << "index build: " << d.count << " vectors in " << secs << " s = " << (double)d.count / secs << " vectors/s" << std::endl;
+    return h;
+}
+
+static int cmd_build(const Args& a) {
+    const std::string dir = a.get("data-dir");
+    size_t dim;
+    double secs;
+    vs_hnsw* h = build(a, dir, read_dataset_toml(dir), dim, secs);
+    uint64_t st[8];
+    ok(vs_hnsw_stats(h, st, 0), "stats");
+    std::cout << "distance evaluations per add: " << (double)st[3] / (double)std::max<uint64_t>(st[5], 1) << std::endl;
+    vs_hnsw_free(h);
+    return 0;
+}
+
+static int cmd_search(const Args& a) {
+    const std::string dir = a.get("data-dir");
+    const size_t limit = (size_t)a.num("limit", 10);
+    const double duration = a.real("duration", 10.0);
+    const unsigned conc = (unsigned)a.num("concurrency", 64);
+    if (limit < 1 || limit > 10000) throw std::runtime_error("--limit must be in 1..=10000");  // main.rs:192,221
+    DatasetConfig cfg = read_dataset_toml(dir);
+    size_t dim;
+    double secs;
+    vs_hnsw* h = build(a, dir, cfg, dim, secs);
+    ok(vs_hnsw_set_expansion_search(h, (size_t)a.num("expansion-search", 64)), "set ef");
+    std::vector<Query> queries = load_queries(dir, cfg, limit);
+    std::atomic<bool> stop{false};
+    std::vector<SearchMeasure> per(conc);
+    std::vector<std::string> errors(conc);
+    auto t0 = Clock::now();
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < conc; ++t)
+        th.emplace_back([&, t] {
+            std::mt19937_64 g(t * 7919 + 13);
+            std::vector<uint64_t> keys(limit);
+            std::vector<float> dist(limit);
+            while (!stop.load(std::memory_order_relaxed)) {
+                const Query& q = queries[g() % queries.size()];
+                size_t found = 0;
+                auto s = Clock::now();
+                int rc = vs_hnsw_search(h, q.query.data(), dim, limit, keys.data(), dist.data(), &found);
+                int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
+                if (rc != VS_OK) {
+                    errors[t] = vs_hnsw_last_error();
+                    break;
+                }
+                per[t].record(ns, recall(q.neighbors, keys.data(), found));
+            }
+        });
+    std::this_thread::sleep_for(std::chrono::duration<double>(duration));
+    stop = true;
+    for (auto& x : th) x.join();
+    double wall = std::chrono::duration<double>(Clock::now() - t0).count();
+    SearchMeasure all;
+    for (auto& m : per) all.append(m);
+    for (auto& e : errors)
+        if (!e.empty()) std::cerr << "search error: " << e << std::endl;
+    std::cout << "concurrency: " << conc << "\n" << all.report(wall);
+    uint64_t st[8];
+    ok(vs_hnsw_stats(h, st, 0), "stats");
+    if (st[2]) std::cout << "distance evaluations per query: " << (double)st[0] / (double)st[2] << std::endl;
+    vs_hnsw_free(h);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::cerr << "usage: vs_bench selftest | gen | build-index | search  (see the header of vs_bench.cpp)" << std::endl;
+        return 2;
+    }
+    Args a;
+    for (int i = 2; i < argc; ++i) {
+        std::string k = argv[i];
+        if (k.rfind("--", 0) != 0) continue;
+        k = k.substr(2);
+        std::string v = (i + 1 < argc && std::string(argv[i + 1]).rfind("--", 0) != 0) ? argv[++i] : "1";
+        a.kv[k] = v;
+    }
+    try {
+        std::string c = argv[1];
+        if (c == "selftest") return cmd_selftest();
+        if (c == "gen") return cmd_gen(a);
+        if (c == "build-index") return cmd_build(a);
+        if (c == "search") return cmd_search(a);
+        std::cerr << "unknown command " << c << std::endl;
+        return 2;
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << std::endl;
+        return 1;
+    }
+}

@@ -216,8 +216,8 @@ struct SelArrays<false> {};
 template <int EFCAP, int NB, bool SEL = false, int CH = 1>
 struct BeamShared : SelArrays<SEL> {
     static constexpr int kChoices = CH;
-    float lst_d[2][EFCAP];
-    uint32_t lst_s[2][EFCAP];
+    float lst_d[1][EFCAP];  // one buffer: list_merge works in place
+    uint32_t lst_s[1][EFCAP];
     alignas(16) uint16_t vis_tag[NB * 8];
     uint32_t vis_cnt[NB / 4];  // one byte per bucket
     uint32_t vis_ovf[kOvf - 2];
@@ -370,15 +370,16 @@ __device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SE
     return cur;
 }
 
-// Merge m new (distance, slot) pairs held by lanes 0..m-1 into the sorted list `cur`
-// (size sz), writing the ef best into the other buffer.  Rank-based merge: O(m + log sz)
-// per lane, no data-dependent divergence.  Returns the new size.
+// Merge m new (distance, slot) pairs held by lanes 0..m-1 into the sorted list (size sz), keeping the
+// ef best.  Rank-based and in place: every lane first reads what it owns into registers and computes
+// final positions (binary search among the old entries, all-pairs among the <= 64 new ones), then,
+// after a barrier, everything is scattered to its final position.  O(m + log sz) per lane, no
+// data-dependent divergence.  Returns the new size.  `cur` is always 0 (kept for call-site symmetry).
 template <int EFCAP, int NB, bool SEL, int CH>
 __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& sh, int cur, uint32_t sz, uint32_t ef,
                                                float nd, uint32_t ns, uint32_t m, int lane) {
-    const int nxt = cur ^ 1;
-    const float* od = sh.lst_d[cur];
-    const uint32_t* os = sh.lst_s[cur];
+    float* od = sh.lst_d[cur];
+    uint32_t* os = sh.lst_s[cur];
     // rank of each new element among the old ones (binary search) ...
     uint32_t r_old = 0;
     if ((uint32_t)lane < m) {
@@ -396,14 +397,9 @@ __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& s
         uint32_t si = (uint32_t)__shfl((int)ns, (int)i);
         r_new += ((uint32_t)lane < m && key_less(di, si, nd, ns)) ? 1u : 0u;
     }
-    if ((uint32_t)lane < m) {
-        uint32_t pos = r_old + r_new;
-        if (pos < ef) {
-            sh.lst_d[nxt][pos] = nd;
-            sh.lst_s[nxt][pos] = ns;
-        }
-    }
     // old entries shift right by the number of new elements ranked at or before them
+    float keep_d[EFCAP / kWave];
+    uint32_t keep_s[EFCAP / kWave], keep_p[EFCAP / kWave];
 #pragma unroll
     for (int r = 0; r < EFCAP / kWave; ++r) {
         uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
@@ -412,14 +408,29 @@ __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& s
             uint32_t rj = (uint32_t)__shfl((int)r_old, (int)j);
             shift += rj <= p ? 1u : 0u;
         }
+        keep_p[r] = kInvalid;
+        keep_d[r] = 0.f;
+        keep_s[r] = 0;
         if (p < sz) {
-            uint32_t np = p + shift;
-            if (np < ef) {
-                sh.lst_d[nxt][np] = od[p];
-                sh.lst_s[nxt][np] = os[p];
-            }
+            keep_d[r] = od[p];
+            keep_s[r] = os[p];
+            if (p + shift < ef) keep_p[r] = p + shift;
         }
     }
+    __syncthreads();  // every read of the old list is done
+    if ((uint32_t)lane < m) {
+        uint32_t pos = r_old + r_new;
+        if (pos < ef) {
+            od[pos] = nd;
+            os[pos] = ns;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < EFCAP / kWave; ++r)
+        if (keep_p[r] != kInvalid) {
+            od[keep_p[r]] = keep_d[r];
+            os[keep_p[r]] = keep_s[r];
+        }
     uint32_t nsz = sz + m;
     return nsz < ef ? nsz : ef;
 }
@@ -528,7 +539,6 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
         ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
         sz = list_merge(sh, cur, sz, ef, nd, ns, ma, lane);
-        cur ^= 1;
         __syncthreads();
     }
     if (sh.overflowed) cnt.overflow += 1;

@@ -224,7 +224,6 @@ __global__ __launch_bounds__(64) void exact_select_kernel(IndexView ix, const fl
         float nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
         uint32_t ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
         sz = list_merge(sh, cur, sz, k, nd, ns, ma, lane);
-        cur ^= 1;
         __syncthreads();
     }
     if (!last) {
@@ -356,7 +355,6 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t* part_key
         float nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
         uint32_t ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
         sz = list_merge(sh, cur, sz, k, nd, ns, ma, lane);
-        cur ^= 1;
         __syncthreads();
     }
     for (uint32_t i = lane; i < k; i += kWave) {

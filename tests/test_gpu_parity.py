@@ -426,3 +426,37 @@ def test_visited_table_overflow_is_graceful():
         same += ok_.tolist() == gk[i].tolist()
         assert np.allclose(gd[i], od_, rtol=1e-5, atol=1e-5)
     assert same >= 58, same
+
+
+@pytest.mark.parametrize("frac", [0.05, 0.4])
+def test_removed_members_are_traversed_but_never_returned(frac):
+    """usearch keeps removed nodes linked; `top` holds ef LIVE members while removed ones still steer
+    the walk.  Same graph + same removals => same ids as the CPU restatement."""
+    v = vs()
+    n, dim, k = 6000, 48, 10
+    data = _dataset(n + 64, dim, 123)
+    base, q = data[:n], data[n:]
+    ix = v.HipUsearchIndex(dim, v.COS)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    rng = np.random.default_rng(8)
+    gone = rng.choice(n, size=int(frac * n), replace=False)
+    for key in gone.tolist():
+        assert ix.remove(key)
+    assert ix.size() == n - len(gone)
+    o = OracleIndex(dim, oracle.COS)
+    o.import_graph(ix.export_graph())  # keys of removed slots are the free key in the export
+    assert o.size() == n - len(gone)
+    gone_set = set(gone.tolist())
+    for ef in (64, 200):
+        ix.set_expansion_search(ef)
+        o.set_expansion_search(ef)
+        gk, gd, gf = ix.search_batch(q, k)
+        same = 0
+        for i in range(len(q)):
+            ok_, od_ = o.search(q[i], k)
+            assert gf[i] == len(ok_) == k
+            assert not (set(gk[i].tolist()) & gone_set)
+            assert np.allclose(gd[i], od_, rtol=1e-5, atol=1e-5)
+            same += ok_.tolist() == gk[i].tolist()
+        assert same >= 60, (frac, ef, same)

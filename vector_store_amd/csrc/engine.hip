@@ -140,6 +140,7 @@ struct Engine {
     std::mutex mod_mu;
     size_t slots = 0, upper_blocks = 0;
     std::atomic<size_t> live{0};
+    std::atomic<size_t> removed{0};  // tombstoned slots not yet reused
     size_t linked = 0;  // nodes present in the graph
     std::unordered_map<uint64_t, uint32_t> lookup;
     std::deque<uint32_t> free_slots;  // usearch ring_gt: FIFO
@@ -262,7 +263,7 @@ struct Engine {
         std::lock_guard<std::mutex> g(mod_mu);
         use_device();
         if (cap < slots) fail(VS_ERR_INVALID_ARGUMENT, "can't reserve less than the current size");
-        if (cap >= (1ull << 31)) fail(VS_ERR_UNSUPPORTED, "capacity must be below 2^31 slots per index");
+        if (cap >= (1ull << 30)) fail(VS_ERR_UNSUPPORTED, "capacity must be below 2^30 slots per index");
         if (cap == capacity) return;
         HIP_OK(hipDeviceSynchronize());
         // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
@@ -339,6 +340,7 @@ struct Engine {
                 if (!free_slots.empty()) {  // usearch index_dense: reuse a removed node in place (update path)
                     slot = free_slots.front();
                     free_slots.pop_front();
+                    --removed;
                     level = h_levels[slot];
                     reused = true;
                     reuse_rows.push_back(slot);
@@ -583,6 +585,7 @@ struct Engine {
         const uint64_t free_key = kFreeKey;
         HIP_OK(hipMemcpy(d_keys + slot, &free_key, 8, hipMemcpyHostToDevice));
         free_slots.push_back(slot);
+        ++removed;
         --live;
         return true;
     }
@@ -608,6 +611,7 @@ struct Engine {
         a.nq = (uint32_t)nq;
         a.k = (uint32_t)k;
         a.ef = ef;
+        a.has_removed = removed.load() ? 1u : 0u;
         a.stress_small_table = stress_small_table ? 1u : 0u;
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
@@ -1038,6 +1042,7 @@ int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const float* vectors, const int32
                 ++live;
             } else {
                 e.free_slots.push_back((uint32_t)s);
+                ++e.removed;
             }
         }
         e.live = live;

@@ -15,8 +15,9 @@
 namespace vs {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
-constexpr uint32_t kExpanded = 0x80000000u;  // MSB of a list entry's slot: already expanded
-constexpr uint32_t kSlotMask = 0x7FFFFFFFu;
+constexpr uint32_t kExpanded = 0x80000000u;  // bit 31 of a list entry's slot: already expanded
+constexpr uint32_t kDead = 0x40000000u;      // bit 30: removed member (free key): traversed, never a result
+constexpr uint32_t kSlotMask = 0x3FFFFFFFu;
 constexpr uint64_t kFreeKey = ~0ull;
 constexpr int kWave = 64;
 
@@ -441,11 +442,12 @@ __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& s
 template <int KIND, int I, int EFCAP, int NB, bool SEL, int CH>
 __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const float4 (&q)[I], float q_inv,
                                 uint32_t start, int level, uint32_t ef, uint32_t self, Counters& cnt, int lane,
-                                int& out_cur) {
+                                int& out_cur, bool tomb = false) {
     visited_clear(sh, lane);
     __syncthreads();
     int cur = 0;
     uint32_t sz = 0;
+    uint32_t live = 0;  // members of the list that can be results (== sz unless the index has removed members)
     if (lane == 0) {
         if (self != kInvalid) visited_test_and_set(sh, self);
         if (start != self) visited_test_and_set(sh, start);
@@ -456,11 +458,13 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, 1, lane);
         __syncthreads();
         cnt.evals += 1;
+        const bool start_dead = tomb && ix.keys[start] == kFreeKey;
         if (lane == 0) {
             sh.lst_d[0][0] = sh.u_dist[0];
-            sh.lst_s[0][0] = start;
+            sh.lst_s[0][0] = start | (start_dead ? kDead : 0u);
         }
         sz = 1;
+        live = start_dead ? 0 : 1;
     }
     __syncthreads();
     // Adjacency prefetch: while hop h evaluates its neighbours, the row of the runner-up candidate is
@@ -481,10 +485,11 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
             if (pick >= 0 && pick2 < 0 && mask) pick2 = r * kWave + (int)__builtin_ctzll(mask);
         }
         if (pick < 0) break;
-        uint32_t c_slot = sh.lst_s[cur][pick];
+        const uint32_t c_entry = sh.lst_s[cur][pick];
+        const uint32_t c_slot = c_entry & kSlotMask;
         uint32_t c2_slot = pick2 >= 0 ? (sh.lst_s[cur][pick2] & kSlotMask) : kInvalid;
         __syncthreads();
-        if (lane == 0) sh.lst_s[cur][pick] = c_slot | kExpanded;
+        if (lane == 0) sh.lst_s[cur][pick] = c_entry | kExpanded;
         cnt.hops += 1;
         // neighbours: one id per lane, exact visited test-and-set, compaction
         uint32_t cap;
@@ -514,7 +519,12 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
         uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
         bool admit = (uint32_t)lane < m;
-        if (sz + m > ef) {
+        if (tomb) {
+            // usearch: `top` holds ef LIVE members; removed ones only live in `next`.  Here both share the
+            // list, which is cut right after its ef-th live entry, so that entry's distance is the radius.
+            if (admit && ix.keys[ns] == kFreeKey) ns |= kDead;
+            if (live >= ef) admit = admit && nd < sh.lst_d[cur][sz - 1];
+        } else if (sz + m > ef) {
             // only elements that can land inside the top-ef matter; prune against the radius when full
             if (sz == ef) admit = admit && nd < sh.lst_d[cur][ef - 1];
         }
@@ -524,7 +534,7 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
                 uint32_t mid = (lo + hi) >> 1;
                 if (key_less(sh.lst_d[cur][mid], sh.lst_s[cur][mid], nd, ns)) lo = mid + 1; else hi = mid;
             }
-            if (admit && lo < sz && (sh.lst_s[cur][lo] & kSlotMask) == ns && sh.lst_d[cur][lo] == nd) admit = false;
+            if (admit && lo < sz && (sh.lst_s[cur][lo] & kSlotMask) == (ns & kSlotMask) && sh.lst_d[cur][lo] == nd) admit = false;
         }
         uint64_t amask = __ballot(admit);
         uint32_t ma = (uint32_t)__popcll(amask);
@@ -538,8 +548,30 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         __syncthreads();
         nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
         ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
-        sz = list_merge(sh, cur, sz, ef, nd, ns, ma, lane);
+        sz = list_merge(sh, cur, sz, tomb ? (uint32_t)EFCAP : ef, nd, ns, ma, lane);
         __syncthreads();
+        if (tomb) {  // cut after the ef-th live entry
+            uint32_t cum = 0, cut = sz;
+            bool found = false;
+#pragma unroll
+            for (int r = 0; r < EFCAP / kWave; ++r) {
+                uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+                bool lv = p < sz && !(sh.lst_s[cur][p] & kDead);
+                uint64_t mask = __ballot(lv);
+                uint32_t c = (uint32_t)__popcll(mask);
+                if (!found && cum + c >= ef) {
+                    uint32_t need = ef - cum;  // the need-th (1-based) live entry of this round
+                    for (uint32_t i = 1; i < need; ++i) mask &= mask - 1;
+                    cut = (uint32_t)r * kWave + (uint32_t)__builtin_ctzll(mask) + 1u;
+                    found = true;
+                }
+                cum += c;
+            }
+            live = found ? ef : cum;
+            sz = cut;
+        } else {
+            live = sz;
+        }
     }
     if (sh.overflowed) cnt.overflow += 1;
     out_cur = cur;

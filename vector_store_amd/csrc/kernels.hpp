@@ -16,6 +16,7 @@ struct SearchArgs {
     const float* queries;  // nq x q_stride floats (unpadded rows)
     uint32_t q_stride;
     uint32_t nq, k, ef;
+    uint32_t has_removed;         // some members carry the free key: the beam keeps ef LIVE entries
     uint32_t stress_small_table;  // test hook: 256-bucket visited table (iters == 1 only) to force overflow
     uint64_t* out_keys;    // nq x k, padded with kFreeKey
     float* out_dist;       // nq x k, padded with +inf

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
     // usearch index_gt::search: search_for_one_ down to level 1, then the base-level beam.
     uint32_t start = greedy_descent<KIND, I>(ix, sh, q, q_inv, ix.entry_slot, ix.max_level, 0, cnt, lane);
     int cur = 0;
-    uint32_t sz = beam_search<KIND, I>(ix, sh, q, q_inv, start, 0, a.ef, kInvalid, cnt, lane, cur);
+    uint32_t sz = beam_search<KIND, I>(ix, sh, q, q_inv, start, 0, a.ef, kInvalid, cnt, lane, cur, a.has_removed != 0);
     __syncthreads();
     // top.sort_ascending(); top.shrink(wanted); removed members (free key) are never results.
     uint32_t written = 0;

@@ -90,6 +90,13 @@ VS_API int vs_hnsw_remove(vs_hnsw* index, uint64_t key, int* removed);
  * keys/distances: caller arrays of length k, ascending by distance; *found <= k. */
 VS_API int vs_hnsw_search(vs_hnsw* index, const float* query, size_t dim, size_t k, uint64_t* keys, float* distances,
                    size_t* found);
+/* Non-blocking form of vs_hnsw_search for async runtimes (the reference runs searches inline on tokio
+ * workers, usearch.rs:928-935; blocking them caps the queries in flight at the worker count).
+ * `query` is copied before the call returns; keys/distances/found must stay valid until `done(ctx,
+ * status)` runs on the engine's dispatcher thread (it must not block; e.g. complete a oneshot). */
+typedef void (*vs_hnsw_completion)(void* ctx, int status);
+VS_API int vs_hnsw_search_async(vs_hnsw* index, const float* query, size_t dim, size_t k, uint64_t* keys,
+                         float* distances, size_t* found, vs_hnsw_completion done, void* ctx);
 /* -- usearch::Index::filtered_search(&[f32], k, |key| bool) (usearch.rs:224-248) --------
  * predicate(key, ctx) != 0 admits the key into the result set. */
 typedef int (*vs_hnsw_predicate)(uint64_t key, void* ctx);

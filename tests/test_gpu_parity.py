@@ -460,3 +460,30 @@ def test_removed_members_are_traversed_but_never_returned(frac):
             assert np.allclose(gd[i], od_, rtol=1e-5, atol=1e-5)
             same += ok_.tolist() == gk[i].tolist()
         assert same >= 60, (frac, ef, same)
+
+
+def test_async_search_matches_blocking_search():
+    v = vs()
+    n, dim, k = 5000, 32, 10
+    data = _dataset(n + 200, dim, 55)
+    ix = v.HipUsearchIndex(dim, v.L2SQ)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), data[:n])
+    want = [ix.search(data[n + i], k) for i in range(200)]
+    got, done, lock = {}, threading.Event(), threading.Lock()
+    holders = []
+
+    def make(i):
+        def on_done(keys, d, status):
+            with lock:
+                got[i] = (keys.copy(), d.copy(), status)
+                if len(got) == 200:
+                    done.set()
+        return on_done
+
+    for i in range(200):
+        holders.append(ix.search_async(data[n + i], k, make(i)))
+    assert done.wait(30)
+    for i in range(200):
+        assert got[i][2] == 0
+        assert got[i][0].tolist() == want[i][0].tolist() and got[i][1].tolist() == want[i][1].tolist()

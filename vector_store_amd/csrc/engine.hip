@@ -12,12 +12,15 @@
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -152,16 +155,6 @@ struct Engine {
     std::atomic<int32_t> max_level{-1};
 
     // batching of concurrent single-vector callers
-    struct PendingSearch {
-        const float* q;
-        size_t k;
-        uint64_t* keys;
-        float* dist;
-        size_t* found;
-        int status = 0;
-        std::string err;
-        bool done = false;
-    };
     struct PendingAdd {
         uint64_t key;
         const float* v;
@@ -169,11 +162,10 @@ struct Engine {
         std::string err;
         bool done = false;
     };
-    std::mutex sq_mu, aq_mu;
-    std::condition_variable sq_cv, aq_cv;
-    std::vector<PendingSearch*> sq;
+    std::mutex aq_mu;
+    std::condition_variable aq_cv;
     std::vector<PendingAdd*> aq;
-    bool s_leader = false, a_leader = false;
+    bool a_leader = false;
 
     void use_device() const { HIP_OK(hipSetDevice(device)); }
 
@@ -659,59 +651,10 @@ struct Engine {
         for (size_t i = 0; i < nq; ++i) found[i] = f32[i];
     }
 
-    // One query per FFI call (reference usearch.rs:212): concurrent callers are coalesced into
-    // one kernel launch; no timer -- a batch is whatever queued while the previous one ran.
-    int search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
-        PendingSearch me;
-        me.q = q;
-        me.k = k;
-        me.keys = keys;
-        me.dist = dist;
-        me.found = found;
-        std::unique_lock<std::mutex> lk(sq_mu);
-        sq.push_back(&me);
-        while (!me.done) {
-            if (!s_leader) {
-                s_leader = true;
-                std::vector<PendingSearch*> batch, rest;
-                for (PendingSearch* p : sq) (p->k == sq.front()->k ? batch : rest).push_back(p);
-                sq.swap(rest);
-                lk.unlock();
-                const size_t nb = batch.size(), kk = batch[0]->k;
-                int hard = VS_OK;
-                std::string msg;
-                std::vector<uint64_t> bk(nb * kk);
-                std::vector<float> bd(nb * kk), bq(nb * (size_t)dim);
-                std::vector<size_t> bf(nb);
-                try {
-                    for (size_t i = 0; i < nb; ++i) std::memcpy(&bq[i * dim], batch[i]->q, (size_t)dim * 4);
-                    search_host(bq.data(), nb, kk, bk.data(), bd.data(), bf.data(), false);
-                } catch (const Fail& f) {
-                    hard = f.code;
-                    msg = f.msg;
-                }
-                lk.lock();
-                for (size_t i = 0; i < nb; ++i) {
-                    PendingSearch* p = batch[i];
-                    p->status = hard;
-                    if (hard == VS_OK) {
-                        std::memcpy(p->keys, &bk[i * kk], bf[i] * 8);
-                        std::memcpy(p->dist, &bd[i * kk], bf[i] * 4);
-                        *p->found = bf[i];
-                    } else {
-                        p->err = msg;
-                    }
-                    p->done = true;
-                }
-                s_leader = false;
-                sq_cv.notify_all();
-            } else {
-                sq_cv.wait(lk);
-            }
-        }
-        if (me.status != VS_OK) g_err = me.err;
-        return me.status;
-    }
+    // One query per FFI call (reference usearch.rs:212): handled by the per-device SearchService below.
+    int search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found);
+    void search_async(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found,
+                      void (*cb)(void*, int), void* ctx);
 
     // All distances from one query to every slot (exhaustive path for filtered search with
     // selective predicates and for k beyond the LDS beam).  Host gets (distance, key) pairs.
@@ -772,6 +715,237 @@ struct Engine {
         return out;
     }
 };
+
+
+// ---------------------------------------------------------------------------------------------
+// SearchService: one dispatcher thread per device turns the stream of single-query calls
+// (vs_hnsw_search / vs_hnsw_search_async, one vector per FFI call as the reference issues them,
+// usearch.rs:212) into kernel launches.  Requests queue under a mutex; the dispatcher drains the queue
+// into one of kSlots pipeline slots (pinned staging, own stream), so up to kSlots batches are in flight
+// and a batch is simply "whatever queued since the last launch" -- no timer, no per-caller HIP calls.
+// Lightly loaded the latency is one graph walk; under load batches grow and the GPU saturates.
+// ---------------------------------------------------------------------------------------------
+struct SearchReq {
+    Engine* e;
+    std::vector<float> q;
+    size_t k;
+    uint64_t* keys;
+    float* dist;
+    size_t* found;
+    void (*cb)(void*, int);
+    void* ctx;
+};
+
+class SearchService {
+   public:
+    static SearchService& get(int device) {
+        static std::mutex mu;
+        static std::unordered_map<int, SearchService*> all;  // leaked on purpose: outlives static teardown
+        std::lock_guard<std::mutex> g(mu);
+        SearchService*& s = all[device];
+        if (!s) s = new SearchService(device);
+        return *s;
+    }
+    void submit(SearchReq&& r) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            pending_.push_back(std::move(r));
+        }
+        cv_.notify_one();
+    }
+
+   private:
+    static constexpr int kSlots = 4;
+    static constexpr size_t kMaxBatch = 8192;
+    struct Slot {
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        float* h_q = nullptr;
+        float* d_q = nullptr;
+        uint64_t* d_k = nullptr;
+        float* d_d = nullptr;
+        uint32_t* d_f = nullptr;
+        uint64_t* h_k = nullptr;
+        float* h_d = nullptr;
+        uint32_t* h_f = nullptr;
+        size_t q_bytes = 0, o_items = 0, f_items = 0;
+        std::vector<SearchReq> reqs;
+        bool busy = false;
+        int status = VS_OK;
+        std::string err;
+    };
+    int device_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<SearchReq> pending_;
+    Slot slots_[kSlots];
+
+    explicit SearchService(int device) : device_(device) {
+        std::thread([this] { run(); }).detach();
+    }
+
+    static void grow(Slot& s, size_t nq, size_t dim, size_t k) {
+        const size_t qb = nq * dim * 4, oi = nq * k;
+        if (qb > s.q_bytes) {
+            if (s.h_q) (void)hipHostFree(s.h_q);
+            if (s.d_q) (void)hipFree(s.d_q);
+            s.q_bytes = qb + qb / 2;
+            HIP_OK(hipHostMalloc((void**)&s.h_q, s.q_bytes, hipHostMallocDefault));
+            HIP_OK(hipMalloc((void**)&s.d_q, s.q_bytes));
+        }
+        if (oi > s.o_items) {
+            if (s.h_k) (void)hipHostFree(s.h_k);
+            if (s.h_d) (void)hipHostFree(s.h_d);
+            if (s.d_k) (void)hipFree(s.d_k);
+            if (s.d_d) (void)hipFree(s.d_d);
+            s.o_items = oi + oi / 2;
+            HIP_OK(hipHostMalloc((void**)&s.h_k, s.o_items * 8, hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void**)&s.h_d, s.o_items * 4, hipHostMallocDefault));
+            HIP_OK(hipMalloc((void**)&s.d_k, s.o_items * 8));
+            HIP_OK(hipMalloc((void**)&s.d_d, s.o_items * 4));
+        }
+        if (nq > s.f_items) {
+            if (s.h_f) (void)hipHostFree(s.h_f);
+            if (s.d_f) (void)hipFree(s.d_f);
+            s.f_items = nq + nq / 2;
+            HIP_OK(hipHostMalloc((void**)&s.h_f, s.f_items * 4, hipHostMallocDefault));
+            HIP_OK(hipMalloc((void**)&s.d_f, s.f_items * 4));
+        }
+    }
+
+    void launch(Slot& s) {
+        s.status = VS_OK;
+        s.err.clear();
+        try {
+            Engine* e = s.reqs[0].e;
+            const size_t nb = s.reqs.size(), k = s.reqs[0].k, dim = e->dim;
+            if (!s.st) {
+                HIP_OK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+                HIP_OK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+            }
+            grow(s, nb, dim, k);
+            for (size_t i = 0; i < nb; ++i) std::memcpy(s.h_q + i * dim, s.reqs[i].q.data(), dim * 4);
+            HIP_OK(hipMemcpyAsync(s.d_q, s.h_q, nb * dim * 4, hipMemcpyHostToDevice, s.st));
+            e->search_device(s.d_q, nb, k, s.d_k, s.d_d, s.d_f, s.st);
+            HIP_OK(hipMemcpyAsync(s.h_k, s.d_k, nb * k * 8, hipMemcpyDeviceToHost, s.st));
+            HIP_OK(hipMemcpyAsync(s.h_d, s.d_d, nb * k * 4, hipMemcpyDeviceToHost, s.st));
+            HIP_OK(hipMemcpyAsync(s.h_f, s.d_f, nb * 4, hipMemcpyDeviceToHost, s.st));
+            HIP_OK(hipEventRecord(s.ev, s.st));
+        } catch (const Fail& f) {
+            s.status = f.code;
+            s.err = f.msg;
+        } catch (const std::exception& x) {
+            s.status = VS_ERR_DEVICE;
+            s.err = x.what();
+        }
+    }
+
+    void deliver(Slot& s) {
+        const size_t k = s.reqs.empty() ? 0 : s.reqs[0].k;
+        for (size_t i = 0; i < s.reqs.size(); ++i) {
+            SearchReq& r = s.reqs[i];
+            if (s.status == VS_OK) {
+                const size_t f = s.h_f[i];
+                std::memcpy(r.keys, s.h_k + i * k, f * 8);
+                std::memcpy(r.dist, s.h_d + i * k, f * 4);
+                *r.found = f;
+            } else {
+                *r.found = 0;
+                g_async_err = s.err;
+            }
+            r.cb(r.ctx, s.status);
+        }
+        s.reqs.clear();
+    }
+
+    void run() {
+        (void)hipSetDevice(device_);
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            bool progressed = false;
+            // reap
+            for (Slot& s : slots_) {
+                if (!s.busy) continue;
+                bool done = s.status != VS_OK || hipEventQuery(s.ev) == hipSuccess;
+                if (done) {
+                    lk.unlock();
+                    deliver(s);
+                    lk.lock();
+                    s.busy = false;
+                    progressed = true;
+                }
+            }
+            // launch
+            if (!pending_.empty()) {
+                for (Slot& s : slots_) {
+                    if (s.busy || pending_.empty()) continue;
+                    Engine* e = pending_.front().e;
+                    const size_t k = pending_.front().k;
+                    std::deque<SearchReq> rest;
+                    while (!pending_.empty()) {
+                        SearchReq& r = pending_.front();
+                        if (r.e == e && r.k == k && s.reqs.size() < kMaxBatch) s.reqs.push_back(std::move(r));
+                        else rest.push_back(std::move(r));
+                        pending_.pop_front();
+                    }
+                    pending_.swap(rest);
+                    s.busy = true;
+                    lk.unlock();
+                    launch(s);
+                    lk.lock();
+                    progressed = true;
+                }
+            }
+            if (progressed) continue;
+            bool any_busy = false;
+            for (Slot& s : slots_) any_busy |= s.busy;
+            if (any_busy) cv_.wait_for(lk, std::chrono::microseconds(20));
+            else cv_.wait(lk, [this] { return !pending_.empty(); });
+        }
+    }
+
+   public:
+    static thread_local std::string g_async_err;
+};
+thread_local std::string SearchService::g_async_err;
+
+void Engine::search_async(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found,
+                          void (*cb)(void*, int), void* ctx) {
+    SearchReq r;
+    r.e = this;
+    r.q.assign(q, q + dim);  // inputs are borrowed for the duration of the call only
+    r.k = k;
+    r.keys = keys;
+    r.dist = dist;
+    r.found = found;
+    r.cb = cb;
+    r.ctx = ctx;
+    SearchService::get(device).submit(std::move(r));
+}
+
+int Engine::search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
+    struct Waiter {
+        std::mutex m;
+        std::condition_variable c;
+        bool done = false;
+        int status = VS_OK;
+        std::string err;
+    } w;
+    search_async(q, k, keys, dist, found,
+                 [](void* p, int status) {
+                     Waiter* w = (Waiter*)p;
+                     std::lock_guard<std::mutex> g(w->m);
+                     w->status = status;
+                     if (status != VS_OK) w->err = SearchService::g_async_err;
+                     w->done = true;
+                     w->c.notify_one();
+                 },
+                 &w);
+    std::unique_lock<std::mutex> lk(w.m);
+    w.c.wait(lk, [&] { return w.done; });
+    if (w.status != VS_OK) g_err = w.err;
+    return w.status;
+}
 
 }  // namespace vs
 
@@ -902,6 +1076,18 @@ int vs_hnsw_search(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* k
         rc = h->e.search_one(q, k, keys, dist, found);
     });
     return g != VS_OK ? g : rc;
+}
+
+int vs_hnsw_search_async(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* keys, float* dist, size_t* found,
+                         vs_hnsw_completion done, void* ctx) {
+    return guarded([&] {
+        need(h && q && keys && dist && found && done, "null argument");
+        check_dim(h, dim);
+        uint32_t ef;
+        h->e.check_search(k, ef);
+        *found = 0;
+        h->e.search_async(q, k, keys, dist, found, done, ctx);
+    });
 }
 
 int vs_hnsw_filtered_search(vs_hnsw* h, const float* q, size_t dim, size_t k, vs_hnsw_predicate pred, void* ctx,

@@ -62,6 +62,32 @@ __device__ __forceinline__ bool key_less(float ad, uint32_t as, float bd, uint32
     return ad < bd || (ad == bd && (as & kSlotMask) < (bs & kSlotMask));
 }
 
+// Sum over each aligned group of `lanes` consecutive lanes (lanes = power of two), result in every lane
+// of the group.  Rows of 16 lanes are all-reduced with four DPP rotations (v_add_f32_dpp row_ror, a few
+// cycles each) instead of a six-deep chain of ds_bpermute (~100+ cycles each): the reduction sits on the
+// critical path of every hop, so this is what sets single-query latency.
+#define VS_DPP_ROR(v, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xF, 0xF, true))
+__device__ __forceinline__ float group_sum(float v, uint32_t lanes) {
+    if (lanes >= 16) {
+        v += VS_DPP_ROR(v, 8);
+        v += VS_DPP_ROR(v, 4);
+        v += VS_DPP_ROR(v, 2);
+        v += VS_DPP_ROR(v, 1);
+        if (lanes == 64) {
+            float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+            float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+            float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+            float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+            v = (a + b) + (c + d);
+        } else if (lanes == 32) {
+            v += __shfl_xor(v, 16);
+        }
+        return v;
+    }
+    for (uint32_t o = lanes >> 1; o; o >>= 1) v += __shfl_xor(v, (int)o);
+    return v;
+}
+
 template <int KIND>
 __device__ __forceinline__ float accumulate(float acc, const float4 a, const float4 b) {
     if (KIND == KL2) {
@@ -120,7 +146,7 @@ __device__ __forceinline__ float inv_norm_of(const IndexView& ix, const float4 (
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < I; ++i) s = accumulate<KDOT>(s, q[i], q[i]);
-    for (uint32_t o = ix.lanes >> 1; o; o >>= 1) s += __shfl_xor(s, (int)o);
+    s = group_sum(s, ix.lanes);
     return s > 0.f ? 1.0f / sqrtf(s) : 0.f;
 }
 
@@ -164,7 +190,7 @@ __device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < I; ++i) acc = accumulate<KIND>(acc, q[i], g.buf[u][i]);
-        for (uint32_t o = ix.lanes >> 1; o; o >>= 1) acc += __shfl_xor(acc, (int)o);
+        acc = group_sum(acc, ix.lanes);
         if (g.slot[u] != kInvalid && li == 0) u_dist[t + (uint32_t)u * V + grp] = finalize(ix.metric, acc, q_inv, g.inv[u]);
     }
 }
@@ -381,42 +407,39 @@ __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& s
                                                float nd, uint32_t ns, uint32_t m, int lane) {
     float* od = sh.lst_d[cur];
     uint32_t* os = sh.lst_s[cur];
-    // rank of each new element among the old ones (binary search) ...
-    uint32_t r_old = 0;
-    if ((uint32_t)lane < m) {
-        uint32_t lo = 0, hi = sz;
-        while (lo < hi) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (key_less(od[mid], os[mid], nd, ns)) lo = mid + 1; else hi = mid;
-        }
-        r_old = lo;
-    }
-    // ... and among the new ones.
-    uint32_t r_new = 0;
-    for (uint32_t i = 0; i < m; ++i) {
-        float di = __shfl(nd, (int)i);
-        uint32_t si = (uint32_t)__shfl((int)ns, (int)i);
-        r_new += ((uint32_t)lane < m && key_less(di, si, nd, ns)) ? 1u : 0u;
-    }
-    // old entries shift right by the number of new elements ranked at or before them
-    float keep_d[EFCAP / kWave];
-    uint32_t keep_s[EFCAP / kWave], keep_p[EFCAP / kWave];
+    constexpr int R = EFCAP / kWave;
+    // own old entries -> registers
+    float keep_d[R];
+    uint32_t keep_s[R], keep_p[R], shift[R];
 #pragma unroll
-    for (int r = 0; r < EFCAP / kWave; ++r) {
+    for (int r = 0; r < R; ++r) {
         uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
-        uint32_t shift = 0;
-        for (uint32_t j = 0; j < m; ++j) {
-            uint32_t rj = (uint32_t)__shfl((int)r_old, (int)j);
-            shift += rj <= p ? 1u : 0u;
+        keep_d[r] = p < sz ? od[p] : __builtin_inff();
+        keep_s[r] = p < sz ? os[p] : kInvalid;
+        shift[r] = 0;
+    }
+    // One pass over the new elements (wave-uniform j, broadcast by v_readlane): its rank among the old
+    // entries by ballot + popcount, among the new ones by comparison; every old entry counts the new
+    // elements that precede it.  No dependent LDS chain (a binary search costs log2(ef) LDS latencies).
+    uint32_t r_old = 0, r_new = 0;
+    for (uint32_t j = 0; j < m; ++j) {
+        const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), (int)j));
+        const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)j);
+        uint32_t below = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool valid = (uint32_t)lane + (uint32_t)r * kWave < sz;
+            const bool less = valid && key_less(keep_d[r], keep_s[r], dj, sj);
+            below += (uint32_t)__popcll(__ballot(less));
+            shift[r] += (valid && !less) ? 1u : 0u;
         }
-        keep_p[r] = kInvalid;
-        keep_d[r] = 0.f;
-        keep_s[r] = 0;
-        if (p < sz) {
-            keep_d[r] = od[p];
-            keep_s[r] = os[p];
-            if (p + shift < ef) keep_p[r] = p + shift;
-        }
+        if ((uint32_t)lane == j) r_old = below;
+        r_new += ((uint32_t)lane < m && key_less(dj, sj, nd, ns)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+        keep_p[r] = (p < sz && p + shift[r] < ef) ? p + shift[r] : kInvalid;
     }
     __syncthreads();  // every read of the old list is done
     if ((uint32_t)lane < m) {

@@ -20,6 +20,7 @@ F32 = 0
 FREE_KEY = 0xFFFFFFFFFFFFFFFF
 
 PRED = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_void_p)
+DONE = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 
 
 class VsError(RuntimeError):
@@ -78,6 +79,7 @@ def lib():
     L.vs_hnsw_add_batch_device.argtypes = [vp, vp, vp, sz, sz]
     L.vs_hnsw_remove.argtypes = [vp, u64, C.POINTER(C.c_int)]
     L.vs_hnsw_search.argtypes = [vp, vp, sz, sz, vp, vp, C.POINTER(sz)]
+    L.vs_hnsw_search_async.argtypes = [vp, vp, sz, sz, vp, vp, C.POINTER(sz), DONE, vp]
     L.vs_hnsw_filtered_search.argtypes = [vp, vp, sz, sz, PRED, vp, vp, vp, C.POINTER(sz)]
     L.vs_hnsw_search_batch.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp]
     L.vs_hnsw_exact_search_batch.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp]
@@ -179,6 +181,25 @@ class HipUsearchIndex:
         found = C.c_size_t(0)
         _check(self.L.vs_hnsw_search(self.h, _p(v), v.size, limit, _p(keys), _p(d), C.byref(found)))
         return keys[: found.value], d[: found.value]
+
+    def search_async(self, vector, limit: int, on_done):
+        """Non-blocking search: `on_done(keys, distances, status)` runs on the engine's dispatcher thread."""
+        v = np.ascontiguousarray(vector, dtype=np.float32)
+        keys = np.zeros(limit, dtype=np.uint64)
+        d = np.zeros(limit, dtype=np.float32)
+        found = C.c_size_t(0)
+        holder = {}
+
+        def _done(_ctx, status):
+            cb = holder.pop("cb", None)  # keeps the ctypes thunk alive until it has run
+            on_done(keys[: found.value], d[: found.value], status)
+            del cb
+
+        holder["cb"] = DONE(_done)
+        holder["bufs"] = (keys, d, found)
+        _check(self.L.vs_hnsw_search_async(self.h, _p(v), v.size, limit, _p(keys), _p(d), C.byref(found), holder["cb"],
+                                           None))
+        return holder
 
     def filtered_search(self, vector, limit: int, predicate):
         v = np.ascontiguousarray(vector, dtype=np.float32)

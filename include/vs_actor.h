@@ -1,0 +1,66 @@
+/* vs_actor.h -- host-side dispatch actor over the HNSW engine (libvs_actor.so).
+ *
+ * Reproduces the concurrency contract of the reference's per-index actor
+ * (crates/vector-store/src/vs_index/usearch.rs:688-1177) for callers that do not bring their own:
+ *   - two bounded channels, search drained before modify      vs_index/mod.rs:30-45 (`biased` select)
+ *   - Operation permits: Insert||Insert, Search||Search, never mixed; Reserve and Remove run alone
+ *                                                              usearch.rs:515-624
+ *   - capacity growth: when capacity - size < the free threshold (reference: 3 x workers; here 4 x workers + 1,
+ *     everything that can be in flight), reserve capacity + 1,000,000 (global index)
+ *     or + 1,000 (local, per-partition-key index)              usearch.rs:442-443, 655-665, 908-921
+ *   - one engine handle per partition, created lazily on its first AddVector   usearch.rs:757-779
+ *   - adds are dropped while the memory guard says Allocate::Cannot           usearch.rs:1156-1177
+ *   - adds / removes are fire-and-forget; searches are a round trip; Count is answered by the actor
+ *   - a fixed pool of `workers` threads, channel depth 3 x workers            worker.rs:44-118, perf.rs:11-25
+ * In a drop-in deployment the Rust actor stays and calls include/vs_hnsw.h directly; this library is
+ * for standalone use (vs_bench mixed workloads, tests written like the reference's unit tests).
+ */
+#ifndef VS_ACTOR_H
+#define VS_ACTOR_H
+
+#include "vs_hnsw.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vs_actor vs_actor;
+
+typedef struct vs_actor_options {
+    vs_hnsw_options index; /* IndexOptions of every partition's engine handle */
+    size_t workers;        /* 0 = hardware concurrency; perf::num_workers() in the reference */
+    int local;             /* 0: global index (+1,000,000 per reserve); 1: local (+1,000) */
+    size_t reserve_increment; /* 0 = the reference's constants above */
+} vs_actor_options;
+
+VS_API int vs_actor_create(const vs_actor_options* options, vs_actor** out);
+/* Closes both channels, drains what is queued, stops every partition, joins the threads. */
+VS_API void vs_actor_stop(vs_actor* actor);
+
+/* VsIndexModify (vs_index/actor.rs:21-44): return once queued; block only while the channel is full. */
+VS_API int vs_actor_add_vector(vs_actor* actor, uint64_t partition, uint64_t primary_id, const float* vector, size_t dim);
+VS_API int vs_actor_remove_vector(vs_actor* actor, uint64_t partition, uint64_t primary_id);
+VS_API int vs_actor_remove_partition(vs_actor* actor, uint64_t partition);
+
+/* VsIndexSearch (vs_index/actor.rs:46-61): blocking round trip.  Unknown / empty partition => found = 0. */
+VS_API int vs_actor_ann(vs_actor* actor, uint64_t partition, const float* query, size_t dim, size_t k, uint64_t* keys,
+                        float* distances, size_t* found);
+VS_API int vs_actor_filtered_ann(vs_actor* actor, uint64_t partition, const float* query, size_t dim, size_t k,
+                                 vs_hnsw_predicate predicate, void* ctx, uint64_t* keys, float* distances, size_t* found);
+VS_API size_t vs_actor_count(vs_actor* actor);
+
+/* Memory guard (memory.rs Allocate::{Can, Cannot}): can = 0 makes the actor drop AddVector messages. */
+VS_API void vs_actor_set_allocate(vs_actor* actor, int can);
+
+/* Introspection for tests. */
+VS_API size_t vs_actor_partition_capacity(vs_actor* actor, uint64_t partition);
+VS_API size_t vs_actor_partitions(vs_actor* actor);
+/* [0] adds executed, [1] adds dropped by the memory guard, [2] reserves, [3] searches, [4] removes,
+ * [5] mode switches, [6] max operations in flight, [7] add/remove errors swallowed (logged in the reference) */
+VS_API void vs_actor_counters(vs_actor* actor, uint64_t out[8]);
+VS_API const char* vs_actor_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

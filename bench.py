@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="vectors per GPU")
+    ap.add_argument("--vectors", "--n", dest="n", type=int, default=1_000_000, help="vectors per GPU")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--nq", type=int, default=10_000, help="queries per step per GPU")
     ap.add_argument("--k", type=int, default=10)
@@ -158,17 +158,24 @@ def main():
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall seconds of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-sharded-leg", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
     import vector_store_amd as vs  # after torch: one HIP runtime per process
     from vector_store_amd import sharded
 

@@ -75,6 +75,8 @@ VS_API void vs_hnsw_free(vs_hnsw* index);
 VS_API int vs_hnsw_reserve(vs_hnsw* index, size_t capacity, size_t threads);
 VS_API size_t vs_hnsw_capacity(const vs_hnsw* index);
 VS_API size_t vs_hnsw_size(const vs_hnsw* index); /* live members; the reference counts outside (usearch.rs:1031) */
+/* bytes of one stored vector: dim*4 (f32), dim*2 (f16, bf16), dim (i8), ceil(dim/8) (b1) */
+VS_API size_t vs_hnsw_bytes_per_vector(const vs_hnsw* index);
 
 /* -- usearch::Index::add(key, &[f32]) (usearch.rs:191-197) ------------------------------ */
 VS_API int vs_hnsw_add(vs_hnsw* index, uint64_t key, const float* vector, size_t dim);
@@ -132,9 +134,9 @@ typedef struct vs_hnsw_graph_info {
     size_t connectivity_base; /* M0 */
 } vs_hnsw_graph_info;
 VS_API int vs_hnsw_graph_info_get(vs_hnsw* index, vs_hnsw_graph_info* info);
-VS_API int vs_hnsw_export_graph(vs_hnsw* index, float* vectors /* slots x dim */, int32_t* levels, uint64_t* keys,
+VS_API int vs_hnsw_export_graph(vs_hnsw* index, void* vectors /* slots x bytes_per_vector, storage format */, int32_t* levels, uint64_t* keys,
                          uint32_t* adj0 /* slots x M0 */, uint32_t* upper_off, uint32_t* upper /* blocks x M */);
-VS_API int vs_hnsw_import_graph(vs_hnsw* index, size_t slots, const float* vectors, const int32_t* levels,
+VS_API int vs_hnsw_import_graph(vs_hnsw* index, size_t slots, const void* vectors /* storage format */, const int32_t* levels,
                          const uint64_t* keys, const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* upper,
                          size_t upper_blocks, int32_t max_level, uint32_t entry_slot);
 

@@ -20,6 +20,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle_hnsw.so")
 
 COS, L2SQ, IP, HAMMING = 0, 1, 2, 3
+F32, F16, BF16, I8, B1 = 0, 1, 2, 3, 4
+SCALARS = {"f32": F32, "f16": F16, "bf16": BF16, "i8": I8, "b1": B1}
 METRICS = {"cos": COS, "l2sq": L2SQ, "ip": IP, "hamming": HAMMING}
 FREE_KEY = 0xFFFFFFFFFFFFFFFF
 INVALID_SLOT = 0xFFFFFFFF
@@ -48,6 +50,12 @@ def lib():
         L.orc_last_error.restype = C.c_char_p
         L.orc_create.restype = vp
         L.orc_create.argtypes = [sz, C.c_int, sz, sz, sz]
+        L.orc_create_ex.restype = vp
+        L.orc_create_ex.argtypes = [sz, C.c_int, C.c_int, sz, sz, sz]
+        L.orc_bytes_per_vector.restype = sz
+        L.orc_bytes_per_vector.argtypes = [vp]
+        L.orc_distance_as.restype = C.c_float
+        L.orc_distance_as.argtypes = [C.c_int, C.c_int, vp, vp, sz]
         L.orc_free.argtypes = [vp]
         L.orc_reserve.argtypes = [vp, sz]
         for f in ("orc_capacity", "orc_size", "orc_slots", "orc_upper_blocks"):
@@ -97,6 +105,13 @@ def f32_to_b1x8(v) -> np.ndarray:
     return out
 
 
+def distance_as(metric: int, scalar: int, a, b) -> float:
+    """Distance between two f32 vectors as an index with the given storage type computes it."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return float(lib().orc_distance_as(metric, scalar, _ptr(a), _ptr(b), a.size))
+
+
 def distance(metric: int, a, b) -> float:
     if metric == HAMMING:
         a = np.ascontiguousarray(a, dtype=np.uint8)
@@ -125,12 +140,16 @@ class OracleIndex:
     """Mirrors the reference's private `trait UsearchIndex` (usearch.rs:142-160)."""
 
     def __init__(self, dim: int, metric: int = COS, connectivity: int = 16, expansion_add: int = 128,
-                 expansion_search: int = 64):
+                 expansion_search: int = 64, quantization: int = F32):
         self.L = lib()
-        self.dim, self.metric = dim, metric
+        if metric == HAMMING:
+            quantization = B1
+        if quantization == B1:
+            metric = HAMMING
+        self.dim, self.metric, self.scalar = dim, metric, quantization
         self.M = connectivity or 16
         self.M0 = 2 * self.M
-        self.h = self.L.orc_create(dim, metric, connectivity, expansion_add, expansion_search)
+        self.h = self.L.orc_create_ex(dim, metric, quantization, connectivity, expansion_add, expansion_search)
         if not self.h:
             raise OracleError(self.L.orc_last_error().decode())
 
@@ -140,8 +159,6 @@ class OracleIndex:
             self.h = None
 
     def _vec(self, v) -> np.ndarray:
-        if self.metric == HAMMING:
-            return f32_to_b1x8(v)
         v = np.ascontiguousarray(v, dtype=np.float32)
         if v.shape[-1] != self.dim:
             raise OracleError("wrong embedding dimension")
@@ -245,10 +262,10 @@ class OracleIndex:
         g["upper"] = g["upper"][:blocks]
         g["max_level"] = self.L.orc_max_level(self.h)
         g["entry_slot"] = self.L.orc_entry_slot(self.h)
-        bpv = (self.dim + 7) // 8 if self.metric == HAMMING else self.dim * 4
+        bpv = self.L.orc_bytes_per_vector(self.h)
         raw = (C.c_uint8 * (n * bpv)).from_address(self.L.orc_vectors(self.h)) if n else b""
-        arr = np.frombuffer(raw, dtype=np.uint8 if self.metric == HAMMING else np.float32).copy()
-        g["vectors"] = arr.reshape(n, -1) if n else arr.reshape(0, self.dim)
+        arr = np.frombuffer(raw, dtype=np.float32 if self.scalar == F32 else np.uint8).copy()  # storage format
+        g["vectors"] = arr.reshape(n, -1) if n else arr.reshape(0, self.dim if self.scalar == F32 else bpv)
         return g
 
     def import_graph(self, g: dict):

@@ -57,8 +57,8 @@ thread_local std::string g_error;
 // [UPSTREAM]).  f32 accumulation.
 // ---------------------------------------------------------------------------
 // AVX2+FMA kernels (8-wide f32, 4 independent accumulators); scalar tail.
+#include <immintrin.h>  // F16C conversions (and the AVX2 kernels below)
 #if defined(__AVX2__) && defined(__FMA__)
-#include <immintrin.h>
 static inline float hsum8(__m256 v) {
     __m128 lo = _mm256_castps256_ps128(v), hi = _mm256_extractf128_ps(v, 1);
     lo = _mm_add_ps(lo, hi);
@@ -175,6 +175,115 @@ static float dist_hamming_b1(const uint8_t* a, const uint8_t* b, size_t bytes) {
 }
 
 // ---------------------------------------------------------------------------
+// Scalar casts applied on add/search when quantization != F32, and the metrics on the
+// stored types (usearch index_plugins.hpp cast_gt / metric_*_gt [UPSTREAM, from memory]):
+//   f16  : IEEE round-to-nearest-even; bf16 : round-to-nearest-even on the high 16 bits;
+//   i8   : trunc(x * 127 / |x|) clamped to [-127, 127] (|x| accumulated in f64);
+//   b1   : bit i of byte j = v[8j+i] > 0 (reference usearch.rs:1179-1205).
+// f16/bf16 metrics widen every element to f32 and run the f32 formulas; i8 metrics run on
+// the integers: cos = 1 - ab/sqrt(a2*b2) (zero rules as above), l2sq = sum (a-b)^2, ip = 1 - ab.
+// ---------------------------------------------------------------------------
+enum Scalar : int { kF32 = 0, kF16 = 1, kBF16 = 2, kI8 = 3, kB1 = 4 };
+
+static inline uint16_t f32_to_f16(float f) { return (uint16_t)_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+static inline float f16_to_f32(uint16_t h) { return _cvtsh_ss(h); }
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+static size_t bytes_per_vector_of(int scalar, size_t dim) {
+    switch (scalar) {
+        case kF32: return dim * 4;
+        case kF16:
+        case kBF16: return dim * 2;
+        case kI8: return dim;
+        default: return (dim + 7) / 8;
+    }
+}
+
+static void cast_from_f32(int scalar, const float* v, size_t dim, uint8_t* out) {
+    switch (scalar) {
+        case kF32: std::memcpy(out, v, dim * 4); break;
+        case kF16:
+            for (size_t i = 0; i < dim; ++i) ((uint16_t*)out)[i] = f32_to_f16(v[i]);
+            break;
+        case kBF16:
+            for (size_t i = 0; i < dim; ++i) ((uint16_t*)out)[i] = f32_to_bf16(v[i]);
+            break;
+        case kI8: {
+            double s = 0.0;
+            for (size_t i = 0; i < dim; ++i) s += (double)v[i] * (double)v[i];
+            float mag = (float)std::sqrt(s);
+            for (size_t i = 0; i < dim; ++i) {
+                float t = mag > 0.f ? (v[i] * 127.0f) / mag : 0.f;
+                t = std::min(std::max(t, -127.f), 127.f);
+                ((int8_t*)out)[i] = (int8_t)(int)t;
+            }
+        } break;
+        default: {
+            size_t nb = (dim + 7) / 8;
+            for (size_t j = 0; j < nb; ++j) {
+                uint8_t byte = 0;
+                for (size_t i = 0; i < 8 && j * 8 + i < dim; ++i)
+                    if (v[j * 8 + i] > 0.0f) byte |= (uint8_t)(1u << i);
+                out[j] = byte;
+            }
+        }
+    }
+}
+
+static void widen(int scalar, const uint16_t* src, size_t d, float* dst) {
+    size_t i = 0;
+#if defined(__AVX2__) && defined(__F16C__)
+    if (scalar == kF16) {
+        for (; i + 8 <= d; i += 8) _mm256_storeu_ps(dst + i, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)(src + i))));
+    } else {
+        for (; i + 8 <= d; i += 8) {
+            __m256i w = _mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)(src + i)));
+            _mm256_storeu_ps(dst + i, _mm256_castsi256_ps(_mm256_slli_epi32(w, 16)));
+        }
+    }
+#endif
+    for (; i < d; ++i) dst[i] = scalar == kF16 ? f16_to_f32(src[i]) : bf16_to_f32(src[i]);
+}
+
+// f16 / bf16: every element widened to f32, then the f32 formulas (products of two half values are exact in f32).
+static float dist_widened(int metric, int scalar, const uint16_t* a, const uint16_t* b, size_t d) {
+    thread_local std::vector<float> fa, fb;
+    fa.resize(d);
+    fb.resize(d);
+    widen(scalar, a, d, fa.data());
+    widen(scalar, b, d, fb.data());
+    if (metric == kL2sq) return dist_l2sq(fa.data(), fb.data(), d);
+    if (metric == kIP) return dist_ip(fa.data(), fb.data(), d);
+    return dist_cos(fa.data(), fb.data(), d);
+}
+
+static float dist_i8(int metric, const int8_t* a, const int8_t* b, size_t d) {
+    int32_t ab = 0, a2 = 0, b2 = 0;
+    for (size_t i = 0; i < d; ++i) {
+        ab += (int32_t)a[i] * b[i];
+        a2 += (int32_t)a[i] * a[i];
+        b2 += (int32_t)b[i] * b[i];
+    }
+    if (metric == kL2sq) return (float)a2 + (float)b2 - 2.0f * (float)ab;
+    if (metric == kIP) return 1.0f - (float)ab;
+    if (a2 == 0 && b2 == 0) return 0.f;
+    if (a2 == 0 || b2 == 0 || ab == 0) return 1.f;
+    float r = 1.0f - (float)ab / (std::sqrt((float)a2) * std::sqrt((float)b2));
+    return r > 0.f ? r : 0.f;
+}
+
+// ---------------------------------------------------------------------------
 // Per-thread search context (usearch index.hpp context_t [UPSTREAM]).
 // ---------------------------------------------------------------------------
 struct Cand {
@@ -285,6 +394,7 @@ struct Index {
     // config (reference usearch.rs:74-82; zero => usearch defaults)
     size_t dim = 0, bytes_per_vector = 0;
     int metric = kCos;
+    int scalar = kF32;
     size_t M = 16, M0 = 32, ef_add = 128, ef_search = 64;
     double inverse_log_connectivity = 0;
     bool b1 = false;
@@ -310,6 +420,7 @@ struct Index {
 
     std::vector<std::unique_ptr<Context>> contexts;
     std::mutex ctx_mutex;
+    std::atomic<uint64_t> batch_distances{0}, batch_cycles{0};  // from per-call contexts of orc_search_batch
 
     Context& ctx(size_t thread) {
         std::lock_guard<std::mutex> g(ctx_mutex);
@@ -322,11 +433,17 @@ struct Index {
 
     float measure(const void* a, const void* b, Context& c) const {
         ++c.computed_distances;
+        switch (scalar) {
+            case kF16:
+            case kBF16: return dist_widened(metric, scalar, (const uint16_t*)a, (const uint16_t*)b, dim);
+            case kI8: return dist_i8(metric, (const int8_t*)a, (const int8_t*)b, dim);
+            case kB1: return dist_hamming_b1((const uint8_t*)a, (const uint8_t*)b, bytes_per_vector);
+            default: break;
+        }
         switch (metric) {
             case kCos: return dist_cos((const float*)a, (const float*)b, dim);
             case kL2sq: return dist_l2sq((const float*)a, (const float*)b, dim);
-            case kIP: return dist_ip((const float*)a, (const float*)b, dim);
-            default: return dist_hamming_b1((const uint8_t*)a, (const uint8_t*)b, bytes_per_vector);
+            default: return dist_ip((const float*)a, (const float*)b, dim);
         }
     }
 
@@ -511,8 +628,12 @@ struct Index {
     }
 
     // --- usearch index_dense_gt::add_ -> index_gt::add / update [UPSTREAM] ---
-    int add(uint64_t key, const void* value, size_t thread, int forced_level) {
+    // `value_f32`: dim floats, cast to the storage type here (usearch casts inside add()).
+    int add(uint64_t key, const void* value_f32, size_t thread, int forced_level) {
         Context& c = ctx(thread);
+        std::vector<uint8_t> casted(bytes_per_vector);
+        cast_from_f32(scalar, (const float*)value_f32, dim, casted.data());
+        const void* value = casted.data();
         if (key == kFreeKey) return fail("Key is reserved for internal use");
         uint32_t free_slot = kInvalidSlot;
         {
@@ -601,8 +722,15 @@ struct Index {
                   size_t thread, uint32_t* out_slots) {
         return search(q, wanted, pred, pctx, out_keys, out_d, ctx(thread), out_slots);
     }
-    size_t search(const void* q, size_t wanted, pred_fn pred, void* pctx, uint64_t* out_keys, float* out_d,
+    size_t search(const void* q_f32, size_t wanted, pred_fn pred, void* pctx, uint64_t* out_keys, float* out_d,
                   Context& c, uint32_t* out_slots) {
+        std::vector<uint8_t> casted;
+        const void* q = q_f32;
+        if (scalar != kF32) {
+            casted.resize(bytes_per_vector);
+            cast_from_f32(scalar, (const float*)q_f32, dim, casted.data());
+            q = casted.data();
+        }
         if (nodes_count.load() == 0 || max_level < 0) return 0;
         size_t expansion = std::max(ef_search, wanted);
         uint32_t closest = search_for_one(q, entry_slot, max_level, 0, c);
@@ -643,17 +771,20 @@ extern "C" {
 
 const char* orc_last_error() { return g_error.c_str(); }
 
-// metric: 0 cos, 1 l2sq, 2 ip, 3 hamming(b1; vectors are ceil(dim/8) bytes)
-void* orc_create(size_t dim, int metric, size_t connectivity, size_t expansion_add, size_t expansion_search) {
+// metric: 0 cos, 1 l2sq, 2 ip, 3 hamming; scalar: 0 f32, 1 f16, 2 bf16, 3 i8, 4 b1.
+// Vectors enter as f32 (add / search) and are cast to the storage type, as usearch does; b1 forces
+// hamming (reference usearch.rs:450-457).  Raw storage rows: orc_add_raw / orc_vectors / import / export.
+void* orc_create_ex(size_t dim, int metric, int scalar, size_t connectivity, size_t expansion_add, size_t expansion_search) {
     if (!dim) {
         g_error = "dimensions must be > 0";
         return nullptr;
     }
     Index* ix = new Index();
     ix->dim = dim;
-    ix->metric = metric;
-    ix->b1 = metric == kHamming;
-    ix->bytes_per_vector = ix->b1 ? (dim + 7) / 8 : dim * sizeof(float);
+    ix->scalar = (metric == kHamming) ? (int)kB1 : scalar;
+    ix->metric = ix->scalar == kB1 ? (int)kHamming : metric;
+    ix->b1 = ix->scalar == kB1;
+    ix->bytes_per_vector = bytes_per_vector_of(ix->scalar, dim);
     ix->M = connectivity ? connectivity : 16;       // usearch default_connectivity()
     ix->M0 = ix->M * 2;                             // connectivity_base
     ix->ef_add = expansion_add ? expansion_add : 128;       // default_expansion_add()
@@ -661,6 +792,10 @@ void* orc_create(size_t dim, int metric, size_t connectivity, size_t expansion_a
     ix->inverse_log_connectivity = 1.0 / std::log((double)ix->M);
     return ix;
 }
+void* orc_create(size_t dim, int metric, size_t connectivity, size_t expansion_add, size_t expansion_search) {
+    return orc_create_ex(dim, metric, kF32, connectivity, expansion_add, expansion_search);
+}
+size_t orc_bytes_per_vector(void* h) { return ((Index*)h)->bytes_per_vector; }
 void orc_free(void* h) { delete (Index*)h; }
 int orc_reserve(void* h, size_t cap) { return ((Index*)h)->reserve(cap); }
 size_t orc_capacity(void* h) { return ((Index*)h)->capacity; }
@@ -706,7 +841,7 @@ int orc_add_batch(void* h, const uint64_t* keys, const void* vecs, size_t n, siz
         for (;;) {
             size_t i = next.fetch_add(1);
             if (i >= n) break;
-            if (ix->add(keys[i], (const uint8_t*)vecs + i * ix->bytes_per_vector, t, -1)) errors.fetch_add(1);
+            if (ix->add(keys[i], (const float*)vecs + i * ix->dim, t, -1)) errors.fetch_add(1);
         }
     };
     std::vector<std::thread> th;
@@ -721,13 +856,14 @@ int orc_search_batch(void* h, const void* Q, size_t nq, size_t k, uint64_t* keys
     Index* ix = (Index*)h;
     if (threads < 1) threads = 1;
     std::atomic<size_t> next{0};
-    for (size_t t = 0; t < threads; ++t) ix->ctx(t);  // contexts exist before the workers start
+    // Every call owns its contexts: concurrent batch calls (search || search) never share scratch state.
+    std::vector<Context> local(threads);
     auto work = [&](size_t t) {
-        Context& c = ix->ctx(t);
+        Context& c = local[t];
         for (;;) {
             size_t i = next.fetch_add(1);
             if (i >= nq) break;
-            found[i] = ix->search((const uint8_t*)Q + i * ix->bytes_per_vector, k, nullptr, nullptr, keys + i * k,
+            found[i] = ix->search((const float*)Q + i * ix->dim, k, nullptr, nullptr, keys + i * k,
                                   d + i * k, c, nullptr);
         }
     };
@@ -735,13 +871,19 @@ int orc_search_batch(void* h, const void* Q, size_t nq, size_t k, uint64_t* keys
     for (size_t t = 1; t < threads; ++t) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
+    for (auto& c : local) {
+        ix->batch_distances += c.computed_distances;
+        ix->batch_cycles += c.iteration_cycles;
+    }
     return 0;
 }
 
 // stats summed over all thread contexts: [0] computed distances, [1] node expansions
 void orc_stats(void* h, uint64_t* out2, int reset) {
     Index* ix = (Index*)h;
-    out2[0] = out2[1] = 0;
+    out2[0] = ix->batch_distances.load();
+    out2[1] = ix->batch_cycles.load();
+    if (reset) ix->batch_distances = ix->batch_cycles = 0;
     for (auto& c : ix->contexts)
         if (c) {
             out2[0] += c->computed_distances;
@@ -755,6 +897,9 @@ int orc_exact_search(void* h, const void* q, size_t k, uint64_t* keys, float* d,
     Index* ix = (Index*)h;
     Context& c = ix->ctx(0);
     size_t n = ix->nodes_count.load();
+    std::vector<uint8_t> casted(ix->bytes_per_vector);
+    cast_from_f32(ix->scalar, (const float*)q, ix->dim, casted.data());
+    q = casted.data();
     std::vector<Cand> all;
     all.reserve(n);
     for (uint32_t s = 0; s < n; ++s)
@@ -864,6 +1009,20 @@ float orc_distance(int metric, const void* a, const void* b, size_t dim) {
         case kIP: return dist_ip((const float*)a, (const float*)b, dim);
         default: return dist_hamming_b1((const uint8_t*)a, (const uint8_t*)b, (dim + 7) / 8);
     }
+}
+
+// distance between two f32 vectors as an index of the given storage type would see them
+float orc_distance_as(int metric, int scalar, const float* a, const float* b, size_t dim) {
+    Index ix;
+    ix.dim = dim;
+    ix.scalar = metric == kHamming ? (int)kB1 : scalar;
+    ix.metric = ix.scalar == kB1 ? (int)kHamming : metric;
+    ix.bytes_per_vector = bytes_per_vector_of(ix.scalar, dim);
+    std::vector<uint8_t> ca(ix.bytes_per_vector), cb(ix.bytes_per_vector);
+    cast_from_f32(ix.scalar, a, dim, ca.data());
+    cast_from_f32(ix.scalar, b, dim, cb.data());
+    Context c;
+    return ix.measure(ca.data(), cb.data(), c);
 }
 
 // reference vs_index/usearch.rs:1179-1205: bit i of byte j set iff v[8j+i] > 0.0; tail zero padded.

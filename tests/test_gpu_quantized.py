@@ -1,0 +1,157 @@
+"""Quantised storage: F16 / BF16 / I8 arenas and B1 + Hamming, against the
+oracle's restatement of the usearch casts and metrics and the reference's quantization KATs
+(crates/vector-store/tests/integration/quantization.rs:95-123, 175-259, 292-358)."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import OracleIndex
+
+pytestmark = pytest.mark.gpu
+KINDS = ["f32", "f16", "bf16", "i8", "b1"]
+
+
+def vs():
+    import vector_store_amd as v
+    return v
+
+
+def close(a, b, tol=1e-5):
+    return abs(float(a) - float(b)) <= tol * max(1.0, abs(float(b)))
+
+
+def _data(n, dim, seed):
+    rng = np.random.default_rng(seed)
+    r = min(16, dim)
+    w = rng.standard_normal((r, dim)).astype(np.float32) / np.sqrt(r)
+    return (rng.standard_normal((n, r)).astype(np.float32) @ w + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_self_distance_is_zero(kind):
+    """quantization.rs:175-259 (d=1536, every kind) and :292-358 (B1, d=100): self-distance == 0.0 exactly."""
+    v = vs()
+    for dim in ((1536, 100) if kind == "b1" else (1536,)):
+        ix = v.HipUsearchIndex(dim, v.L2SQ, quantization=v.SCALARS[kind])
+        ix.reserve(8)
+        x = np.full(dim, 0.5, dtype=np.float32)
+        ix.add(1, x)
+        keys, d = ix.search(x, 1)
+        assert keys.tolist() == [1] and d.tolist() == [0.0], (kind, dim, d)
+
+
+def test_f32_vs_i8_precision_kat():
+    """quantization.rs:95-123: [0.9,0.1,0.1] vs [1,0,0]: F32 < 0.1 (0.03), I8 > 300 (342 = 2^2 + 13^2 + 13^2)."""
+    v = vs()
+    out = {}
+    for kind in ("f32", "i8"):
+        ix = v.HipUsearchIndex(3, v.L2SQ, quantization=v.SCALARS[kind])
+        ix.reserve(4)
+        ix.add(1, [0.9, 0.1, 0.1])
+        keys, d = ix.search([1.0, 0.0, 0.0], 1)
+        assert keys.tolist() == [1]
+        out[kind] = float(d[0])
+    assert out["f32"] < 0.1 and abs(out["f32"] - 0.03) < 1e-6
+    assert out["i8"] > 300 and out["i8"] == 342.0
+    assert oracle.distance_as(oracle.L2SQ, oracle.I8, [0.9, 0.1, 0.1], [1.0, 0.0, 0.0]) == 342.0
+
+
+def test_b1_requires_and_forces_hamming():
+    v = vs()
+    ix = v.HipUsearchIndex(16, v.COS, quantization=v.B1)  # reference metric_kind(): B1 => Hamming
+    ix.reserve(4)
+    a = np.array([1, -1] * 8, dtype=np.float32)
+    ix.add(7, a)
+    keys, d = ix.search(-a, 1)
+    assert keys.tolist() == [7] and d.tolist() == [16.0]
+    assert v.distance_valid(float(d[0]), v.HAMMING, 16) and v.similarity_score(16.0, v.HAMMING, 16) == 0.0
+    with pytest.raises(v.VsError, match="B1"):
+        v.HipUsearchIndex(16, v.HAMMING, quantization=v.F32)
+    assert ix.bytes_per_vector() == 2
+
+
+@pytest.mark.parametrize("kind,metric", [("f16", "cos"), ("f16", "l2sq"), ("bf16", "cos"), ("bf16", "ip"), ("i8", "cos"),
+                                         ("i8", "l2sq"), ("i8", "ip"), ("b1", "hamming")])
+@pytest.mark.parametrize("dim,n", [(768, 3000), (100, 3000), (24, 2000)])
+def test_search_matches_oracle_on_same_graph(kind, metric, dim, n):
+    """Same graph (oracle-built with the same storage type, imported in storage format), same queries =>
+    same ids; distances equal up to f32 re-association (integer metrics: exactly)."""
+    v = vs()
+    data = _data(n + 48, dim, 3 + dim)
+    base, q = data[:n], data[n:]
+    o = OracleIndex(dim, oracle.METRICS[metric], quantization=oracle.SCALARS[kind])
+    o.reserve(n)
+    o.add_batch(np.arange(n, dtype=np.uint64) + 11, base, threads=4)
+    g = o.export_graph()
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS[kind])
+    assert ix.bytes_per_vector() == g["vectors"].shape[1] * g["vectors"].itemsize
+    ix.import_graph(g)
+    back = ix.export_graph()
+    assert np.array_equal(back["vectors"], g["vectors"]) and np.array_equal(back["adj0"], g["adj0"])
+    exact_int = kind in ("i8", "b1")
+    for ef, k in ((64, 10), (200, 50)):
+        o.set_expansion_search(ef)
+        ix.set_expansion_search(ef)
+        gk, gd, gf = ix.search_batch(q, k)
+        same = 0
+        for i in range(len(q)):
+            ok_, od_ = o.search(q[i], k)
+            assert gf[i] == len(ok_)
+            if exact_int and metric != "cos":
+                assert gd[i, : len(ok_)].tolist() == od_.tolist(), (kind, metric, i)
+            else:
+                assert all(close(gd[i, j], od_[j]) for j in range(len(ok_))), (kind, metric, i)
+            same += gk[i, : len(ok_)].tolist() == ok_.tolist()
+        # integer metrics have few distinct distances: ids legitimately permute inside tie groups (the oracle
+        # breaks ties by insertion order, the engine by slot), so only the distances are compared there
+        if not exact_int:
+            assert same >= 0.9 * len(q), (kind, metric, ef, same)
+
+
+@pytest.mark.parametrize("kind", ["f16", "bf16", "i8", "b1"])
+def test_gpu_quantise_on_add_equals_oracle_cast(kind):
+    """vs_hnsw_add casts f32 -> storage on the GPU exactly as the oracle's restatement of usearch's casts."""
+    v = vs()
+    n, dim = 500, 100
+    data = _data(n, dim, 17)
+    data[3] = 0.0  # zero vector
+    data[4, :5] = [1e-8, -1e-8, 65504.0 * 4, -3.3e38, 1.0]  # subnormal-in-f16, overflow-in-f16 inputs
+    ix = v.HipUsearchIndex(dim, v.L2SQ, quantization=v.SCALARS[kind])
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), data)
+    o = OracleIndex(dim, oracle.L2SQ, quantization=oracle.SCALARS[kind])
+    o.reserve(n)
+    o.add_batch(np.arange(n, dtype=np.uint64), data, threads=1)
+    gv, ov = ix.export_graph()["vectors"], o.export_graph()["vectors"]
+    assert gv.shape == ov.shape
+    assert np.array_equal(gv, ov), np.argwhere(gv != ov)[:5]
+
+
+@pytest.mark.parametrize("kind,metric", [("f16", "cos"), ("bf16", "l2sq"), ("i8", "cos"), ("b1", "hamming")])
+def test_gpu_build_recall_and_exact(kind, metric):
+    v = vs()
+    n, dim, k = 20000, 256, 10
+    data = _data(n + 100, dim, 29)
+    base, q = data[:n], data[n:]
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS[kind])
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    tk, td, tf = ix.exact_search_batch(q, k)  # exact in the quantised space
+    o = OracleIndex(dim, oracle.METRICS[metric], quantization=oracle.SCALARS[kind])
+    o.import_graph(ix.export_graph())
+    for i in range(0, 100, 9):
+        ek, ed = o.exact_search(q[i], k)
+        assert all(close(td[i, j], ed[j], 1e-4) for j in range(k)), (kind, i, td[i], ed)
+    ix.set_expansion_search(128)
+    gk, gd, _ = ix.search_batch(q, k)
+    # recall on distances (ties are common for i8 / b1): a result counts when it is as close as the k-th exact one
+    rec = np.mean([np.mean(gd[i] <= td[i, -1] * (1 + 1e-5) + 1e-6) for i in range(len(q))])
+    assert rec >= 0.9, (kind, rec)
+    if kind in ("f16", "bf16"):  # half precision barely moves the true neighbours
+        f32 = v.HipUsearchIndex(dim, v.METRICS[metric])
+        f32.reserve(n)
+        f32.add_batch(np.arange(n, dtype=np.uint64), base)
+        fk, _, _ = f32.exact_search_batch(q, k)
+        overlap = np.mean([len(set(fk[i].tolist()) & set(tk[i].tolist())) / k for i in range(len(q))])
+        assert overlap >= (0.95 if kind == "f16" else 0.85), overlap
+    assert ix.stats()["visited_overflow"] == 0

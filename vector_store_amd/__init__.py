@@ -6,6 +6,6 @@ thin host-side binding used by tests and bench.py; it mirrors the reference's pr
 back to a CPU path: if the library or a GPU is missing, it raises.
 """
 from .index import (  # noqa: F401
-    COS, HAMMING, IP, L2SQ, METRICS, HipUsearchIndex, VsError, distance_valid, f32_to_b1x8, lib, lib_path,
+    B1, BF16, COS, F16, F32, HAMMING, I8, IP, L2SQ, METRICS, SCALARS, HipUsearchIndex, VsError, distance_valid, f32_to_b1x8, lib, lib_path,
     similarity_score, topk_merge_device, version,
 )

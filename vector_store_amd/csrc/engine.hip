@@ -106,12 +106,6 @@ struct Lease {
     WorkCtx* operator->() { return ctx.get(); }
 };
 
-static uint32_t pow2_ceil(uint32_t x) {
-    uint32_t p = 1;
-    while (p < x) p <<= 1;
-    return p;
-}
-
 // Sub-batches stay below 1/16 of the graph they are inserted into (nodes of one sub-batch do
 // not see each other during their search phase); capped so one sub-batch fills the chip
 // (256 CUs x ~6 resident waves) a few times over.
@@ -126,11 +120,13 @@ struct Engine {
     int metric = VS_METRIC_COS;
     int device = 0;
     bool stress_small_table = false;  // vs_hnsw_options.reserved bit 0 (tests only)
+    int scalar = VS_SCALAR_F32;
     uint32_t lanes = 64, lanes_log2 = 6, iters = 1, stride4 = 64;
+    uint32_t row_bytes = 0;  // payload bytes of one stored vector (usearch bytes_per_vector)
 
     // HBM arenas
-    float* d_vectors = nullptr;
-    float* d_inv_norm = nullptr;
+    uint4* d_vectors = nullptr;
+    float* d_aux = nullptr;
     uint32_t* d_adj0 = nullptr;
     uint32_t* d_upper = nullptr;
     uint32_t* d_upper_off = nullptr;
@@ -171,8 +167,8 @@ struct Engine {
 
     IndexView view() const {
         IndexView v;
-        v.vectors = reinterpret_cast<const float4*>(d_vectors);
-        v.inv_norm = d_inv_norm;
+        v.vectors = d_vectors;
+        v.aux = d_aux;
         v.adj0 = d_adj0;
         v.upper = d_upper;
         v.upper_off = d_upper_off;
@@ -184,6 +180,7 @@ struct Engine {
         v.M = M;
         v.M0 = M0;
         v.metric = metric;
+        v.scalar = scalar;
         v.entry_slot = entry_slot.load();
         v.max_level = max_level.load();
         return v;
@@ -192,19 +189,22 @@ struct Engine {
     ~Engine() {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
-        for (void* p : {(void*)d_vectors, (void*)d_inv_norm, (void*)d_adj0, (void*)d_upper, (void*)d_upper_off,
+        for (void* p : {(void*)d_vectors, (void*)d_aux, (void*)d_adj0, (void*)d_upper, (void*)d_upper_off,
                         (void*)d_keys, (void*)d_levels, (void*)d_stats})
             if (p) (void)hipFree(p);
     }
 
     void init(const vs_hnsw_options& o) {
         if (!o.dimensions) fail(VS_ERR_INVALID_ARGUMENT, "dimensions must be > 0");
-        if (o.quantization != VS_SCALAR_F32)
-            fail(VS_ERR_UNSUPPORTED, "only f32 storage is implemented (quantization f16/bf16/i8/b1: not yet)");
-        if (o.metric != VS_METRIC_COS && o.metric != VS_METRIC_L2SQ && o.metric != VS_METRIC_IP)
-            fail(VS_ERR_UNSUPPORTED, "metric must be cos, l2sq or ip (hamming/b1: not yet)");
-        dim = (uint32_t)o.dimensions;
+        if (o.quantization < VS_SCALAR_F32 || o.quantization > VS_SCALAR_B1)
+            fail(VS_ERR_INVALID_ARGUMENT, "unknown quantization");
+        scalar = o.quantization;
         metric = o.metric;
+        // reference metric_kind() (usearch.rs:450-487): B1 always means Hamming; Hamming needs B1.
+        if (scalar == VS_SCALAR_B1) metric = VS_METRIC_HAMMING;
+        else if (metric == VS_METRIC_HAMMING) fail(VS_ERR_INVALID_ARGUMENT, "Binary space type requires B1 quantization.");
+        if (metric < VS_METRIC_COS || metric > VS_METRIC_HAMMING) fail(VS_ERR_INVALID_ARGUMENT, "unknown metric");
+        dim = (uint32_t)o.dimensions;
         stress_small_table = (o.reserved & 1) != 0;
         M = o.connectivity ? (uint32_t)o.connectivity : 16;  // usearch default_connectivity
         if (M < 2 || M > 32) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 32]");
@@ -213,19 +213,26 @@ struct Engine {
         ef_search = o.expansion_search ? (uint32_t)o.expansion_search : 64;
         if (ef_add > 256) fail(VS_ERR_UNSUPPORTED, "expansion_add > 256 is not supported");
         inv_log_m = 1.0 / std::log((double)M);
-        uint32_t dim4 = (dim + 3) / 4;
-        lanes = std::min<uint32_t>(64, pow2_ceil(dim4));
-        lanes_log2 = 0;
-        while ((1u << lanes_log2) < lanes) ++lanes_log2;
-        uint32_t need = (dim4 + lanes - 1) / lanes;
+        // Row layout: 16-byte chunks, lanes x iters of them, the (lanes, iters) pair with the least padding
+        // (ties: more lanes).  768 f32 = 192 chunks = 64 x 3; 768 f16 = 96 = 32 x 3; 768 i8 = 48 = 16 x 3.
+        static const uint32_t bits[] = {32, 16, 16, 8, 1};
+        row_bytes = (uint32_t)(((uint64_t)dim * bits[scalar] + 7) / 8);
+        const uint32_t chunks = (row_bytes + 15) / 16;
         static const uint32_t ok_iters[] = {1, 2, 3, 4, 6, 8};
+        uint32_t best = 0;
         iters = 0;
-        for (uint32_t it : ok_iters)
-            if (it >= need) {
-                iters = it;
-                break;
+        for (uint32_t lg = 0; lg <= 6; ++lg)
+            for (uint32_t it : ok_iters) {
+                uint32_t cap = (1u << lg) * it;
+                if (cap < chunks) continue;
+                if (!iters || cap < best || (cap == best && (1u << lg) > lanes)) {
+                    best = cap;
+                    lanes = 1u << lg;
+                    lanes_log2 = lg;
+                    iters = it;
+                }
             }
-        if (!iters) fail(VS_ERR_UNSUPPORTED, "dimensions > 2048 are not supported");
+        if (!iters) fail(VS_ERR_UNSUPPORTED, "vectors above 8 KiB per row are not supported");
         stride4 = iters * lanes;
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count == 0) fail(VS_ERR_DEVICE, "no HIP device available");
@@ -260,14 +267,13 @@ struct Engine {
         HIP_OK(hipDeviceSynchronize());
         // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
         // coexist with the old ones while rows are copied across.
-        const size_t row_bytes = (size_t)stride4 * 16 + 4 + (size_t)M0 * 4 + 4 + 8 + 4 + (size_t)M * 4 / 8;
+        const size_t slot_bytes = (size_t)stride4 * 16 + 4 + (size_t)M0 * 4 + 4 + 8 + 4 + (size_t)M * 4 / 8;
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
-        if (cap > capacity && cap * row_bytes > free_b)
+        if (cap > capacity && cap * slot_bytes > free_b)
             fail(VS_ERR_OUT_OF_MEMORY, "not enough HBM to reserve " + std::to_string(cap) + " vectors");
-        const size_t sf = (size_t)stride4 * 4;
-        regrow(d_vectors, slots * sf, cap * sf, -1);
-        regrow(d_inv_norm, slots, cap, 0);
+        regrow(d_vectors, slots * (size_t)stride4, cap * (size_t)stride4, -1);
+        regrow(d_aux, slots, cap, 0);
         regrow(d_adj0, capacity * M0, cap * M0, 0xFF);
         regrow(d_upper_off, capacity, cap, 0xFF);
         regrow(d_keys, capacity, cap, 0xFF);
@@ -418,8 +424,7 @@ struct Engine {
                 src = stg;
             }
             (void)contiguous;
-            HIP_OK(launch_scatter_rows(d_vectors, stride4 * 4, src, dim, dim, d_src_slots, 0, m, st));
-            if (metric == VS_METRIC_COS) HIP_OK(launch_inv_norms(ix, d_inv_norm, d_slots, 0, m, st));
+            HIP_OK(launch_quantise_rows(ix, d_vectors, d_aux, src, dim, d_src_slots, 0, m, st));
             HIP_OK(launch_scatter_u64(d_keys, d_slots, d_keyv, m, st));
             HIP_OK(launch_scatter_u32((uint32_t*)d_levels, d_slots, (const uint32_t*)d_lv, m, st));
             HIP_OK(launch_scatter_u32(d_upper_off, d_slots, d_uoff, m, st));
@@ -625,7 +630,7 @@ struct Engine {
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;
-        void* scratch = w.f.ensure(exact_scratch_bytes((uint32_t)nq, (uint32_t)k));
+        void* scratch = w.f.ensure(exact_scratch_bytes((uint32_t)nq, (uint32_t)k, dim));
         HIP_OK(launch_exact(a, scratch, st));
     }
 
@@ -668,7 +673,7 @@ struct Engine {
         if (!n) return;
         float* d_q = (float*)w->a.ensure((size_t)dim * 4);
         HIP_OK(hipMemcpyAsync(d_q, q, (size_t)dim * 4, hipMemcpyHostToDevice, st));
-        HIP_OK(launch_distance_row(view(), d_q, (uint32_t)n, (float*)w->f.ensure(n * 4 + 64), st, dist.data()));
+        HIP_OK(launch_distance_row(view(), d_q, (uint32_t)n, (float*)w->f.ensure((n + dim + 64) * 4), st, dist.data()));
         HIP_OK(hipMemcpyAsync(keys.data(), d_keys, n * 8, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
     }
@@ -1013,6 +1018,7 @@ int vs_hnsw_reserve(vs_hnsw* h, size_t capacity, size_t /*threads*/) {
 }
 size_t vs_hnsw_capacity(const vs_hnsw* h) { return h ? h->e.capacity : 0; }
 size_t vs_hnsw_size(const vs_hnsw* h) { return h ? h->e.live.load() : 0; }
+size_t vs_hnsw_bytes_per_vector(const vs_hnsw* h) { return h ? h->e.row_bytes : 0; }
 
 int vs_hnsw_add(vs_hnsw* h, uint64_t key, const float* v, size_t dim) {
     int rc = VS_OK;
@@ -1167,7 +1173,7 @@ int vs_hnsw_graph_info_get(vs_hnsw* h, vs_hnsw_graph_info* info) {
     });
 }
 
-int vs_hnsw_export_graph(vs_hnsw* h, float* vectors, int32_t* levels, uint64_t* keys, uint32_t* adj0, uint32_t* upper_off,
+int vs_hnsw_export_graph(vs_hnsw* h, void* vectors, int32_t* levels, uint64_t* keys, uint32_t* adj0, uint32_t* upper_off,
                          uint32_t* upper) {
     return guarded([&] {
         need(h, "null index");
@@ -1177,11 +1183,12 @@ int vs_hnsw_export_graph(vs_hnsw* h, float* vectors, int32_t* levels, uint64_t* 
         HIP_OK(hipDeviceSynchronize());
         const size_t n = e.slots;
         if (!n) return;
-        if (vectors) {
+        if (vectors) {  // storage format, unpadded: row_bytes per vector (f32 storage: the floats themselves)
             vs::Lease w(e.device);
-            float* tmp = (float*)w->a.ensure(n * e.dim * 4);
-            HIP_OK(vs::launch_gather_rows(e.d_vectors, e.stride4 * 4, tmp, e.dim, (uint32_t)n, w->stream));
-            HIP_OK(hipMemcpyAsync(vectors, tmp, n * e.dim * 4, hipMemcpyDeviceToHost, w->stream));
+            void* tmp = w->a.ensure(n * (size_t)e.row_bytes);
+            HIP_OK(vs::launch_copy_rows(tmp, e.row_bytes, e.d_vectors, e.stride4 * 16, e.row_bytes, e.row_bytes, (uint32_t)n,
+                                        w->stream));
+            HIP_OK(hipMemcpyAsync(vectors, tmp, n * (size_t)e.row_bytes, hipMemcpyDeviceToHost, w->stream));
             HIP_OK(hipStreamSynchronize(w->stream));
         }
         if (levels) HIP_OK(hipMemcpy(levels, e.d_levels, n * 4, hipMemcpyDeviceToHost));
@@ -1192,7 +1199,7 @@ int vs_hnsw_export_graph(vs_hnsw* h, float* vectors, int32_t* levels, uint64_t* 
     });
 }
 
-int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const float* vectors, const int32_t* levels, const uint64_t* keys,
+int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const void* vectors, const int32_t* levels, const uint64_t* keys,
                          const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* upper, size_t upper_blocks,
                          int32_t max_level, uint32_t entry_slot) {
     return guarded([&] {
@@ -1205,11 +1212,12 @@ int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const float* vectors, const int32
         if (!n) return;
         e.ensure_upper(upper_blocks);
         vs::Lease w(e.device);
-        float* tmp = (float*)w->a.ensure(n * e.dim * 4);
-        HIP_OK(hipMemcpyAsync(tmp, vectors, n * e.dim * 4, hipMemcpyHostToDevice, w->stream));
-        HIP_OK(vs::launch_scatter_rows(e.d_vectors, e.stride4 * 4, tmp, e.dim, e.dim, nullptr, 0, (uint32_t)n, w->stream));
+        void* tmp = w->a.ensure(n * (size_t)e.row_bytes);
+        HIP_OK(hipMemcpyAsync(tmp, vectors, n * (size_t)e.row_bytes, hipMemcpyHostToDevice, w->stream));
+        HIP_OK(vs::launch_copy_rows(e.d_vectors, e.stride4 * 16, tmp, e.row_bytes, e.row_bytes, e.stride4 * 16, (uint32_t)n,
+                                    w->stream));
         vs::IndexView ix = e.view();
-        if (e.metric == VS_METRIC_COS) HIP_OK(vs::launch_inv_norms(ix, e.d_inv_norm, nullptr, 0, (uint32_t)n, w->stream));
+        HIP_OK(vs::launch_aux_rows(ix, e.d_aux, (uint32_t)n, w->stream));
         HIP_OK(hipStreamSynchronize(w->stream));
         HIP_OK(hipMemcpy(e.d_levels, levels, n * 4, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(e.d_keys, keys, n * 8, hipMemcpyHostToDevice));

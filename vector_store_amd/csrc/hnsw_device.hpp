@@ -9,8 +9,11 @@
 // one restated in oracle/cpu_hnsw.cpp (search_for_one / search_to_insert /
 // search_to_find_in_base / refine / reconnect_neighbor_nodes).
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 namespace vs {
 
@@ -21,18 +24,25 @@ constexpr uint32_t kSlotMask = 0x3FFFFFFFu;
 constexpr uint64_t kFreeKey = ~0ull;
 constexpr int kWave = 64;
 
-enum : int { COS = 0, L2SQ = 1, IP = 2 };  // vs_metric_kind
-enum : int { KDOT = 0, KL2 = 1 };            // arithmetic kind: cos and ip share the dot product
+enum : int { COS = 0, L2SQ = 1, IP = 2, HAMMING = 3 };                     // vs_metric_kind
+enum : int { SC_F32 = 0, SC_F16 = 1, SC_BF16 = 2, SC_I8 = 3, SC_B1 = 4 };  // vs_scalar_kind (storage type)
+// Arithmetic of one (storage type, metric family) pair -- the kernels' template parameter.
+// cos and ip share the dot product; i8 derives every metric from the integer dot product and the stored
+// sums of squares; b1 is popcount(xor).
+enum : int { AR_F32_DOT = 0, AR_F32_L2 = 1, AR_F16_DOT = 2, AR_F16_L2 = 3, AR_BF16_DOT = 4, AR_BF16_L2 = 5, AR_I8 = 6, AR_B1 = 7 };
+constexpr int KDOT = AR_F32_DOT, KL2 = AR_F32_L2;  // the f32 pair under its old name
 
 // HBM layout (see DESIGN.md "Data layout"):
-//  vectors  [capacity][stride4] float4, row = iters*lanes float4, zero padded
-//  inv_norm [capacity] f32 (cosine only; 0 marks the zero vector)
+//  vectors  [capacity][stride4] 16-byte chunks, row = iters*lanes chunks, zero padded; a chunk holds
+//           4 f32 | 8 f16 | 8 bf16 | 16 i8 | 128 bits, elements in order
+//  aux      [capacity] f32: f32/f16/bf16 + cosine: 1/|row| (0 marks the zero vector);
+//           i8: sum of squares of the stored bytes (exact integer); unused otherwise
 //  adj0     [capacity][M0] u32 slots, kInvalid padded (128 B at M0=32: one cache line/expansion)
 //  upper    [blocks][M] u32; node s, level l>=1 lives in block upper_off[s]+l-1
 //  keys     [capacity] u64, kFreeKey = removed / never used
 struct IndexView {
-    const float4* vectors;
-    const float* inv_norm;
+    const uint4* vectors;
+    const float* aux;
     uint32_t* adj0;
     uint32_t* upper;
     const uint32_t* upper_off;
@@ -42,7 +52,8 @@ struct IndexView {
     uint32_t lanes;       // lanes cooperating on one vector (power of two <= 64)
     uint32_t lanes_log2;
     uint32_t M, M0;
-    int32_t metric;       // COS / L2SQ / IP
+    int32_t metric;       // COS / L2SQ / IP / HAMMING
+    int32_t scalar;       // SC_*
     uint32_t entry_slot;
     int32_t max_level;    // -1: empty index
 };
@@ -88,66 +99,219 @@ __device__ __forceinline__ float group_sum(float v, uint32_t lanes) {
     return v;
 }
 
-template <int KIND>
-__device__ __forceinline__ float accumulate(float acc, const float4 a, const float4 b) {
-    if (KIND == KL2) {
-        float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
-        acc = fmaf(dx, dx, acc);
-        acc = fmaf(dy, dy, acc);
-        acc = fmaf(dz, dz, acc);
-        acc = fmaf(dw, dw, acc);
-    } else {
-        acc = fmaf(a.x, b.x, acc);
-        acc = fmaf(a.y, b.y, acc);
-        acc = fmaf(a.z, b.z, acc);
-        acc = fmaf(a.w, b.w, acc);
+__device__ __forceinline__ int group_sum(int v, uint32_t lanes) {  // integer twin (i8 dot products, popcounts)
+    if (lanes >= 16) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x120 + 8, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x120 + 4, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x120 + 2, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x120 + 1, 0xF, 0xF, true);
+        if (lanes == 64) {
+            v = (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+                (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+        } else if (lanes == 32) {
+            v += __shfl_xor(v, 16);
+        }
+        return v;
+    }
+    for (uint32_t o = lanes >> 1; o; o >>= 1) v += __shfl_xor(v, (int)o);
+    return v;
+}
+__device__ __forceinline__ double group_sum(double v, uint32_t lanes) {  // query / row preparation only
+    for (uint32_t o = lanes >> 1; o; o >>= 1) v += __shfl_xor(v, (int)o);
+    return v;
+}
+
+template <int AR>
+struct Arith {
+    static constexpr bool is_int = AR == AR_I8 || AR == AR_B1;
+    static constexpr bool is_l2 = AR == AR_F32_L2 || AR == AR_F16_L2 || AR == AR_BF16_L2;
+    static constexpr int scalar = AR <= AR_F32_L2 ? SC_F32 : AR <= AR_F16_L2 ? SC_F16 : AR <= AR_BF16_L2 ? SC_BF16 : AR == AR_I8 ? SC_I8 : SC_B1;
+    static constexpr uint32_t epc = scalar == SC_F32 ? 4 : scalar == SC_I8 ? 16 : scalar == SC_B1 ? 128 : 8;  // elements per chunk
+    using acc_t = typename std::conditional<is_int, int, float>::type;
+};
+
+__device__ __forceinline__ float half_bits_to_float(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)h)); }
+__device__ __forceinline__ uint32_t float_to_half_bits(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t float_to_bf16_bits(float f) {  // round to nearest even; NaN stays NaN
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int AR>
+__device__ __forceinline__ void unpack8(const uint4 c, float (&f)[8]) {  // f16 / bf16 chunk -> 8 floats
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (Arith<AR>::scalar == SC_F16) {
+            f[2 * j] = half_bits_to_float(w[j] & 0xFFFFu);
+            f[2 * j + 1] = half_bits_to_float(w[j] >> 16);
+        } else {
+            f[2 * j] = bf16_bits_to_float(w[j] & 0xFFFFu);
+            f[2 * j + 1] = bf16_bits_to_float(w[j] >> 16);
+        }
+    }
+}
+
+// acc += partial metric of one 16-byte chunk of the query (a) against one chunk of a row (b).
+template <int AR>
+__device__ __forceinline__ typename Arith<AR>::acc_t accumulate(typename Arith<AR>::acc_t acc, const uint4 a, const uint4 b) {
+    if constexpr (AR == AR_F32_DOT || AR == AR_F32_L2) {
+        const float ax = __uint_as_float(a.x), ay = __uint_as_float(a.y), az = __uint_as_float(a.z), aw = __uint_as_float(a.w);
+        const float bx = __uint_as_float(b.x), by = __uint_as_float(b.y), bz = __uint_as_float(b.z), bw = __uint_as_float(b.w);
+        if constexpr (AR == AR_F32_L2) {
+            float dx = ax - bx, dy = ay - by, dz = az - bz, dw = aw - bw;
+            acc = fmaf(dx, dx, acc);
+            acc = fmaf(dy, dy, acc);
+            acc = fmaf(dz, dz, acc);
+            acc = fmaf(dw, dw, acc);
+        } else {
+            acc = fmaf(ax, bx, acc);
+            acc = fmaf(ay, by, acc);
+            acc = fmaf(az, bz, acc);
+            acc = fmaf(aw, bw, acc);
+        }
+    } else if constexpr (AR == AR_I8) {
+        acc = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, acc, false);
+        acc = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, acc, false);
+        acc = __builtin_amdgcn_sdot4((int)a.z, (int)b.z, acc, false);
+        acc = __builtin_amdgcn_sdot4((int)a.w, (int)b.w, acc, false);
+    } else if constexpr (AR == AR_B1) {
+        acc += __popc(a.x ^ b.x) + __popc(a.y ^ b.y) + __popc(a.z ^ b.z) + __popc(a.w ^ b.w);
+    } else {  // f16 / bf16: every element widened to f32, arithmetic in f32 (products are exact)
+        float fa[8], fb[8];
+        unpack8<AR>(a, fa);
+        unpack8<AR>(b, fb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (Arith<AR>::is_l2) {
+                float d = fa[j] - fb[j];
+                acc = fmaf(d, d, acc);
+            } else {
+                acc = fmaf(fa[j], fb[j], acc);
+            }
+        }
     }
     return acc;
 }
 
-// usearch metric_cos_gt / l2sq / ip with the SimSIMD zero rules (oracle dist_cos):
-// both zero -> 0, one zero or ab == 0 -> 1, clamp to [0, 2] so Distance::try_from
-// (reference distance.rs:65-70) never rejects a result.
-__device__ __forceinline__ float finalize(int metric, float acc, float a_inv, float b_inv) {
-    if (metric == L2SQ) return acc;
-    if (metric == IP) return 1.0f - acc;
-    if (a_inv == 0.f && b_inv == 0.f) return 0.f;
-    if (a_inv == 0.f || b_inv == 0.f || acc == 0.f) return 1.f;
-    float r = 1.0f - acc * (a_inv * b_inv);
-    return fminf(fmaxf(r, 0.f), 2.f);
-}
-
-// Row -> registers: lane li of a `lanes`-wide group holds float4 li, li+lanes, ...
-template <int I>
-__device__ __forceinline__ void load_row(const IndexView& ix, uint32_t slot, float4 (&r)[I], int lane) {
-    const uint32_t li = lane & (ix.lanes - 1);
-    const float4* row = ix.vectors + (size_t)slot * ix.stride4 + li;
-#pragma unroll
-    for (int i = 0; i < I; ++i) r[i] = row[(size_t)i * ix.lanes];
-}
-
-// A caller-provided (unpadded, possibly unaligned) f32 vector -> registers, zero padded.
-template <int I>
-__device__ __forceinline__ void load_query(const IndexView& ix, const float* q, float4 (&r)[I], int lane) {
-    const uint32_t li = lane & (ix.lanes - 1);
-#pragma unroll
-    for (int i = 0; i < I; ++i) {
-        uint32_t e = ((uint32_t)i * ix.lanes + li) * 4u;
-        r[i].x = e + 0 < ix.dim ? q[e + 0] : 0.f;
-        r[i].y = e + 1 < ix.dim ? q[e + 1] : 0.f;
-        r[i].z = e + 2 < ix.dim ? q[e + 2] : 0.f;
-        r[i].w = e + 3 < ix.dim ? q[e + 3] : 0.f;
+// usearch metric_cos_gt / l2sq / ip with the SimSIMD zero rules (oracle dist_cos): both zero -> 0, one zero
+// or ab == 0 -> 1, clamp to [0, 2] so Distance::try_from (reference distance.rs:65-70) never rejects a
+// result.  Float storage: aux = 1/|v| (cosine).  i8: aux = sum of squares; cos = 1 - ab/sqrt(a2*b2),
+// l2sq = a2 + b2 - 2ab, ip = 1 - ab, all on the stored integers.  b1: the popcount itself.
+template <int AR>
+__device__ __forceinline__ float finalize(int metric, typename Arith<AR>::acc_t acc, float a_aux, float b_aux) {
+    if constexpr (AR == AR_B1) {
+        return (float)acc;
+    } else if constexpr (AR == AR_I8) {
+        const float ab = (float)acc;
+        if (metric == L2SQ) return a_aux + b_aux - 2.0f * ab;
+        if (metric == IP) return 1.0f - ab;
+        if (a_aux == 0.f && b_aux == 0.f) return 0.f;
+        if (a_aux == 0.f || b_aux == 0.f || acc == 0) return 1.f;
+        float r = 1.0f - ab / (sqrtf(a_aux) * sqrtf(b_aux));
+        return fminf(fmaxf(r, 0.f), 2.f);
+    } else {
+        if (metric == L2SQ) return acc;
+        if (metric == IP) return 1.0f - acc;
+        if (a_aux == 0.f && b_aux == 0.f) return 0.f;
+        if (a_aux == 0.f || b_aux == 0.f || acc == 0.f) return 1.f;
+        float r = 1.0f - acc * (a_aux * b_aux);
+        return fminf(fmaxf(r, 0.f), 2.f);
     }
 }
 
-// 1/|q| over one lane group (every group holds a replica of q); 0 for the zero vector.
-template <int I>
-__device__ __forceinline__ float inv_norm_of(const IndexView& ix, const float4 (&q)[I]) {
-    float s = 0.f;
+template <int AR>
+__device__ __forceinline__ bool needs_aux(int metric) {
+    return AR == AR_I8 || (AR != AR_B1 && metric == COS);
+}
+
+// A vector held in registers in STORAGE format: lane li of a `lanes`-wide group holds chunks li, li+lanes, ...
+template <int AR, int I>
+struct Query {
+    uint4 c[I];
+    float aux;  // see finalize
+};
+
+template <int AR, int I>
+__device__ __forceinline__ void query_from_row(const IndexView& ix, uint32_t slot, Query<AR, I>& q, int lane) {
+    const uint32_t li = lane & (ix.lanes - 1);
+    const uint4* row = ix.vectors + (size_t)slot * ix.stride4 + li;
 #pragma unroll
-    for (int i = 0; i < I; ++i) s = accumulate<KDOT>(s, q[i], q[i]);
-    s = group_sum(s, ix.lanes);
-    return s > 0.f ? 1.0f / sqrtf(s) : 0.f;
+    for (int i = 0; i < I; ++i) q.c[i] = row[(size_t)i * ix.lanes];
+    q.aux = needs_aux<AR>(ix.metric) ? ix.aux[slot] : 0.f;
+}
+
+// Quantise `EPC` consecutive f32 elements starting at e0 into one chunk (the casts usearch applies when
+// quantization != F32: f16 IEEE round-to-nearest, bf16 round-to-nearest-even, i8 = trunc(x*127/|x|) clamped
+// to [-127,127], b1 = (x > 0), LSB first as reference usearch.rs:1179-1205).  `scale` is 127/|x| for i8.
+template <int AR>
+__device__ __forceinline__ uint4 quantise_chunk(const float* v, uint32_t e0, uint32_t dim, float mag) {
+    auto at = [&](uint32_t e) { return e < dim ? v[e] : 0.f; };
+    uint32_t w[4] = {0, 0, 0, 0};
+    if constexpr (Arith<AR>::scalar == SC_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = __float_as_uint(at(e0 + j));
+    } else if constexpr (Arith<AR>::scalar == SC_F16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = float_to_half_bits(at(e0 + 2 * j)) | (float_to_half_bits(at(e0 + 2 * j + 1)) << 16);
+    } else if constexpr (Arith<AR>::scalar == SC_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = float_to_bf16_bits(at(e0 + 2 * j)) | (float_to_bf16_bits(at(e0 + 2 * j + 1)) << 16);
+    } else if constexpr (Arith<AR>::scalar == SC_I8) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float t = mag > 0.f ? (at(e0 + j) * 127.0f) / mag : 0.f;
+            t = fminf(fmaxf(t, -127.f), 127.f);
+            w[j >> 2] |= ((uint32_t)(int)t & 0xFFu) << ((j & 3) * 8);
+        }
+    } else {
+        for (int j = 0; j < 128; ++j)
+            if (at(e0 + j) > 0.0f) w[j >> 5] |= 1u << (j & 31);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// |v| for the i8 cast, accumulated in f64 so that the value does not depend on the summation order
+// (the oracle sums sequentially, the GPU across lanes): (float)sqrt(sum x^2).
+__device__ __forceinline__ float magnitude_f64(const float* v, uint32_t dim, uint32_t lanes, uint32_t li) {
+    double s = 0.0;
+    for (uint32_t e = li; e < dim; e += lanes) s += (double)v[e] * (double)v[e];
+    s = group_sum(s, lanes);
+    return (float)sqrt(s);
+}
+
+// Sum of squares (float kinds: of the dequantised values, in f32; i8: of the bytes, exact) of the chunks in
+// registers, reduced over the lane group -> the aux value of finalize().
+template <int AR, int I>
+__device__ __forceinline__ float aux_of(const IndexView& ix, const Query<AR, I>& q) {
+    if constexpr (AR == AR_B1) {
+        return 0.f;
+    } else if constexpr (AR == AR_I8) {
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < I; ++i) s = accumulate<AR_I8>(s, q.c[i], q.c[i]);
+        return (float)group_sum(s, ix.lanes);
+    } else {
+        constexpr int DOT = Arith<AR>::scalar == SC_F32 ? AR_F32_DOT : Arith<AR>::scalar == SC_F16 ? AR_F16_DOT : AR_BF16_DOT;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < I; ++i) s = accumulate<DOT>(s, q.c[i], q.c[i]);
+        s = group_sum(s, ix.lanes);
+        return s > 0.f ? 1.0f / sqrtf(s) : 0.f;
+    }
+}
+
+// A caller-provided (unpadded, possibly unaligned) f32 vector -> storage format in registers.
+template <int AR, int I>
+__device__ __forceinline__ void query_from_f32(const IndexView& ix, const float* v, Query<AR, I>& q, int lane) {
+    const uint32_t li = lane & (ix.lanes - 1);
+    float mag = 0.f;
+    if constexpr (AR == AR_I8) mag = magnitude_f64(v, ix.dim, ix.lanes, li);
+#pragma unroll
+    for (int i = 0; i < I; ++i) q.c[i] = quantise_chunk<AR>(v, ((uint32_t)i * ix.lanes + li) * Arith<AR>::epc, ix.dim, mag);
+    q.aux = needs_aux<AR>(ix.metric) ? aux_of<AR, I>(ix, q) : 0.f;
 }
 
 // Distances from q to u_slot[0..m).  64/lanes vectors per wave-load, U wave-loads per group, and the
@@ -156,48 +320,48 @@ __device__ __forceinline__ float inv_norm_of(const IndexView& ix, const float4 (
 // (memory-level parallelism is what bounds this kernel: MI355X_MICROARCH "Indexed rows").
 template <int I, int U>
 struct RowGroup {
-    float4 buf[U][I];
+    uint4 buf[U][I];
     uint32_t slot[U];
-    float inv[U];
+    float aux[U];
 };
 
-template <int I, int U>
+template <int AR, int I, int U>
 __device__ __forceinline__ void group_issue(const IndexView& ix, RowGroup<I, U>& g, const uint32_t* u_slot, uint32_t m,
                                             uint32_t t, uint32_t V, uint32_t grp, uint32_t li) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         uint32_t idx = t + (uint32_t)u * V + grp;
         g.slot[u] = idx < m ? u_slot[idx] : kInvalid;
-        g.inv[u] = 0.f;
+        g.aux[u] = 0.f;
         if (g.slot[u] != kInvalid) {
-            const float4* row = ix.vectors + (size_t)g.slot[u] * ix.stride4 + li;
+            const uint4* row = ix.vectors + (size_t)g.slot[u] * ix.stride4 + li;
 #pragma unroll
             for (int i = 0; i < I; ++i) g.buf[u][i] = row[(size_t)i * ix.lanes];
-            if (ix.metric == COS) g.inv[u] = ix.inv_norm[g.slot[u]];
+            if (needs_aux<AR>(ix.metric)) g.aux[u] = ix.aux[g.slot[u]];
         } else {
 #pragma unroll
-            for (int i = 0; i < I; ++i) g.buf[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < I; ++i) g.buf[u][i] = make_uint4(0u, 0u, 0u, 0u);
         }
     }
 }
 
-template <int KIND, int I, int U>
-__device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup<I, U>& g, const float4 (&q)[I],
-                                             float q_inv, float* u_dist, uint32_t t, uint32_t V, uint32_t grp,
-                                             uint32_t li) {
+template <int AR, int I, int U>
+__device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup<I, U>& g, const Query<AR, I>& q,
+                                             float* u_dist, uint32_t t, uint32_t V, uint32_t grp, uint32_t li) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        float acc = 0.f;
+        typename Arith<AR>::acc_t acc = 0;
 #pragma unroll
-        for (int i = 0; i < I; ++i) acc = accumulate<KIND>(acc, q[i], g.buf[u][i]);
+        for (int i = 0; i < I; ++i) acc = accumulate<AR>(acc, q.c[i], g.buf[u][i]);
         acc = group_sum(acc, ix.lanes);
-        if (g.slot[u] != kInvalid && li == 0) u_dist[t + (uint32_t)u * V + grp] = finalize(ix.metric, acc, q_inv, g.inv[u]);
+        if (g.slot[u] != kInvalid && li == 0)
+            u_dist[t + (uint32_t)u * V + grp] = finalize<AR>(ix.metric, acc, q.aux, g.aux[u]);
     }
 }
 
-template <int KIND, int I>
-__device__ __forceinline__ void eval_batch(const IndexView& ix, const float4 (&q)[I], float q_inv,
-                                           const uint32_t* u_slot, float* u_dist, uint32_t m, int lane) {
+template <int AR, int I>
+__device__ __forceinline__ void eval_batch(const IndexView& ix, const Query<AR, I>& q, const uint32_t* u_slot,
+                                           float* u_dist, uint32_t m, int lane) {
     constexpr int U = I >= 6 ? 2 : (I >= 2 ? 4 : 8);
     const uint32_t lg = ix.lanes_log2;
     const uint32_t V = 64u >> lg;
@@ -205,15 +369,15 @@ __device__ __forceinline__ void eval_batch(const IndexView& ix, const float4 (&q
     const uint32_t G = V * U;  // vectors per group
     if (m == 0) return;
     RowGroup<I, U> a, b;
-    group_issue<I, U>(ix, a, u_slot, m, 0, V, grp, li);
+    group_issue<AR, I, U>(ix, a, u_slot, m, 0, V, grp, li);
     uint32_t t = 0;
     for (;;) {
-        if (t + G < m) group_issue<I, U>(ix, b, u_slot, m, t + G, V, grp, li);
-        group_reduce<KIND, I, U>(ix, a, q, q_inv, u_dist, t, V, grp, li);
+        if (t + G < m) group_issue<AR, I, U>(ix, b, u_slot, m, t + G, V, grp, li);
+        group_reduce<AR, I, U>(ix, a, q, u_dist, t, V, grp, li);
         t += G;
         if (t >= m) break;
-        if (t + G < m) group_issue<I, U>(ix, a, u_slot, m, t + G, V, grp, li);
-        group_reduce<KIND, I, U>(ix, b, q, q_inv, u_dist, t, V, grp, li);
+        if (t + G < m) group_issue<AR, I, U>(ix, a, u_slot, m, t + G, V, grp, li);
+        group_reduce<AR, I, U>(ix, b, q, u_dist, t, V, grp, li);
         t += G;
         if (t >= m) break;
     }
@@ -351,13 +515,13 @@ __device__ __forceinline__ const uint32_t* adjacency(const IndexView& ix, uint32
 }
 
 // usearch search_for_one_: greedy walk on levels (from_level .. to_level+1].
-template <int KIND, int I, int EFCAP, int NB, bool SEL, int CH>
-__device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const float4 (&q)[I], float q_inv,
+template <int AR, int I, int EFCAP, int NB, bool SEL, int CH>
+__device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const Query<AR, I>& q,
                                    uint32_t start, int from_level, int to_level, Counters& cnt, int lane) {
     uint32_t cur = start;
     if (lane == 0) sh.u_slot[0] = cur;
     __syncthreads();
-    eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, 1, lane);
+    eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, 1, lane);
     __syncthreads();
     float cur_d = sh.u_dist[0];
     cnt.evals += 1;
@@ -371,7 +535,7 @@ __device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SE
             __syncthreads();
             if (n != kInvalid) sh.u_slot[mbcnt(mask)] = n;
             __syncthreads();
-            eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, m, lane);
+            eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, m, lane);
             __syncthreads();
             cnt.evals += m;
             cnt.hops += 1;
@@ -462,8 +626,8 @@ __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& s
 // usearch search_to_insert_ / search_to_find_in_base_ (unfiltered): beam search on one level.
 // On return the sorted candidates are in sh.lst_*[cur] (cur returned through `out_cur`).
 // `self` (or kInvalid): slot that is never evaluated, expanded nor returned.
-template <int KIND, int I, int EFCAP, int NB, bool SEL, int CH>
-__device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const float4 (&q)[I], float q_inv,
+template <int AR, int I, int EFCAP, int NB, bool SEL, int CH>
+__device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const Query<AR, I>& q,
                                 uint32_t start, int level, uint32_t ef, uint32_t self, Counters& cnt, int lane,
                                 int& out_cur, bool tomb = false) {
     visited_clear(sh, lane);
@@ -478,7 +642,7 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
     }
     __syncthreads();
     if (start != self) {
-        eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, 1, lane);
+        eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, 1, lane);
         __syncthreads();
         cnt.evals += 1;
         const bool start_dead = tomb && ix.keys[start] == kFreeKey;
@@ -535,7 +699,7 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         if (fresh) sh.u_slot[mbcnt(fmask)] = n;
         __syncthreads();
         if (m == 0) continue;
-        eval_batch<KIND, I>(ix, q, q_inv, sh.u_slot, sh.u_dist, m, lane);
+        eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, m, lane);
         __syncthreads();
         cnt.evals += m;
         // admission: top not full, or closer than the current radius (usearch: `top.size() < top_limit || d < radius`)
@@ -604,7 +768,7 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
 // usearch refine_: neighbour-selection heuristic over the sorted candidates in
 // sh.lst_*[cur][0..sz).  Accept c iff for every already accepted a: d(c, a) >= d(c, centre).
 // Result in sh.sel_s / sh.sel_d (ascending); returns the number selected (<= needed).
-template <int KIND, int I, class Sh>
+template <int AR, int I, class Sh>
 __device__ uint32_t refine(const IndexView& ix, Sh& sh, int cur, uint32_t sz, uint32_t needed,
                            Counters& cnt, int lane) {
     if (sz < needed || sz == 0) {
@@ -626,10 +790,9 @@ __device__ uint32_t refine(const IndexView& ix, Sh& sh, int cur, uint32_t sz, ui
     for (uint32_t c = 1; c < sz && nsel < needed; ++c) {
         const uint32_t cs = sh.lst_s[cur][c] & kSlotMask;
         const float cd = sh.lst_d[cur][c];
-        float4 cv[I];
-        load_row<I>(ix, cs, cv, lane);
-        const float c_inv = ix.metric == COS ? ix.inv_norm[cs] : 0.f;
-        eval_batch<KIND, I>(ix, cv, c_inv, sh.sel_s, sh.u_dist, nsel, lane);
+        Query<AR, I> cv;
+        query_from_row<AR, I>(ix, cs, cv, lane);
+        eval_batch<AR, I>(ix, cv, sh.sel_s, sh.u_dist, nsel, lane);
         __syncthreads();
         cnt.evals += nsel;
         bool bad = (uint32_t)lane < nsel && sh.u_dist[lane] < cd;

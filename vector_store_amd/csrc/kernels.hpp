@@ -44,6 +44,12 @@ struct LinkArgs {
     unsigned long long* stats;
 };
 
+// per-arithmetic launchers (explicitly specialised in kernels_arith.hip, one object per arithmetic)
+template <int AR> hipError_t launch_search_ar(const SearchArgs& a, uint32_t iters, hipStream_t s);
+template <int AR> hipError_t launch_insert_ar(const InsertArgs& a, uint32_t iters, hipStream_t s);
+template <int AR> hipError_t launch_link_ar(const LinkArgs& a, uint32_t iters, hipStream_t s);
+int arith_of(int scalar, int metric);
+
 // iters = stride4 / lanes must be one of {1,2,3,4,6,8}; ef <= 256.
 bool search_supported(uint32_t iters, uint32_t ef);
 hipError_t launch_search(const SearchArgs& a, uint32_t iters, hipStream_t s);
@@ -52,13 +58,15 @@ hipError_t launch_link(const LinkArgs& a, uint32_t iters, hipStream_t s);
 // bits of slot ids the visited table of the kernel chosen for `ef` can distinguish
 uint32_t visited_domain_bits(uint32_t ef);
 
-// inv_norm[slot] = 1/|row| (0 for the zero row) for slots[0..n) (slots == nullptr: first + i)
-hipError_t launch_inv_norms(const IndexView& ix, float* inv_norm, const uint32_t* slots, uint32_t first, uint32_t n,
-                            hipStream_t s);
-// dst rows (padded stride) <- src rows (dim floats, src_stride floats apart), rows given by slots or first+i
-hipError_t launch_scatter_rows(float* vectors, uint32_t stride_f, const float* src, uint32_t src_stride, uint32_t dim,
-                               const uint32_t* slots, uint32_t first, uint32_t n, hipStream_t s);
-hipError_t launch_gather_rows(const float* vectors, uint32_t stride_f, float* dst, uint32_t dim, uint32_t n, hipStream_t s);
+// f32 rows (dim floats, src_stride apart) -> storage rows (cast as usearch does, zero padded) + aux;
+// rows given by slots[] or first + i
+hipError_t launch_quantise_rows(const IndexView& ix, uint4* vectors, float* aux, const float* src, uint32_t src_stride,
+                                const uint32_t* slots, uint32_t first, uint32_t n, hipStream_t s);
+// aux[] of rows 0..n that are already stored (import path)
+hipError_t launch_aux_rows(const IndexView& ix, float* aux, uint32_t n, hipStream_t s);
+// n rows: dst[r][0..dst_fill_to) = src[r][0..row_bytes) followed by zeros
+hipError_t launch_copy_rows(void* dst, uint32_t dst_stride, const void* src, uint32_t src_stride, uint32_t row_bytes,
+                            uint32_t dst_fill_to, uint32_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t* p, uint32_t value, size_t n, hipStream_t s);
 hipError_t launch_fill_rows_u32(uint32_t* base, uint32_t row_words, const uint32_t* rows, uint32_t nrows, uint32_t value,
                                 hipStream_t s);
@@ -75,10 +83,11 @@ struct ExactArgs {
     float* out_dist;
     uint32_t* out_found;
 };
-size_t exact_scratch_bytes(uint32_t nq, uint32_t k);
+size_t exact_scratch_bytes(uint32_t nq, uint32_t k, uint32_t dim);
 hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s);
 
-// out[s] = distance(query, row s) for s in [0, n): one wave per row; result copied to host_out
+// out[s] = distance(query, row s) for s in [0, n): one wave per row; result copied to host_out.
+// d_scratch: n + dim + 64 floats.
 hipError_t launch_distance_row(const IndexView& ix, const float* d_query, uint32_t n, float* d_scratch, hipStream_t s,
                                float* host_out);
 

@@ -1,0 +1,271 @@
+// kernels_arith.hip -- hnsw_search / hnsw_insert / hnsw_link for ONE arithmetic (-DVS_AR=0..7, see the AR_*
+// enum in hnsw_device.hpp).  Compiled once per arithmetic so the eight variants build in parallel.
+//
+// hnsw_search_kernel : one wavefront per query (K5 of SURVEY.md section 2.3); replaces usearch::Index::search
+//                      as called at reference vs_index/usearch.rs:210-212.
+// hnsw_insert_kernel / hnsw_link_kernel : batched insertion (K7); replaces usearch::Index::add (usearch.rs:194-196).
+//   A sub-batch of new nodes is inserted against the graph frozen at the start of the sub-batch (the host
+//   keeps sub-batches small relative to the index, see engine.hip):
+//     1. hnsw_insert_kernel : one wave per new node -- greedy descent, per-level beam search (expansion_add),
+//        neighbour-selection heuristic, forward links, reverse-link requests;
+//     2. radix sort of the requests by (level, target)   (kernels_sort.hip);
+//     3. hnsw_link_kernel   : one wave per (level, target) group -- append or re-run the heuristic on the
+//        target's list (usearch reconnect_neighbor_nodes_).
+//   No locks: every adjacency row is written by exactly one wave per kernel.
+#include "kernels.hpp"
+
+#ifndef VS_AR
+#error "compile with -DVS_AR=<arithmetic>"
+#endif
+
+namespace vs {
+
+template <int AR, int I, int EFCAP, int NB, int CH>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
+    __shared__ BeamShared<EFCAP, NB, false, CH> sh;
+    const IndexView& ix = a.ix;
+    const int lane = lane_id();
+    const uint32_t qi = blockIdx.x;
+    uint64_t* ok = a.out_keys + (size_t)qi * a.k;
+    float* od = a.out_dist + (size_t)qi * a.k;
+    if (ix.max_level < 0) {
+        for (uint32_t i = lane; i < a.k; i += kWave) {
+            ok[i] = kFreeKey;
+            od[i] = __builtin_inff();
+        }
+        if (lane == 0) a.out_found[qi] = 0;
+        return;
+    }
+    Query<AR, I> q;
+    query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
+    Counters cnt = {0, 0, 0};
+    // usearch index_gt::search: search_for_one_ down to level 1, then the base-level beam.
+    uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
+    int cur = 0;
+    uint32_t sz = beam_search<AR, I>(ix, sh, q, start, 0, a.ef, kInvalid, cnt, lane, cur, a.has_removed != 0);
+    __syncthreads();
+    // top.sort_ascending(); top.shrink(wanted); removed members (free key) are never results.
+    uint32_t written = 0;
+#pragma unroll
+    for (int r = 0; r < EFCAP / kWave; ++r) {
+        uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+        bool okp = p < sz;
+        uint32_t slot = okp ? (sh.lst_s[cur][p] & kSlotMask) : 0u;
+        uint64_t key = okp ? ix.keys[slot] : kFreeKey;
+        okp = okp && key != kFreeKey;
+        uint64_t mask = __ballot(okp);
+        uint32_t pos = written + mbcnt(mask);
+        if (okp && pos < a.k) {
+            ok[pos] = key;
+            od[pos] = sh.lst_d[cur][p];
+        }
+        written += (uint32_t)__popcll(mask);
+    }
+    uint32_t found = written < a.k ? written : a.k;
+    for (uint32_t i = found + lane; i < a.k; i += kWave) {
+        ok[i] = kFreeKey;
+        od[i] = __builtin_inff();
+    }
+    if (lane == 0) {
+        a.out_found[qi] = found;
+        atomicAdd(&a.stats[ST_SEARCH_EVALS], cnt.evals);
+        atomicAdd(&a.stats[ST_SEARCH_HOPS], cnt.hops);
+        atomicAdd(&a.stats[ST_QUERIES], 1ull);
+        if (cnt.overflow) atomicAdd(&a.stats[ST_OVERFLOW], cnt.overflow);
+    }
+}
+
+
+template <int AR, int I, int EFCAP, int NB, int CH>
+__global__ __launch_bounds__(64) void hnsw_insert_kernel(InsertArgs a) {
+    __shared__ BeamShared<EFCAP, NB, true, CH> sh;
+    const IndexView& ix = a.ix;
+    const int lane = lane_id();
+    const uint32_t b = blockIdx.x;
+    const uint32_t slot = a.slots[b];
+    const int level = a.levels[b];
+    Query<AR, I> q;
+    query_from_row<AR, I>(ix, slot, q, lane);
+    Counters cnt = {0, 0, 0};
+    uint32_t closest = ix.entry_slot;
+    if (ix.max_level > level)
+        closest = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, level, cnt, lane);
+    const int top = level < ix.max_level ? level : ix.max_level;
+    uint32_t req = a.req_off[b] - a.req_base;
+    for (int l = top; l >= 0; --l) {
+        int cur = 0;
+        uint32_t sz = beam_search<AR, I>(ix, sh, q, closest, l, a.ef_add, slot, cnt, lane, cur);
+        // usearch connect_new_node_: forward links are refined to `connectivity` on every level
+        uint32_t nsel = refine<AR, I>(ix, sh, cur, sz, ix.M, cnt, lane);
+        uint32_t cap;
+        uint32_t* row = const_cast<uint32_t*>(adjacency(ix, slot, l, cap));
+        if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < nsel ? sh.sel_s[lane] : kInvalid;
+        if ((uint32_t)lane < ix.M) {
+            bool on = (uint32_t)lane < nsel;
+            a.req_key[req + lane] = on ? (((uint64_t)(uint32_t)l << 32) | sh.sel_s[lane]) : ~0ull;
+            a.req_val[req + lane] = on ? (((uint64_t)__float_as_uint(sh.sel_d[lane]) << 32) | slot) : 0ull;
+        }
+        req += ix.M;
+        if (nsel) closest = sh.sel_s[0];
+        __syncthreads();
+    }
+    if (lane == 0) {
+        atomicAdd(&a.stats[ST_ADD_EVALS], cnt.evals);
+        atomicAdd(&a.stats[ST_ADD_HOPS], cnt.hops);
+        atomicAdd(&a.stats[ST_ADDED], 1ull);
+        if (cnt.overflow) atomicAdd(&a.stats[ST_OVERFLOW], cnt.overflow);
+    }
+}
+
+struct LinkShared {
+    float lst_d[1][128];
+    uint32_t lst_s[1][128];
+    float t_d[128];
+    uint32_t t_s[128];
+    uint32_t u_slot[64];
+    float u_dist[64];
+    uint32_t sel_s[64];
+    float sel_d[64];
+};
+
+constexpr uint32_t kMaxNewPerTarget = 64;
+
+template <int AR, int I>
+__global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
+    __shared__ LinkShared sh;
+    const IndexView& ix = a.ix;
+    const int lane = lane_id();
+    const uint32_t r = blockIdx.x;
+    const uint64_t key = a.req_key[r];
+    if (key == ~0ull) return;
+    if (r > 0 && a.req_key[r - 1] == key) return;  // not the head of its (level, target) group
+    uint32_t n_new;
+    {
+        uint32_t idx = r + (uint32_t)lane;
+        bool same = idx < a.total && a.req_key[idx] == key;
+        uint64_t mask = __ballot(same);
+        n_new = ~mask ? (uint32_t)__builtin_ctzll(~mask) : kMaxNewPerTarget;
+    }
+    const uint32_t target = (uint32_t)key;
+    const int level = (int)(key >> 32);
+    uint32_t cap;
+    uint32_t* row = const_cast<uint32_t*>(adjacency(ix, target, level, cap));
+    uint32_t src = kInvalid;
+    float src_d = 0.f;
+    if ((uint32_t)lane < n_new) {
+        uint64_t v = a.req_val[r + lane];
+        src = (uint32_t)v;
+        src_d = __uint_as_float((uint32_t)(v >> 32));
+    }
+    // existing links; a link to a source being (re)inserted is superseded by the new request
+    uint32_t ex = (uint32_t)lane < cap ? row[lane] : kInvalid;
+    for (uint32_t j = 0; j < n_new; ++j) {
+        uint32_t sj = (uint32_t)__shfl((int)src, (int)j);
+        if (ex == sj) ex = kInvalid;
+    }
+    uint64_t emask = __ballot(ex != kInvalid);
+    const uint32_t cnt = (uint32_t)__popcll(emask);
+    if (ex != kInvalid) sh.u_slot[mbcnt(emask)] = ex;
+    __syncthreads();
+    if (cnt + n_new <= cap) {  // usearch: close_header.push_back(new_slot)
+        const bool is_new = lane >= (int)cnt && lane < (int)(cnt + n_new);
+        const uint32_t from_new = (uint32_t)__shfl((int)src, is_new ? lane - (int)cnt : 0);
+        if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < cnt ? sh.u_slot[lane] : (is_new ? from_new : kInvalid);
+        return;
+    }
+    // usearch: top = {new} U existing, all measured from `close_slot`; refine_(connectivity_max)
+    Counters c = {0, 0, 0};
+    Query<AR, I> q;
+    query_from_row<AR, I>(ix, target, q, lane);
+    eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, cnt, lane);
+    __syncthreads();
+    c.evals += cnt;
+    const uint32_t total = cnt + n_new;  // <= 32 + 64
+    if ((uint32_t)lane < cnt) {
+        sh.t_d[lane] = sh.u_dist[lane];
+        sh.t_s[lane] = sh.u_slot[lane];
+    }
+    if ((uint32_t)lane < n_new) {
+        sh.t_d[cnt + lane] = src_d;
+        sh.t_s[cnt + lane] = src;
+    }
+    __syncthreads();
+    for (uint32_t e = (uint32_t)lane; e < total; e += kWave) {  // rank sort, ascending (distance, slot)
+        float ed = sh.t_d[e];
+        uint32_t es = sh.t_s[e];
+        uint32_t rank = 0;
+        for (uint32_t f = 0; f < total; ++f) rank += key_less(sh.t_d[f], sh.t_s[f], ed, es) ? 1u : 0u;
+        sh.lst_d[0][rank] = ed;
+        sh.lst_s[0][rank] = es;
+    }
+    __syncthreads();
+    uint32_t nsel = refine<AR, I>(ix, sh, 0, total, cap, c, lane);
+    if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < nsel ? sh.sel_s[lane] : kInvalid;
+    if (lane == 0) atomicAdd(&a.stats[ST_ADD_EVALS], c.evals);
+}
+
+
+template <int AR, int I>
+static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
+    dim3 grid(a.nq), block(64);
+    if (I == 1 && a.stress_small_table && a.ef <= 128)
+        hipLaunchKernelGGL((hnsw_search_kernel<AR, 1, 128, 256, 1>), grid, block, 0, s, a);
+    else if (a.ef <= 128)
+        hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+template <int AR, int I>
+static hipError_t insert_ef(const InsertArgs& a, hipStream_t s) {
+    dim3 grid(a.n), block(64);
+    if (a.ef_add <= 128)
+        hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 128, 1024, 1>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 256, 1024, 2>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t launch_search_ar<VS_AR>(const SearchArgs& a, uint32_t iters, hipStream_t s) {
+    switch (iters) {
+        case 1: return search_ef<VS_AR, 1>(a, s);
+        case 2: return search_ef<VS_AR, 2>(a, s);
+        case 3: return search_ef<VS_AR, 3>(a, s);
+        case 4: return search_ef<VS_AR, 4>(a, s);
+        case 6: return search_ef<VS_AR, 6>(a, s);
+        case 8: return search_ef<VS_AR, 8>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <>
+hipError_t launch_insert_ar<VS_AR>(const InsertArgs& a, uint32_t iters, hipStream_t s) {
+    switch (iters) {
+        case 1: return insert_ef<VS_AR, 1>(a, s);
+        case 2: return insert_ef<VS_AR, 2>(a, s);
+        case 3: return insert_ef<VS_AR, 3>(a, s);
+        case 4: return insert_ef<VS_AR, 4>(a, s);
+        case 6: return insert_ef<VS_AR, 6>(a, s);
+        case 8: return insert_ef<VS_AR, 8>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <>
+hipError_t launch_link_ar<VS_AR>(const LinkArgs& a, uint32_t iters, hipStream_t s) {
+    dim3 grid(a.total), block(64);
+    switch (iters) {
+        case 1: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 1>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 2>), grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 3>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 4>), grid, block, 0, s, a); break;
+        case 6: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 6>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 8>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace vs

@@ -1,0 +1,69 @@
+// kernels_dispatch.hip -- picks the arithmetic (storage type x metric family) and forwards to the per-arithmetic
+// translation units (kernels_arith.hip, one object per -DVS_AR); also hosts the request sort of the build path.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "kernels.hpp"
+
+namespace vs {
+
+int arith_of(int scalar, int metric) {
+    switch (scalar) {
+        case SC_F32: return metric == L2SQ ? AR_F32_L2 : AR_F32_DOT;
+        case SC_F16: return metric == L2SQ ? AR_F16_L2 : AR_F16_DOT;
+        case SC_BF16: return metric == L2SQ ? AR_BF16_L2 : AR_BF16_DOT;
+        case SC_I8: return AR_I8;
+        default: return AR_B1;
+    }
+}
+
+bool search_supported(uint32_t iters, uint32_t ef) {
+    return (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8) && ef >= 1 && ef <= 256;
+}
+
+uint32_t visited_domain_bits(uint32_t ef) { return ef <= 128 ? VisitedCfg<1024, 1>::domain_bits : VisitedCfg<1024, 2>::domain_bits; }
+
+#define VS_DISPATCH(fn, args)                                  \
+    switch (arith_of(a.ix.scalar, a.ix.metric)) {              \
+        case AR_F32_DOT: return fn<AR_F32_DOT> args;           \
+        case AR_F32_L2: return fn<AR_F32_L2> args;             \
+        case AR_F16_DOT: return fn<AR_F16_DOT> args;           \
+        case AR_F16_L2: return fn<AR_F16_L2> args;             \
+        case AR_BF16_DOT: return fn<AR_BF16_DOT> args;         \
+        case AR_BF16_L2: return fn<AR_BF16_L2> args;           \
+        case AR_I8: return fn<AR_I8> args;                     \
+        default: return fn<AR_B1> args;                        \
+    }
+
+hipError_t launch_search(const SearchArgs& a, uint32_t iters, hipStream_t s) {
+    if (a.nq == 0) return hipSuccess;
+    if (!search_supported(iters, a.ef)) return hipErrorInvalidValue;
+    VS_DISPATCH(launch_search_ar, (a, iters, s))
+}
+
+hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    if (!search_supported(iters, a.ef_add)) return hipErrorInvalidValue;
+    VS_DISPATCH(launch_insert_ar, (a, iters, s))
+}
+
+hipError_t launch_link(const LinkArgs& a, uint32_t iters, hipStream_t s) {
+    if (a.total == 0) return hipSuccess;
+    VS_DISPATCH(launch_link_ar, (a, iters, s))
+}
+
+size_t sort_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    uint64_t* k = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, n ? n : 1, 0, 64, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in,
+                      uint64_t* vals_out, size_t n, unsigned end_bit, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, s);
+}
+
+}  // namespace vs

@@ -4,50 +4,90 @@
 namespace vs {
 
 // ---------------------------------------------------------------- row staging / small utilities
-__global__ void inv_norms_kernel(IndexView ix, float* inv_norm, const uint32_t* slots, uint32_t first, uint32_t n) {
+// f32 rows (dim floats, src_stride apart) -> storage rows (quantised, zero padded) + aux.  One wave per row.
+template <int AR>
+__global__ void quantise_rows_kernel(IndexView ix, uint4* vectors, float* aux, const float* src, uint32_t src_stride,
+                                     const uint32_t* slots, uint32_t first, uint32_t n) {
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = lane_id();
     if (w >= n) return;
     const uint32_t slot = slots ? slots[w] : first + w;
-    const float4* row = ix.vectors + (size_t)slot * ix.stride4;
-    float s = 0.f;
-    for (uint32_t i = lane; i < ix.stride4; i += kWave) s = accumulate<KDOT>(s, row[i], row[i]);
-    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) inv_norm[slot] = s > 0.f ? 1.0f / sqrtf(s) : 0.f;
+    const float* v = src + (size_t)w * src_stride;
+    float mag = 0.f;
+    if constexpr (AR == AR_I8) mag = magnitude_f64(v, ix.dim, 64, (uint32_t)lane);
+    uint4* row = vectors + (size_t)slot * ix.stride4;
+    typename Arith<AR>::acc_t sq = 0;
+    constexpr int SELF = Arith<AR>::scalar == SC_F32 ? AR_F32_DOT : Arith<AR>::scalar == SC_F16 ? AR_F16_DOT
+                         : Arith<AR>::scalar == SC_BF16 ? AR_BF16_DOT : AR;
+    for (uint32_t c = lane; c < ix.stride4; c += kWave) {
+        uint4 q = quantise_chunk<AR>(v, c * Arith<AR>::epc, ix.dim, mag);
+        row[c] = q;
+        if constexpr (AR != AR_B1) sq = accumulate<SELF>(sq, q, q);
+    }
+    if (needs_aux<AR>(ix.metric)) {
+        sq = group_sum(sq, 64);
+        if (lane == 0) {
+            if constexpr (AR == AR_I8) aux[slot] = (float)sq;
+            else aux[slot] = (float)sq > 0.f ? 1.0f / sqrtf((float)sq) : 0.f;
+        }
+    }
 }
 
-hipError_t launch_inv_norms(const IndexView& ix, float* inv_norm, const uint32_t* slots, uint32_t first, uint32_t n,
-                            hipStream_t s) {
+#define VS_AR_SWITCH(ar, CALL)                       \
+    switch (ar) {                                    \
+        case AR_F32_DOT: case AR_F32_L2: { constexpr int A = AR_F32_DOT; CALL; } break;   \
+        case AR_F16_DOT: case AR_F16_L2: { constexpr int A = AR_F16_DOT; CALL; } break;   \
+        case AR_BF16_DOT: case AR_BF16_L2: { constexpr int A = AR_BF16_DOT; CALL; } break; \
+        case AR_I8: { constexpr int A = AR_I8; CALL; } break;                              \
+        default: { constexpr int A = AR_B1; CALL; } break;                                 \
+    }
+
+hipError_t launch_quantise_rows(const IndexView& ix, uint4* vectors, float* aux, const float* src, uint32_t src_stride,
+                                const uint32_t* slots, uint32_t first, uint32_t n, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(inv_norms_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ix, inv_norm, slots, first, n);
+    const int ar = arith_of(ix.scalar, ix.metric);
+    VS_AR_SWITCH(ar, hipLaunchKernelGGL((quantise_rows_kernel<A>), dim3((n + 3) / 4), dim3(256), 0, s, ix, vectors, aux, src,
+                                        src_stride, slots, first, n))
     return hipGetLastError();
 }
 
-__global__ void scatter_rows_kernel(float* vectors, uint32_t stride_f, const float* src, uint32_t src_stride, uint32_t dim,
-                                    const uint32_t* slots, uint32_t first) {
-    const uint32_t r = blockIdx.x;
-    const uint32_t slot = slots ? slots[r] : first + r;
-    float* dst = vectors + (size_t)slot * stride_f;
-    const float* s = src + (size_t)r * src_stride;
-    for (uint32_t c = threadIdx.x; c < stride_f; c += blockDim.x) dst[c] = c < dim ? s[c] : 0.f;
+// aux of rows that are already in storage format (import path).
+template <int AR>
+__global__ void aux_rows_kernel(IndexView ix, float* aux, uint32_t n) {
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    if (w >= n) return;
+    const uint4* row = ix.vectors + (size_t)w * ix.stride4;
+    typename Arith<AR>::acc_t sq = 0;
+    for (uint32_t c = lane; c < ix.stride4; c += kWave) sq = accumulate<AR>(sq, row[c], row[c]);
+    sq = group_sum(sq, 64);
+    if (lane == 0) {
+        if constexpr (AR == AR_I8) aux[w] = (float)sq;
+        else aux[w] = (float)sq > 0.f ? 1.0f / sqrtf((float)sq) : 0.f;
+    }
 }
 
-hipError_t launch_scatter_rows(float* vectors, uint32_t stride_f, const float* src, uint32_t src_stride, uint32_t dim,
-                               const uint32_t* slots, uint32_t first, uint32_t n, hipStream_t s) {
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(stride_f >= 256 ? 256 : 64), 0, s, vectors, stride_f, src,
-                       src_stride, dim, slots, first);
+hipError_t launch_aux_rows(const IndexView& ix, float* aux, uint32_t n, hipStream_t s) {
+    const int ar = arith_of(ix.scalar, ix.metric);
+    if (!n || ar == AR_B1) return hipSuccess;
+    VS_AR_SWITCH(ar, hipLaunchKernelGGL((aux_rows_kernel<A>), dim3((n + 3) / 4), dim3(256), 0, s, ix, aux, n))
     return hipGetLastError();
 }
 
-__global__ void gather_rows_kernel(const float* vectors, uint32_t stride_f, float* dst, uint32_t dim) {
+// storage rows <-> unpadded raw rows (export / import): row_bytes payload, stride_bytes padded row.
+__global__ void copy_rows_kernel(uint8_t* dst, uint32_t dst_stride, const uint8_t* src, uint32_t src_stride,
+                                 uint32_t row_bytes, uint32_t dst_fill_to) {
     const uint32_t r = blockIdx.x;
-    for (uint32_t c = threadIdx.x; c < dim; c += blockDim.x) dst[(size_t)r * dim + c] = vectors[(size_t)r * stride_f + c];
+    uint8_t* d = dst + (size_t)r * dst_stride;
+    const uint8_t* sp = src + (size_t)r * src_stride;
+    for (uint32_t c = threadIdx.x; c < dst_fill_to; c += blockDim.x) d[c] = c < row_bytes ? sp[c] : (uint8_t)0;
 }
 
-hipError_t launch_gather_rows(const float* vectors, uint32_t stride_f, float* dst, uint32_t dim, uint32_t n, hipStream_t s) {
+hipError_t launch_copy_rows(void* dst, uint32_t dst_stride, const void* src, uint32_t src_stride, uint32_t row_bytes,
+                            uint32_t dst_fill_to, uint32_t n, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(dim >= 256 ? 256 : 64), 0, s, vectors, stride_f, dst, dim);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(n), dim3(256), 0, s, (uint8_t*)dst, dst_stride, (const uint8_t*)src, src_stride,
+                       row_bytes, dst_fill_to);
     return hipGetLastError();
 }
 
@@ -103,48 +143,111 @@ hipError_t launch_scatter_u32(uint32_t* dst, const uint32_t* idx, const uint32_t
 constexpr uint32_t kExactQB = 1024;   // queries per pass
 constexpr uint32_t kExactCH = 65536;  // base rows per pass
 
-__global__ void query_inv_norms_kernel(const float* q, uint32_t q_stride, uint32_t dim, uint32_t nq, float* out) {
+// Element k..k+3 of a stored row as floats (f16/bf16 widened, i8 as integers, b1 as 0/1).
+__device__ __forceinline__ void load4_dequant(const IndexView& ix, size_t row, uint32_t k, float (&o)[4]) {
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(ix.vectors) + row * (size_t)ix.stride4 * 16;
+    const uint32_t epc = ix.scalar == SC_F32 ? 4 : ix.scalar == SC_I8 ? 16 : ix.scalar == SC_B1 ? 128 : 8;
+    if (k >= ix.stride4 * epc) {  // the k extent of a tile may run past a short row: zeros, like the row's own padding
+        o[0] = o[1] = o[2] = o[3] = 0.f;
+        return;
+    }
+    switch (ix.scalar) {
+        case SC_F32: {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)k * 4);
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        } break;
+        case SC_F16: {
+            const uint2 v = *reinterpret_cast<const uint2*>(base + (size_t)k * 2);
+            o[0] = half_bits_to_float(v.x & 0xFFFFu); o[1] = half_bits_to_float(v.x >> 16);
+            o[2] = half_bits_to_float(v.y & 0xFFFFu); o[3] = half_bits_to_float(v.y >> 16);
+        } break;
+        case SC_BF16: {
+            const uint2 v = *reinterpret_cast<const uint2*>(base + (size_t)k * 2);
+            o[0] = bf16_bits_to_float(v.x & 0xFFFFu); o[1] = bf16_bits_to_float(v.x >> 16);
+            o[2] = bf16_bits_to_float(v.y & 0xFFFFu); o[3] = bf16_bits_to_float(v.y >> 16);
+        } break;
+        case SC_I8: {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(base + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (float)(int)(int8_t)((v >> (8 * j)) & 0xFFu);
+        } break;
+        default: {
+            const uint32_t v = base[k >> 3] >> (k & 7);  // k is a multiple of 4
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (float)((v >> j) & 1u);
+        } break;
+    }
+}
+
+// Exact path, step 0: queries -> the values the metric really sees (quantised, then widened back to f32),
+// kpad floats per query, plus the query-side aux of finalize().
+template <int AR>
+__global__ void prepare_queries_kernel(IndexView ix, const float* q, uint32_t q_stride, uint32_t nq, uint32_t kpad, float* qd,
+                                       float* q_aux) {
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = lane_id();
     if (w >= nq) return;
-    float s = 0.f;
-    for (uint32_t i = lane; i < dim; i += kWave) {
-        float x = q[(size_t)w * q_stride + i];
-        s = fmaf(x, x, s);
+    const float* v = q + (size_t)w * q_stride;
+    float mag = 0.f;
+    if constexpr (AR == AR_I8) mag = magnitude_f64(v, ix.dim, 64, (uint32_t)lane);
+    float sq = 0.f;
+    for (uint32_t c = lane; c * Arith<AR>::epc < kpad; c += kWave) {
+        const uint4 ch = quantise_chunk<AR>(v, c * Arith<AR>::epc, ix.dim, mag);
+        const uint32_t wds[4] = {ch.x, ch.y, ch.z, ch.w};
+        for (uint32_t j = 0; j < Arith<AR>::epc; ++j) {
+            const uint32_t e = c * Arith<AR>::epc + j;
+            if (e >= kpad) break;
+            float f;
+            if constexpr (Arith<AR>::scalar == SC_F32) f = __uint_as_float(wds[j]);
+            else if constexpr (Arith<AR>::scalar == SC_F16) f = half_bits_to_float((wds[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+            else if constexpr (Arith<AR>::scalar == SC_BF16) f = bf16_bits_to_float((wds[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+            else if constexpr (Arith<AR>::scalar == SC_I8) f = (float)(int)(int8_t)((wds[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+            else f = (float)((wds[j >> 5] >> (j & 31)) & 1u);
+            qd[(size_t)w * kpad + e] = f;
+            sq = fmaf(f, f, sq);
+        }
     }
-    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) out[w] = s > 0.f ? 1.0f / sqrtf(s) : 0.f;
+    for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) q_aux[w] = AR == AR_I8 ? sq : (sq > 0.f ? 1.0f / sqrtf(sq) : 0.f);
 }
 
+__device__ __forceinline__ float finalize_exact(const IndexView& ix, float acc, float q_aux, float r_aux) {
+    switch (ix.scalar) {
+        case SC_I8: return finalize<AR_I8>(ix.metric, (int)lrintf(acc), q_aux, r_aux);
+        case SC_B1: return acc;  // sum of (a-b)^2 over 0/1 values == popcount(xor)
+        default: return finalize<AR_F32_DOT>(ix.metric, acc, q_aux, r_aux);
+    }
+}
+__device__ __forceinline__ bool exact_needs_aux(const IndexView& ix) {
+    return ix.scalar == SC_I8 || (ix.scalar != SC_B1 && ix.metric == COS);
+}
+
+// KIND: KDOT accumulates a*b, KL2 accumulates (a-b)^2 (l2sq on float storage, hamming on b1).
 template <int KIND>
-__global__ __launch_bounds__(256) void exact_dist_kernel(IndexView ix, const float* queries, uint32_t q_stride,
-                                                         const float* q_inv, uint32_t q0, uint32_t nq_blk, uint32_t n0,
-                                                         uint32_t n_blk, float* D) {
+__global__ __launch_bounds__(256) void exact_dist_kernel(IndexView ix, const float* qd, uint32_t kpad, const float* q_aux,
+                                                         uint32_t q0, uint32_t nq_blk, uint32_t n0, uint32_t n_blk, float* D) {
     __shared__ float As[16][65];
     __shared__ float Bs[16][65];
     const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const uint32_t qt = blockIdx.y * 64, nt = blockIdx.x * 64;
     const uint32_t lrow = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;
-    const uint32_t stride_f = ix.stride4 * 4;
-    const float* vec = reinterpret_cast<const float*>(ix.vectors);
     float acc[4][4] = {};
-    for (uint32_t k0 = 0; k0 < stride_f; k0 += 16) {
+    for (uint32_t k0 = 0; k0 < kpad; k0 += 16) {
         {
-            uint32_t qi = qt + lrow;
-            const float* src = queries + (size_t)(q0 + qi) * q_stride;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t k = k0 + lk + j;
-                As[lk + j][lrow] = (qi < nq_blk && k < ix.dim) ? src[k] : 0.f;
-            }
-            uint32_t ni = nt + lrow;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ni < n_blk && k0 + lk < stride_f)
-                v = *reinterpret_cast<const float4*>(vec + (size_t)(n0 + ni) * stride_f + k0 + lk);
-            Bs[lk + 0][lrow] = v.x;
-            Bs[lk + 1][lrow] = v.y;
-            Bs[lk + 2][lrow] = v.z;
-            Bs[lk + 3][lrow] = v.w;
+            const uint32_t qi = qt + lrow;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi < nq_blk) a = *reinterpret_cast<const float4*>(qd + (size_t)(q0 + qi) * kpad + k0 + lk);
+            As[lk + 0][lrow] = a.x;
+            As[lk + 1][lrow] = a.y;
+            As[lk + 2][lrow] = a.z;
+            As[lk + 3][lrow] = a.w;
+            const uint32_t ni = nt + lrow;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ni < n_blk) load4_dequant(ix, (size_t)(n0 + ni), k0 + lk, v);
+            Bs[lk + 0][lrow] = v[0];
+            Bs[lk + 1][lrow] = v[1];
+            Bs[lk + 2][lrow] = v[2];
+            Bs[lk + 3][lrow] = v[3];
         }
         __syncthreads();
 #pragma unroll
@@ -169,17 +272,18 @@ __global__ __launch_bounds__(256) void exact_dist_kernel(IndexView ix, const flo
         }
         __syncthreads();
     }
+    const bool aux = exact_needs_aux(ix);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint32_t qi = qt + ty * 4 + i;
         if (qi >= nq_blk) continue;
-        float qinv = ix.metric == COS ? q_inv[q0 + qi] : 0.f;
+        float qa = aux ? q_aux[q0 + qi] : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint32_t ni = nt + tx * 4 + j;
             if (ni >= n_blk) continue;
-            float binv = ix.metric == COS ? ix.inv_norm[n0 + ni] : 0.f;
-            D[(size_t)qi * kExactCH + ni] = finalize(ix.metric, acc[i][j], qinv, binv);
+            float ra = aux ? ix.aux[n0 + ni] : 0.f;
+            D[(size_t)qi * kExactCH + ni] = finalize_exact(ix, acc[i][j], qa, ra);
         }
     }
 }
@@ -241,13 +345,28 @@ __global__ __launch_bounds__(64) void exact_select_kernel(IndexView ix, const fl
     if (lane == 0) out_found[qg] = sz;
 }
 
-size_t exact_scratch_bytes(uint32_t nq, uint32_t k) {
-    return (size_t)kExactQB * kExactCH * 4 + (size_t)nq * k * 8 + (size_t)nq * 8 + 256;
+static uint32_t exact_kpad(const IndexView& ix) {
+    return (ix.dim + 15u) & ~15u;  // k extent of the tiles; load4_dequant pads short rows with zeros
+}
+// the dot product is what cos / ip / every i8 metric are made of; l2sq and hamming accumulate (a-b)^2
+static bool exact_uses_l2(const IndexView& ix) { return ix.scalar == SC_B1 || (ix.scalar != SC_I8 && ix.metric == L2SQ); }
+
+size_t exact_scratch_bytes(uint32_t nq, uint32_t k, uint32_t dim) {
+    return (size_t)kExactQB * kExactCH * 4 + (size_t)nq * k * 8 + (size_t)nq * 8 + (size_t)nq * (dim + 16) * 4 + 1024;
+}
+
+static hipError_t prepare_queries(const IndexView& ix, const float* q, uint32_t q_stride, uint32_t nq, uint32_t kpad, float* qd,
+                                  float* q_aux, hipStream_t s) {
+    const int ar = arith_of(ix.scalar, ix.metric);
+    VS_AR_SWITCH(ar, hipLaunchKernelGGL((prepare_queries_kernel<A>), dim3((nq + 3) / 4), dim3(256), 0, s, ix, q, q_stride, nq, kpad,
+                                        qd, q_aux))
+    return hipGetLastError();
 }
 
 hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
     if (a.k == 0 || a.k > 256) return hipErrorInvalidValue;
+    const uint32_t kpad = exact_kpad(a.ix);
     char* p = (char*)scratch;
     float* D = (float*)p;
     p += (size_t)kExactQB * kExactCH * 4;
@@ -257,9 +376,12 @@ hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s) {
     p += (size_t)a.nq * a.k * 4;
     uint32_t* st_n = (uint32_t*)p;
     p += (size_t)a.nq * 4;
-    float* q_inv = (float*)p;
-    hipLaunchKernelGGL(query_inv_norms_kernel, dim3((a.nq + 3) / 4), dim3(256), 0, s, a.queries, a.q_stride, a.ix.dim,
-                       a.nq, q_inv);
+    float* q_aux = (float*)p;
+    p += (size_t)a.nq * 4;
+    p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    float* qd = (float*)p;
+    hipError_t e = prepare_queries(a.ix, a.queries, a.q_stride, a.nq, kpad, qd, q_aux, s);
+    if (e != hipSuccess) return e;
     if (a.slots == 0) {  // empty index: found = 0 everywhere
         hipLaunchKernelGGL(fill_u32_kernel, dim3(64), dim3(256), 0, s, a.out_found, 0u, (size_t)a.nq);
         hipLaunchKernelGGL(fill_u32_kernel, dim3(256), dim3(256), 0, s, (uint32_t*)a.out_keys, 0xFFFFFFFFu,
@@ -268,17 +390,16 @@ hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s) {
                            (size_t)a.nq * a.k);
         return hipGetLastError();
     }
+    const bool l2 = exact_uses_l2(a.ix);
     for (uint32_t q0 = 0; q0 < a.nq; q0 += kExactQB) {
         uint32_t nqb = a.nq - q0 < kExactQB ? a.nq - q0 : kExactQB;
         for (uint32_t n0 = 0; n0 < a.slots; n0 += kExactCH) {
             uint32_t nb = a.slots - n0 < kExactCH ? a.slots - n0 : kExactCH;
             dim3 grid((nb + 63) / 64, (nqb + 63) / 64);
-            if (a.ix.metric == L2SQ)
-                hipLaunchKernelGGL((exact_dist_kernel<KL2>), grid, dim3(256), 0, s, a.ix, a.queries, a.q_stride, q_inv, q0,
-                                   nqb, n0, nb, D);
+            if (l2)
+                hipLaunchKernelGGL((exact_dist_kernel<KL2>), grid, dim3(256), 0, s, a.ix, qd, kpad, q_aux, q0, nqb, n0, nb, D);
             else
-                hipLaunchKernelGGL((exact_dist_kernel<KDOT>), grid, dim3(256), 0, s, a.ix, a.queries, a.q_stride, q_inv, q0,
-                                   nqb, n0, nb, D);
+                hipLaunchKernelGGL((exact_dist_kernel<KDOT>), grid, dim3(256), 0, s, a.ix, qd, kpad, q_aux, q0, nqb, n0, nb, D);
             int first = n0 == 0, last = n0 + kExactCH >= a.slots;
             hipLaunchKernelGGL(exact_select_kernel, dim3(nqb), dim3(64), 0, s, a.ix, D, q0, n0, nb, a.k, first, last, st_d,
                                st_s, st_n, a.out_keys, a.out_dist, a.out_found);
@@ -288,38 +409,44 @@ hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s) {
 }
 
 // One query against every row (exhaustive path of filtered search / k beyond the LDS beam).
-__global__ void distance_row_kernel(IndexView ix, const float* q, uint32_t n, float* out) {
+// qd / q_aux: the prepared query (prepare_queries_kernel).  One wave per row.
+__global__ void distance_row_kernel(IndexView ix, const float* qd, const float* q_aux, uint32_t kpad, uint32_t n, float* out) {
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = lane_id();
     if (w >= n) return;
-    const float4* row = ix.vectors + (size_t)w * ix.stride4;
-    float acc = 0.f, q2 = 0.f;
-    for (uint32_t i = lane; i < ix.stride4; i += kWave) {
-        float4 v = row[i];
-        uint32_t e = i * 4;
-        float4 qv;
-        qv.x = e + 0 < ix.dim ? q[e + 0] : 0.f;
-        qv.y = e + 1 < ix.dim ? q[e + 1] : 0.f;
-        qv.z = e + 2 < ix.dim ? q[e + 2] : 0.f;
-        qv.w = e + 3 < ix.dim ? q[e + 3] : 0.f;
-        acc = ix.metric == L2SQ ? accumulate<KL2>(acc, qv, v) : accumulate<KDOT>(acc, qv, v);
-        q2 = accumulate<KDOT>(q2, qv, qv);
+    const bool l2 = ix.scalar == SC_B1 || (ix.scalar != SC_I8 && ix.metric == L2SQ);
+    float acc = 0.f;
+    for (uint32_t k = (uint32_t)lane * 4; k < kpad; k += kWave * 4) {
+        float v[4];
+        load4_dequant(ix, (size_t)w, k, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = qd[k + j];
+            if (l2) {
+                float d = a - v[j];
+                acc = fmaf(d, d, acc);
+            } else {
+                acc = fmaf(a, v[j], acc);
+            }
+        }
     }
-    for (int o = 32; o; o >>= 1) {
-        acc += __shfl_xor(acc, o);
-        q2 += __shfl_xor(q2, o);
-    }
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) {
-        float q_inv = q2 > 0.f ? 1.0f / sqrtf(q2) : 0.f;
-        out[w] = finalize(ix.metric, acc, q_inv, ix.metric == COS ? ix.inv_norm[w] : 0.f);
+        const bool aux = exact_needs_aux(ix);
+        out[w] = finalize_exact(ix, acc, aux ? q_aux[0] : 0.f, aux ? ix.aux[w] : 0.f);
     }
 }
 
 hipError_t launch_distance_row(const IndexView& ix, const float* d_query, uint32_t n, float* d_scratch, hipStream_t s,
                                float* host_out) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(distance_row_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ix, d_query, n, d_scratch);
-    hipError_t e = hipGetLastError();
+    const uint32_t kpad = exact_kpad(ix);
+    float* qd = d_scratch + n;  // scratch: n distances, then the prepared query and its aux
+    float* q_aux = qd + kpad;
+    hipError_t e = prepare_queries(ix, d_query, ix.dim, 1, kpad, qd, q_aux, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(distance_row_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ix, qd, q_aux, kpad, n, d_scratch);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(host_out, d_scratch, (size_t)n * 4, hipMemcpyDeviceToHost, s);
 }

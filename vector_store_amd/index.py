@@ -16,7 +16,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 COS, L2SQ, IP, HAMMING = 0, 1, 2, 3
 METRICS = {"cos": COS, "l2sq": L2SQ, "ip": IP, "hamming": HAMMING}
-F32 = 0
+F32, F16, BF16, I8, B1 = 0, 1, 2, 3, 4
+SCALARS = {"f32": F32, "f16": F16, "bf16": BF16, "i8": I8, "b1": B1}
 FREE_KEY = 0xFFFFFFFFFFFFFFFF
 
 PRED = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_void_p)
@@ -74,6 +75,8 @@ def lib():
     L.vs_hnsw_capacity.argtypes = [vp]
     L.vs_hnsw_size.restype = sz
     L.vs_hnsw_size.argtypes = [vp]
+    L.vs_hnsw_bytes_per_vector.restype = sz
+    L.vs_hnsw_bytes_per_vector.argtypes = [vp]
     L.vs_hnsw_add.argtypes = [vp, u64, vp, sz]
     L.vs_hnsw_add_batch.argtypes = [vp, vp, vp, sz, sz]
     L.vs_hnsw_add_batch_device.argtypes = [vp, vp, vp, sz, sz]
@@ -139,7 +142,9 @@ class HipUsearchIndex:
     def __init__(self, dimensions: int, metric: int = COS, connectivity: int = 16, expansion_add: int = 128,
                  expansion_search: int = 64, quantization: int = F32, device: int = -1, _stress: int = 0):
         self.L = lib()
-        self.dim, self.metric = int(dimensions), int(metric)
+        if quantization == B1:  # reference metric_kind(): B1 => Hamming (usearch.rs:450-457)
+            metric = HAMMING
+        self.dim, self.metric, self.scalar = int(dimensions), int(metric), int(quantization)
         self.M = connectivity or 16
         self.M0 = 2 * self.M
         o = _Options(dimensions, connectivity, expansion_add, expansion_search, metric, quantization, device, _stress)
@@ -164,6 +169,9 @@ class HipUsearchIndex:
 
     def size(self) -> int:
         return self.L.vs_hnsw_size(self.h)
+
+    def bytes_per_vector(self) -> int:
+        return self.L.vs_hnsw_bytes_per_vector(self.h)
 
     def add(self, primary_id: int, vector):
         v = np.ascontiguousarray(vector, dtype=np.float32)
@@ -267,7 +275,9 @@ class HipUsearchIndex:
         gi = self.graph_info()
         n, blocks = gi["slots"], gi["upper_blocks"]
         g = {
-            "vectors": np.zeros((n, self.dim), dtype=np.float32),
+            # storage format: f32 rows for F32, raw bytes (bytes_per_vector per row) otherwise
+            "vectors": np.zeros((n, self.dim), dtype=np.float32) if self.scalar == F32
+            else np.zeros((n, self.bytes_per_vector()), dtype=np.uint8),
             "levels": np.zeros(n, dtype=np.int32),
             "keys": np.zeros(n, dtype=np.uint64),
             "adj0": np.zeros((n, self.M0), dtype=np.uint32),
@@ -287,7 +297,7 @@ class HipUsearchIndex:
         if blocks == 0:
             upper = np.zeros((1, self.M), dtype=np.uint32)
         _check(self.L.vs_hnsw_import_graph(
-            self.h, n, _p(np.ascontiguousarray(g["vectors"], dtype=np.float32)),
+            self.h, n, _p(np.ascontiguousarray(g["vectors"], dtype=np.float32 if self.scalar == F32 else np.uint8)),
             _p(np.ascontiguousarray(g["levels"], dtype=np.int32)), _p(np.ascontiguousarray(g["keys"], dtype=np.uint64)),
             _p(np.ascontiguousarray(g["adj0"], dtype=np.uint32)),
             _p(np.ascontiguousarray(g["upper_off"], dtype=np.uint32)), _p(upper), blocks, int(g["max_level"]),

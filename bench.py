@@ -84,9 +84,9 @@ class Searcher:
         return self.keys.cpu().numpy().copy(), self.dist.cpu().numpy().copy()
 
 
-def build_index(vs, base, keys, metric, ef_add=128):
+def build_index(vs, base, keys, metric, ef_add=128, quantization="f32"):
     n, dim = base.shape
-    ix = vs.HipUsearchIndex(dim, vs.METRICS[metric], 16, ef_add, 64)
+    ix = vs.HipUsearchIndex(dim, vs.METRICS[metric], 16, ef_add, 64, quantization=vs.SCALARS[quantization])
     ix.reserve(n)
     torch.cuda.synchronize()
     t = time.perf_counter()
@@ -122,7 +122,7 @@ def cpu_baseline(ix, queries_host, k, ef, seconds):
     the host cores of this box: one query per call from T threads (reference usearch.rs:212)."""
     import oracle
     g = ix.export_graph()
-    o = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef)
+    o = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef, quantization=ix.scalar)
     o.import_graph(g)
     del g
     o.set_expansion_search(ef)
@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--rank", type=int, default=24, help="latent dimension of the lowrank generator")
     ap.add_argument("--ef", type=int, default=0, help="expansion_search; 0 = smallest of 64,96,..,256 with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.95)
+    ap.add_argument("--quantization", default="f32", choices=["f32", "f16", "bf16", "i8", "b1"], help="storage type (usearch ScalarKind)")
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall seconds of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-sharded-leg", action="store_true")
@@ -189,7 +190,7 @@ def main():
     base = make_data(n, dim, a.dist, 1234 + (rank if shard_mode else 0), dev, a.rank)
     queries = make_data(nq, dim, a.dist, 4321 + (0 if shard_mode else rank), dev, a.rank)
     keys = np.arange(n, dtype=np.uint64) + (np.uint64(rank * n) if shard_mode else np.uint64(0))
-    ix, build_s = build_index(vs, base, keys, a.metric)
+    ix, build_s = build_index(vs, base, keys, a.metric, quantization=a.quantization)
     st = ix.stats(reset=True)
     build_info = {"vectors_per_s": n / build_s, "seconds": build_s, "vectors": n,
                   "evals_per_add": st["add_evals"] / max(st["added"], 1)}
@@ -249,7 +250,8 @@ def main():
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))  # HIP events on the launch stream
     e_q = st["search_evals"] / max(st["queries"], 1)
     h_q = st["search_hops"] / max(st["queries"], 1)
-    b_q = e_q * dim * 4 + h_q * ADJ_BYTES + dim * 4  # algorithmic bytes per query
+    row_b = ix.bytes_per_vector()  # dim * s, s = stored scalar size
+    b_q = e_q * row_b + h_q * ADJ_BYTES + dim * 4  # algorithmic bytes per query
     achieved = b_q * nq / (kernel_ms * 1e-3) / 1e9
     total_q = nq * a.steps * (1 if shard_mode else world)
     value = total_q / elapsed
@@ -258,8 +260,8 @@ def main():
         "metric": "QPS at recall@10>=0.95 (hnsw_search, inputs resident in HBM)",
         "value": value, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n}x{dim} {a.metric} top-{k} per GPU, {nq} queries/step, M=16 ef_add=128 ef_search={ef}",
+        "vs_baseline": None, "dtype": a.quantization, "data": "synthetic",
+        "config": {"workload": f"{n}x{dim} {a.metric} top-{k} per GPU, {nq} queries/step, M=16 ef_add=128 ef_search={ef}" + ("" if a.quantization == "f32" else f" {a.quantization}"),
                    "distribution": a.dist + (f"{a.rank}" if a.dist == "lowrank" else ""), "mode": a.mode if world > 1 else "single",
                    "index_vectors_total": n * (world if shard_mode else 1)},
         "recall_at_10": round(recall, 4), "ef_search": ef, "ef_sweep": sweep,
@@ -283,7 +285,7 @@ def main():
         try:
             sbase = make_data(n, dim, a.dist, 777 + rank, dev, a.rank)
             skeys = np.arange(n, dtype=np.uint64) + np.uint64(rank * n)
-            six, sbuild = build_index(vs, sbase, skeys, a.metric)
+            six, sbuild = build_index(vs, sbase, skeys, a.metric, quantization=a.quantization)
             six.set_expansion_search(ef)
             sq = make_data(nq, dim, a.dist, 4321, dev, a.rank)
             gs = sharded.ShardedSearcher(six, sq, k, dist, vs)

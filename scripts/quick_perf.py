@@ -36,12 +36,13 @@ def main():
     ap.add_argument("--efs", default="64,128,256")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--rank", type=int, default=32)
+    ap.add_argument("--quant", default="f32")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     base = make_data(a.n, a.dim, a.dist, 1234, dev, a.rank)
     q = make_data(a.nq, a.dim, a.dist, 4321, dev, a.rank)
     torch.cuda.synchronize()
-    ix = vs.HipUsearchIndex(a.dim, vs.METRICS[a.metric])
+    ix = vs.HipUsearchIndex(a.dim, vs.METRICS[a.metric], quantization=vs.SCALARS[a.quant])
     ix.reserve(a.n)
     keys = np.arange(a.n, dtype=np.uint64)
     t = time.time()
@@ -79,7 +80,7 @@ def main():
         eq, hq = st["search_evals"] / st["queries"], st["search_hops"] / st["queries"]
         got = ok.cpu().numpy()
         rec = np.mean([len(set(truth[i].tolist()) & set(got[i].tolist())) / k for i in range(0, a.nq, 5)])
-        bq = eq * a.dim * 4 + hq * 132 + a.dim * 4
+        bq = eq * ix.bytes_per_vector() + hq * 132 + a.dim * 4
         print(f"ef={ef}: {ms:.2f} ms/batch, {a.nq / ms * 1e3:.0f} QPS, recall@{k}={rec:.4f}, E_q={eq:.0f} H_q={hq:.0f} "
               f"B_q={bq / 1e6:.2f} MB -> {bq * a.nq / ms / 1e6:.0f} GB/s ({bq * a.nq / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s) "
               f"overflow={st['visited_overflow']}", flush=True)

@@ -310,7 +310,12 @@ __device__ __forceinline__ void query_from_f32(const IndexView& ix, const float*
     float mag = 0.f;
     if constexpr (AR == AR_I8) mag = magnitude_f64(v, ix.dim, ix.lanes, li);
 #pragma unroll
-    for (int i = 0; i < I; ++i) q.c[i] = quantise_chunk<AR>(v, ((uint32_t)i * ix.lanes + li) * Arith<AR>::epc, ix.dim, mag);
+    for (int i = 0; i < I; ++i) {
+        q.c[i] = quantise_chunk<AR>(v, ((uint32_t)i * ix.lanes + li) * Arith<AR>::epc, ix.dim, mag);
+        // keep each chunk's loads next to their use: without it the scheduler hoists all 16*I element loads
+        // of the i8 cast and the kernel spills
+        if constexpr (Arith<AR>::epc > 8) __builtin_amdgcn_sched_barrier(0);
+    }
     q.aux = needs_aux<AR>(ix.metric) ? aux_of<AR, I>(ix, q) : 0.f;
 }
 
@@ -362,7 +367,7 @@ __device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup
 template <int AR, int I>
 __device__ __forceinline__ void eval_batch(const IndexView& ix, const Query<AR, I>& q, const uint32_t* u_slot,
                                            float* u_dist, uint32_t m, int lane) {
-    constexpr int U = I >= 6 ? 2 : (I >= 2 ? 4 : 8);
+    constexpr int U = (I >= 6 || (AR == AR_I8 && I >= 3)) ? 2 : 4;
     const uint32_t lg = ix.lanes_log2;
     const uint32_t V = 64u >> lg;
     const uint32_t grp = (uint32_t)lane >> lg, li = (uint32_t)lane & (ix.lanes - 1);

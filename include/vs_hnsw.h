@@ -64,7 +64,8 @@ typedef struct vs_hnsw_options {
     int metric;       /* vs_metric_kind */
     int quantization; /* vs_scalar_kind */
     int device;       /* HIP device ordinal; -1 = current device */
-    int reserved;     /* 0; bit 0 = test hook: tiny visited table in search (forces the overflow path) */
+    int reserved;     /* 0; test hooks: bit 0 = tiny visited table in search (forces the overflow path),
+                         bit 1 = exact search on the VALU tile kernel instead of MFMA */
 } vs_hnsw_options;
 
 /* -- lifecycle: usearch::Index::new (usearch.rs:172), drop ------------------------------- */

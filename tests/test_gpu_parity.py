@@ -487,3 +487,34 @@ def test_async_search_matches_blocking_search():
     for i in range(200):
         assert got[i][2] == 0
         assert got[i][0].tolist() == want[i][0].tolist() and got[i][1].tolist() == want[i][1].tolist()
+
+
+@pytest.mark.parametrize("metric,quant", [("cos", "f32"), ("ip", "f32"), ("cos", "f16"), ("ip", "i8")])
+def test_exact_mfma_block_distances_equal_valu_kernel(metric, quant):
+    """K8: the MFMA block-distance kernel (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain) returns what the
+    VALU tile kernel returns -- same keys, distances to the last bit or within 1 ulp-scale tolerance."""
+    v = vs()
+    n, dim, k = 30000, 768, 10
+    data = _dataset(n + 256, dim, 91)
+    base, q = data[:n], data[n:]
+    if metric == "ip":
+        base = base / np.linalg.norm(base, axis=1, keepdims=True)
+    out = {}
+    for hook in (0, 2):  # options.reserved bit 1: dot-product family on the VALU kernel
+        ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS[quant], _stress=hook)
+        ix.reserve(n)
+        ix.add_batch(np.arange(n, dtype=np.uint64), base)
+        out[hook] = ix.exact_search_batch(q, k)  # q = 256: the batched configuration C5 of BASELINE.json
+    (mk, md, mf), (vk, vd, vf) = out[0], out[2]
+    assert (mf == k).all() and (vf == k).all()
+    assert np.allclose(md, vd, rtol=1e-6, atol=1e-6)
+    assert np.mean([mk[i].tolist() == vk[i].tolist() for i in range(len(q))]) >= 0.99
+    if quant == "f32":
+        b64, q64 = base.astype(np.float64), q.astype(np.float64)
+        if metric == "ip":
+            D = 1.0 - q64 @ b64.T
+        else:
+            D = 1.0 - (q64 / np.linalg.norm(q64, axis=1, keepdims=True)) @ (b64 / np.linalg.norm(b64, axis=1, keepdims=True)).T
+        truth = np.argsort(D, axis=1, kind="stable")[:, :k]
+        assert np.mean([set(mk[i].tolist()) == set(truth[i].tolist()) for i in range(len(q))]) >= 0.99
+        assert all(close(md[i, j], D[i, int(mk[i, j])]) for i in range(0, 256, 17) for j in range(k))

@@ -117,6 +117,7 @@ struct Engine {
     // configuration (reference usearch.rs:74-82)
     uint32_t dim = 0, M = 16, M0 = 32, ef_add = 128;
     std::atomic<uint32_t> ef_search{64};
+    std::atomic<int> exact_valu{0};  // VS_HNSW_EXACT_VALU=1 or options.reserved bit 1: exact search without MFMA
     int metric = VS_METRIC_COS;
     int device = 0;
     bool stress_small_table = false;  // vs_hnsw_options.reserved bit 0 (tests only)
@@ -206,6 +207,7 @@ struct Engine {
         if (metric < VS_METRIC_COS || metric > VS_METRIC_HAMMING) fail(VS_ERR_INVALID_ARGUMENT, "unknown metric");
         dim = (uint32_t)o.dimensions;
         stress_small_table = (o.reserved & 1) != 0;
+        exact_valu = (o.reserved & 2) ? 1 : 0;
         M = o.connectivity ? (uint32_t)o.connectivity : 16;  // usearch default_connectivity
         if (M < 2 || M > 32) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 32]");
         M0 = 2 * M;
@@ -627,6 +629,7 @@ struct Engine {
         a.nq = (uint32_t)nq;
         a.k = (uint32_t)k;
         a.slots = (uint32_t)slots;
+        a.use_valu = exact_valu.load() ? 1u : 0u;
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;

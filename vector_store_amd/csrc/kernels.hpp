@@ -79,6 +79,7 @@ struct ExactArgs {
     const float* queries;
     uint32_t q_stride, nq, k;
     uint32_t slots;  // rows [0, slots) are scanned; removed rows skipped
+    uint32_t use_valu;  // 1: dot-product family on the VALU tile kernel instead of MFMA (cross-check)
     uint64_t* out_keys;
     float* out_dist;
     uint32_t* out_found;

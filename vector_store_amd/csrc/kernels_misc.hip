@@ -288,6 +288,76 @@ __global__ __launch_bounds__(256) void exact_dist_kernel(IndexView ix, const flo
     }
 }
 
+// K8 of SURVEY.md section 2.3 -- block distances on the matrix cores: a dense Q[128 x K] . C^T[K x 128] tile per
+// workgroup with v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate: bit-for-bit a k-ordered fmaf chain, so the
+// scores equal the VALU kernel's).  This is the one place of the path that really is a dense contraction
+// (exact search, ground truth, the q = 256 batched inner-product configuration); the graph walk is a gather.
+// Dot-product family only (cos / ip / every i8 metric); l2sq and hamming keep the (a-b)^2 VALU kernel.
+// 4 waves, each a 64 x 64 quadrant = 2 x 2 MFMA tiles (64 accumulator registers); K staged 32 deep through LDS.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kMfmaKC = 32;
+
+__global__ __launch_bounds__(256) void exact_dist_mfma_kernel(IndexView ix, const float* qd, uint32_t kpad, const float* q_aux,
+                                                              uint32_t q0, uint32_t nq_blk, uint32_t n0, uint32_t n_blk, float* D) {
+    __shared__ float As[kMfmaKC][132];
+    __shared__ float Bs[kMfmaKC][132];
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t wy = w >> 1, wx = w & 1;
+    const uint32_t qt = blockIdx.y * 128, nt = blockIdx.x * 128;
+    const uint32_t lrow = t >> 1, lf4 = (t & 1) * 4;  // staging: row of the tile, first of 4 float4 of the K chunk
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (uint32_t k0 = 0; k0 < kpad; k0 += kMfmaKC) {
+        float a[16], b[16];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t k = k0 + (lf4 + f) * 4;
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qt + lrow < nq_blk && k < kpad) av = *reinterpret_cast<const float4*>(qd + (size_t)(q0 + qt + lrow) * kpad + k);
+            a[4 * f] = av.x; a[4 * f + 1] = av.y; a[4 * f + 2] = av.z; a[4 * f + 3] = av.w;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (nt + lrow < n_blk && k < kpad) load4_dequant(ix, (size_t)(n0 + nt + lrow), k, bv);
+            b[4 * f] = bv[0]; b[4 * f + 1] = bv[1]; b[4 * f + 2] = bv[2]; b[4 * f + 3] = bv[3];
+        }
+        __syncthreads();  // the previous chunk's fragments have been consumed
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            As[lf4 * 4 + e][lrow] = a[e];
+            Bs[lf4 * 4 + e][lrow] = b[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kMfmaKC / 2; ++kk) {
+            const uint32_t kr = 2 * kk + (lane >> 5), c = lane & 31;
+            const float a0 = As[kr][wy * 64 + c], a1 = As[kr][wy * 64 + 32 + c];
+            const float b0 = Bs[kr][wx * 64 + c], b1 = Bs[kr][wx * 64 + 32 + c];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    const bool aux = exact_needs_aux(ix);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t ni = nt + wx * 64 + j * 32 + (lane & 31);  // C/D layout: column on the lane,
+            const float ra = (aux && ni < n_blk) ? ix.aux[n0 + ni] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t qi = qt + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // row in the registers
+                if (qi < nq_blk && ni < n_blk)
+                    D[(size_t)qi * kExactCH + ni] = finalize_exact(ix, acc[i][j][r], aux ? q_aux[q0 + qi] : 0.f, ra);
+            }
+        }
+}
+
 using SelectShared = BeamShared<256, 256>;
 
 __global__ __launch_bounds__(64) void exact_select_kernel(IndexView ix, const float* D, uint32_t q0, uint32_t n0,
@@ -398,8 +468,11 @@ hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s) {
             dim3 grid((nb + 63) / 64, (nqb + 63) / 64);
             if (l2)
                 hipLaunchKernelGGL((exact_dist_kernel<KL2>), grid, dim3(256), 0, s, a.ix, qd, kpad, q_aux, q0, nqb, n0, nb, D);
-            else
+            else if (a.use_valu)
                 hipLaunchKernelGGL((exact_dist_kernel<KDOT>), grid, dim3(256), 0, s, a.ix, qd, kpad, q_aux, q0, nqb, n0, nb, D);
+            else
+                hipLaunchKernelGGL(exact_dist_mfma_kernel, dim3((nb + 127) / 128, (nqb + 127) / 128), dim3(256), 0, s, a.ix, qd,
+                                   kpad, q_aux, q0, nqb, n0, nb, D);
             int first = n0 == 0, last = n0 + kExactCH >= a.slots;
             hipLaunchKernelGGL(exact_select_kernel, dim3(nqb), dim3(64), 0, s, a.ix, D, q0, n0, nb, a.k, first, last, st_d,
                                st_s, st_n, a.out_keys, a.out_dist, a.out_found);

@@ -518,3 +518,32 @@ def test_exact_mfma_block_distances_equal_valu_kernel(metric, quant):
         truth = np.argsort(D, axis=1, kind="stable")[:, :k]
         assert np.mean([set(mk[i].tolist()) == set(truth[i].tolist()) for i in range(len(q))]) >= 0.99
         assert all(close(md[i, j], D[i, int(mk[i, j])]) for i in range(0, 256, 17) for j in range(k))
+
+
+@pytest.mark.parametrize("metric,dim", [("cos", 768), ("l2sq", 100)])
+def test_wide_beam_up_to_512(metric, dim):
+    """k = 500 (CQL LIMIT 100 x oversampling 5, validator quantization_and_rescoring.rs:109) stays on the LDS
+    beam kernel (ef <= 512) and matches the CPU algorithm on the same graph."""
+    v = vs()
+    n = 6000
+    data = _dataset(n + 32, dim, 333)
+    o = OracleIndex(dim, oracle.METRICS[metric])
+    o.reserve(n)
+    o.add_batch(np.arange(n, dtype=np.uint64), data[:n], threads=4)
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric])
+    ix.import_graph(o.export_graph())
+    for ef, k in ((300, 100), (64, 500)):
+        o.set_expansion_search(ef)
+        ix.set_expansion_search(ef)
+        ix.stats(reset=True)
+        gk, gd, gf = ix.search_batch(data[n:], k)
+        assert ix.stats()["queries"] == 32  # the beam kernel ran (the exhaustive path does not count queries)
+        same = 0
+        for i in range(32):
+            ok_, od_ = o.search(data[n + i], k)
+            assert gf[i] == len(ok_) == k
+            assert np.allclose(gd[i], od_, rtol=1e-5, atol=1e-5)
+            same += gk[i].tolist() == ok_.tolist()
+        assert same >= 29, (ef, k, same)
+    k1, d1 = ix.search(data[n], 500)  # single-query entry point too
+    assert len(k1) == 500

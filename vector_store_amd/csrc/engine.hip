@@ -112,6 +112,7 @@ struct Lease {
 constexpr uint32_t kMaxSubBatch = 8192;
 constexpr uint32_t kSubBatchRatio = 16;
 constexpr uint32_t kChunk = 32768;  // vectors staged per host->device copy
+constexpr uint32_t kMaxBeam = 512;  // widest beam (and k) the LDS search kernel holds
 
 struct Engine {
     // configuration (reference usearch.rs:74-82)
@@ -593,8 +594,8 @@ struct Engine {
     void check_search(size_t k, uint32_t& ef) const {
         if (k == 0) fail(VS_ERR_INVALID_ARGUMENT, "k must be > 0");
         ef = (uint32_t)std::max<size_t>(ef_search.load(), k);  // usearch: expansion = max(expansion_search, wanted)
-        if (ef > 256)
-            fail(VS_ERR_UNSUPPORTED, "k / expansion_search above 256 needs the exhaustive path (use exact search)");
+        if (ef > kMaxBeam)
+            fail(VS_ERR_UNSUPPORTED, "k / expansion_search above 512 needs the exhaustive path (use exact search)");
         if (slots > (1ull << visited_domain_bits(ef)))
             fail(VS_ERR_UNSUPPORTED, "index too large for the LDS visited table of this beam width");
     }
@@ -691,7 +692,7 @@ struct Engine {
         if (!n_live) return 0;
         size_t fetch = std::max<size_t>(k, ef_search.load());
         for (;;) {
-            if (fetch > 256 || fetch >= n_live) break;
+            if (fetch > kMaxBeam || fetch >= n_live) break;
             std::vector<uint64_t> kk(fetch);
             std::vector<float> dd(fetch);
             size_t f = 0;
@@ -709,16 +710,24 @@ struct Engine {
         std::vector<float> dd;
         std::vector<uint64_t> kk;
         all_distances(q, dd, kk);
-        std::vector<uint32_t> order;
-        order.reserve(dd.size());
+        // Walk the members in ascending distance and ask the predicate lazily: about k / selectivity calls
+        // instead of one per member (the reference's predicate takes a table read-lock per call).
+        std::vector<uint32_t> heap;
+        heap.reserve(dd.size());
         for (uint32_t s = 0; s < dd.size(); ++s)
-            if (kk[s] != kFreeKey && pred(kk[s], pctx)) order.push_back(s);
-        size_t out = std::min(k, order.size());
-        std::partial_sort(order.begin(), order.begin() + out, order.end(),
-                          [&](uint32_t a, uint32_t b) { return dd[a] < dd[b] || (dd[a] == dd[b] && a < b); });
-        for (size_t i = 0; i < out; ++i) {
-            keys[i] = kk[order[i]];
-            dist[i] = dd[order[i]];
+            if (kk[s] != kFreeKey) heap.push_back(s);
+        auto farther = [&](uint32_t a, uint32_t b) { return dd[a] > dd[b] || (dd[a] == dd[b] && a > b); };
+        std::make_heap(heap.begin(), heap.end(), farther);
+        size_t out = 0;
+        while (out < k && !heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), farther);
+            const uint32_t s = heap.back();
+            heap.pop_back();
+            if (pred(kk[s], pctx)) {
+                keys[out] = kk[s];
+                dist[out] = dd[s];
+                ++out;
+            }
         }
         return out;
     }
@@ -1072,7 +1081,7 @@ int vs_hnsw_search(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* k
         check_dim(h, dim);
         uint32_t ef;
         *found = 0;
-        if (k > 256 || std::max<size_t>(k, h->e.ef_search.load()) > 256) {
+        if (k > vs::kMaxBeam || std::max<size_t>(k, h->e.ef_search.load()) > vs::kMaxBeam) {
             // beyond the LDS beam: exhaustive ranking (exact, superset of what the beam would find)
             struct All {
                 static int yes(uint64_t, void*) { return 1; }

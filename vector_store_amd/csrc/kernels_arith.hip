@@ -212,8 +212,10 @@ static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((hnsw_search_kernel<AR, 1, 128, 256, 1>), grid, block, 0, s, a);
     else if (a.ef <= 128)
         hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1>), grid, block, 0, s, a);
-    else
+    else if (a.ef <= 256)
         hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2>), grid, block, 0, s, a);
+    else  // wide beams (k up to 512: CQL LIMIT x oversampling): 39 KB LDS, 4 waves per CU
+        hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 512, 2048, 2>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

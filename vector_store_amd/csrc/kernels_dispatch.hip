@@ -19,10 +19,12 @@ int arith_of(int scalar, int metric) {
 }
 
 bool search_supported(uint32_t iters, uint32_t ef) {
-    return (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8) && ef >= 1 && ef <= 256;
+    return (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8) && ef >= 1 && ef <= 512;
 }
 
-uint32_t visited_domain_bits(uint32_t ef) { return ef <= 128 ? VisitedCfg<1024, 1>::domain_bits : VisitedCfg<1024, 2>::domain_bits; }
+uint32_t visited_domain_bits(uint32_t ef) {
+    return ef <= 128 ? VisitedCfg<1024, 1>::domain_bits : ef <= 256 ? VisitedCfg<1024, 2>::domain_bits : VisitedCfg<2048, 2>::domain_bits;
+}
 
 #define VS_DISPATCH(fn, args)                                  \
     switch (arith_of(a.ix.scalar, a.ix.metric)) {              \
@@ -44,7 +46,7 @@ hipError_t launch_search(const SearchArgs& a, uint32_t iters, hipStream_t s) {
 
 hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    if (!search_supported(iters, a.ef_add)) return hipErrorInvalidValue;
+    if (!search_supported(iters, a.ef_add) || a.ef_add > 256) return hipErrorInvalidValue;
     VS_DISPATCH(launch_insert_ar, (a, iters, s))
 }
 

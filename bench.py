@@ -6,7 +6,7 @@
 
 A "step" is one pass of the hot path (hnsw_search, one wavefront per query) over one batch of
 `--nq` synthetic queries that are already resident in HBM.  Workload at N=1 = BASELINE.json
-configs[1]: 1M x 768 cosine, top-10 (ef_search chosen as the smallest of {64,96,...,256} reaching
+configs[1]: 1M x 768 cosine, top-10 (ef_search chosen as the smallest of {64,96,...,256,320,...,512} reaching
 recall@10 >= 0.95 against the exact brute-force ground truth computed on the GPU).
 
 Multi-GPU (`--mode replica`, default): the reference scales by replication -- every vector-store
@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--metric", default="cos", choices=["cos", "l2sq", "ip"])
     ap.add_argument("--dist", default="lowrank", choices=["lowrank", "gaussian"])
     ap.add_argument("--rank", type=int, default=24, help="latent dimension of the lowrank generator")
-    ap.add_argument("--ef", type=int, default=0, help="expansion_search; 0 = smallest of 64,96,..,256 with recall >= target")
+    ap.add_argument("--ef", type=int, default=0, help="expansion_search; 0 = smallest of 64,96,..,512 with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--quantization", default="f32", choices=["f32", "f16", "bf16", "i8", "b1"], help="storage type (usearch ScalarKind)")
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
@@ -205,10 +205,10 @@ def main():
         step = se.step
         result_keys = lambda: se.keys.cpu().numpy()
 
-    # ---- beam width: smallest of {64,96,...,256} reaching the recall target
+    # ---- beam width: smallest of {64,96,...,256,320,...,512} reaching the recall target
     sweep = []
     chosen = None
-    for ef in ([a.ef] if a.ef else [64, 96, 128, 160, 192, 224, 256]):
+    for ef in ([a.ef] if a.ef else [64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512]):
         ix.set_expansion_search(ef)
         step()
         torch.cuda.synchronize()

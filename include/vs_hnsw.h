@@ -79,7 +79,11 @@ VS_API size_t vs_hnsw_size(const vs_hnsw* index); /* live members; the reference
 /* bytes of one stored vector: dim*4 (f32), dim*2 (f16, bf16), dim (i8), ceil(dim/8) (b1) */
 VS_API size_t vs_hnsw_bytes_per_vector(const vs_hnsw* index);
 
-/* -- usearch::Index::add(key, &[f32]) (usearch.rs:191-197) ------------------------------ */
+/* -- usearch::Index::add(key, &[f32]) (usearch.rs:191-197) ------------------------------
+ * Validates (reserved / duplicate key, capacity, dimension) and copies the vector before returning.  The
+ * graph insertion itself is deferred and done in bulk: every later call on the index (search, remove,
+ * reserve, size, stats, export ...) first inserts what is staged, so callers observe exactly the
+ * sequential semantics -- adds are fire-and-forget in the reference too (usearch.rs:1028-1034). */
 VS_API int vs_hnsw_add(vs_hnsw* index, uint64_t key, const float* vector, size_t dim);
 /* n vectors, row-major n x dim.  The benchmark driver's bulk path (crates/benchmark build-index). */
 VS_API int vs_hnsw_add_batch(vs_hnsw* index, const uint64_t* keys, const float* vectors, size_t n, size_t dim);

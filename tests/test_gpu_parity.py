@@ -268,7 +268,7 @@ def test_gpu_build_recall_and_invariants(metric, dim, n):
 
 
 def test_sequential_adds_build_the_oracle_graph():
-    """One add per call (sub-batch of 1) is the sequential usearch algorithm: adjacency rows match
+    """One add at a time (a barrier after each: sub-batch of 1) is the sequential usearch algorithm: adjacency rows match
     the single-threaded CPU restatement except where an f32 near-tie flips a heuristic decision."""
     v = vs()
     n, dim = 1500, 16
@@ -280,6 +280,7 @@ def test_sequential_adds_build_the_oracle_graph():
     for i in range(n):
         o.add(i, base[i])
         ix.add(i, base[i])
+        assert ix.size() == i + 1  # size() is a barrier: the staged vector is inserted now, alone
     go, gg = o.export_graph(), ix.export_graph()
     assert (go["levels"] == gg["levels"]).all()
     assert go["entry_slot"] == gg["entry_slot"] and go["max_level"] == gg["max_level"]

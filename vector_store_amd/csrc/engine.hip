@@ -136,6 +136,7 @@ struct Engine {
     int32_t* d_levels = nullptr;
     unsigned long long* d_stats = nullptr;
     size_t capacity = 0, upper_cap = 0;
+    std::atomic<size_t> capacity_atomic{0};  // mirror of `capacity` for lock-free reads in add_one
 
     // host bookkeeping (guarded by mod_mu)
     std::mutex mod_mu;
@@ -153,17 +154,24 @@ struct Engine {
     std::atomic<int32_t> max_level{-1};
 
     // batching of concurrent single-vector callers
-    struct PendingAdd {
-        uint64_t key;
-        const float* v;
-        int status = 0;
-        std::string err;
-        bool done = false;
+    // Deferred single-vector adds (vs_hnsw_add): validated and queued under pend_mu, inserted in bulk by
+    // flush_pending() -- see add_one().
+    struct Pending {
+        std::vector<uint64_t> keys;
+        std::vector<float> vecs;
+        std::unordered_set<uint64_t> keyset;
+        void clear() {
+            keys.clear();
+            vecs.clear();
+            keyset.clear();
+        }
     };
-    std::mutex aq_mu;
-    std::condition_variable aq_cv;
-    std::vector<PendingAdd*> aq;
-    bool a_leader = false;
+    std::mutex pend_mu;
+    Pending pend;
+    std::unordered_set<uint64_t> flushing_keys;  // taken out of `pend`, not yet in `lookup`
+    std::atomic<size_t> queued{0};               // pending + being flushed
+    std::atomic<size_t> committed{0};            // live members + staged adds: what capacity is checked against
+    std::mutex key_mu;                           // guards `lookup` membership (adds validate against it concurrently)
 
     void use_device() const { HIP_OK(hipSetDevice(device)); }
 
@@ -284,6 +292,7 @@ struct Engine {
         h_levels.resize(cap, 0);
         h_upper_off.resize(cap, kInvalid);
         capacity = cap;
+        capacity_atomic = cap;
         ensure_upper(cap / 8 + 64);
     }
 
@@ -304,7 +313,7 @@ struct Engine {
     // ------------------------------------------------------------------ add
     // Returns per-item status (VS_OK / VS_ERR_*), all items attempted.
     void add_batch(const uint64_t* keys, const float* vecs, bool on_device, size_t n, std::vector<int>& status,
-                   std::string& first_err) {
+                   std::string& first_err, bool staged = false) {
         status.assign(n, VS_OK);
         if (!n) return;
         std::lock_guard<std::mutex> g(mod_mu);
@@ -331,7 +340,12 @@ struct Engine {
                     bad(VS_ERR_INVALID_ARGUMENT, "Key is reserved for internal use");
                     continue;
                 }
-                if (lookup.count(key) || !in_chunk.insert(key).second) {
+                bool known;
+                {
+                    std::lock_guard<std::mutex> kg(key_mu);
+                    known = lookup.count(key) != 0;
+                }
+                if (known || !in_chunk.insert(key).second) {
                     bad(VS_ERR_DUPLICATE_KEY, "Duplicate keys not allowed in high-level wrappers");
                     continue;
                 }
@@ -513,56 +527,88 @@ struct Engine {
                 linked += take;
             }
             HIP_OK(hipStreamSynchronize(st));
-            for (uint32_t i = 0; i < m; ++i) lookup.emplace(key_v[i], slot_v[i]);
+            {
+                std::lock_guard<std::mutex> kg(key_mu);
+                for (uint32_t i = 0; i < m; ++i) lookup.emplace(key_v[i], slot_v[i]);
+            }
             live += m;
+            if (!staged) committed += m;  // staged vectors were counted when add_one accepted them
         }
     }
 
-    // Single-vector callers (one add per FFI call from <= num_workers()+1 threads, reference
-    // worker.rs:44-118) are combined: whoever finds no batch in flight becomes the leader and
-    // inserts everything queued so far.
+    // Single-vector callers (one add per FFI call from <= num_workers()+1 threads, reference worker.rs:44-118).
+    // An insert is one graph walk (~1.4 ms of latency for a lone wave), so inserting per call would cap the build
+    // at the walk latency.  The reference treats adds as fire-and-forget messages (usearch.rs:1028-1034), which
+    // allows the same "as-if" here: add_one validates synchronously (reserved / duplicate key, capacity), stages
+    // the vector and returns; staged vectors are inserted in bulk when kFlushThreshold of them are waiting and,
+    // at the latest, before any other operation observes the index (search, remove, reserve, size, stats,
+    // export), so every call still sees the effect of all adds that returned before it.
+    static constexpr size_t kFlushThreshold = 4096;
+
     int add_one(uint64_t key, const float* v) {
-        PendingAdd me;
-        me.key = key;
-        me.v = v;
-        std::unique_lock<std::mutex> lk(aq_mu);
-        aq.push_back(&me);
-        while (!me.done) {
-            if (!a_leader) {
-                a_leader = true;
-                std::vector<PendingAdd*> batch;
-                batch.swap(aq);
-                lk.unlock();
-                std::vector<uint64_t> keys(batch.size());
-                std::vector<float> vecs(batch.size() * (size_t)dim);
-                for (size_t i = 0; i < batch.size(); ++i) {
-                    keys[i] = batch[i]->key;
-                    std::memcpy(&vecs[i * dim], batch[i]->v, (size_t)dim * 4);
-                }
-                std::vector<int> status;
-                std::string err;
-                int hard = VS_OK;
-                std::string hard_msg;
-                try {
-                    add_batch(keys.data(), vecs.data(), false, batch.size(), status, err);
-                } catch (const Fail& f) {
-                    hard = f.code;
-                    hard_msg = f.msg;
-                }
-                lk.lock();
-                for (size_t i = 0; i < batch.size(); ++i) {
-                    batch[i]->status = hard != VS_OK ? hard : status[i];
-                    if (batch[i]->status != VS_OK) batch[i]->err = hard != VS_OK ? hard_msg : error_text(batch[i]->status);
-                    batch[i]->done = true;
-                }
-                a_leader = false;
-                aq_cv.notify_all();
-            } else {
-                aq_cv.wait(lk);
-            }
+        std::unique_lock<std::mutex> lk(pend_mu);
+        if (key == kFreeKey) {
+            g_err = error_text(VS_ERR_INVALID_ARGUMENT);
+            return VS_ERR_INVALID_ARGUMENT;
         }
-        if (me.status != VS_OK) g_err = me.err;
-        return me.status;
+        bool dup = pend.keyset.count(key) || flushing_keys.count(key);
+        if (!dup) {
+            std::lock_guard<std::mutex> kg(key_mu);
+            dup = lookup.count(key) != 0;
+        }
+        if (dup) {
+            g_err = error_text(VS_ERR_DUPLICATE_KEY);
+            return VS_ERR_DUPLICATE_KEY;
+        }
+        if (committed.load() >= capacity_atomic.load()) {
+            g_err = error_text(VS_ERR_CAPACITY);
+            return VS_ERR_CAPACITY;
+        }
+        pend.keys.push_back(key);
+        pend.vecs.insert(pend.vecs.end(), v, v + dim);
+        pend.keyset.insert(key);
+        ++queued;
+        ++committed;
+        if (pend.keys.size() < kFlushThreshold) return VS_OK;
+        return flush_locked(lk);
+    }
+
+    // Inserts everything staged so far.  Called with pend_mu held; releases it while the GPU works so that
+    // other callers keep staging into the fresh buffer.
+    int flush_locked(std::unique_lock<std::mutex>& lk) {
+        if (pend.keys.empty()) return VS_OK;
+        Pending take;
+        std::swap(take, pend);
+        for (uint64_t k : take.keys) flushing_keys.insert(k);
+        lk.unlock();
+        std::vector<int> status;
+        std::string err;
+        int rc = VS_OK;
+        try {
+            add_batch(take.keys.data(), take.vecs.data(), false, take.keys.size(), status, err, true);
+            for (int st : status)
+                if (st != VS_OK) --committed;  // accepted at staging time, rejected at insertion (cannot normally happen)
+        } catch (const Fail& f) {
+            rc = f.code;
+            g_err = f.msg;
+        } catch (const std::exception& e) {
+            rc = VS_ERR_DEVICE;
+            g_err = e.what();
+        }
+        lk.lock();
+        for (uint64_t k : take.keys) flushing_keys.erase(k);
+        queued -= take.keys.size();
+        return rc;
+    }
+
+    // Barrier used by every operation that observes the index.
+    void flush_pending() {
+        {
+            std::unique_lock<std::mutex> lk(pend_mu);
+            int rc = flush_locked(lk);
+            if (rc != VS_OK) fail(rc, g_err);
+        }
+        std::lock_guard<std::mutex> g(mod_mu);  // a flush started by another caller has finished too
     }
 
     static const char* error_text(int code) {
@@ -587,6 +633,7 @@ struct Engine {
         free_slots.push_back(slot);
         ++removed;
         --live;
+        --committed;
         return true;
     }
 
@@ -1025,11 +1072,19 @@ void vs_hnsw_free(vs_hnsw* h) {
 int vs_hnsw_reserve(vs_hnsw* h, size_t capacity, size_t /*threads*/) {
     return guarded([&] {
         need(h, "null index");
+        h->e.flush_pending();
         h->e.reserve(capacity);
     });
 }
 size_t vs_hnsw_capacity(const vs_hnsw* h) { return h ? h->e.capacity : 0; }
-size_t vs_hnsw_size(const vs_hnsw* h) { return h ? h->e.live.load() : 0; }
+size_t vs_hnsw_size(const vs_hnsw* h) {
+    if (!h) return 0;
+    try {
+        const_cast<vs_hnsw*>(h)->e.flush_pending();  // staged adds count: they are indexed before anyone can look
+    } catch (...) {
+    }
+    return h->e.live.load();
+}
 size_t vs_hnsw_bytes_per_vector(const vs_hnsw* h) { return h ? h->e.row_bytes : 0; }
 
 int vs_hnsw_add(vs_hnsw* h, uint64_t key, const float* v, size_t dim) {
@@ -1046,6 +1101,7 @@ static int add_many(vs_hnsw* h, const uint64_t* keys, const float* vecs, size_t 
     return guarded([&] {
         need(h && (n == 0 || (keys && vecs)), "null argument");
         check_dim(h, dim);
+        h->e.flush_pending();
         std::vector<int> status;
         std::string err;
         h->e.add_batch(keys, vecs, on_device, n, status, err);
@@ -1069,6 +1125,7 @@ int vs_hnsw_add_batch_device(vs_hnsw* h, const uint64_t* keys, const float* d_ve
 int vs_hnsw_remove(vs_hnsw* h, uint64_t key, int* removed) {
     return guarded([&] {
         need(h, "null index");
+        h->e.flush_pending();
         bool r = h->e.remove(key);
         if (removed) *removed = r ? 1 : 0;
     });
@@ -1079,6 +1136,7 @@ int vs_hnsw_search(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* k
     int g = guarded([&] {
         need(h && q && keys && dist && found, "null argument");
         check_dim(h, dim);
+        h->e.flush_pending();
         uint32_t ef;
         *found = 0;
         if (k > vs::kMaxBeam || std::max<size_t>(k, h->e.ef_search.load()) > vs::kMaxBeam) {
@@ -1101,6 +1159,7 @@ int vs_hnsw_search_async(vs_hnsw* h, const float* q, size_t dim, size_t k, uint6
     return guarded([&] {
         need(h && q && keys && dist && found && done, "null argument");
         check_dim(h, dim);
+        h->e.flush_pending();
         uint32_t ef;
         h->e.check_search(k, ef);
         *found = 0;
@@ -1114,6 +1173,7 @@ int vs_hnsw_filtered_search(vs_hnsw* h, const float* q, size_t dim, size_t k, vs
         need(h && q && keys && dist && found && pred, "null argument");
         need(k > 0, "k must be > 0");
         check_dim(h, dim);
+        h->e.flush_pending();
         *found = h->e.filtered(q, k, pred, ctx, keys, dist);
     });
 }
@@ -1123,6 +1183,7 @@ int vs_hnsw_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim, size
     return guarded([&] {
         need(h && (nq == 0 || (q && keys && dist && found)), "null argument");
         check_dim(h, dim);
+        h->e.flush_pending();
         h->e.search_host(q, nq, k, keys, dist, found, false);
     });
 }
@@ -1131,6 +1192,7 @@ int vs_hnsw_exact_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim
     return guarded([&] {
         need(h && (nq == 0 || (q && keys && dist && found)), "null argument");
         check_dim(h, dim);
+        h->e.flush_pending();
         h->e.search_host(q, nq, k, keys, dist, found, true);
     });
 }
@@ -1139,6 +1201,7 @@ int vs_hnsw_search_batch_device(vs_hnsw* h, const float* d_q, size_t nq, size_t 
     return guarded([&] {
         need(h && (nq == 0 || (d_q && d_keys && d_dist && d_found)), "null argument");
         check_dim(h, dim);
+        h->e.flush_pending();
         h->e.use_device();
         h->e.search_device(d_q, nq, k, d_keys, d_dist, d_found, (hipStream_t)stream);
     });
@@ -1148,6 +1211,7 @@ int vs_hnsw_exact_search_batch_device(vs_hnsw* h, const float* d_q, size_t nq, s
     return guarded([&] {
         need(h && (nq == 0 || (d_q && d_keys && d_dist && d_found)), "null argument");
         check_dim(h, dim);
+        h->e.flush_pending();
         h->e.use_device();
         vs::Lease w(h->e.device);
         h->e.exact_device(d_q, nq, k, d_keys, d_dist, d_found, (hipStream_t)stream, *w.ctx);
@@ -1165,6 +1229,7 @@ int vs_hnsw_set_expansion_search(vs_hnsw* h, size_t ef) {
 int vs_hnsw_stats(vs_hnsw* h, uint64_t out[8], int reset) {
     return guarded([&] {
         need(h && out, "null argument");
+        h->e.flush_pending();
         h->e.use_device();
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemcpy(out, h->e.d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -1175,6 +1240,7 @@ int vs_hnsw_stats(vs_hnsw* h, uint64_t out[8], int reset) {
 int vs_hnsw_graph_info_get(vs_hnsw* h, vs_hnsw_graph_info* info) {
     return guarded([&] {
         need(h && info, "null argument");
+        h->e.flush_pending();
         std::lock_guard<std::mutex> g(h->e.mod_mu);
         info->slots = h->e.slots;
         info->upper_blocks = h->e.upper_blocks;
@@ -1190,6 +1256,7 @@ int vs_hnsw_export_graph(vs_hnsw* h, void* vectors, int32_t* levels, uint64_t* k
     return guarded([&] {
         need(h, "null index");
         Engine& e = h->e;
+        e.flush_pending();
         std::lock_guard<std::mutex> g(e.mod_mu);
         e.use_device();
         HIP_OK(hipDeviceSynchronize());
@@ -1252,6 +1319,7 @@ int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const void* vectors, const int32_
             }
         }
         e.live = live;
+        e.committed = live;
         e.max_level = max_level;
         e.entry_slot = entry_slot;
     });

@@ -5,6 +5,7 @@
 //   vs_bench gen          --data-dir D --n N --dim D [--queries Q] [--neighbors K] [--dist lowrank|gaussian]
 //                         [--rank R] [--metric cos|l2sq|ip] [--seed S]
 //   vs_bench build-index  --data-dir D [--metric M] [--connectivity C] [--expansion-add E]
+//                         [--concurrency C [--max-vectors N]]   (one vector per call from C threads)
 //   vs_bench search       --data-dir D --limit K --duration SEC --concurrency C [--expansion-search E]
 //                         [--metric M] [--connectivity C] [--expansion-add E]
 //
@@ -187,8 +188,39 @@ static vs_hnsw* build(const Args& a, const std::string& dir, const DatasetConfig
     return h;
 }
 
+// One vector per call from `concurrency` threads: how the reference's service feeds the index
+// (monitor_items -> actor -> worker pool -> usearch::Index::add, one vector per FFI call).
+static int cmd_build_single(const Args& a, unsigned conc) {
+    const std::string dir = a.get("data-dir");
+    DatasetConfig cfg = read_dataset_toml(dir);
+    Matrix d = read_bin(dir + "/" + cfg.data_fbin, false);
+    const size_t n = std::min<size_t>(d.count, (size_t)a.num("max-vectors", d.count));
+    vs_hnsw* h = make_index(a, d.dim, n);
+    std::atomic<size_t> next{0};
+    std::atomic<int> errors{0};
+    auto t0 = Clock::now();
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < conc; ++t)
+        th.emplace_back([&] {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                if (vs_hnsw_add(h, i, d.f.data() + i * d.dim, d.dim) != VS_OK) errors.fetch_add(1);
+            }
+        });
+    for (auto& x : th) x.join();
+    const size_t indexed = vs_hnsw_size(h);  // barrier: staged vectors are inserted before the clock stops
+    double secs = std::chrono::duration<double>(Clock::now() - t0).count();
+    if (indexed != n - (size_t)errors.load()) std::cerr << "size mismatch: " << indexed << std::endl;
+    std::cout << "index build (one vector per call, concurrency " << conc << "): " << n << " vectors in " << secs << " s = "
+              << (double)n / secs << " vectors/s, errors " << errors.load() << std::endl;
+    vs_hnsw_free(h);
+    return errors.load() ? 1 : 0;
+}
+
 static int cmd_build(const Args& a) {
     const std::string dir = a.get("data-dir");
+    if (a.kv.count("concurrency")) return cmd_build_single(a, (unsigned)a.num("concurrency", 16));
     size_t dim;
     double secs;
     vs_hnsw* h = build(a, dir, read_dataset_toml(dir), dim, secs);

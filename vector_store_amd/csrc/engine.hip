@@ -326,10 +326,8 @@ struct Engine {
             std::vector<uint32_t> slot_v, src_row, reuse_rows, reuse_upper;
             std::vector<int32_t> level_v;
             std::vector<uint64_t> key_v;
-            std::vector<uint8_t> reused_v;
             std::unordered_set<uint64_t> in_chunk;
             slot_v.reserve(cn);
-            bool contiguous = true;
             for (size_t i = 0; i < cn; ++i) {
                 const uint64_t key = keys[c0 + i];
                 auto bad = [&](int code, const char* m) {
@@ -351,13 +349,11 @@ struct Engine {
                 }
                 uint32_t slot;
                 int32_t level;
-                bool reused = false;
                 if (!free_slots.empty()) {  // usearch index_dense: reuse a removed node in place (update path)
                     slot = free_slots.front();
                     free_slots.pop_front();
                     --removed;
                     level = h_levels[slot];
-                    reused = true;
                     reuse_rows.push_back(slot);
                     for (int l = 0; l < level; ++l) reuse_upper.push_back(h_upper_off[slot] + l);
                 } else {
@@ -374,13 +370,10 @@ struct Engine {
                         upper_blocks += (size_t)level;
                     }
                 }
-                if (!slot_v.empty() && (slot != slot_v.back() + 1 || i != src_row.back() + 1)) contiguous = false;
-                if (reused) contiguous = false;
                 slot_v.push_back(slot);
                 level_v.push_back(level);
                 key_v.push_back(key);
                 src_row.push_back((uint32_t)i);
-                reused_v.push_back(reused);
             }
             const uint32_t m = (uint32_t)slot_v.size();
             if (!m) continue;
@@ -394,7 +387,6 @@ struct Engine {
             std::vector<uint32_t> req_off(m + 1, 0);
             {
                 int32_t ml = max_level.load();
-                size_t lk = linked;
                 for (uint32_t i = 0; i < m; ++i) {
                     uint32_t cnt = 0;
                     if (ml < 0) {
@@ -403,7 +395,6 @@ struct Engine {
                         cnt = (uint32_t)(std::min(level_v[i], ml) + 1) * M;
                         if (level_v[i] > ml) ml = level_v[i];
                     }
-                    (void)lk;
                     req_off[i + 1] = req_off[i] + cnt;
                 }
             }
@@ -440,7 +431,6 @@ struct Engine {
                 }
                 src = stg;
             }
-            (void)contiguous;
             HIP_OK(launch_quantise_rows(ix, d_vectors, d_aux, src, dim, d_src_slots, 0, m, st));
             HIP_OK(launch_scatter_u64(d_keys, d_slots, d_keyv, m, st));
             HIP_OK(launch_scatter_u32((uint32_t*)d_levels, d_slots, (const uint32_t*)d_lv, m, st));
@@ -624,10 +614,14 @@ struct Engine {
     bool remove(uint64_t key) {
         std::lock_guard<std::mutex> g(mod_mu);
         use_device();
-        auto it = lookup.find(key);
-        if (it == lookup.end()) return false;
-        uint32_t slot = it->second;
-        lookup.erase(it);
+        uint32_t slot;
+        {
+            std::lock_guard<std::mutex> kg(key_mu);
+            auto it = lookup.find(key);
+            if (it == lookup.end()) return false;
+            slot = it->second;
+            lookup.erase(it);
+        }
         const uint64_t free_key = kFreeKey;
         HIP_OK(hipMemcpy(d_keys + slot, &free_key, 8, hipMemcpyHostToDevice));
         free_slots.push_back(slot);

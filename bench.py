@@ -43,6 +43,17 @@ def make_data(n, dim, kind, seed, device, rank=24):
     g.manual_seed(seed)
     if kind == "gaussian":
         return torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+    if kind == "clustered":  # 256 Gaussian centres (seed 99), sigma = 0.2 around them
+        gc = torch.Generator(device=device)
+        gc.manual_seed(99)
+        centres = torch.randn((256, dim), generator=gc, device=device, dtype=torch.float32)
+        which = torch.randint(0, 256, (n,), generator=g, device=device)
+        out = centres[which]
+        chunk = 1 << 18
+        for i in range(0, n, chunk):
+            m = min(chunk, n - i)
+            out[i:i + m] += 0.2 * torch.randn((m, dim), generator=g, device=device, dtype=torch.float32)
+        return out
     gw = torch.Generator(device=device)
     gw.manual_seed(99)
     w = torch.randn((rank, dim), generator=gw, device=device, dtype=torch.float32) / rank ** 0.5
@@ -151,7 +162,7 @@ def main():
     ap.add_argument("--nq", type=int, default=10_000, help="queries per step per GPU")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="cos", choices=["cos", "l2sq", "ip"])
-    ap.add_argument("--dist", default="lowrank", choices=["lowrank", "gaussian"])
+    ap.add_argument("--dist", default="lowrank", choices=["lowrank", "gaussian", "clustered"])
     ap.add_argument("--rank", type=int, default=24, help="latent dimension of the lowrank generator")
     ap.add_argument("--ef", type=int, default=0, help="expansion_search; 0 = smallest of 64,96,..,512 with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.95)

@@ -312,8 +312,9 @@ __global__ __launch_bounds__(256) void exact_dist_mfma_kernel(IndexView ix, cons
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (uint32_t k0 = 0; k0 < kpad; k0 += kMfmaKC) {
-        float a[16], b[16];
+    // Software pipeline: the global loads of chunk c+1 are in flight while the MFMAs of chunk c run.
+    float a[16], b[16];
+    auto fetch = [&](uint32_t k0) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const uint32_t k = k0 + (lf4 + f) * 4;
@@ -324,6 +325,9 @@ __global__ __launch_bounds__(256) void exact_dist_mfma_kernel(IndexView ix, cons
             if (nt + lrow < n_blk && k < kpad) load4_dequant(ix, (size_t)(n0 + nt + lrow), k, bv);
             b[4 * f] = bv[0]; b[4 * f + 1] = bv[1]; b[4 * f + 2] = bv[2]; b[4 * f + 3] = bv[3];
         }
+    };
+    fetch(0);
+    for (uint32_t k0 = 0; k0 < kpad; k0 += kMfmaKC) {
         __syncthreads();  // the previous chunk's fragments have been consumed
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(256) void exact_dist_mfma_kernel(IndexView ix, cons
             Bs[lf4 * 4 + e][lrow] = b[e];
         }
         __syncthreads();
+        if (k0 + kMfmaKC < kpad) fetch(k0 + kMfmaKC);
 #pragma unroll
         for (int kk = 0; kk < kMfmaKC / 2; ++kk) {
             const uint32_t kr = 2 * kk + (lane >> 5), c = lane & 31;

@@ -6,7 +6,7 @@
 //                         [--rank R] [--metric cos|l2sq|ip] [--seed S]
 //   vs_bench build-index  --data-dir D [--metric M] [--connectivity C] [--expansion-add E]
 //                         [--concurrency C [--max-vectors N]]   (one vector per call from C threads)
-//   vs_bench search       --data-dir D --limit K --duration SEC --concurrency C [--expansion-search E]
+//   vs_bench search       --data-dir D --limit K --duration SEC --concurrency C [--inflight D] [--expansion-search E]
 //                         [--metric M] [--connectivity C] [--expansion-add E]
 //
 // `search` is the reference's search-http / search-cql loop (main.rs:435-525): `concurrency` workers
@@ -17,6 +17,8 @@
 #include <atomic>
 #include <chrono>
 #include <cinttypes>
+#include <condition_variable>
+#include <mutex>
 #include <cstdlib>
 #include <iostream>
 #include <random>
@@ -246,24 +248,94 @@ static int cmd_search(const Args& a) {
     std::atomic<bool> stop{false};
     std::vector<SearchMeasure> per(conc);
     std::vector<std::string> errors(conc);
+    const unsigned inflight = (unsigned)std::max<long>(1, a.num("inflight", 1));
     auto t0 = Clock::now();
     std::vector<std::thread> th;
     for (unsigned t = 0; t < conc; ++t)
         th.emplace_back([&, t] {
             std::mt19937_64 g(t * 7919 + 13);
-            std::vector<uint64_t> keys(limit);
-            std::vector<float> dist(limit);
-            while (!stop.load(std::memory_order_relaxed)) {
-                const Query& q = queries[g() % queries.size()];
-                size_t found = 0;
-                auto s = Clock::now();
-                int rc = vs_hnsw_search(h, q.query.data(), dim, limit, keys.data(), dist.data(), &found);
-                int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
-                if (rc != VS_OK) {
-                    errors[t] = vs_hnsw_last_error();
-                    break;
+            if (inflight == 1) {  // blocking call per query: what a thread of the reference's worker pool does
+                std::vector<uint64_t> keys(limit);
+                std::vector<float> dist(limit);
+                while (!stop.load(std::memory_order_relaxed)) {
+                    const Query& q = queries[g() % queries.size()];
+                    size_t found = 0;
+                    auto s = Clock::now();
+                    int rc = vs_hnsw_search(h, q.query.data(), dim, limit, keys.data(), dist.data(), &found);
+                    int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
+                    if (rc != VS_OK) {
+                        errors[t] = vs_hnsw_last_error();
+                        break;
+                    }
+                    per[t].record(ns, recall(q.neighbors, keys.data(), found));
                 }
-                per[t].record(ns, recall(q.neighbors, keys.data(), found));
+                return;
+            }
+            // --inflight D: the non-blocking entry point, D queries outstanding per worker (an async runtime)
+            struct Slot {
+                std::vector<uint64_t> keys;
+                std::vector<float> dist;
+                size_t found = 0;
+                const Query* q = nullptr;
+                Clock::time_point start;
+                int status = 0;
+                bool done = true;
+                std::mutex* mu;
+                std::condition_variable* cv;
+            };
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<Slot> slots(inflight);
+            for (auto& sl : slots) {
+                sl.keys.resize(limit);
+                sl.dist.resize(limit);
+                sl.mu = &mu;
+                sl.cv = &cv;
+            }
+            auto done = [](void* ctx, int status) {
+                Slot* sl = (Slot*)ctx;
+                std::lock_guard<std::mutex> lk(*sl->mu);
+                sl->status = status;
+                sl->done = true;
+                sl->cv->notify_one();
+            };
+            size_t outstanding = 0;
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                bool stopping = stop.load(std::memory_order_relaxed);
+                for (auto& sl : slots) {
+                    if (!sl.done) continue;
+                    if (sl.q) {  // a completed query
+                        int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - sl.start).count();
+                        if (sl.status != VS_OK) errors[t] = "async search failed";
+                        else per[t].record(ns, recall(sl.q->neighbors, sl.keys.data(), sl.found));
+                        sl.q = nullptr;
+                        --outstanding;
+                    }
+                    if (stopping) continue;
+                    sl.q = &queries[g() % queries.size()];
+                    sl.done = false;
+                    sl.start = Clock::now();
+                    ++outstanding;
+                    lk.unlock();
+                    int rc = vs_hnsw_search_async(h, sl.q->query.data(), dim, limit, sl.keys.data(), sl.dist.data(), &sl.found,
+                                                  done, &sl);
+                    lk.lock();
+                    if (rc != VS_OK) {
+                        errors[t] = vs_hnsw_last_error();
+                        sl.done = true;
+                        sl.q = nullptr;
+                        --outstanding;
+                        stopping = true;
+                        stop = true;
+                    }
+                }
+                if (stopping && outstanding == 0) break;
+                cv.wait(lk, [&] {
+                    for (auto& sl : slots)
+                        if (sl.done && sl.q) return true;
+                    return stop.load() && outstanding == 0;
+                });
             }
         });
     std::this_thread::sleep_for(std::chrono::duration<double>(duration));
@@ -274,7 +346,7 @@ static int cmd_search(const Args& a) {
     for (auto& m : per) all.append(m);
     for (auto& e : errors)
         if (!e.empty()) std::cerr << "search error: " << e << std::endl;
-    std::cout << "concurrency: " << conc << "\n" << all.report(wall);
+    std::cout << "concurrency: " << conc << (inflight > 1 ? " x inflight " + std::to_string(inflight) : std::string()) << "\n" << all.report(wall);
     uint64_t st[8];
     ok(vs_hnsw_stats(h, st, 0), "stats");
     if (st[2]) std::cout << "distance evaluations per query: " << (double)st[0] / (double)st[2] << std::endl;

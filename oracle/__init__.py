@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle_hnsw.so")
+_LIB_PATH = os.environ.get("VS_ORACLE_LIB") or os.path.join(_HERE, "liboracle_hnsw.so")  # VS_ORACLE_LIB: sanitizer build
 
 COS, L2SQ, IP, HAMMING = 0, 1, 2, 3
 F32, F16, BF16, I8, B1 = 0, 1, 2, 3, 4

@@ -5,9 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (hnsw_search, one wavefront per query) over one batch of
-`--nq` synthetic queries that are already resident in HBM.  Workload at N=1 = BASELINE.json
-configs[1]: 1M x 768 cosine, top-10 (ef_search chosen as the smallest of {64,96,...,256,320,...,512} reaching
-recall@10 >= 0.95 against the exact brute-force ground truth computed on the GPU).
+`--nq` synthetic queries that are already resident in HBM.  Workload at N=1 = the configuration
+BASELINE.json's metric is quoted on: 10M x 768 cosine, top-10, one GPU (31 GB of vectors + 1.4 GB of graph
+in HBM); ef_search = the smallest of {64,96,...,256,320,...,512} reaching recall@10 >= 0.95 against the exact
+brute-force ground truth computed on the GPU.  `--vectors 1000000` is configs[1] (ef_search 128).
 
 Multi-GPU (`--mode replica`, default): the reference scales by replication -- every vector-store
 process holds the whole index -- so each rank builds a full replica and
@@ -132,8 +133,8 @@ def cpu_baseline(ix, queries_host, k, ef, seconds):
     """The CPU restatement of the usearch algorithm (oracle/, kind "port") searching the SAME graph on
     the host cores of this box: one query per call from T threads (reference usearch.rs:212)."""
     import oracle
-    g = ix.export_graph()
     o = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef, quantization=ix.scalar)
+    g = ix.export_graph(vectors_out=o.vector_arena(ix.graph_info()["slots"]))  # straight into the oracle's arena
     o.import_graph(g)
     del g
     o.set_expansion_search(ef)
@@ -157,7 +158,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--vectors", "--n", dest="n", type=int, default=1_000_000, help="vectors per GPU")
+    ap.add_argument("--vectors", "--n", dest="n", type=int, default=10_000_000,
+                    help="vectors per GPU; default = the headline workload BASELINE.json's metric is quoted on (10M x 768 cosine); 1000000 = configs[1]")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--nq", type=int, default=10_000, help="queries per step per GPU")
     ap.add_argument("--k", type=int, default=10)
@@ -268,7 +270,7 @@ def main():
     value = total_q / elapsed
 
     out = {
-        "metric": "QPS at recall@10>=0.95 (hnsw_search, inputs resident in HBM)",
+        "metric": "QPS at recall@10>=0.95 (HNSW search, inputs resident in HBM)",
         "value": value, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.quantization, "data": "synthetic",
@@ -282,8 +284,9 @@ def main():
                      "visited_overflow": st["visited_overflow"]},
         "build": build_info,
     }
-    tr = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr):  # PMC-measured HBM bytes per launch for this exact workload (see profiles/README.md)
+    # PMC-measured HBM bytes per launch for this exact workload (profiles/*traffic.json, see profiles/README.md)
+    import glob
+    for tr in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
         try:
             rec = json.load(open(tr))
             if rec.get("workload") == out["config"]["workload"]:

@@ -268,6 +268,15 @@ class OracleIndex:
         g["vectors"] = arr.reshape(n, -1) if n else arr.reshape(0, self.dim if self.scalar == F32 else bpv)
         return g
 
+    def vector_arena(self, n: int) -> np.ndarray:
+        """Writable view of the first n rows of the index's own vector arena (storage format), after reserving
+        n slots: export a graph's vectors straight into it, then import_graph() skips the copy."""
+        if n > self.capacity():
+            self.reserve(n)
+        bpv = self.L.orc_bytes_per_vector(self.h)
+        raw = (C.c_uint8 * (n * bpv)).from_address(self.L.orc_vectors(self.h))
+        return np.frombuffer(raw, dtype=np.float32 if self.scalar == F32 else np.uint8).reshape(n, -1)
+
     def import_graph(self, g: dict):
         n = len(g["levels"])
         vec = np.ascontiguousarray(g["vectors"])

@@ -952,7 +952,8 @@ int orc_import_graph(void* h, size_t n, const void* vectors, const int32_t* leve
                      uint32_t entry_slot) {
     Index* ix = (Index*)h;
     if (n > ix->capacity && ix->reserve(n)) return -1;
-    std::memcpy(ix->vectors.data(), vectors, n * ix->bytes_per_vector);
+    // vectors == arena: the caller exported straight into orc_vectors() (bench.py at 10M: no second 30 GB copy)
+    if (vectors && vectors != (const void*)ix->vectors.data()) std::memcpy(ix->vectors.data(), vectors, n * ix->bytes_per_vector);
     ix->slot_lookup.clear();
     ix->free_slots.clear();
     ix->live = 0;

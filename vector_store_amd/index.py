@@ -271,12 +271,15 @@ class HipUsearchIndex:
         _check(self.L.vs_hnsw_graph_info_get(self.h, C.byref(gi)))
         return {f[0]: getattr(gi, f[0]) for f in _GraphInfo._fields_}
 
-    def export_graph(self) -> dict:
+    def export_graph(self, vectors_out=None) -> dict:
         gi = self.graph_info()
         n, blocks = gi["slots"], gi["upper_blocks"]
+        if vectors_out is not None:
+            assert vectors_out.flags.c_contiguous and vectors_out.nbytes == n * self.bytes_per_vector()
         g = {
             # storage format: f32 rows for F32, raw bytes (bytes_per_vector per row) otherwise
-            "vectors": np.zeros((n, self.dim), dtype=np.float32) if self.scalar == F32
+            "vectors": vectors_out if vectors_out is not None
+            else np.zeros((n, self.dim), dtype=np.float32) if self.scalar == F32
             else np.zeros((n, self.bytes_per_vector()), dtype=np.uint8),
             "levels": np.zeros(n, dtype=np.int32),
             "keys": np.zeros(n, dtype=np.uint64),

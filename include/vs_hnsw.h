@@ -65,7 +65,9 @@ typedef struct vs_hnsw_options {
     int quantization; /* vs_scalar_kind */
     int device;       /* HIP device ordinal; -1 = current device */
     int reserved;     /* 0; test hooks: bit 0 = tiny visited table in search (forces the overflow path),
-                         bit 1 = exact search on the VALU tile kernel instead of MFMA */
+                         bit 1 = exact search on the VALU tile kernel instead of MFMA,
+                         bit 2 = always serve a query with a team of wavefronts, bit 3 = never (default: batches
+                         of at most one team per CU) */
 } vs_hnsw_options;
 
 /* -- lifecycle: usearch::Index::new (usearch.rs:172), drop ------------------------------- */

@@ -122,6 +122,8 @@ struct Engine {
     int metric = VS_METRIC_COS;
     int device = 0;
     bool stress_small_table = false;  // vs_hnsw_options.reserved bit 0 (tests only)
+    int team_mode = 0;                // 0 = by batch size; reserved bit 2 = always a team per query, bit 3 = never
+    uint32_t team_max_nq = 256;       // batches up to one team per CU take the team kernel
     int scalar = VS_SCALAR_F32;
     uint32_t lanes = 64, lanes_log2 = 6, iters = 1, stride4 = 64;
     uint32_t row_bytes = 0;  // payload bytes of one stored vector (usearch bytes_per_vector)
@@ -217,6 +219,7 @@ struct Engine {
         dim = (uint32_t)o.dimensions;
         stress_small_table = (o.reserved & 1) != 0;
         exact_valu = (o.reserved & 2) ? 1 : 0;
+        team_mode = (o.reserved & 4) ? 1 : (o.reserved & 8) ? 2 : 0;
         M = o.connectivity ? (uint32_t)o.connectivity : 16;  // usearch default_connectivity
         if (M < 2 || M > 32) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 32]");
         M0 = 2 * M;
@@ -654,6 +657,7 @@ struct Engine {
         a.ef = ef;
         a.has_removed = removed.load() ? 1u : 0u;
         a.stress_small_table = stress_small_table ? 1u : 0u;
+        a.team = (team_mode == 1 || (team_mode == 0 && nq <= team_max_nq)) ? (uint32_t)kSearchTeam : 1u;
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;

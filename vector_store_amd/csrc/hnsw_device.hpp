@@ -330,12 +330,14 @@ struct RowGroup {
     float aux[U];
 };
 
-template <int AR, int I, int U>
+// A TEAM of waves (one workgroup) may share one batch: wave-load L of wave w covers vectors
+// ((L * TEAM + w) * V + grp); TEAM == 1, w == 0 is the one-wave-per-query layout.
+template <int AR, int I, int U, int TEAM>
 __device__ __forceinline__ void group_issue(const IndexView& ix, RowGroup<I, U>& g, const uint32_t* u_slot, uint32_t m,
-                                            uint32_t t, uint32_t V, uint32_t grp, uint32_t li) {
+                                            uint32_t L, uint32_t w, uint32_t vshift, uint32_t grp, uint32_t li) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        uint32_t idx = t + (uint32_t)u * V + grp;
+        uint32_t idx = (((L + (uint32_t)u) * (uint32_t)TEAM + w) << vshift) + grp;
         g.slot[u] = idx < m ? u_slot[idx] : kInvalid;
         g.aux[u] = 0.f;
         if (g.slot[u] != kInvalid) {
@@ -350,9 +352,9 @@ __device__ __forceinline__ void group_issue(const IndexView& ix, RowGroup<I, U>&
     }
 }
 
-template <int AR, int I, int U>
+template <int AR, int I, int U, int TEAM>
 __device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup<I, U>& g, const Query<AR, I>& q,
-                                             float* u_dist, uint32_t t, uint32_t V, uint32_t grp, uint32_t li) {
+                                             float* u_dist, uint32_t L, uint32_t w, uint32_t vshift, uint32_t grp, uint32_t li) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         typename Arith<AR>::acc_t acc = 0;
@@ -360,31 +362,32 @@ __device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup
         for (int i = 0; i < I; ++i) acc = accumulate<AR>(acc, q.c[i], g.buf[u][i]);
         acc = group_sum(acc, ix.lanes);
         if (g.slot[u] != kInvalid && li == 0)
-            u_dist[t + (uint32_t)u * V + grp] = finalize<AR>(ix.metric, acc, q.aux, g.aux[u]);
+            u_dist[(((L + (uint32_t)u) * (uint32_t)TEAM + w) << vshift) + grp] = finalize<AR>(ix.metric, acc, q.aux, g.aux[u]);
     }
 }
 
-template <int AR, int I>
+template <int AR, int I, int TEAM = 1>
 __device__ __forceinline__ void eval_batch(const IndexView& ix, const Query<AR, I>& q, const uint32_t* u_slot,
-                                           float* u_dist, uint32_t m, int lane) {
+                                           float* u_dist, uint32_t m, int lane, uint32_t w = 0) {
     constexpr int U = (I >= 6 || (AR == AR_I8 && I >= 3)) ? 2 : 4;
     const uint32_t lg = ix.lanes_log2;
-    const uint32_t V = 64u >> lg;
+    const uint32_t vshift = 6u - lg;  // V = 64 >> lg vectors per wave-load
     const uint32_t grp = (uint32_t)lane >> lg, li = (uint32_t)lane & (ix.lanes - 1);
-    const uint32_t G = V * U;  // vectors per group
-    if (m == 0) return;
+    const uint32_t nl_all = (m + (1u << vshift) - 1u) >> vshift;  // wave-loads in the batch
+    const uint32_t nl = TEAM == 1 ? nl_all : (nl_all > w ? (nl_all - w + (uint32_t)TEAM - 1u) / (uint32_t)TEAM : 0u);  // mine
+    if (nl == 0) return;
     RowGroup<I, U> a, b;
-    group_issue<AR, I, U>(ix, a, u_slot, m, 0, V, grp, li);
-    uint32_t t = 0;
+    group_issue<AR, I, U, TEAM>(ix, a, u_slot, m, 0, w, vshift, grp, li);
+    uint32_t L = 0;
     for (;;) {
-        if (t + G < m) group_issue<AR, I, U>(ix, b, u_slot, m, t + G, V, grp, li);
-        group_reduce<AR, I, U>(ix, a, q, u_dist, t, V, grp, li);
-        t += G;
-        if (t >= m) break;
-        if (t + G < m) group_issue<AR, I, U>(ix, a, u_slot, m, t + G, V, grp, li);
-        group_reduce<AR, I, U>(ix, b, q, u_dist, t, V, grp, li);
-        t += G;
-        if (t >= m) break;
+        if (L + U < nl) group_issue<AR, I, U, TEAM>(ix, b, u_slot, m, L + U, w, vshift, grp, li);
+        group_reduce<AR, I, U, TEAM>(ix, a, q, u_dist, L, w, vshift, grp, li);
+        L += U;
+        if (L >= nl) break;
+        if (L + U < nl) group_issue<AR, I, U, TEAM>(ix, a, u_slot, m, L + U, w, vshift, grp, li);
+        group_reduce<AR, I, U, TEAM>(ix, b, q, u_dist, L, w, vshift, grp, li);
+        L += U;
+        if (L >= nl) break;
     }
 }
 
@@ -408,10 +411,23 @@ struct SelArrays {  // heuristic output (insert / link kernels only)
 template <>
 struct SelArrays<false> {};
 
+// TEAM > 1: a workgroup of TEAM waves serves ONE query (small batches, where most of the chip would idle):
+// wave 0 walks the graph, all waves evaluate each hop's neighbour batch.  team_m is the mailbox.
+constexpr uint32_t kTeamExit = 0xFFFFFFFFu;
+template <int TM>
+struct TeamBox {
+    uint32_t team_m;
+};
+template <>
+struct TeamBox<1> {};
+
 // EFCAP=128, NB=1024, no SelArrays: 20,480 B -> 8 single-wave workgroups per CU (160 KiB LDS).
-template <int EFCAP, int NB, bool SEL = false, int CH = 1>
-struct BeamShared : SelArrays<SEL> {
+template <int EFCAP, int NB, bool SEL = false, int CH = 1, int TM = 1>
+struct BeamShared : SelArrays<SEL>, TeamBox<TM> {
     static constexpr int kChoices = CH;
+    static constexpr int kEfCap = EFCAP;
+    static constexpr int kNB = NB;
+    static constexpr int kTeam = TM;
     float lst_d[1][EFCAP];  // one buffer: list_merge works in place
     uint32_t lst_s[1][EFCAP];
     alignas(16) uint16_t vis_tag[NB * 8];
@@ -423,6 +439,52 @@ struct BeamShared : SelArrays<SEL> {
     float u_dist[64];
 };
 
+// LDS hand-over between the lanes of the walking wave.  One wave per workgroup: the workgroup barrier (free).
+// Team: only a wave-level ordering point -- the helper waves are parked at the team barrier and must not be released.
+template <class Sh>
+__device__ __forceinline__ void wsync() {
+    if constexpr (Sh::kTeam == 1) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Distances of sh.u_slot[0..m) -> sh.u_dist, visible to every lane of the walking wave on return.
+template <int AR, int I, class Sh>
+__device__ __forceinline__ void eval_shared(const IndexView& ix, const Query<AR, I>& q, Sh& sh, uint32_t m, int lane) {
+    if constexpr (Sh::kTeam == 1) {
+        eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, m, lane);
+        __syncthreads();
+    } else {
+        if (lane == 0) sh.team_m = m;
+        __syncthreads();  // releases the helpers (see team_helper_loop)
+        eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, 0);
+        __syncthreads();  // every wave's distances are in LDS
+    }
+}
+
+// Waves 1..TEAM-1 of a team workgroup: evaluate their share of every batch until the walker says stop.
+template <int AR, int I, class Sh>
+__device__ __forceinline__ void team_helper_loop(const IndexView& ix, const Query<AR, I>& q, Sh& sh, int lane, uint32_t w) {
+    for (;;) {
+        __syncthreads();
+        const uint32_t m = sh.team_m;
+        if (m == kTeamExit) return;
+        eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, w);
+        __syncthreads();
+    }
+}
+
+template <class Sh>
+__device__ __forceinline__ void team_release(Sh& sh, int lane) {  // walker: no more batches
+    if constexpr (Sh::kTeam > 1) {
+        if (lane == 0) sh.team_m = kTeamExit;
+        __syncthreads();
+    }
+}
+
 template <int NB, int CH = 1>
 struct VisitedCfg {
     static constexpr int log2nb = NB == 256 ? 8 : NB == 512 ? 9 : NB == 1024 ? 10 : NB == 2048 ? 11 : 12;
@@ -431,9 +493,9 @@ struct VisitedCfg {
     static constexpr uint32_t domain_mask = (1u << domain_bits) - 1u;
 };
 
-template <int EFCAP, int NB, bool SEL, int CH>
-__device__ __forceinline__ void visited_clear(BeamShared<EFCAP, NB, SEL, CH>& sh, int lane) {
-    for (int i = lane; i < NB / 4; i += kWave) sh.vis_cnt[i] = 0;
+template <class Sh>
+__device__ __forceinline__ void visited_clear(Sh& sh, int lane) {
+    for (int i = lane; i < Sh::kNB / 4; i += kWave) sh.vis_cnt[i] = 0;
     if (lane == 0) {
         sh.ovf_cnt = 0;
         sh.overflowed = 0;
@@ -459,8 +521,9 @@ __device__ __forceinline__ bool bucket_has(const Sh& sh, uint32_t b, uint32_t cn
 // CH == 2 (two-choice): a slot may live in bucket b1 (tag as is) or in b2 = b1 ^ alt(tag) (tag | 0x8000);
 // it goes to the emptier one, which keeps 8-entry buckets overflow-free up to ~85 % load.
 // (bucket, stored tag) still identifies the slot: b1 is recovered from b2 and the tag.
-template <int EFCAP, int NB, bool SEL, int CH>
-__device__ __forceinline__ bool visited_test_and_set(BeamShared<EFCAP, NB, SEL, CH>& sh, uint32_t slot) {
+template <class Sh>
+__device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
+    constexpr int NB = Sh::kNB, CH = Sh::kChoices;
     using C = VisitedCfg<NB, CH>;
     const uint32_t m = (slot * 0x9E3779B1u) & C::domain_mask;
     const uint32_t b1 = m >> C::tag_bits;
@@ -520,14 +583,13 @@ __device__ __forceinline__ const uint32_t* adjacency(const IndexView& ix, uint32
 }
 
 // usearch search_for_one_: greedy walk on levels (from_level .. to_level+1].
-template <int AR, int I, int EFCAP, int NB, bool SEL, int CH>
-__device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const Query<AR, I>& q,
+template <int AR, int I, class Sh>
+__device__ uint32_t greedy_descent(const IndexView& ix, Sh& sh, const Query<AR, I>& q,
                                    uint32_t start, int from_level, int to_level, Counters& cnt, int lane) {
     uint32_t cur = start;
     if (lane == 0) sh.u_slot[0] = cur;
-    __syncthreads();
-    eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, 1, lane);
-    __syncthreads();
+    wsync<Sh>();
+    eval_shared<AR, I>(ix, q, sh, 1, lane);
     float cur_d = sh.u_dist[0];
     cnt.evals += 1;
     for (int level = from_level; level > to_level; --level) {
@@ -537,11 +599,10 @@ __device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SE
             uint32_t n = (uint32_t)lane < cap ? row[lane] : kInvalid;
             uint64_t mask = __ballot(n != kInvalid);
             uint32_t m = (uint32_t)__popcll(mask);
-            __syncthreads();
+            wsync<Sh>();
             if (n != kInvalid) sh.u_slot[mbcnt(mask)] = n;
-            __syncthreads();
-            eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, m, lane);
-            __syncthreads();
+            wsync<Sh>();
+            eval_shared<AR, I>(ix, q, sh, m, lane);
             cnt.evals += m;
             cnt.hops += 1;
             float d = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
@@ -571,9 +632,10 @@ __device__ uint32_t greedy_descent(const IndexView& ix, BeamShared<EFCAP, NB, SE
 // final positions (binary search among the old entries, all-pairs among the <= 64 new ones), then,
 // after a barrier, everything is scattered to its final position.  O(m + log sz) per lane, no
 // data-dependent divergence.  Returns the new size.  `cur` is always 0 (kept for call-site symmetry).
-template <int EFCAP, int NB, bool SEL, int CH>
-__device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& sh, int cur, uint32_t sz, uint32_t ef,
+template <class Sh>
+__device__ __forceinline__ uint32_t list_merge(Sh& sh, int cur, uint32_t sz, uint32_t ef,
                                                float nd, uint32_t ns, uint32_t m, int lane) {
+    constexpr int EFCAP = Sh::kEfCap;
     float* od = sh.lst_d[cur];
     uint32_t* os = sh.lst_s[cur];
     constexpr int R = EFCAP / kWave;
@@ -610,7 +672,7 @@ __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& s
         uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
         keep_p[r] = (p < sz && p + shift[r] < ef) ? p + shift[r] : kInvalid;
     }
-    __syncthreads();  // every read of the old list is done
+    wsync<Sh>();  // every read of the old list is done
     if ((uint32_t)lane < m) {
         uint32_t pos = r_old + r_new;
         if (pos < ef) {
@@ -631,12 +693,13 @@ __device__ __forceinline__ uint32_t list_merge(BeamShared<EFCAP, NB, SEL, CH>& s
 // usearch search_to_insert_ / search_to_find_in_base_ (unfiltered): beam search on one level.
 // On return the sorted candidates are in sh.lst_*[cur] (cur returned through `out_cur`).
 // `self` (or kInvalid): slot that is never evaluated, expanded nor returned.
-template <int AR, int I, int EFCAP, int NB, bool SEL, int CH>
-__device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, CH>& sh, const Query<AR, I>& q,
+template <int AR, int I, class Sh>
+__device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>& q,
                                 uint32_t start, int level, uint32_t ef, uint32_t self, Counters& cnt, int lane,
                                 int& out_cur, bool tomb = false) {
+    constexpr int EFCAP = Sh::kEfCap;
     visited_clear(sh, lane);
-    __syncthreads();
+    wsync<Sh>();
     int cur = 0;
     uint32_t sz = 0;
     uint32_t live = 0;  // members of the list that can be results (== sz unless the index has removed members)
@@ -645,10 +708,9 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         if (start != self) visited_test_and_set(sh, start);
         sh.u_slot[0] = start;
     }
-    __syncthreads();
+    wsync<Sh>();
     if (start != self) {
-        eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, 1, lane);
-        __syncthreads();
+        eval_shared<AR, I>(ix, q, sh, 1, lane);
         cnt.evals += 1;
         const bool start_dead = tomb && ix.keys[start] == kFreeKey;
         if (lane == 0) {
@@ -658,7 +720,7 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         sz = 1;
         live = start_dead ? 0 : 1;
     }
-    __syncthreads();
+    wsync<Sh>();
     // Adjacency prefetch: while hop h evaluates its neighbours, the row of the runner-up candidate is
     // already on its way; it is used when that candidate is indeed expanded next (no closer one arrived).
     uint32_t pf_slot = kInvalid, pf_n = kInvalid;
@@ -680,7 +742,7 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         const uint32_t c_entry = sh.lst_s[cur][pick];
         const uint32_t c_slot = c_entry & kSlotMask;
         uint32_t c2_slot = pick2 >= 0 ? (sh.lst_s[cur][pick2] & kSlotMask) : kInvalid;
-        __syncthreads();
+        wsync<Sh>();
         if (lane == 0) sh.lst_s[cur][pick] = c_entry | kExpanded;
         cnt.hops += 1;
         // neighbours: one id per lane, exact visited test-and-set, compaction
@@ -702,10 +764,9 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         uint64_t fmask = __ballot(fresh);
         uint32_t m = (uint32_t)__popcll(fmask);
         if (fresh) sh.u_slot[mbcnt(fmask)] = n;
-        __syncthreads();
+        wsync<Sh>();
         if (m == 0) continue;
-        eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, m, lane);
-        __syncthreads();
+        eval_shared<AR, I>(ix, q, sh, m, lane);
         cnt.evals += m;
         // admission: top not full, or closer than the current radius (usearch: `top.size() < top_limit || d < radius`)
         float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
@@ -731,17 +792,17 @@ __device__ uint32_t beam_search(const IndexView& ix, BeamShared<EFCAP, NB, SEL, 
         uint64_t amask = __ballot(admit);
         uint32_t ma = (uint32_t)__popcll(amask);
         if (ma == 0) continue;
-        __syncthreads();
+        wsync<Sh>();
         if (admit) {
             uint32_t r = mbcnt(amask);
             sh.u_dist[r] = nd;
             sh.u_slot[r] = ns;
         }
-        __syncthreads();
+        wsync<Sh>();
         nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
         ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
         sz = list_merge(sh, cur, sz, tomb ? (uint32_t)EFCAP : ef, nd, ns, ma, lane);
-        __syncthreads();
+        wsync<Sh>();
         if (tomb) {  // cut after the ef-th live entry
             uint32_t cum = 0, cut = sz;
             bool found = false;

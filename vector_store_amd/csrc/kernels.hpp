@@ -11,6 +11,8 @@ namespace vs {
 // stats layout == vs_hnsw_stats() (include/vs_hnsw.h)
 enum : int { ST_SEARCH_EVALS = 0, ST_SEARCH_HOPS, ST_QUERIES, ST_ADD_EVALS, ST_ADD_HOPS, ST_ADDED, ST_OVERFLOW, ST_RESERVED, ST_COUNT };
 
+constexpr int kSearchTeam = 8;  // 512-thread workgroups: one team per CU at the kernel's register footprint
+
 struct SearchArgs {
     IndexView ix;
     const float* queries;  // nq x q_stride floats (unpadded rows)
@@ -18,6 +20,7 @@ struct SearchArgs {
     uint32_t nq, k, ef;
     uint32_t has_removed;         // some members carry the free key: the beam keeps ef LIVE entries
     uint32_t stress_small_table;  // test hook: 256-bucket visited table (iters == 1 only) to force overflow
+    uint32_t team;                // waves per query: 1, or kSearchTeam for batches too small to fill the chip
     uint64_t* out_keys;    // nq x k, padded with kFreeKey
     float* out_dist;       // nq x k, padded with +inf
     uint32_t* out_found;   // nq

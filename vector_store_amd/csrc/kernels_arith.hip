@@ -20,9 +20,13 @@
 
 namespace vs {
 
-template <int AR, int I, int EFCAP, int NB, int CH>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
-    __shared__ BeamShared<EFCAP, NB, false, CH> sh;
+// TEAM == 1: one wavefront per query (full batches).  TEAM > 1: one workgroup of TEAM waves per query for small
+// batches -- wave 0 walks exactly as before, every wave evaluates its share of each hop's neighbours, so a lone
+// query has TEAM times the loads in flight; results are identical (same distances, same order of decisions).
+template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1>
+__global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
+    using Sh = BeamShared<EFCAP, NB, false, CH, TEAM>;
+    __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
     const uint32_t qi = blockIdx.x;
@@ -38,12 +42,20 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a) {
     }
     Query<AR, I> q;
     query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
+    if constexpr (TEAM > 1) {
+        const uint32_t w = threadIdx.x >> 6;
+        if (w != 0) {
+            team_helper_loop<AR, I>(ix, q, sh, lane, w);
+            return;
+        }
+    }
     Counters cnt = {0, 0, 0};
     // usearch index_gt::search: search_for_one_ down to level 1, then the base-level beam.
     uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
     int cur = 0;
     uint32_t sz = beam_search<AR, I>(ix, sh, q, start, 0, a.ef, kInvalid, cnt, lane, cur, a.has_removed != 0);
-    __syncthreads();
+    team_release(sh, lane);
+    wsync<Sh>();
     // top.sort_ascending(); top.shrink(wanted); removed members (free key) are never results.
     uint32_t written = 0;
 #pragma unroll
@@ -208,6 +220,14 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
 template <int AR, int I>
 static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
     dim3 grid(a.nq), block(64);
+    if (a.team == kSearchTeam && a.ef <= 256 && !a.stress_small_table) {
+        dim3 tblock(64 * kSearchTeam);
+        if (a.ef <= 128)
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, kSearchTeam>), grid, tblock, 0, s, a);
+        else
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, kSearchTeam>), grid, tblock, 0, s, a);
+        return hipGetLastError();
+    }
     if (I == 1 && a.stress_small_table && a.ef <= 128)
         hipLaunchKernelGGL((hnsw_search_kernel<AR, 1, 128, 256, 1>), grid, block, 0, s, a);
     else if (a.ef <= 128)

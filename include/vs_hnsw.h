@@ -130,6 +130,12 @@ VS_API int vs_hnsw_set_expansion_search(vs_hnsw* index, size_t expansion_search)
  * [3] distance evaluations in add, [4] node expansions in add, [5] vectors added,
  * [6] visited-table overflows (must stay 0), [7] reserved */
 VS_API int vs_hnsw_stats(vs_hnsw* index, uint64_t out[8], int reset);
+/* HBM held by the index: [0] bytes in all arenas, [1] of which grow in place (virtual range + mapped chunks),
+ * [2] physical chunks mapped, [3] bytes copied device-to-device by arena growth so far (process-wide). */
+VS_API int vs_hnsw_memory_info(vs_hnsw* index, uint64_t out[4]);
+/* Single-query dispatcher (vs_hnsw_search / _async), process-wide: [0] kernel launches, [1] queries,
+ * [2] launches and [3] queries that took the team kernel (8 wavefronts per query, lightly loaded device). */
+VS_API int vs_search_service_stats(uint64_t out[4]);
 
 /* -- graph export / import (flat layout; see oracle/cpu_hnsw.cpp orc_export_graph) ------- */
 typedef struct vs_hnsw_graph_info {

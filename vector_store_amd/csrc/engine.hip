@@ -64,6 +64,193 @@ struct DeviceBuf {  // grow-only device scratch
     }
 };
 
+// HBM arena that grows in place.  Above kVmmThreshold the arena is a reserved virtual range with physical chunks
+// mapped behind it on demand (hipMemAddressReserve / hipMemCreate / hipMemMap): growing maps one more chunk --
+// no second copy of the index in HBM while it grows, no D2D copy, stable addresses -- so an index can keep
+// following the reference's "+1,000,000" growth policy (usearch.rs:442, :908-921) up to the whole 288 GB.
+// When the virtual range itself runs out, the SAME physical chunks are remapped into a range twice as large
+// (still no copy).  Small arenas (thousands of per-partition indexes) stay on hipMalloc + copy.
+constexpr size_t kVmmThreshold = 64ull << 20;
+struct Arena {
+    void* base = nullptr;
+    size_t bytes = 0;  // usable bytes behind base
+    bool vmm = false;
+    size_t va_bytes = 0;
+    struct Chunk {
+        hipMemGenericAllocationHandle_t h;
+        size_t off, size;
+    };
+    std::vector<Chunk> chunks;
+    static inline std::atomic<unsigned long long> copied_bytes{0};  // D2D bytes moved by growth (process-wide)
+
+    static bool vmm_supported(int device) {
+        static std::mutex mu;
+        static std::unordered_map<int, int> cache;
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(device);
+        if (it != cache.end()) return it->second != 0;
+        int v = 0;
+        const char* off = std::getenv("VS_HNSW_NO_VMM");
+        if (!(off && off[0] == '1') &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeVirtualMemoryManagementSupported, device) != hipSuccess)
+            v = 0;
+        if (off && off[0] == '1') v = 0;
+        cache[device] = v;
+        return v != 0;
+    }
+    static hipMemAllocationProp prop(int device) {
+        hipMemAllocationProp p = {};
+        p.type = hipMemAllocationTypePinned;
+        p.location.type = hipMemLocationTypeDevice;
+        p.location.id = device;
+        return p;
+    }
+    static size_t granularity(int device) {  // the runtime reports 4 KiB; chunks are kept 2 MiB-aligned (large-page friendly)
+        hipMemAllocationProp p = prop(device);
+        size_t g = 0;
+        HIP_OK(hipMemGetAllocationGranularity(&g, &p, hipMemAllocationGranularityRecommended));
+        return std::max<size_t>(g, 2ull << 20);
+    }
+    static size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
+
+    // Additional HBM that resize(want) would take.
+    size_t extra_needed(size_t want, int device) const {
+        want = std::max<size_t>(want, 1);
+        if (vmm) return want > bytes ? want - bytes : 0;
+        if (want >= kVmmThreshold && vmm_supported(device)) return want;  // transition: old block freed after the copy
+        return want == bytes ? 0 : want;
+    }
+
+    void set_access(char* p, size_t n, int device) {
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        HIP_OK(hipMemSetAccess(p, n, &acc, 1));
+    }
+    void map_chunk(size_t size, int device) {  // at the end of the mapped range
+        hipMemAllocationProp p = prop(device);
+        Chunk c{};
+        c.off = bytes;
+        c.size = size;
+        hipError_t e = hipMemCreate(&c.h, size, &p, 0);
+        if (e == hipErrorOutOfMemory) ::vs::fail(VS_ERR_OUT_OF_MEMORY, "not enough HBM to grow the index");
+        HIP_OK(e);
+        e = hipMemMap((char*)base + c.off, size, 0, c.h, 0);
+        if (e != hipSuccess) {
+            (void)hipMemRelease(c.h);
+            HIP_OK(e);
+        }
+        chunks.push_back(c);
+        bytes += size;
+        // Access is always (re)set over the WHOLE mapped range: on ROCm 7.2 hipMemSetAccess on the sub-range of a
+        // later chunk intermittently returns "invalid argument" (scripts/probe/vmm_probe3.cpp: 20 x 12 growth steps
+        // fail with sub-ranges, pass with the whole range, with and without remapping).
+        try {
+            set_access((char*)base, bytes, device);
+        } catch (...) {  // leave the arena as it was
+            (void)hipMemUnmap((char*)base + c.off, size);
+            (void)hipMemRelease(c.h);
+            chunks.pop_back();
+            bytes -= size;
+            throw;
+        }
+    }
+
+    // Make [0, want) usable; the first `keep` bytes survive.  Returns the (possibly new) base.
+    void* resize(size_t want, size_t keep, int device) {
+        want = std::max<size_t>(want, 1);
+        if (!vmm && !(want >= kVmmThreshold && vmm_supported(device))) {  // plain block + copy
+            if (want == bytes && base) return base;
+            void* np = nullptr;
+            hipError_t e = hipMalloc(&np, want);
+            if (e == hipErrorOutOfMemory) ::vs::fail(VS_ERR_OUT_OF_MEMORY, "not enough HBM to grow the index");
+            HIP_OK(e);
+            keep = std::min(keep, std::min(want, bytes));
+            if (base && keep) {
+                HIP_OK(hipMemcpy(np, base, keep, hipMemcpyDeviceToDevice));
+                copied_bytes += keep;
+            }
+            if (base) HIP_OK(hipFree(base));
+            base = np;
+            bytes = want;
+            return base;
+        }
+        const size_t g = granularity(device);
+        const size_t need = round_up(want, g);
+        if (!vmm) {  // first time above the threshold: move the plain block behind a virtual range
+            void* old = base;
+            const size_t old_bytes = bytes;
+            void* va = nullptr;
+            const size_t vb = round_up(std::max<size_t>(2 * need, 256ull << 20), g);
+            HIP_OK(hipMemAddressReserve(&va, vb, 0, nullptr, 0));
+            base = va;
+            va_bytes = vb;
+            bytes = 0;
+            vmm = true;
+            try {
+                map_chunk(need, device);
+            } catch (...) {
+                (void)hipMemAddressFree(va, vb);
+                base = old;
+                bytes = old_bytes;
+                va_bytes = 0;
+                vmm = false;
+                throw;
+            }
+            keep = std::min(keep, std::min(want, old_bytes));
+            if (old && keep) {
+                HIP_OK(hipMemcpy(base, old, keep, hipMemcpyDeviceToDevice));
+                copied_bytes += keep;
+            }
+            if (old) HIP_OK(hipFree(old));
+            return base;
+        }
+        if (need < bytes) {  // give whole chunks beyond the new end back
+            while (!chunks.empty() && chunks.back().off >= need) {
+                Chunk c = chunks.back();
+                HIP_OK(hipMemUnmap((char*)base + c.off, c.size));
+                HIP_OK(hipMemRelease(c.h));
+                bytes = c.off;
+                chunks.pop_back();
+            }
+            return base;
+        }
+        if (need == bytes) return base;
+        if (need > va_bytes) {  // remap the same physical chunks into a larger range: no copy
+            void* va = nullptr;
+            const size_t vb = round_up(2 * need, g);
+            HIP_OK(hipMemAddressReserve(&va, vb, 0, nullptr, 0));
+            for (const Chunk& c : chunks) {
+                HIP_OK(hipMemUnmap((char*)base + c.off, c.size));
+                HIP_OK(hipMemMap((char*)va + c.off, c.size, 0, c.h, 0));
+            }
+            if (bytes) set_access((char*)va, bytes, device);
+            HIP_OK(hipMemAddressFree(base, va_bytes));
+            base = va;
+            va_bytes = vb;
+        }
+        map_chunk(need - bytes, device);
+        return base;
+    }
+
+    void release() {
+        if (vmm) {
+            for (const Chunk& c : chunks) {
+                (void)hipMemUnmap((char*)base + c.off, c.size);
+                (void)hipMemRelease(c.h);
+            }
+            if (base) (void)hipMemAddressFree(base, va_bytes);
+        } else if (base) {
+            (void)hipFree(base);
+        }
+        base = nullptr;
+        bytes = va_bytes = 0;
+        chunks.clear();
+        vmm = false;
+    }
+};
+
 // Stream + scratch leased per host call.  Shared by every index on the device, so thousands
 // of per-partition handles (reference usearch.rs:704-705,766-778) do not each own a stream.
 struct WorkCtx {
@@ -128,7 +315,8 @@ struct Engine {
     uint32_t lanes = 64, lanes_log2 = 6, iters = 1, stride4 = 64;
     uint32_t row_bytes = 0;  // payload bytes of one stored vector (usearch bytes_per_vector)
 
-    // HBM arenas
+    // HBM arenas (the typed pointers below alias ar_*.base)
+    Arena ar_vectors, ar_aux, ar_adj0, ar_upper, ar_upper_off, ar_keys, ar_levels;
     uint4* d_vectors = nullptr;
     float* d_aux = nullptr;
     uint32_t* d_adj0 = nullptr;
@@ -201,9 +389,8 @@ struct Engine {
     ~Engine() {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
-        for (void* p : {(void*)d_vectors, (void*)d_aux, (void*)d_adj0, (void*)d_upper, (void*)d_upper_off,
-                        (void*)d_keys, (void*)d_levels, (void*)d_stats})
-            if (p) (void)hipFree(p);
+        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels}) a->release();
+        if (d_stats) (void)hipFree(d_stats);
     }
 
     void init(const vs_hnsw_options& o) {
@@ -220,6 +407,7 @@ struct Engine {
         stress_small_table = (o.reserved & 1) != 0;
         exact_valu = (o.reserved & 2) ? 1 : 0;
         team_mode = (o.reserved & 4) ? 1 : (o.reserved & 8) ? 2 : 0;
+        if (const char* t = std::getenv("VS_HNSW_TEAM")) team_mode = !std::strcmp(t, "always") ? 1 : !std::strcmp(t, "never") ? 2 : team_mode;
         M = o.connectivity ? (uint32_t)o.connectivity : 16;  // usearch default_connectivity
         if (M < 2 || M > 32) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 32]");
         M0 = 2 * M;
@@ -262,13 +450,9 @@ struct Engine {
     }
 
     template <class T>
-    static void regrow(T*& ptr, size_t old_n, size_t new_n, int fill_byte) {
-        T* np = nullptr;
-        HIP_OK(hipMalloc(&np, std::max<size_t>(new_n, 1) * sizeof(T)));
-        if (fill_byte >= 0 && new_n > old_n) HIP_OK(hipMemset(np + old_n, fill_byte, (new_n - old_n) * sizeof(T)));
-        if (ptr && old_n) HIP_OK(hipMemcpy(np, ptr, std::min(old_n, new_n) * sizeof(T), hipMemcpyDeviceToDevice));
-        if (ptr) HIP_OK(hipFree(ptr));
-        ptr = np;
+    void regrow(Arena& ar, T*& ptr, size_t old_n, size_t new_n, int fill_byte) {
+        ptr = (T*)ar.resize(new_n * sizeof(T), old_n * sizeof(T), device);
+        if (fill_byte >= 0 && new_n > old_n) HIP_OK(hipMemset(ptr + old_n, fill_byte, (new_n - old_n) * sizeof(T)));
     }
 
     // usearch reserve_capacity_and_threads (reference usearch.rs:181-185); exclusive by contract.
@@ -281,17 +465,19 @@ struct Engine {
         HIP_OK(hipDeviceSynchronize());
         // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
         // coexist with the old ones while rows are copied across.
-        const size_t slot_bytes = (size_t)stride4 * 16 + 4 + (size_t)M0 * 4 + 4 + 8 + 4 + (size_t)M * 4 / 8;
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
-        if (cap > capacity && cap * slot_bytes > free_b)
+        const size_t extra = ar_vectors.extra_needed(cap * (size_t)stride4 * 16, device) + ar_aux.extra_needed(cap * 4, device) +
+                             ar_adj0.extra_needed(cap * M0 * 4, device) + ar_upper_off.extra_needed(cap * 4, device) +
+                             ar_keys.extra_needed(cap * 8, device) + ar_levels.extra_needed(cap * 4, device);
+        if (cap > capacity && extra > free_b)
             fail(VS_ERR_OUT_OF_MEMORY, "not enough HBM to reserve " + std::to_string(cap) + " vectors");
-        regrow(d_vectors, slots * (size_t)stride4, cap * (size_t)stride4, -1);
-        regrow(d_aux, slots, cap, 0);
-        regrow(d_adj0, capacity * M0, cap * M0, 0xFF);
-        regrow(d_upper_off, capacity, cap, 0xFF);
-        regrow(d_keys, capacity, cap, 0xFF);
-        regrow(d_levels, capacity, cap, 0);
+        regrow(ar_vectors, d_vectors, slots * (size_t)stride4, cap * (size_t)stride4, -1);
+        regrow(ar_aux, d_aux, slots, cap, 0);
+        regrow(ar_adj0, d_adj0, capacity * M0, cap * M0, 0xFF);
+        regrow(ar_upper_off, d_upper_off, capacity, cap, 0xFF);
+        regrow(ar_keys, d_keys, capacity, cap, 0xFF);
+        regrow(ar_levels, d_levels, capacity, cap, 0);
         h_levels.resize(cap, 0);
         h_upper_off.resize(cap, kInvalid);
         capacity = cap;
@@ -303,7 +489,7 @@ struct Engine {
         if (blocks <= upper_cap) return;
         HIP_OK(hipDeviceSynchronize());
         size_t ncap = std::max(blocks, upper_cap * 2);
-        regrow(d_upper, upper_cap * M, ncap * M, 0xFF);
+        regrow(ar_upper, d_upper, upper_cap * M, ncap * M, 0xFF);
         upper_cap = ncap;
     }
 
@@ -644,8 +830,10 @@ struct Engine {
             fail(VS_ERR_UNSUPPORTED, "index too large for the LDS visited table of this beam width");
     }
 
+    // `load`: queries that will be on the device together with this batch (other pipeline slots included);
+    // the team kernel only pays while the chip has idle CUs.
     void search_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
-                       hipStream_t st) {
+                       hipStream_t st, size_t load = 0) {
         uint32_t ef;
         check_search(k, ef);
         SearchArgs a;
@@ -657,7 +845,7 @@ struct Engine {
         a.ef = ef;
         a.has_removed = removed.load() ? 1u : 0u;
         a.stress_small_table = stress_small_table ? 1u : 0u;
-        a.team = (team_mode == 1 || (team_mode == 0 && nq <= team_max_nq)) ? (uint32_t)kSearchTeam : 1u;
+        a.team = (team_mode == 1 || (team_mode == 0 && std::max(nq, load) <= team_max_nq)) ? (uint32_t)kSearchTeam : 1u;
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;
@@ -888,7 +1076,16 @@ class SearchService {
             grow(s, nb, dim, k);
             for (size_t i = 0; i < nb; ++i) std::memcpy(s.h_q + i * dim, s.reqs[i].q.data(), dim * 4);
             HIP_OK(hipMemcpyAsync(s.d_q, s.h_q, nb * dim * 4, hipMemcpyHostToDevice, s.st));
-            e->search_device(s.d_q, nb, k, s.d_k, s.d_d, s.d_f, s.st);
+            size_t load = 0;  // this batch + the batches of the other slots still in flight
+            for (const Slot& o : slots_) load += o.busy ? o.reqs.size() : 0;
+            e->search_device(s.d_q, nb, k, s.d_k, s.d_d, s.d_f, s.st, load);
+            const bool team = e->team_mode == 1 || (e->team_mode == 0 && std::max(nb, load) <= e->team_max_nq);
+            n_batches += 1;
+            n_queries += nb;
+            if (team) {
+                n_team_batches += 1;
+                n_team_queries += nb;
+            }
             HIP_OK(hipMemcpyAsync(s.h_k, s.d_k, nb * k * 8, hipMemcpyDeviceToHost, s.st));
             HIP_OK(hipMemcpyAsync(s.h_d, s.d_d, nb * k * 4, hipMemcpyDeviceToHost, s.st));
             HIP_OK(hipMemcpyAsync(s.h_f, s.d_f, nb * 4, hipMemcpyDeviceToHost, s.st));
@@ -968,6 +1165,8 @@ class SearchService {
 
    public:
     static thread_local std::string g_async_err;
+    // launches / queries, and how many of them went to the team kernel (process-wide; vs_search_service_stats)
+    static inline std::atomic<unsigned long long> n_batches{0}, n_team_batches{0}, n_queries{0}, n_team_queries{0};
 };
 thread_local std::string SearchService::g_async_err;
 
@@ -1232,6 +1431,32 @@ int vs_hnsw_stats(vs_hnsw* h, uint64_t out[8], int reset) {
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemcpy(out, h->e.d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         if (reset) HIP_OK(hipMemset(h->e.d_stats, 0, 8 * sizeof(uint64_t)));
+    });
+}
+
+int vs_search_service_stats(uint64_t out[4]) {
+    if (!out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = vs::SearchService::n_batches.load();
+    out[1] = vs::SearchService::n_queries.load();
+    out[2] = vs::SearchService::n_team_batches.load();
+    out[3] = vs::SearchService::n_team_queries.load();
+    return VS_OK;
+}
+
+int vs_hnsw_memory_info(vs_hnsw* h, uint64_t out[4]) {
+    return guarded([&] {
+        need(h && out, "null argument");
+        std::lock_guard<std::mutex> g(h->e.mod_mu);
+        Engine& e = h->e;
+        out[0] = out[1] = out[2] = 0;
+        for (const vs::Arena* a : {&e.ar_vectors, &e.ar_aux, &e.ar_adj0, &e.ar_upper, &e.ar_upper_off, &e.ar_keys, &e.ar_levels}) {
+            out[0] += a->bytes;
+            if (a->vmm) {
+                out[1] += a->bytes;
+                out[2] += a->chunks.size();
+            }
+        }
+        out[3] = vs::Arena::copied_bytes.load();
     });
 }
 

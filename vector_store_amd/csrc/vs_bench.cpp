@@ -350,6 +350,10 @@ static int cmd_search(const Args& a) {
     uint64_t st[8];
     ok(vs_hnsw_stats(h, st, 0), "stats");
     if (st[2]) std::cout << "distance evaluations per query: " << (double)st[0] / (double)st[2] << std::endl;
+    uint64_t sv[4];
+    if (vs_search_service_stats(sv) == 0 && sv[0])
+        std::cout << "kernel launches: " << sv[0] << " (mean batch " << (double)sv[1] / (double)sv[0] << "), team-kernel launches: " << sv[2]
+                  << " (" << sv[3] << " queries)" << std::endl;
     vs_hnsw_free(h);
     return 0;
 }

@@ -90,6 +90,7 @@ def lib():
     L.vs_hnsw_exact_search_batch_device.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp]
     L.vs_hnsw_set_expansion_search.argtypes = [vp, sz]
     L.vs_hnsw_stats.argtypes = [vp, vp, C.c_int]
+    L.vs_hnsw_memory_info.argtypes = [vp, vp]
     L.vs_hnsw_graph_info_get.argtypes = [vp, C.POINTER(_GraphInfo)]
     L.vs_hnsw_export_graph.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.vs_hnsw_import_graph.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz, C.c_int32, C.c_uint32]
@@ -265,6 +266,11 @@ class HipUsearchIndex:
         names = ["search_evals", "search_hops", "queries", "add_evals", "add_hops", "added", "visited_overflow",
                  "reserved"]
         return {n: int(v) for n, v in zip(names, out)}
+
+    def memory_info(self) -> dict:
+        out = np.zeros(4, dtype=np.uint64)
+        _check(self.L.vs_hnsw_memory_info(self.h, _p(out)))
+        return {n: int(v) for n, v in zip(["bytes", "in_place_bytes", "chunks", "copied_bytes"], out)}
 
     def graph_info(self) -> dict:
         gi = _GraphInfo()

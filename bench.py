@@ -7,7 +7,7 @@
 A "step" is one pass of the hot path (hnsw_search, one wavefront per query) over one batch of
 `--nq` synthetic queries that are already resident in HBM.  Workload at N=1 = the configuration
 BASELINE.json's metric is quoted on: 10M x 768 cosine, top-10, one GPU (31 GB of vectors + 1.4 GB of graph
-in HBM); ef_search = the smallest of {64,96,...,256,320,...,512} reaching recall@10 >= 0.95 against the exact
+in HBM); ef_search = the smallest beam width (coarse sweep 64,96,...,256,320,...,512, then bisection in steps of 8) reaching recall@10 >= 0.95 against the exact
 brute-force ground truth computed on the GPU.  `--vectors 1000000` is configs[1] (ef_search 128).
 
 Multi-GPU (`--mode replica`, default): the reference scales by replication -- every vector-store
@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--metric", default="cos", choices=["cos", "l2sq", "ip"])
     ap.add_argument("--dist", default="lowrank", choices=["lowrank", "gaussian", "clustered"])
     ap.add_argument("--rank", type=int, default=24, help="latent dimension of the lowrank generator")
-    ap.add_argument("--ef", type=int, default=0, help="expansion_search; 0 = smallest of 64,96,..,512 with recall >= target")
+    ap.add_argument("--ef", type=int, default=0, help="expansion_search; 0 = smallest multiple of 8 (coarse sweep + bisection) with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--quantization", default="f32", choices=["f32", "f16", "bf16", "i8", "b1"], help="storage type (usearch ScalarKind)")
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
@@ -221,7 +221,8 @@ def main():
     # ---- beam width: smallest of {64,96,...,256,320,...,512} reaching the recall target
     sweep = []
     chosen = None
-    for ef in ([a.ef] if a.ef else [64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512]):
+
+    def probe(ef):
         ix.set_expansion_search(ef)
         step()
         torch.cuda.synchronize()
@@ -231,9 +232,24 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             r = float(t.item())
         sweep.append({"ef": ef, "recall": round(r, 4)})
-        if chosen is None and r >= a.target_recall:
+        return r
+
+    prev = None
+    for ef in ([a.ef] if a.ef else [64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512]):
+        r = probe(ef)
+        if r >= a.target_recall:
             chosen = (ef, r)
             break
+        prev = ef
+    if chosen is not None and prev is not None and not a.ef:  # refine between the last miss and the first hit, in steps of 8
+        lo, hi = prev, chosen[0]
+        while hi - lo > 8:
+            mid = (lo + hi) // 16 * 8
+            r = probe(mid)
+            if r >= a.target_recall:
+                hi, chosen = mid, (mid, r)
+            else:
+                lo = mid
     if chosen is None:
         chosen = (sweep[-1]["ef"], sweep[-1]["recall"])
     ef, recall = chosen

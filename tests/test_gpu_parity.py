@@ -403,7 +403,7 @@ def test_visited_table_overflow_is_graceful():
     duplicate-free and identical to the CPU algorithm on the same graph.  The test hook
     (options.reserved bit 0) swaps in a 256-bucket table so that every query overflows."""
     v = vs()
-    n, dim, k = 60000, 128, 100
+    n, dim, k = 60000, 32, 100  # 32 f32 = 8 chunks = 8 lanes x 1: the hook exists for 1-chunk-per-lane layouts
     data = _dataset(n + 64, dim, 77)
     base, q = data[:n], data[n:]
     ix = v.HipUsearchIndex(dim, v.L2SQ, _stress=1)

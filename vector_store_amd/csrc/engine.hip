@@ -415,20 +415,34 @@ struct Engine {
         ef_search = o.expansion_search ? (uint32_t)o.expansion_search : 64;
         if (ef_add > 256) fail(VS_ERR_UNSUPPORTED, "expansion_add > 256 is not supported");
         inv_log_m = 1.0 / std::log((double)M);
-        // Row layout: 16-byte chunks, lanes x iters of them, the (lanes, iters) pair with the least padding
-        // (ties: more lanes).  768 f32 = 192 chunks = 64 x 3; 768 f16 = 96 = 32 x 3; 768 i8 = 48 = 16 x 3.
+        // Row layout: 16-byte chunks, lanes x iters of them.  Least padding first.  Among equals: the FEWEST lanes
+        // that still read >= 128 contiguous bytes of a row per load instruction (lanes >= 8) with iters <= 6 --
+        // a wave-load then carries 64/lanes rows, so a hop's ~20 neighbours need fewer load/reduce rounds, and
+        // each reduction spans fewer lanes (measured at 1M, ef 128: 128-d 2.26M -> 3.11M QPS, 256-d 1.45M -> 2.20M,
+        // 768-d unchanged for search, +6 % for build) -- else the most lanes.
+        // 768 f32 = 192 chunks = 32 x 6; 128 f32 = 32 = 8 x 4; 768 f16 = 96 = 16 x 6; 768 i8 = 48 = 8 x 6; 1536 f32 = 64 x 6.
         static const uint32_t bits[] = {32, 16, 16, 8, 1};
         row_bytes = (uint32_t)(((uint64_t)dim * bits[scalar] + 7) / 8);
         const uint32_t chunks = (row_bytes + 15) / 16;
         static const uint32_t ok_iters[] = {1, 2, 3, 4, 6, 8};
         uint32_t best = 0;
+        bool best_pref = false;
         iters = 0;
-        for (uint32_t lg = 0; lg <= 6; ++lg)
+        uint32_t max_lg = 6;
+        if (const char* ml = std::getenv("VS_HNSW_MAX_LANES_LOG2")) max_lg = std::min<uint32_t>(6, (uint32_t)std::atoi(ml));  // layout experiments
+        for (uint32_t lg = 0; lg <= max_lg; ++lg)
             for (uint32_t it : ok_iters) {
-                uint32_t cap = (1u << lg) * it;
+                const uint32_t cap = (1u << lg) * it;
                 if (cap < chunks) continue;
-                if (!iters || cap < best || (cap == best && (1u << lg) > lanes)) {
+                const bool pref = lg >= 3 && it <= 6;  // preferred family: fewest lanes first (lg ascends)
+                bool take;
+                if (!iters || cap < best) take = true;
+                else if (cap > best) take = false;
+                else if (best_pref) take = false;               // an earlier (fewer-lane) preferred layout stands
+                else take = pref || (1u << lg) > lanes;         // first preferred one, or more lanes among the rest
+                if (take) {
                     best = cap;
+                    best_pref = pref;
                     lanes = 1u << lg;
                     lanes_log2 = lg;
                     iters = it;

@@ -85,3 +85,12 @@ def test_vs_bench_gen_build_search(tmp_path):
     assert float(kv["recall avg"]) >= 90.0
     for p in ("P01", "P10", "P25", "P50", "P75", "P90", "P99"):
         assert f"latency {p}" in kv
+
+
+def test_vs_httpd_selftest():
+    """Request parser (bit-exact float fast path, malformed bodies), filter compiler and number rendering of the native
+    /ann server; no GPU needed."""
+    httpd = os.path.join(os.path.dirname(VS_BENCH), "vs_httpd")
+    out = subprocess.check_output([httpd, "selftest"]).decode()
+    assert "selftest ok" in out
+

@@ -1019,20 +1019,21 @@ class SearchService {
     }
 
    private:
-    static constexpr int kSlots = 4;
+    static constexpr int kSlots = 2;
     static constexpr size_t kMaxBatch = 8192;
     struct Slot {
         hipStream_t st = nullptr;
         hipEvent_t ev = nullptr;
         float* h_q = nullptr;
         float* d_q = nullptr;
-        uint64_t* d_k = nullptr;
-        float* d_d = nullptr;
-        uint32_t* d_f = nullptr;
-        uint64_t* h_k = nullptr;
-        float* h_d = nullptr;
-        uint32_t* h_f = nullptr;
-        size_t q_bytes = 0, o_items = 0, f_items = 0;
+        // results of one batch live in ONE block, device and pinned host alike: [keys nb*k u64 | dist nb*k f32 | found nb u32],
+        // so a batch costs one copy in and one copy out
+        char* d_out = nullptr;
+        char* h_out = nullptr;
+        uint64_t *d_k = nullptr, *h_k = nullptr;
+        float *d_d = nullptr, *h_d = nullptr;
+        uint32_t *d_f = nullptr, *h_f = nullptr;
+        size_t q_bytes = 0, out_bytes = 0;
         std::vector<SearchReq> reqs;
         bool busy = false;
         int status = VS_OK;
@@ -1049,7 +1050,7 @@ class SearchService {
     }
 
     static void grow(Slot& s, size_t nq, size_t dim, size_t k) {
-        const size_t qb = nq * dim * 4, oi = nq * k;
+        const size_t qb = nq * dim * 4, ob = nq * k * 12 + nq * 4;
         if (qb > s.q_bytes) {
             if (s.h_q) (void)hipHostFree(s.h_q);
             if (s.d_q) (void)hipFree(s.d_q);
@@ -1057,24 +1058,19 @@ class SearchService {
             HIP_OK(hipHostMalloc((void**)&s.h_q, s.q_bytes, hipHostMallocDefault));
             HIP_OK(hipMalloc((void**)&s.d_q, s.q_bytes));
         }
-        if (oi > s.o_items) {
-            if (s.h_k) (void)hipHostFree(s.h_k);
-            if (s.h_d) (void)hipHostFree(s.h_d);
-            if (s.d_k) (void)hipFree(s.d_k);
-            if (s.d_d) (void)hipFree(s.d_d);
-            s.o_items = oi + oi / 2;
-            HIP_OK(hipHostMalloc((void**)&s.h_k, s.o_items * 8, hipHostMallocDefault));
-            HIP_OK(hipHostMalloc((void**)&s.h_d, s.o_items * 4, hipHostMallocDefault));
-            HIP_OK(hipMalloc((void**)&s.d_k, s.o_items * 8));
-            HIP_OK(hipMalloc((void**)&s.d_d, s.o_items * 4));
+        if (ob > s.out_bytes) {
+            if (s.h_out) (void)hipHostFree(s.h_out);
+            if (s.d_out) (void)hipFree(s.d_out);
+            s.out_bytes = ob + ob / 2;
+            HIP_OK(hipHostMalloc((void**)&s.h_out, s.out_bytes, hipHostMallocDefault));
+            HIP_OK(hipMalloc((void**)&s.d_out, s.out_bytes));
         }
-        if (nq > s.f_items) {
-            if (s.h_f) (void)hipHostFree(s.h_f);
-            if (s.d_f) (void)hipFree(s.d_f);
-            s.f_items = nq + nq / 2;
-            HIP_OK(hipHostMalloc((void**)&s.h_f, s.f_items * 4, hipHostMallocDefault));
-            HIP_OK(hipMalloc((void**)&s.d_f, s.f_items * 4));
-        }
+        s.d_k = (uint64_t*)s.d_out;
+        s.h_k = (uint64_t*)s.h_out;
+        s.d_d = (float*)(s.d_out + nq * k * 8);
+        s.h_d = (float*)(s.h_out + nq * k * 8);
+        s.d_f = (uint32_t*)(s.d_out + nq * k * 12);
+        s.h_f = (uint32_t*)(s.h_out + nq * k * 12);
     }
 
     void launch(Slot& s) {
@@ -1100,9 +1096,7 @@ class SearchService {
                 n_team_batches += 1;
                 n_team_queries += nb;
             }
-            HIP_OK(hipMemcpyAsync(s.h_k, s.d_k, nb * k * 8, hipMemcpyDeviceToHost, s.st));
-            HIP_OK(hipMemcpyAsync(s.h_d, s.d_d, nb * k * 4, hipMemcpyDeviceToHost, s.st));
-            HIP_OK(hipMemcpyAsync(s.h_f, s.d_f, nb * 4, hipMemcpyDeviceToHost, s.st));
+            HIP_OK(hipMemcpyAsync(s.h_out, s.d_out, nb * k * 12 + nb * 4, hipMemcpyDeviceToHost, s.st));
             HIP_OK(hipEventRecord(s.ev, s.st));
         } catch (const Fail& f) {
             s.status = f.code;
@@ -1125,6 +1119,7 @@ class SearchService {
             } else {
                 *r.found = 0;
                 g_async_err = s.err;
+                g_err = s.err;  // vs_hnsw_last_error() inside the completion callback
             }
             r.cb(r.ctx, s.status);
         }

@@ -8,12 +8,20 @@
 //                         [--concurrency C [--max-vectors N]]   (one vector per call from C threads)
 //   vs_bench search       --data-dir D --limit K --duration SEC --concurrency C [--inflight D] [--expansion-search E]
 //                         [--metric M] [--connectivity C] [--expansion-add E]
+//   vs_bench search-http  --data-dir D --limit K --duration SEC --concurrency C [--host H] [--port P]
+//                         [--keyspace K] [--index I]      (against a running vs_httpd / vector-store: POST .../ann)
 //
 // `search` is the reference's search-http / search-cql loop (main.rs:435-525): `concurrency` workers
 // each pick a random query and issue ONE query per call (vs_hnsw_search, as client.ann does), recording
 // latency into a 10,000-bucket histogram and recall against query.ibin.  The reference measures a
 // running service; here the index is built in-process first (its wall time is what `build-index`
 // reports: main.rs:285-306 times CREATE INDEX until SERVING).
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <chrono>
 #include <cinttypes>
@@ -358,9 +366,145 @@ static int cmd_search(const Args& a) {
     return 0;
 }
 
+// ---- search-http: the reference's `search-http` scenario (main.rs:435-525) against a running /ann server
+// (vs_httpd, or the reference service): `concurrency` keep-alive connections, one query per request.
+struct HttpConn {
+    int fd = -1;
+    std::string buf;
+    bool connect_to(const std::string& host, int port) {
+        fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (fd < 0) return false;
+        int one = 1;
+        setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        sockaddr_in sa{};
+        sa.sin_family = AF_INET;
+        sa.sin_port = htons((uint16_t)port);
+        if (inet_pton(AF_INET, host.c_str(), &sa.sin_addr) != 1) return false;
+        return ::connect(fd, (sockaddr*)&sa, sizeof sa) == 0;
+    }
+    // Sends one request, returns the status code and the body.
+    int roundtrip(const std::string& req, std::string& body) {
+        size_t off = 0;
+        while (off < req.size()) {
+            ssize_t n = ::send(fd, req.data() + off, req.size() - off, MSG_NOSIGNAL);
+            if (n <= 0) return -1;
+            off += (size_t)n;
+        }
+        buf.clear();
+        size_t he = std::string::npos, clen = 0;
+        char tmp[16384];
+        for (;;) {
+            if (he == std::string::npos) {
+                he = buf.find("\r\n\r\n");
+                if (he != std::string::npos) {
+                    std::string head = buf.substr(0, he);
+                    for (auto& ch : head) ch = (char)std::tolower((unsigned char)ch);
+                    size_t p = head.find("content-length:");
+                    clen = p == std::string::npos ? 0 : (size_t)std::strtoull(head.c_str() + p + 15, nullptr, 10);
+                }
+            }
+            if (he != std::string::npos && buf.size() >= he + 4 + clen) break;
+            ssize_t n = ::recv(fd, tmp, sizeof tmp, 0);
+            if (n <= 0) return -1;
+            buf.append(tmp, (size_t)n);
+        }
+        body.assign(buf, he + 4, clen);
+        return std::atoi(buf.c_str() + 9);  // "HTTP/1.1 200 ..."
+    }
+    ~HttpConn() {
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+static int cmd_search_http(const Args& a) {
+    const std::string dir = a.get("data-dir");
+    const size_t limit = (size_t)a.num("limit", 10);
+    const double duration = a.real("duration", 10.0);
+    const unsigned conc = (unsigned)a.num("concurrency", 64);
+    const std::string host = a.get("host", "127.0.0.1");
+    const int port = (int)a.num("port", 6080);
+    const std::string base = "/api/v1/indexes/" + a.get("keyspace", "vsb_keyspace") + "/" + a.get("index", "vsb_index");
+    DatasetConfig cfg = read_dataset_toml(dir);
+    std::vector<Query> queries = load_queries(dir, cfg, limit);
+    // wait for SERVING, as the reference's wait_for_index_ready does (vs.rs:17-39)
+    {
+        const std::string req = "GET " + base + "/status HTTP/1.1\r\nhost: " + host + "\r\n\r\n";
+        for (int tries = 0;; ++tries) {
+            HttpConn c;
+            std::string body;
+            if (c.connect_to(host, port) && c.roundtrip(req, body) == 200 && body.find("\"SERVING\"") != std::string::npos) break;
+            if (tries > 3600) throw std::runtime_error("index never reached SERVING");
+            std::this_thread::sleep_for(std::chrono::milliseconds(500));
+        }
+    }
+    // one pre-rendered request per query (the client's JSON encoding is not what is measured)
+    std::vector<std::string> reqs(queries.size());
+    for (size_t i = 0; i < queries.size(); ++i) {
+        std::string body = "{\"vector\":[";
+        char num[32];
+        for (size_t j = 0; j < queries[i].query.size(); ++j) {
+            std::snprintf(num, sizeof num, j ? ",%.9g" : "%.9g", (double)queries[i].query[j]);
+            body += num;
+        }
+        body += "],\"limit\":" + std::to_string(limit) + "}";
+        reqs[i] = "POST " + base + "/ann HTTP/1.1\r\nhost: " + host + "\r\ncontent-type: application/json\r\ncontent-length: " +
+                  std::to_string(body.size()) + "\r\n\r\n" + body;
+    }
+    std::atomic<bool> stop{false};
+    std::vector<SearchMeasure> per(conc);
+    std::vector<std::string> errors(conc);
+    auto t0 = Clock::now();
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < conc; ++t)
+        th.emplace_back([&, t] {
+            std::mt19937_64 g(t * 7919 + 13);
+            HttpConn c;
+            if (!c.connect_to(host, port)) {
+                errors[t] = "connect failed";
+                return;
+            }
+            std::string body;
+            std::vector<uint64_t> keys;
+            while (!stop.load(std::memory_order_relaxed)) {
+                const size_t qi = g() % queries.size();
+                auto s = Clock::now();
+                int code = c.roundtrip(reqs[qi], body);
+                int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
+                if (code != 200) {
+                    errors[t] = "HTTP " + std::to_string(code) + ": " + body.substr(0, 200);
+                    break;
+                }
+                keys.clear();
+                size_t p = body.find("\"primary_keys\"");
+                p = p == std::string::npos ? p : body.find('[', p);
+                if (p != std::string::npos) {
+                    const char* q = body.c_str() + p + 1;
+                    while (*q && *q != ']') {
+                        char* e = nullptr;
+                        unsigned long long v = std::strtoull(q, &e, 10);
+                        if (e == q) break;
+                        keys.push_back(v);
+                        q = *e == ',' ? e + 1 : e;
+                    }
+                }
+                per[t].record(ns, recall(queries[qi].neighbors, keys.data(), keys.size()));
+            }
+        });
+    std::this_thread::sleep_for(std::chrono::duration<double>(duration));
+    stop = true;
+    for (auto& x : th) x.join();
+    double wall = std::chrono::duration<double>(Clock::now() - t0).count();
+    SearchMeasure all;
+    for (auto& m : per) all.append(m);
+    for (auto& e : errors)
+        if (!e.empty()) std::cerr << "search-http error: " << e << std::endl;
+    std::cout << "search-http concurrency: " << conc << "\n" << all.report(wall);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) {
-        std::cerr << "usage: vs_bench selftest | gen | build-index | search  (see the header of vs_bench.cpp)" << std::endl;
+        std::cerr << "usage: vs_bench selftest | gen | build-index | search | search-http  (see the header of vs_bench.cpp)" << std::endl;
         return 2;
     }
     Args a;
@@ -377,6 +521,7 @@ int main(int argc, char** argv) {
         if (c == "gen") return cmd_gen(a);
         if (c == "build-index") return cmd_build(a);
         if (c == "search") return cmd_search(a);
+        if (c == "search-http") return cmd_search_http(a);
         std::cerr << "unknown command " << c << std::endl;
         return 2;
     } catch (const std::exception& e) {

@@ -103,3 +103,23 @@ def test_default_policy_small_batches_take_the_team_kernel_and_match():
     for lo in range(0, 1024, 256):                     # 4 x 256 queries: team kernel
         k, d, _ = a.search_batch(q[lo:lo + 256], 10)
         assert np.array_equal(k, big_k[lo:lo + 256]) and np.array_equal(d, big_d[lo:lo + 256])
+
+
+def test_team_insert_builds_the_same_graph():
+    """Sub-batches of at most 256 nodes take the team insert kernel (always, with the test hook): same links, same
+    levels, same entry point as the one-wave-per-node kernel -- wave 0 decides, the helpers only measure."""
+    v = vs()
+    for kind, metric, dim in (("f32", "cos", 768), ("f32", "l2sq", 48), ("f16", "ip", 200), ("i8", "cos", 256), ("b1", "hamming", 512)):
+        n = 3000
+        base = _data(n, dim, 41)
+        graphs = []
+        for stress in (TEAM_NEVER, TEAM_ALWAYS):
+            ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS[kind], _stress=stress)
+            ix.reserve(n)
+            ix.add_batch(np.arange(n, dtype=np.uint64), base)
+            graphs.append(ix.export_graph())
+        a, b = graphs
+        assert a["max_level"] == b["max_level"] and a["entry_slot"] == b["entry_slot"]
+        assert np.array_equal(a["levels"], b["levels"])
+        assert np.array_equal(a["adj0"], b["adj0"]), (kind, metric, dim)
+        assert np.array_equal(a["upper"], b["upper"])

@@ -697,6 +697,7 @@ struct Engine {
                 ia.req_off = d_reqoff + pos;
                 ia.n = take;
                 ia.ef_add = ef_add;
+                ia.team = (team_mode == 1 || (team_mode == 0 && take <= team_max_nq)) ? (uint32_t)kSearchTeam : 1u;
                 ia.req_base = req_off[pos];
                 ia.req_key = rk_in;
                 ia.req_val = rv_in;

@@ -417,6 +417,7 @@ constexpr uint32_t kTeamExit = 0xFFFFFFFFu;
 template <int TM>
 struct TeamBox {
     uint32_t team_m;
+    uint32_t team_q;  // kInvalid: distances from the walker's own query to u_slot[]; else from stored row team_q to sel_s[] (refine)
 };
 template <>
 struct TeamBox<1> {};
@@ -428,6 +429,7 @@ struct BeamShared : SelArrays<SEL>, TeamBox<TM> {
     static constexpr int kEfCap = EFCAP;
     static constexpr int kNB = NB;
     static constexpr int kTeam = TM;
+    static constexpr bool kSel = SEL;
     float lst_d[1][EFCAP];  // one buffer: list_merge works in place
     uint32_t lst_s[1][EFCAP];
     alignas(16) uint16_t vis_tag[NB * 8];
@@ -458,10 +460,30 @@ __device__ __forceinline__ void eval_shared(const IndexView& ix, const Query<AR,
         eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, m, lane);
         __syncthreads();
     } else {
-        if (lane == 0) sh.team_m = m;
+        if (lane == 0) {
+            sh.team_m = m;
+            sh.team_q = kInvalid;
+        }
         __syncthreads();  // releases the helpers (see team_helper_loop)
         eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, 0);
         __syncthreads();  // every wave's distances are in LDS
+    }
+}
+
+// refine's inner step: distances from stored row `cs` (already in `cv`) to sh.sel_s[0..m) -> sh.u_dist.
+template <int AR, int I, class Sh>
+__device__ __forceinline__ void eval_selected(const IndexView& ix, uint32_t cs, const Query<AR, I>& cv, Sh& sh, uint32_t m, int lane) {
+    if constexpr (Sh::kTeam == 1) {
+        eval_batch<AR, I>(ix, cv, sh.sel_s, sh.u_dist, m, lane);
+        __syncthreads();
+    } else {
+        if (lane == 0) {
+            sh.team_m = m;
+            sh.team_q = cs;
+        }
+        __syncthreads();
+        eval_batch<AR, I, Sh::kTeam>(ix, cv, sh.sel_s, sh.u_dist, m, lane, 0);
+        __syncthreads();
     }
 }
 
@@ -472,7 +494,17 @@ __device__ __forceinline__ void team_helper_loop(const IndexView& ix, const Quer
         __syncthreads();
         const uint32_t m = sh.team_m;
         if (m == kTeamExit) return;
-        eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, w);
+        if constexpr (Sh::kSel) {  // insert kernel: the heuristic measures from a stored row against sel_s[]
+            const uint32_t qs = sh.team_q;
+            const uint32_t vshift = 6u - ix.lanes_log2;
+            const bool mine = w < ((m + (1u << vshift) - 1u) >> vshift);  // only waves that get a share fetch the row
+            Query<AR, I> use = q;
+            if (qs != kInvalid && mine) query_from_row<AR, I>(ix, qs, use, lane);
+            const uint32_t* list = qs == kInvalid ? sh.u_slot : sh.sel_s;
+            if (mine) eval_batch<AR, I, Sh::kTeam>(ix, use, list, sh.u_dist, m, lane, w);
+        } else {
+            eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, w);
+        }
         __syncthreads();
     }
 }
@@ -838,39 +870,38 @@ template <int AR, int I, class Sh>
 __device__ uint32_t refine(const IndexView& ix, Sh& sh, int cur, uint32_t sz, uint32_t needed,
                            Counters& cnt, int lane) {
     if (sz < needed || sz == 0) {
-        __syncthreads();
+        wsync<Sh>();
         if ((uint32_t)lane < sz) {
             sh.sel_s[lane] = sh.lst_s[cur][lane] & kSlotMask;
             sh.sel_d[lane] = sh.lst_d[cur][lane];
         }
-        __syncthreads();
+        wsync<Sh>();
         return sz;
     }
-    __syncthreads();
+    wsync<Sh>();
     if (lane == 0) {
         sh.sel_s[0] = sh.lst_s[cur][0] & kSlotMask;
         sh.sel_d[0] = sh.lst_d[cur][0];
     }
-    __syncthreads();
+    wsync<Sh>();
     uint32_t nsel = 1;
     for (uint32_t c = 1; c < sz && nsel < needed; ++c) {
         const uint32_t cs = sh.lst_s[cur][c] & kSlotMask;
         const float cd = sh.lst_d[cur][c];
         Query<AR, I> cv;
         query_from_row<AR, I>(ix, cs, cv, lane);
-        eval_batch<AR, I>(ix, cv, sh.sel_s, sh.u_dist, nsel, lane);
-        __syncthreads();
+        eval_selected<AR, I>(ix, cs, cv, sh, nsel, lane);
         cnt.evals += nsel;
         bool bad = (uint32_t)lane < nsel && sh.u_dist[lane] < cd;
         bool reject = __ballot(bad) != 0ull;
-        __syncthreads();
+        wsync<Sh>();
         if (!reject) {
             if (lane == 0) {
                 sh.sel_s[nsel] = cs;
                 sh.sel_d[nsel] = cd;
             }
             ++nsel;
-            __syncthreads();
+            wsync<Sh>();
         }
     }
     return nsel;

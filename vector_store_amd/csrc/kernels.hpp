@@ -33,6 +33,7 @@ struct InsertArgs {
     const int32_t* levels;    // n
     const uint32_t* req_off;  // n: first request index of node b (levels*(M) requests, one block per level)
     uint32_t n, ef_add;
+    uint32_t team;            // waves per new node: 1, or kSearchTeam for sub-batches too small to fill the chip
     uint32_t req_base;        // req_off[first node of this sub-batch]
     uint64_t* req_key;        // (level << 32) | target, ~0 = unused
     uint64_t* req_val;        // (float bits of d(source,target) << 32) | source

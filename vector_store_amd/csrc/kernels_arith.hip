@@ -88,9 +88,12 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
 }
 
 
-template <int AR, int I, int EFCAP, int NB, int CH>
-__global__ __launch_bounds__(64) void hnsw_insert_kernel(InsertArgs a) {
-    __shared__ BeamShared<EFCAP, NB, true, CH> sh;
+// TEAM > 1: small sub-batches (the first geometric steps of a build, streaming adds between searches) get a
+// workgroup of TEAM waves per new node, as the search kernel does for small query batches; same decisions, same graph.
+template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1>
+__global__ __launch_bounds__(64 * TEAM) void hnsw_insert_kernel(InsertArgs a) {
+    using Sh = BeamShared<EFCAP, NB, true, CH, TEAM>;
+    __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
     const uint32_t b = blockIdx.x;
@@ -98,6 +101,13 @@ __global__ __launch_bounds__(64) void hnsw_insert_kernel(InsertArgs a) {
     const int level = a.levels[b];
     Query<AR, I> q;
     query_from_row<AR, I>(ix, slot, q, lane);
+    if constexpr (TEAM > 1) {
+        const uint32_t w = threadIdx.x >> 6;
+        if (w != 0) {
+            team_helper_loop<AR, I>(ix, q, sh, lane, w);
+            return;
+        }
+    }
     Counters cnt = {0, 0, 0};
     uint32_t closest = ix.entry_slot;
     if (ix.max_level > level)
@@ -119,8 +129,9 @@ __global__ __launch_bounds__(64) void hnsw_insert_kernel(InsertArgs a) {
         }
         req += ix.M;
         if (nsel) closest = sh.sel_s[0];
-        __syncthreads();
+        wsync<Sh>();
     }
+    team_release(sh, lane);
     if (lane == 0) {
         atomicAdd(&a.stats[ST_ADD_EVALS], cnt.evals);
         atomicAdd(&a.stats[ST_ADD_HOPS], cnt.hops);
@@ -130,6 +141,7 @@ __global__ __launch_bounds__(64) void hnsw_insert_kernel(InsertArgs a) {
 }
 
 struct LinkShared {
+    static constexpr int kTeam = 1;
     float lst_d[1][128];
     uint32_t lst_s[1][128];
     float t_d[128];
@@ -242,6 +254,14 @@ static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
 template <int AR, int I>
 static hipError_t insert_ef(const InsertArgs& a, hipStream_t s) {
     dim3 grid(a.n), block(64);
+    if (a.team == kSearchTeam) {
+        dim3 tblock(64 * kSearchTeam);
+        if (a.ef_add <= 128)
+            hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 128, 1024, 1, kSearchTeam>), grid, tblock, 0, s, a);
+        else
+            hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 256, 1024, 2, kSearchTeam>), grid, tblock, 0, s, a);
+        return hipGetLastError();
+    }
     if (a.ef_add <= 128)
         hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 128, 1024, 1>), grid, block, 0, s, a);
     else

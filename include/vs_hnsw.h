@@ -128,7 +128,7 @@ VS_API int vs_hnsw_set_expansion_search(vs_hnsw* index, size_t expansion_search)
 /* -- counters for the roofline figure: cumulative since reset -----
  * [0] distance evaluations in search, [1] node expansions in search, [2] queries,
  * [3] distance evaluations in add, [4] node expansions in add, [5] vectors added,
- * [6] visited-table overflows (must stay 0), [7] reserved */
+ * [6] visited-table overflows (must stay 0), [7] the part of [3] spent re-selecting neighbours' links */
 VS_API int vs_hnsw_stats(vs_hnsw* index, uint64_t out[8], int reset);
 /* HBM held by the index: [0] bytes in all arenas, [1] of which grow in place (virtual range + mapped chunks),
  * [2] physical chunks mapped, [3] bytes copied device-to-device by arena growth so far (process-wide). */

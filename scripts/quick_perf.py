@@ -49,7 +49,7 @@ def main():
     ix.add_batch_device(keys, base.data_ptr(), a.n, a.dim)
     tb = time.time() - t
     st = ix.stats(reset=True)
-    print(f"build n={a.n} dim={a.dim}: {tb:.2f}s = {a.n / tb:.0f} vec/s; evals/add={st['add_evals'] / max(st['added'], 1):.0f} "
+    print(f"build n={a.n} dim={a.dim}: {tb:.2f}s = {a.n / tb:.0f} vec/s; evals/add={st['add_evals'] / max(st['added'], 1):.0f} (link {st['link_evals'] / max(st['added'], 1):.0f}) "
           f"hops/add={st['add_hops'] / max(st['added'], 1):.0f} overflow={st['visited_overflow']}", flush=True)
     k = a.k
     ok = torch.empty((a.nq, k), dtype=torch.int64, device=dev)

@@ -9,7 +9,7 @@
 namespace vs {
 
 // stats layout == vs_hnsw_stats() (include/vs_hnsw.h)
-enum : int { ST_SEARCH_EVALS = 0, ST_SEARCH_HOPS, ST_QUERIES, ST_ADD_EVALS, ST_ADD_HOPS, ST_ADDED, ST_OVERFLOW, ST_RESERVED, ST_COUNT };
+enum : int { ST_SEARCH_EVALS = 0, ST_SEARCH_HOPS, ST_QUERIES, ST_ADD_EVALS, ST_ADD_HOPS, ST_ADDED, ST_OVERFLOW, ST_LINK_EVALS, ST_COUNT };  // ST_LINK_EVALS: the part of ST_ADD_EVALS spent in hnsw_link_kernel
 
 constexpr int kSearchTeam = 8;  // 512-thread workgroups: one team per CU at the kernel's register footprint
 

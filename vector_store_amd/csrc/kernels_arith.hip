@@ -225,7 +225,10 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
     __syncthreads();
     uint32_t nsel = refine<AR, I>(ix, sh, 0, total, cap, c, lane);
     if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < nsel ? sh.sel_s[lane] : kInvalid;
-    if (lane == 0) atomicAdd(&a.stats[ST_ADD_EVALS], c.evals);
+    if (lane == 0) {
+        atomicAdd(&a.stats[ST_ADD_EVALS], c.evals);
+        atomicAdd(&a.stats[ST_LINK_EVALS], c.evals);
+    }
 }
 
 

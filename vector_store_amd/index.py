@@ -264,7 +264,7 @@ class HipUsearchIndex:
         out = np.zeros(8, dtype=np.uint64)
         _check(self.L.vs_hnsw_stats(self.h, _p(out), int(reset)))
         names = ["search_evals", "search_hops", "queries", "add_evals", "add_hops", "added", "visited_overflow",
-                 "reserved"]
+                 "link_evals"]
         return {n: int(v) for n, v in zip(names, out)}
 
     def memory_info(self) -> dict:

@@ -122,5 +122,5 @@ class ShardedIndex:
     def stats(self, reset: bool = False) -> dict:
         out = np.zeros(8, dtype=np.uint64)
         self._check(self.L.vs_shards_stats(self.h, out.ctypes.data, int(reset)))
-        names = ["search_evals", "search_hops", "queries", "add_evals", "add_hops", "added", "visited_overflow", "reserved"]
+        names = ["search_evals", "search_hops", "queries", "add_evals", "add_hops", "added", "visited_overflow", "link_evals"]
         return {n: int(v) for n, v in zip(names, out)}

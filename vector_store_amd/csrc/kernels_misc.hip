@@ -365,52 +365,75 @@ __global__ __launch_bounds__(256) void exact_dist_mfma_kernel(IndexView ix, cons
 
 using SelectShared = BeamShared<256, 256>;
 
+// Grid (queries, S): with few queries a score row is cut into S segments, each with its own running top-k
+// (state index qg * S + seg), merged by exact_finish_kernel at the end -- 256 queries alone would put one wave
+// on each CU.  S == 1: the single state is written out directly by the last tile.
 __global__ __launch_bounds__(64) void exact_select_kernel(IndexView ix, const float* D, uint32_t q0, uint32_t n0,
-                                                          uint32_t n_blk, uint32_t k, int first, int last, float* st_d,
+                                                          uint32_t n_all, uint32_t k, int first, int last, float* st_d,
                                                           uint32_t* st_s, uint32_t* st_n, uint64_t* out_keys,
                                                           float* out_dist, uint32_t* out_found) {
     __shared__ SelectShared sh;
     const int lane = lane_id();
     const uint32_t ql = blockIdx.x, qg = q0 + ql;
+    const uint32_t S = gridDim.y, seg = blockIdx.y;
+    const size_t sg = (size_t)qg * S + seg;
+    const uint32_t per = ((n_all + S - 1) / S + kWave - 1) / kWave * kWave;  // columns of one segment
+    const uint32_t c0 = seg * per;
+    const uint32_t n_blk = c0 >= n_all ? 0u : (n_all - c0 < per ? n_all - c0 : per);
+    n0 += c0;
     int cur = 0;
     uint32_t sz = 0;
     if (!first) {
-        sz = st_n[qg];
+        sz = st_n[sg];
         for (uint32_t i = lane; i < sz; i += kWave) {
-            sh.lst_d[0][i] = st_d[(size_t)qg * k + i];
-            sh.lst_s[0][i] = st_s[(size_t)qg * k + i];
+            sh.lst_d[0][i] = st_d[sg * k + i];
+            sh.lst_s[0][i] = st_s[sg * k + i];
         }
     }
     __syncthreads();
-    const float* row = D + (size_t)ql * kExactCH;
-    for (uint32_t j0 = 0; j0 < n_blk; j0 += kWave) {
-        uint32_t j = j0 + lane;
-        bool ok = j < n_blk;
-        float d = ok ? row[j] : __builtin_inff();
-        uint32_t slot = n0 + j;
-        ok = ok && ix.keys[ok ? slot : 0] != kFreeKey;
-        if (ok && sz == k) ok = key_less(d, slot, sh.lst_d[cur][k - 1], sh.lst_s[cur][k - 1]);
-        uint64_t mask = __ballot(ok);
-        if (!mask) continue;
-        uint32_t ma = (uint32_t)__popcll(mask);
-        __syncthreads();
-        if (ok) {
-            uint32_t r = mbcnt(mask);
-            sh.u_dist[r] = d;
-            sh.u_slot[r] = slot;
+    const float* row = D + (size_t)ql * kExactCH + c0;
+    // UN independent score loads in flight per lane (a lone wave per query is latency-bound otherwise: with 256
+    // queries the chip holds one wave per CU); the member check (removed keys) is only paid by scores that beat
+    // the current k-th -- a stale threshold merely admits candidates that list_merge drops again.
+    constexpr uint32_t UN = 8;
+    for (uint32_t j0 = 0; j0 < n_blk; j0 += kWave * UN) {
+        float dv[UN];
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) {
+            const uint32_t j = j0 + u * kWave + (uint32_t)lane;
+            dv[u] = j < n_blk ? row[j] : __builtin_inff();
         }
-        __syncthreads();
-        float nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
-        uint32_t ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
-        sz = list_merge(sh, cur, sz, k, nd, ns, ma, lane);
-        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) {
+            const uint32_t j = j0 + u * kWave + (uint32_t)lane;
+            const float d = dv[u];
+            const uint32_t slot = n0 + j;
+            bool ok = j < n_blk;
+            if (ok && sz == k) ok = key_less(d, slot, sh.lst_d[cur][k - 1], sh.lst_s[cur][k - 1]);
+            if (!__ballot(ok)) continue;
+            ok = ok && ix.keys[ok ? slot : 0] != kFreeKey;
+            uint64_t mask = __ballot(ok);
+            if (!mask) continue;
+            uint32_t ma = (uint32_t)__popcll(mask);
+            __syncthreads();
+            if (ok) {
+                uint32_t r = mbcnt(mask);
+                sh.u_dist[r] = d;
+                sh.u_slot[r] = slot;
+            }
+            __syncthreads();
+            float nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
+            uint32_t ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
+            sz = list_merge(sh, cur, sz, k, nd, ns, ma, lane);
+            __syncthreads();
+        }
     }
-    if (!last) {
+    if (!last || S > 1) {
         for (uint32_t i = lane; i < sz; i += kWave) {
-            st_d[(size_t)qg * k + i] = sh.lst_d[cur][i];
-            st_s[(size_t)qg * k + i] = sh.lst_s[cur][i];
+            st_d[sg * k + i] = sh.lst_d[cur][i];
+            st_s[sg * k + i] = sh.lst_s[cur][i];
         }
-        if (lane == 0) st_n[qg] = sz;
+        if (lane == 0) st_n[sg] = sz;
         return;
     }
     for (uint32_t i = lane; i < k; i += kWave) {
@@ -420,6 +443,46 @@ __global__ __launch_bounds__(64) void exact_select_kernel(IndexView ix, const fl
     if (lane == 0) out_found[qg] = sz;
 }
 
+// Merges the S per-segment states of one query into its result.
+__global__ __launch_bounds__(64) void exact_finish_kernel(IndexView ix, uint32_t q0, uint32_t S, uint32_t k, const float* st_d,
+                                                          const uint32_t* st_s, const uint32_t* st_n, uint64_t* out_keys,
+                                                          float* out_dist, uint32_t* out_found) {
+    __shared__ SelectShared sh;
+    const int lane = lane_id();
+    const uint32_t qg = q0 + blockIdx.x;
+    const size_t s0 = (size_t)qg * S;
+    uint32_t sz = st_n[s0];
+    for (uint32_t i = lane; i < sz; i += kWave) {
+        sh.lst_d[0][i] = st_d[s0 * k + i];
+        sh.lst_s[0][i] = st_s[s0 * k + i];
+    }
+    __syncthreads();
+    for (uint32_t seg = 1; seg < S; ++seg) {
+        const size_t sg = s0 + seg;
+        const uint32_t n = st_n[sg];
+        for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
+            const uint32_t m = n - i0 < (uint32_t)kWave ? n - i0 : (uint32_t)kWave;
+            float nd = (uint32_t)lane < m ? st_d[sg * k + i0 + lane] : __builtin_inff();
+            uint32_t ns = (uint32_t)lane < m ? st_s[sg * k + i0 + lane] : kInvalid;
+            sz = list_merge(sh, 0, sz, k, nd, ns, m, lane);
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = lane; i < k; i += kWave) {
+        out_keys[(size_t)qg * k + i] = i < sz ? ix.keys[sh.lst_s[0][i] & kSlotMask] : kFreeKey;
+        out_dist[(size_t)qg * k + i] = i < sz ? sh.lst_d[0][i] : __builtin_inff();
+    }
+    if (lane == 0) out_found[qg] = sz;
+}
+
+// Segments per query: enough waves (~4096) to cover the select pass's load latency, at most 16.
+static uint32_t exact_segments(uint32_t nq) {
+    const uint32_t nqb = nq < kExactQB ? nq : kExactQB;
+    uint32_t S = 1;
+    while (S < 16 && nqb * (S * 2) <= 4096) S *= 2;
+    return S;
+}
+
 static uint32_t exact_kpad(const IndexView& ix) {
     return (ix.dim + 15u) & ~15u;  // k extent of the tiles; load4_dequant pads short rows with zeros
 }
@@ -427,7 +490,8 @@ static uint32_t exact_kpad(const IndexView& ix) {
 static bool exact_uses_l2(const IndexView& ix) { return ix.scalar == SC_B1 || (ix.scalar != SC_I8 && ix.metric == L2SQ); }
 
 size_t exact_scratch_bytes(uint32_t nq, uint32_t k, uint32_t dim) {
-    return (size_t)kExactQB * kExactCH * 4 + (size_t)nq * k * 8 + (size_t)nq * 8 + (size_t)nq * (dim + 16) * 4 + 1024;
+    const size_t S = exact_segments(nq);
+    return (size_t)kExactQB * kExactCH * 4 + (size_t)nq * S * k * 8 + (size_t)nq * S * 4 + (size_t)nq * 4 + (size_t)nq * (dim + 16) * 4 + 1024;
 }
 
 static hipError_t prepare_queries(const IndexView& ix, const float* q, uint32_t q_stride, uint32_t nq, uint32_t kpad, float* qd,
@@ -445,12 +509,13 @@ hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s) {
     char* p = (char*)scratch;
     float* D = (float*)p;
     p += (size_t)kExactQB * kExactCH * 4;
+    const uint32_t S = exact_segments(a.nq);
     float* st_d = (float*)p;
-    p += (size_t)a.nq * a.k * 4;
+    p += (size_t)a.nq * S * a.k * 4;
     uint32_t* st_s = (uint32_t*)p;
-    p += (size_t)a.nq * a.k * 4;
+    p += (size_t)a.nq * S * a.k * 4;
     uint32_t* st_n = (uint32_t*)p;
-    p += (size_t)a.nq * 4;
+    p += (size_t)a.nq * S * 4;
     float* q_aux = (float*)p;
     p += (size_t)a.nq * 4;
     p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
@@ -479,9 +544,12 @@ hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s) {
                 hipLaunchKernelGGL(exact_dist_mfma_kernel, dim3((nb + 127) / 128, (nqb + 127) / 128), dim3(256), 0, s, a.ix, qd,
                                    kpad, q_aux, q0, nqb, n0, nb, D);
             int first = n0 == 0, last = n0 + kExactCH >= a.slots;
-            hipLaunchKernelGGL(exact_select_kernel, dim3(nqb), dim3(64), 0, s, a.ix, D, q0, n0, nb, a.k, first, last, st_d,
+            hipLaunchKernelGGL(exact_select_kernel, dim3(nqb, S), dim3(64), 0, s, a.ix, D, q0, n0, nb, a.k, first, last, st_d,
                                st_s, st_n, a.out_keys, a.out_dist, a.out_found);
         }
+        if (S > 1)
+            hipLaunchKernelGGL(exact_finish_kernel, dim3(nqb), dim3(64), 0, s, a.ix, q0, S, a.k, st_d, st_s, st_n, a.out_keys,
+                               a.out_dist, a.out_found);
     }
     return hipGetLastError();
 }

@@ -299,8 +299,8 @@ constexpr int kMfmaKC = 32;
 
 __global__ __launch_bounds__(256) void exact_dist_mfma_kernel(IndexView ix, const float* qd, uint32_t kpad, const float* q_aux,
                                                               uint32_t q0, uint32_t nq_blk, uint32_t n0, uint32_t n_blk, float* D) {
-    __shared__ float As[kMfmaKC][132];
-    __shared__ float Bs[kMfmaKC][132];
+    __shared__ float As[kMfmaKC][133];  // 133: rows e and 16 + e (written by lanes t, t ^ 1) fall 16 banks apart
+    __shared__ float Bs[kMfmaKC][133];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t wy = w >> 1, wx = w & 1;
     const uint32_t qt = blockIdx.y * 128, nt = blockIdx.x * 128;

@@ -129,12 +129,16 @@ def effective_cores() -> int:
     return n
 
 
-def cpu_baseline(ix, queries_host, k, ef, seconds):
-    """The CPU restatement of the usearch algorithm (oracle/, kind "port") searching the SAME graph on
-    the host cores of this box: one query per call from T threads (reference usearch.rs:212)."""
+def cpu_baseline(ix, queries_host, k, ef, seconds, extra_host=None):
+    """The CPU restatement of the usearch algorithm (oracle/, kind "port") on the host cores of this box, on the
+    SAME graph: searches one query per call from T threads (reference usearch.rs:212), then -- the build half of the
+    metric -- inserts `extra_host` further vectors into that full-size index from T threads (usearch.rs:194-196)."""
     import oracle
     o = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef, quantization=ix.scalar)
-    g = ix.export_graph(vectors_out=o.vector_arena(ix.graph_info()["slots"]))  # straight into the oracle's arena
+    slots = ix.graph_info()["slots"]
+    extra = 0 if extra_host is None else len(extra_host)
+    o.reserve(slots + extra)
+    g = ix.export_graph(vectors_out=o.vector_arena(slots))  # straight into the oracle's arena
     o.import_graph(g)
     del g
     o.set_expansion_search(ef)
@@ -148,9 +152,16 @@ def cpu_baseline(ix, queries_host, k, ef, seconds):
         el = time.perf_counter() - t0
         if el >= seconds:
             break
-    return {"value": done / el, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"{done} queries ({done // nq} passes over the bench batch) in {el:.1f}s on the GPU-built graph, "
-                      f"ef_search={ef}, usearch-algorithm CPU restatement (not the usearch binary)"}, keys
+    out = {"value": done / el, "unit": "queries/s", "cores": threads, "kind": "port",
+           "sample": f"{done} queries ({done // nq} passes over the bench batch) in {el:.1f}s on the GPU-built graph, "
+                     f"ef_search={ef}, usearch-algorithm CPU restatement (not the usearch binary)"}
+    if extra:
+        t0 = time.perf_counter()
+        o.add_batch(np.arange(slots, slots + extra, dtype=np.uint64) + np.uint64(1 << 40), extra_host, threads=threads)
+        el = time.perf_counter() - t0
+        out["build_vectors_per_s"] = extra / el
+        out["build_sample"] = f"{extra} further vectors inserted into the {slots}-vector index in {el:.1f}s, {threads} threads"
+    return out, keys
 
 
 def main():
@@ -171,6 +182,7 @@ def main():
     ap.add_argument("--quantization", default="f32", choices=["f32", "f16", "bf16", "i8", "b1"], help="storage type (usearch ScalarKind)")
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall seconds of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-build-vectors", type=int, default=20_000, help="vectors the cpu_baseline leg inserts into the full-size index (0 = skip)")
     ap.add_argument("--no-sharded-leg", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0")
@@ -342,7 +354,8 @@ def main():
     # ---- CPU baseline: rank 0, N=1 only, bounded
     if world == 1 and a.cpu_seconds > 0:
         try:
-            cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds)
+            extra = make_data(a.cpu_build_vectors, dim, a.dist, 97531, dev, a.rank).cpu().numpy() if a.cpu_build_vectors else None
+            cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds, extra)
             cb["recall_at_10"] = round(recall_at_k(truth, ckeys), 4)
             out["cpu_baseline"] = cb
         except Exception as e:

@@ -123,3 +123,29 @@ def test_team_insert_builds_the_same_graph():
         assert np.array_equal(a["levels"], b["levels"])
         assert np.array_equal(a["adj0"], b["adj0"]), (kind, metric, dim)
         assert np.array_equal(a["upper"], b["upper"])
+
+
+def test_link_kernel_with_accepted_rows_in_lds_builds_the_same_graph(monkeypatch):
+    """The link kernel re-selects a full neighbour list with the accepted rows cached in LDS (one HBM read per candidate);
+    VS_HNSW_LINK_CACHE=0 is the plain refine_ from HBM, =3 forces the mixed path (3 rows cached, the rest from HBM)."""
+    v = vs()
+    for kind, metric, dim in (("f32", "cos", 768), ("f32", "l2sq", 100), ("f32", "ip", 1536), ("f16", "cos", 384), ("i8", "l2sq", 128),
+                              ("b1", "hamming", 256)):
+        n = 6000
+        base = _data(n, dim, 51)
+        graphs = []
+        for cache in ("0", None, "3"):
+            if cache is None:
+                monkeypatch.delenv("VS_HNSW_LINK_CACHE", raising=False)
+            else:
+                monkeypatch.setenv("VS_HNSW_LINK_CACHE", cache)
+            ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS[kind])
+            ix.reserve(n)
+            ix.add_batch(np.arange(n, dtype=np.uint64), base)
+            graphs.append((ix.export_graph(), ix.stats()))
+        (a, sa), (b, sb), (c, sc) = graphs
+        assert sa["link_evals"] > 0 and sa["link_evals"] == sb["link_evals"] == sc["link_evals"]
+        for g in (b, c):
+            assert np.array_equal(a["adj0"], g["adj0"]), (kind, metric, dim)
+            assert np.array_equal(a["upper"], g["upper"])
+            assert a["entry_slot"] == g["entry_slot"] and a["max_level"] == g["max_level"]

@@ -45,6 +45,7 @@ struct LinkArgs {
     const uint64_t* req_key;  // sorted
     const uint64_t* req_val;
     uint32_t total;
+    uint32_t cache_rows;      // accepted neighbours whose rows the re-selection keeps in LDS (0 = none)
     unsigned long long* stats;
 };
 

@@ -154,6 +154,90 @@ struct LinkShared {
 
 constexpr uint32_t kMaxNewPerTarget = 64;
 
+// refine_ for the link kernel with the ACCEPTED rows kept in LDS.  The heuristic measures every candidate against all
+// neighbours accepted so far: read from HBM that is (accepted so far) rows per candidate, ~165 row reads for a
+// 33-candidate list.  A candidate's row is in registers when it is accepted, so it is written to LDS once and every
+// later candidate is measured against LDS copies: one HBM row read per candidate.  Same accumulate / group_sum /
+// finalize as eval_batch, so the distances -- and the selected links -- are bit-identical to refine().
+// rowbuf: cache_rows x stride4 chunks (row layout as in HBM), then cache_rows aux values.
+template <int AR, int I>
+__device__ uint32_t refine_cached(const IndexView& ix, LinkShared& sh, uint4* rowbuf, uint32_t cache_rows, uint32_t sz,
+                                  uint32_t needed, Counters& cnt, int lane) {
+    float* aux_lds = reinterpret_cast<float*>(rowbuf + (size_t)cache_rows * ix.stride4);
+    const uint32_t lg = ix.lanes_log2, V = 64u >> lg;
+    const uint32_t grp = (uint32_t)lane >> lg, li = (uint32_t)lane & (ix.lanes - 1);
+    auto keep = [&](uint32_t pos, const Query<AR, I>& row, uint32_t slot) {  // accepted neighbour `pos` := row
+        if (pos < cache_rows && grp == 0) {
+#pragma unroll
+            for (int i = 0; i < I; ++i) rowbuf[(size_t)pos * ix.stride4 + li + (uint32_t)i * ix.lanes] = row.c[i];
+            if (li == 0) aux_lds[pos] = needs_aux<AR>(ix.metric) ? ix.aux[slot] : 0.f;
+        }
+    };
+    if (sz == 0) return 0;
+    __syncthreads();
+    if (sz < needed) {  // usearch: fewer candidates than slots -> all of them
+        if ((uint32_t)lane < sz) {
+            sh.sel_s[lane] = sh.lst_s[0][lane] & kSlotMask;
+            sh.sel_d[lane] = sh.lst_d[0][lane];
+        }
+        __syncthreads();
+        return sz;
+    }
+    {
+        const uint32_t s0 = sh.lst_s[0][0] & kSlotMask;
+        if (lane == 0) {
+            sh.sel_s[0] = s0;
+            sh.sel_d[0] = sh.lst_d[0][0];
+        }
+        Query<AR, I> first;
+        query_from_row<AR, I>(ix, s0, first, lane);
+        keep(0, first, s0);
+    }
+    __syncthreads();
+    uint32_t nsel = 1;
+    Query<AR, I> nextv;  // the next candidate's row is already on its way while this one is measured
+    if (sz > 1) query_from_row<AR, I>(ix, sh.lst_s[0][1] & kSlotMask, nextv, lane);
+    for (uint32_t c = 1; c < sz && nsel < needed; ++c) {
+        const uint32_t cs = sh.lst_s[0][c] & kSlotMask;
+        const float cd = sh.lst_d[0][c];
+        Query<AR, I> cv = nextv;
+        if (c + 1 < sz) query_from_row<AR, I>(ix, sh.lst_s[0][c + 1] & kSlotMask, nextv, lane);
+        const uint32_t in_lds = nsel < cache_rows ? nsel : cache_rows;
+        bool bad = false;
+        for (uint32_t a0 = 0; a0 < in_lds; a0 += V) {
+            const uint32_t a = a0 + grp;
+            const bool valid = a < in_lds;
+            typename Arith<AR>::acc_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < I; ++i) {
+                const uint4 r = valid ? rowbuf[(size_t)a * ix.stride4 + li + (uint32_t)i * ix.lanes] : make_uint4(0u, 0u, 0u, 0u);
+                acc = accumulate<AR>(acc, cv.c[i], r);
+            }
+            acc = group_sum(acc, ix.lanes);
+            if (valid && li == 0) bad = bad || finalize<AR>(ix.metric, acc, cv.aux, aux_lds[a]) < cd;
+        }
+        bool reject = __ballot(bad) != 0ull;
+        if (!reject && nsel > in_lds) {  // accepted beyond the cache: measured from HBM as before
+            eval_batch<AR, I>(ix, cv, sh.sel_s + in_lds, sh.u_dist, nsel - in_lds, lane);
+            __syncthreads();
+            bool bad2 = (uint32_t)lane < nsel - in_lds && sh.u_dist[lane] < cd;
+            reject = __ballot(bad2) != 0ull;
+            __syncthreads();
+        }
+        cnt.evals += nsel;
+        if (!reject) {
+            if (lane == 0) {
+                sh.sel_s[nsel] = cs;
+                sh.sel_d[nsel] = cd;
+            }
+            keep(nsel, cv, cs);
+            ++nsel;
+            __syncthreads();
+        }
+    }
+    return nsel;
+}
+
 template <int AR, int I>
 __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
     __shared__ LinkShared sh;
@@ -223,7 +307,9 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
         sh.lst_s[0][rank] = es;
     }
     __syncthreads();
-    uint32_t nsel = refine<AR, I>(ix, sh, 0, total, cap, c, lane);
+    extern __shared__ uint4 link_rowbuf[];
+    uint32_t nsel = a.cache_rows ? refine_cached<AR, I>(ix, sh, link_rowbuf, a.cache_rows, total, cap, c, lane)
+                                 : refine<AR, I>(ix, sh, 0, total, cap, c, lane);
     if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < nsel ? sh.sel_s[lane] : kInvalid;
     if (lane == 0) {
         atomicAdd(&a.stats[ST_ADD_EVALS], c.evals);
@@ -301,13 +387,14 @@ hipError_t launch_insert_ar<VS_AR>(const InsertArgs& a, uint32_t iters, hipStrea
 template <>
 hipError_t launch_link_ar<VS_AR>(const LinkArgs& a, uint32_t iters, hipStream_t s) {
     dim3 grid(a.total), block(64);
+    const size_t dyn = a.cache_rows ? (size_t)a.cache_rows * ((size_t)a.ix.stride4 * 16 + 4) : 0;
     switch (iters) {
-        case 1: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 1>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 2>), grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 3>), grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 4>), grid, block, 0, s, a); break;
-        case 6: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 6>), grid, block, 0, s, a); break;
-        case 8: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 8>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 1>), grid, block, dyn, s, a); break;
+        case 2: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 2>), grid, block, dyn, s, a); break;
+        case 3: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 3>), grid, block, dyn, s, a); break;
+        case 4: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 4>), grid, block, dyn, s, a); break;
+        case 6: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 6>), grid, block, dyn, s, a); break;
+        case 8: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 8>), grid, block, dyn, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

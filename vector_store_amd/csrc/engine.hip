@@ -312,6 +312,7 @@ struct Engine {
     int device = 0;
     bool stress_small_table = false;  // vs_hnsw_options.reserved bit 0 (tests only)
     uint32_t max_sub_batch = kMaxSubBatch;
+    int nt_policy = 0;                // 0 = by table size; VS_HNSW_NT_ROWS=1 / 0 forces non-temporal row loads on / off
     uint32_t link_cache_rows = 0;     // accepted rows the link kernel's re-selection keeps in LDS (set in init)
     uint32_t chunk_rows = kChunk;
     int team_mode = 0;                // 0 = by batch size; reserved bit 2 = always a team per query, bit 3 = never
@@ -388,6 +389,7 @@ struct Engine {
         v.scalar = scalar;
         v.entry_slot = entry_slot.load();
         v.max_level = max_level.load();
+        v.nt_rows = nt_policy == 1 || (nt_policy == 0 && slots * (size_t)stride4 * 16 >= (2ull << 30)) ? 1u : 0u;
         return v;
     }
 
@@ -461,6 +463,7 @@ struct Engine {
         // link kernel: ~18 KiB of accepted rows per wave in LDS (7 waves per CU; measured at 2M x 768: 3 / 4 / 6 / 8 / 11 rows ->
         // link kernel 0.79 / 0.73 / 0.62 / 0.64 / 0.79 s, 0.98 s without), at most the M0 a list can hold
         link_cache_rows = std::min<uint32_t>(2 * M, std::max<uint32_t>(2, (18u << 10) / (stride4 * 16 + 4) + 1));
+        if (const char* nt = std::getenv("VS_HNSW_NT_ROWS")) nt_policy = nt[0] == '1' ? 1 : 2;
         if (const char* lc = std::getenv("VS_HNSW_LINK_CACHE")) link_cache_rows = (uint32_t)std::max(0, std::atoi(lc));  // experiments
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count == 0) fail(VS_ERR_DEVICE, "no HIP device available");

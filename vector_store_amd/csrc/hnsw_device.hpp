@@ -56,6 +56,7 @@ struct IndexView {
     int32_t scalar;       // SC_*
     uint32_t entry_slot;
     int32_t max_level;    // -1: empty index
+    uint32_t nt_rows;     // 1: vector rows are loaded non-temporally (table far larger than the caches)
 };
 
 struct Counters {
@@ -234,6 +235,20 @@ struct Query {
     float aux;  // see finalize
 };
 
+// Vector rows are read once per evaluation and are ~99 % of the traffic.  When the table is far larger than the
+// caches (IndexView::nt_rows, set by the host above 2 GiB of vectors) they are loaded non-temporally so that they do
+// not displace the adjacency rows and upper levels, which are re-used across queries, from L2 / Infinity Cache
+// (10M x 768 f32: 24.4 -> 22.4 ms per 10,000 queries; a 0.5-1.5 GB table that partly lives in the 256 MB Infinity
+// Cache loses 4 % with the hint, hence the threshold).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_row_chunk(const uint4* p, bool nt) {
+    if (nt) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+
 template <int AR, int I>
 __device__ __forceinline__ void query_from_row(const IndexView& ix, uint32_t slot, Query<AR, I>& q, int lane) {
     const uint32_t li = lane & (ix.lanes - 1);
@@ -343,7 +358,7 @@ __device__ __forceinline__ void group_issue(const IndexView& ix, RowGroup<I, U>&
         if (g.slot[u] != kInvalid) {
             const uint4* row = ix.vectors + (size_t)g.slot[u] * ix.stride4 + li;
 #pragma unroll
-            for (int i = 0; i < I; ++i) g.buf[u][i] = row[(size_t)i * ix.lanes];
+            for (int i = 0; i < I; ++i) g.buf[u][i] = load_row_chunk(row + (size_t)i * ix.lanes, ix.nt_rows != 0);
             if (needs_aux<AR>(ix.metric)) g.aux[u] = ix.aux[g.slot[u]];
         } else {
 #pragma unroll

@@ -241,12 +241,14 @@ struct Query {
 // (10M x 768 f32: 24.4 -> 22.4 ms per 10,000 queries; a 0.5-1.5 GB table that partly lives in the 256 MB Infinity
 // Cache loses 4 % with the hint, hence the threshold).
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 load_row_chunk(const uint4* p, bool nt) {
-    if (nt) {
+template <bool NT>
+__device__ __forceinline__ uint4 load_row_chunk(const uint4* p) {
+    if constexpr (NT) {
         const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
         return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
     }
-    return *p;
 }
 
 template <int AR, int I>
@@ -347,7 +349,7 @@ struct RowGroup {
 
 // A TEAM of waves (one workgroup) may share one batch: wave-load L of wave w covers vectors
 // ((L * TEAM + w) * V + grp); TEAM == 1, w == 0 is the one-wave-per-query layout.
-template <int AR, int I, int U, int TEAM>
+template <int AR, int I, int U, int TEAM, bool NT>
 __device__ __forceinline__ void group_issue(const IndexView& ix, RowGroup<I, U>& g, const uint32_t* u_slot, uint32_t m,
                                             uint32_t L, uint32_t w, uint32_t vshift, uint32_t grp, uint32_t li) {
 #pragma unroll
@@ -358,7 +360,7 @@ __device__ __forceinline__ void group_issue(const IndexView& ix, RowGroup<I, U>&
         if (g.slot[u] != kInvalid) {
             const uint4* row = ix.vectors + (size_t)g.slot[u] * ix.stride4 + li;
 #pragma unroll
-            for (int i = 0; i < I; ++i) g.buf[u][i] = load_row_chunk(row + (size_t)i * ix.lanes, ix.nt_rows != 0);
+            for (int i = 0; i < I; ++i) g.buf[u][i] = load_row_chunk<NT>(row + (size_t)i * ix.lanes);
             if (needs_aux<AR>(ix.metric)) g.aux[u] = ix.aux[g.slot[u]];
         } else {
 #pragma unroll
@@ -381,7 +383,9 @@ __device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup
     }
 }
 
-template <int AR, int I, int TEAM = 1>
+// NT: the cache policy of the row loads is a property of the kernel instance (a run-time choice inside the unrolled
+// load loops, or two copies of this function in one kernel, cost registers and spill).
+template <int AR, int I, int TEAM = 1, bool NT = false>
 __device__ __forceinline__ void eval_batch(const IndexView& ix, const Query<AR, I>& q, const uint32_t* u_slot,
                                            float* u_dist, uint32_t m, int lane, uint32_t w = 0) {
     constexpr int U = (I >= 6 || (AR == AR_I8 && I >= 3)) ? 2 : 4;  // more loads per group at I <= 2 measured no gain
@@ -392,14 +396,14 @@ __device__ __forceinline__ void eval_batch(const IndexView& ix, const Query<AR, 
     const uint32_t nl = TEAM == 1 ? nl_all : (nl_all > w ? (nl_all - w + (uint32_t)TEAM - 1u) / (uint32_t)TEAM : 0u);  // mine
     if (nl == 0) return;
     RowGroup<I, U> a, b;
-    group_issue<AR, I, U, TEAM>(ix, a, u_slot, m, 0, w, vshift, grp, li);
+    group_issue<AR, I, U, TEAM, NT>(ix, a, u_slot, m, 0, w, vshift, grp, li);
     uint32_t L = 0;
     for (;;) {
-        if (L + U < nl) group_issue<AR, I, U, TEAM>(ix, b, u_slot, m, L + U, w, vshift, grp, li);
+        if (L + U < nl) group_issue<AR, I, U, TEAM, NT>(ix, b, u_slot, m, L + U, w, vshift, grp, li);
         group_reduce<AR, I, U, TEAM>(ix, a, q, u_dist, L, w, vshift, grp, li);
         L += U;
         if (L >= nl) break;
-        if (L + U < nl) group_issue<AR, I, U, TEAM>(ix, a, u_slot, m, L + U, w, vshift, grp, li);
+        if (L + U < nl) group_issue<AR, I, U, TEAM, NT>(ix, a, u_slot, m, L + U, w, vshift, grp, li);
         group_reduce<AR, I, U, TEAM>(ix, b, q, u_dist, L, w, vshift, grp, li);
         L += U;
         if (L >= nl) break;
@@ -438,8 +442,9 @@ template <>
 struct TeamBox<1> {};
 
 // EFCAP=128, NB=1024, no SelArrays: 20,480 B -> 8 single-wave workgroups per CU (160 KiB LDS).
-template <int EFCAP, int NB, bool SEL = false, int CH = 1, int TM = 1>
+template <int EFCAP, int NB, bool SEL = false, int CH = 1, int TM = 1, bool NT = false>
 struct BeamShared : SelArrays<SEL>, TeamBox<TM> {
+    static constexpr bool kNT = NT;  // walk evaluations load vector rows non-temporally (IndexView::nt_rows, host-chosen)
     static constexpr int kChoices = CH;
     static constexpr int kEfCap = EFCAP;
     static constexpr int kNB = NB;
@@ -472,7 +477,7 @@ __device__ __forceinline__ void wsync() {
 template <int AR, int I, class Sh>
 __device__ __forceinline__ void eval_shared(const IndexView& ix, const Query<AR, I>& q, Sh& sh, uint32_t m, int lane) {
     if constexpr (Sh::kTeam == 1) {
-        eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, m, lane);
+        eval_batch<AR, I, 1, Sh::kNT>(ix, q, sh.u_slot, sh.u_dist, m, lane);
         __syncthreads();
     } else {
         if (lane == 0) {
@@ -480,7 +485,7 @@ __device__ __forceinline__ void eval_shared(const IndexView& ix, const Query<AR,
             sh.team_q = kInvalid;
         }
         __syncthreads();  // releases the helpers (see team_helper_loop)
-        eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, 0);
+        eval_batch<AR, I, Sh::kTeam, Sh::kNT>(ix, q, sh.u_slot, sh.u_dist, m, lane, 0);
         __syncthreads();  // every wave's distances are in LDS
     }
 }

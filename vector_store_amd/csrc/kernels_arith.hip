@@ -23,9 +23,10 @@ namespace vs {
 // TEAM == 1: one wavefront per query (full batches).  TEAM > 1: one workgroup of TEAM waves per query for small
 // batches -- wave 0 walks exactly as before, every wave evaluates its share of each hop's neighbours, so a lone
 // query has TEAM times the loads in flight; results are identical (same distances, same order of decisions).
-template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1>
+// NT: vector rows loaded non-temporally (tables far larger than the caches; chosen by the host, IndexView::nt_rows).
+template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1, bool NT = false>
 __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
-    using Sh = BeamShared<EFCAP, NB, false, CH, TEAM>;
+    using Sh = BeamShared<EFCAP, NB, false, CH, TEAM, NT>;
     __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
@@ -90,9 +91,9 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
 
 // TEAM > 1: small sub-batches (the first geometric steps of a build, streaming adds between searches) get a
 // workgroup of TEAM waves per new node, as the search kernel does for small query batches; same decisions, same graph.
-template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1>
+template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1, bool NT = false>
 __global__ __launch_bounds__(64 * TEAM) void hnsw_insert_kernel(InsertArgs a) {
-    using Sh = BeamShared<EFCAP, NB, true, CH, TEAM>;
+    using Sh = BeamShared<EFCAP, NB, true, CH, TEAM, NT>;
     __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
@@ -329,13 +330,20 @@ static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, kSearchTeam>), grid, tblock, 0, s, a);
         return hipGetLastError();
     }
+    const bool nt = a.ix.nt_rows != 0;
     if (I == 1 && a.stress_small_table && a.ef <= 128)
         hipLaunchKernelGGL((hnsw_search_kernel<AR, 1, 128, 256, 1>), grid, block, 0, s, a);
+    else if (a.ef <= 128 && nt)
+        hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, 1, true>), grid, block, 0, s, a);
     else if (a.ef <= 128)
         hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1>), grid, block, 0, s, a);
+    else if (a.ef <= 256 && nt)
+        hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, 1, true>), grid, block, 0, s, a);
     else if (a.ef <= 256)
         hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2>), grid, block, 0, s, a);
-    else  // wide beams (k up to 512: CQL LIMIT x oversampling): 39 KB LDS, 4 waves per CU
+    else if (nt)  // wide beams (k up to 512: CQL LIMIT x oversampling): 39 KB LDS, 4 waves per CU
+        hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 512, 2048, 2, 1, true>), grid, block, 0, s, a);
+    else
         hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 512, 2048, 2>), grid, block, 0, s, a);
     return hipGetLastError();
 }
@@ -351,8 +359,13 @@ static hipError_t insert_ef(const InsertArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 256, 1024, 2, kSearchTeam>), grid, tblock, 0, s, a);
         return hipGetLastError();
     }
-    if (a.ef_add <= 128)
+    const bool nt = a.ix.nt_rows != 0;
+    if (a.ef_add <= 128 && nt)
+        hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 128, 1024, 1, 1, true>), grid, block, 0, s, a);
+    else if (a.ef_add <= 128)
         hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 128, 1024, 1>), grid, block, 0, s, a);
+    else if (nt)
+        hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 256, 1024, 2, 1, true>), grid, block, 0, s, a);
     else
         hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 256, 1024, 2>), grid, block, 0, s, a);
     return hipGetLastError();

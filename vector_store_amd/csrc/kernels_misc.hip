@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void exact_dist_mfma_kernel(IndexView ix, cons
     __shared__ float Bs[kMfmaKC][133];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t wy = w >> 1, wx = w & 1;
-    const uint32_t qt = blockIdx.y * 128, nt = blockIdx.x * 128;
+    // query tile on the fast grid index: the workgroups that share a 128-row base tile run back to back, so the tile is
+    // read from HBM once per launch and served from L2 to the other query tiles (the queries, <= 3 MB, stay in L2 anyway)
+    const uint32_t qt = blockIdx.x * 128, nt = blockIdx.y * 128;
     const uint32_t lrow = t >> 1, lf4 = (t & 1) * 4;  // staging: row of the tile, first of 4 float4 of the K chunk
     f32x16 acc[2][2];
 #pragma unroll
@@ -541,7 +543,7 @@ hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s) {
             else if (a.use_valu)
                 hipLaunchKernelGGL((exact_dist_kernel<KDOT>), grid, dim3(256), 0, s, a.ix, qd, kpad, q_aux, q0, nqb, n0, nb, D);
             else
-                hipLaunchKernelGGL(exact_dist_mfma_kernel, dim3((nb + 127) / 128, (nqb + 127) / 128), dim3(256), 0, s, a.ix, qd,
+                hipLaunchKernelGGL(exact_dist_mfma_kernel, dim3((nqb + 127) / 128, (nb + 127) / 128), dim3(256), 0, s, a.ix, qd,
                                    kpad, q_aux, q0, nqb, n0, nb, D);
             int first = n0 == 0, last = n0 + kExactCH >= a.slots;
             hipLaunchKernelGGL(exact_select_kernel, dim3(nqb, S), dim3(64), 0, s, a.ix, D, q0, n0, nb, a.k, first, last, st_d,

@@ -994,6 +994,52 @@ static int selftest() {
         }
         expect(threw, broken);
     }
+    // mutated bodies: the parser either returns a value or throws JsonError -- never reads out of bounds (run under
+    // -fsanitize=address,undefined by `make -C vector_store_amd/csrc sanitize-httpd`)
+    {
+        const std::string seed_doc = "{\"vector\":[0.25,-1e-3,3,4.5e+2,7],\"limit\":3,\"filter\":{\"restrictions\":[{\"type\":\"()IN()\",\"lhs\":[\"id\"],"
+                                     "\"rhs\":[[1],[2]]},{\"type\":\"<\",\"lhs\":\"id\",\"rhs\":9}],\"allow_filtering\":true},\"x\":\"a\\u00e9\\n\"}";
+        uint64_t r = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&] {
+            r ^= r << 13;
+            r ^= r >> 7;
+            r ^= r << 17;
+            return r;
+        };
+        const char alphabet[] = "{}[]\",:.-+eE0123456789 tfn\\u\"";
+        size_t parsed = 0, rejected = 0;
+        for (int it = 0; it < 20000; ++it) {
+            std::string d = seed_doc;
+            const int edits = 1 + (int)(rnd() % 4);
+            for (int e = 0; e < edits; ++e) {
+                const size_t pos = rnd() % d.size();
+                switch (rnd() % 3) {
+                    case 0: d[pos] = alphabet[rnd() % (sizeof alphabet - 1)]; break;
+                    case 1: d.erase(pos, 1 + rnd() % 3); break;
+                    default: d.insert(pos, 1, alphabet[rnd() % (sizeof alphabet - 1)]);
+                }
+                if (d.empty()) d = "x";
+            }
+            // exact-size heap buffer: an over-read is an ASAN report
+            std::unique_ptr<char[]> buf(new char[d.size()]);
+            std::memcpy(buf.get(), d.data(), d.size());
+            try {
+                JVal v = JsonParser(buf.get(), d.size()).parse();
+                ++parsed;
+                if (v.kind == JVal::Obj)
+                    if (const JVal* f = v.get("filter"))
+                        if (f->kind == JVal::Obj) {
+                            try {
+                                (void)compile_filter(*f, "id");
+                            } catch (const BadRequest&) {
+                            }
+                        }
+            } catch (const JsonError&) {
+                ++rejected;
+            }
+        }
+        expect(parsed > 100 && rejected > 1000, "mutation run saw both outcomes");
+    }
     // filters: every restriction form one integer column admits (httpapi/src/lib.rs:323-366)
     auto rows = [&](const std::string& restrictions) {
         std::string f = "{\"restrictions\":" + restrictions + ",\"allow_filtering\":true}";

@@ -153,6 +153,10 @@ def test_filters_on_the_key_column(tmp_path):
         assert ann([{"type": "()IN()", "lhs": ["id"], "rhs": [[7], [9]]}]) == [7, 9]
         assert ann([{"type": "()<()", "lhs": ["id"], "rhs": [2]}]) == [0, 1]
         assert ann([{"type": "()>=()", "lhs": ["id"], "rhs": [28]}]) == [28, 29]
+        st, body = s.ann({"vector": t["query"], "limit": 1000})       # any limit is accepted (httproutes.rs:842-847)
+        assert st == 200 and sorted(json.loads(body)["primary_keys"]["id"]) == list(range(30))
+        d = json.loads(body)["distances"]
+        assert d == sorted(d)
         st, _ = s.ann({"vector": t["query"], "limit": 5, "filter": {"restrictions": [{"type": "<", "lhs": "ck", "rhs": 3}]}})
         assert st == 400
         st, _ = s.ann({"vector": t["query"], "limit": 5, "filter": {"restrictions": [{"type": "~", "lhs": "id", "rhs": 3}]}})

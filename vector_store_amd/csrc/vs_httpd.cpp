@@ -515,6 +515,7 @@ struct Pending {  // one query in flight
     std::string err;
     bool keep_alive = true;
     std::vector<Test> tests;  // filtered queries
+    bool blocking = false;    // served by the pool through a blocking call (filters; limits beyond the LDS beam)
 };
 
 std::string ann_body(const Pending& p) {
@@ -564,8 +565,11 @@ struct FilterPool {
                             if (!t(row)) return 0;
                         return 1;
                     };
-                    p->status = vs_hnsw_filtered_search(p->s->h, p->q.data(), p->q.size(), p->k, pred, &p->tests, p->keys.data(),
-                                                        p->dist.data(), &p->found);
+                    if (p->tests.empty())  // no filter: a limit beyond the LDS beam (exhaustive ranking inside the engine)
+                        p->status = vs_hnsw_search(p->s->h, p->q.data(), p->q.size(), p->k, p->keys.data(), p->dist.data(), &p->found);
+                    else
+                        p->status = vs_hnsw_filtered_search(p->s->h, p->q.data(), p->q.size(), p->k, pred, &p->tests, p->keys.data(),
+                                                            p->dist.data(), &p->found);
                     if (p->status != VS_OK) p->err = vs_hnsw_last_error();
                     done(std::move(p));
                 }
@@ -769,7 +773,8 @@ struct Worker {
                 p->keys.resize(p->k);
                 p->dist.resize(p->k);
                 c.busy = true;
-                if (!p->tests.empty()) {
+                p->blocking = !p->tests.empty() || p->k > 512;  // the reference accepts any limit (httproutes.rs:842-847)
+                if (p->blocking) {
                     srv->filters.submit(std::move(p));
                     return true;
                 }

@@ -88,6 +88,8 @@ def check_surface(make_index):
     assert ann([{"type": "()==()", "lhs": ["id"], "rhs": [7]}]) == [7]
     assert ann([{"type": "()IN()", "lhs": ["id"], "rhs": [[7], [9]]}]) == [7, 9]
     assert ann([{"type": "()<()", "lhs": ["id"], "rhs": [2]}]) == [0, 1]
+    r = c.post("/api/v1/indexes/ks/idx/ann", json={"vector": t["query"], "limit": 1000})   # any limit (httproutes.rs:842-847)
+    assert r.status_code == 200 and sorted(r.json()["primary_keys"]["id"]) == list(range(30))
     r = c.post("/api/v1/indexes/ks/idx/ann", json={"vector": t["query"], "limit": 5,
                                                    "filter": {"restrictions": [{"type": "<", "lhs": "ck", "rhs": 3}]}})
     assert r.status_code == 400

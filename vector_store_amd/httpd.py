@@ -172,7 +172,7 @@ def create_app(indexes: dict, engine_version: str = "hip-hnsw", node_status: str
         q = np.asarray(vector, dtype=np.float32)
         try:
             loop = asyncio.get_running_loop()
-            if pred is None and hasattr(s.index, "search_async"):
+            if pred is None and limit <= 512 and hasattr(s.index, "search_async"):  # beyond the LDS beam: blocking exhaustive path
                 fut = loop.create_future()
 
                 def on_done(keys, dist, status):

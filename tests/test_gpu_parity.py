@@ -548,3 +548,41 @@ def test_wide_beam_up_to_512(metric, dim):
         assert same >= 29, (ef, k, same)
     k1, d1 = ix.search(data[n], 500)  # single-query entry point too
     assert len(k1) == 500
+
+
+@pytest.mark.parametrize("metric", ["ip", "cos", "l2sq"])
+def test_exhaustive_ranking_on_the_device_matches_numpy(metric):
+    """k beyond the LDS beam and selective filters rank every member on the device (distances, 64-bit radix sort of
+    (distance, slot), members in ascending order, fetched in chunks): against a float64 numpy ranking, with removed
+    members, negative distances (ip) and a predicate that only a few members pass."""
+    v = vs()
+    n, dim, k = 30000, 48, 3000
+    rng = np.random.default_rng(17)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric])
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    removed = set(range(0, n, 7))
+    for key in removed:
+        assert ix.remove(key)
+    b64, q64 = base.astype(np.float64), q.astype(np.float64)
+    if metric == "ip":
+        ref = 1.0 - b64 @ q64
+    elif metric == "cos":
+        ref = 1.0 - (b64 @ q64) / (np.linalg.norm(b64, axis=1) * np.linalg.norm(q64))
+    else:
+        ref = ((b64 - q64) ** 2).sum(axis=1)
+    live = np.array([i for i in range(n) if i not in removed])
+    order = live[np.argsort(ref[live], kind="stable")]
+    keys, dist = ix.search(q, k)                       # k = 3000 > 512: exhaustive
+    assert len(keys) == k and (np.diff(dist) >= 0).all() and not (set(keys.tolist()) & removed)
+    assert len(set(keys.tolist()) ^ set(order[:k].tolist())) <= 4          # f32 near-ties at the cut only
+    assert np.allclose(dist, ref[keys.astype(np.int64)], rtol=1e-4, atol=1e-4)
+    if metric == "ip":
+        assert dist[0] < 0                               # negative distances keep their order
+    fk, fd = ix.filtered_search(q, 50, lambda key: key % 101 == 5)         # ~1 % pass: far beyond any beam
+    want = [int(x) for x in order if x % 101 == 5][:50]
+    assert len(fk) == 50 and len(set(fk.tolist()) ^ set(want)) <= 2
+    allk, alld = ix.search(q, 40000)                   # more than the members: everything live, once, in order
+    assert len(allk) == len(live) and len(set(allk.tolist())) == len(live) and (np.diff(alld) >= 0).all()

@@ -105,4 +105,14 @@ size_t sort_temp_bytes(size_t n);
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in,
                       uint64_t* vals_out, size_t n, unsigned end_bit, hipStream_t s);
 
+// keys only, all 64 bits
+size_t sort_keys_temp_bytes(size_t n);
+hipError_t sort_keys(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, size_t n, hipStream_t s);
+
+// Exhaustive ranking of every member against one query, on the device (k beyond the LDS beam, selective filters):
+//   rank_keys   : rank[s] = (order-preserving bits of d[s]) << 32 | s, or ~0 for removed members (they sort last)
+//   rank_emit   : sorted rank keys -> (member key, distance) in ascending (distance, slot) order
+hipError_t launch_rank_keys(const IndexView& ix, const float* d, uint32_t n, uint64_t* rank, hipStream_t s);
+hipError_t launch_rank_emit(const IndexView& ix, const uint64_t* sorted, uint32_t n, uint64_t* out_keys, float* out_dist, hipStream_t s);
+
 }  // namespace vs

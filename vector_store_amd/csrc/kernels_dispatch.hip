@@ -68,4 +68,16 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, ui
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, s);
 }
 
+size_t sort_keys_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    uint64_t* k = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, k, k, n ? n : 1, 0, 64, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t sort_keys(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, n, 0u, 64u, s);
+}
+
 }  // namespace vs

@@ -653,7 +653,45 @@ hipError_t launch_distance_row(const IndexView& ix, const float* d_query, uint32
     hipLaunchKernelGGL(distance_row_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ix, qd, q_aux, kpad, n, d_scratch);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (!host_out) return hipSuccess;  // the caller keeps working on the device
     return hipMemcpyAsync(host_out, d_scratch, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+}
+
+// ---------------------------------------------------------------- exhaustive ranking on the device
+__global__ void rank_keys_kernel(IndexView ix, const float* d, uint32_t n, uint64_t* rank) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    if (ix.keys[s] == kFreeKey) {
+        rank[s] = ~0ull;
+        return;
+    }
+    const uint32_t b = __float_as_uint(d[s]);
+    const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // unsigned order == float order (ip distances go negative)
+    rank[s] = ((uint64_t)ord << 32) | s;
+}
+__global__ void rank_emit_kernel(IndexView ix, const uint64_t* sorted, uint32_t n, uint64_t* out_keys, float* out_dist) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = sorted[i];
+    if (r == ~0ull) {
+        out_keys[i] = kFreeKey;
+        out_dist[i] = __builtin_inff();
+        return;
+    }
+    const uint32_t ord = (uint32_t)(r >> 32);
+    const uint32_t b = (ord & 0x80000000u) ? (ord & 0x7FFFFFFFu) : ~ord;
+    out_keys[i] = ix.keys[(uint32_t)r];
+    out_dist[i] = __uint_as_float(b);
+}
+hipError_t launch_rank_keys(const IndexView& ix, const float* d, uint32_t n, uint64_t* rank, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(rank_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ix, d, n, rank);
+    return hipGetLastError();
+}
+hipError_t launch_rank_emit(const IndexView& ix, const uint64_t* sorted, uint32_t n, uint64_t* out_keys, float* out_dist, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(rank_emit_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ix, sorted, n, out_keys, out_dist);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- multi-GPU top-k merge (after the RCCL all-gather)

@@ -980,7 +980,10 @@ struct Engine {
                     ++out;
                 }
             if (out == k) return out;
-            fetch *= 2;
+            // the share that passed predicts the beam that would yield k: go there directly, or straight to the
+            // exhaustive ranking when no LDS beam can (a graph walk per doubling step costs more than ranking)
+            const size_t projected = out ? (size_t)(1.5 * (double)k * (double)f / (double)out) + 1 : kMaxBeam + 1;
+            fetch = std::max(fetch * 2, projected);
         }
         // Walk the members in ascending (distance, slot) order and ask the predicate lazily: about k / selectivity calls
         // instead of one per member (the reference's predicate takes a table read-lock per call).

@@ -307,7 +307,7 @@ struct Engine {
     // configuration (reference usearch.rs:74-82)
     uint32_t dim = 0, M = 16, M0 = 32, ef_add = 128;
     std::atomic<uint32_t> ef_search{64};
-    std::atomic<int> exact_valu{0};  // VS_HNSW_EXACT_VALU=1 or options.reserved bit 1: exact search without MFMA
+    std::atomic<int> exact_valu{0};  // options.reserved bit 1: exact search without MFMA
     int metric = VS_METRIC_COS;
     int device = 0;
     bool stress_small_table = false;  // vs_hnsw_options.reserved bit 0 (tests only)

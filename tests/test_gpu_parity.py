@@ -586,3 +586,33 @@ def test_exhaustive_ranking_on_the_device_matches_numpy(metric):
     assert len(fk) == 50 and len(set(fk.tolist()) ^ set(want)) <= 2
     allk, alld = ix.search(q, 40000)                   # more than the members: everything live, once, in order
     assert len(allk) == len(live) and len(set(allk.tolist())) == len(live) and (np.diff(alld) >= 0).all()
+
+
+@pytest.mark.timeout(120)
+def test_non_finite_inputs_do_not_hang_or_poison_the_index():
+    """NaN / Inf in a query or in a stored vector: the reference would surface an out-of-range distance as an error
+    (distance.rs:58-105); the engine must at least stay bounded (every walk ends) and keep answering clean queries."""
+    v = vs()
+    n, dim = 5000, 64
+    base = _dataset(n + 8, dim, 23)
+    ix = v.HipUsearchIndex(dim, v.COS, expansion_search=64)
+    ix.reserve(n + 16)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base[:n])
+    good_k, good_d = ix.search(base[n], 10)
+    for bad in (np.nan, np.inf, -np.inf):
+        q = base[n + 1].copy()
+        q[3] = bad
+        keys, dist = ix.search(q, 10)                 # must return (whatever it returns) without hanging
+        assert len(keys) <= 10
+        kb, db, fb = ix.search_batch(np.stack([q, base[n]]), 10)
+        assert np.array_equal(kb[1], good_k) and np.array_equal(db[1], good_d)   # the clean neighbour query is untouched
+    poisoned = base[n + 2].copy()
+    poisoned[0] = np.nan
+    ix.add(n + 1, poisoned)                           # a stored NaN vector
+    ix.add_batch(np.arange(n + 2, n + 6, dtype=np.uint64), base[n + 2:n + 6])
+    assert ix.size() == n + 5
+    k2, d2 = ix.search(base[n], 10)
+    assert len(k2) == 10 and np.isfinite(d2[:9]).all()
+    assert len(set(k2.tolist()) & set(good_k.tolist())) >= 8
+    tk, td, _ = ix.exact_search_batch(base[n:n + 1], 10)
+    assert len(set(tk[0].tolist()) & set(good_k.tolist())) >= 8

@@ -109,6 +109,9 @@ def test_wire_format_status_codes_and_scores(tmp_path):
         assert s.ann({"vector": [0.0], "limit": 1.5})[0] == 400
         assert s.ann({"vector": [True]})[0] == 400
         assert s.ann(raw=b"{not json")[0] == 400
+        st, body = s.ann(raw=b'{"vector":[1e999],"limit":3}')   # inf query: l2sq = +inf is in range (distance.rs:72-75) ...
+        assert st == 200 and [np.float32(x) for x in json.loads(body)["distances"]] == [np.finfo(np.float32).max] * 3   # ... saturated (lib.rs:397-409)
+        assert json.loads(body)["similarity_scores"] == [0.0, 0.0, 0.0]
         assert s.get("/api/v1/nothing")[0] == 404
         # keep-alive: several requests on one connection, answers in order
         c = http.client.HTTPConnection("127.0.0.1", s.port, timeout=30)
@@ -131,6 +134,14 @@ def test_empty_index_and_dot_product_scores(tmp_path):
     try:
         body = json.loads(s.ann({"vector": t["query"], "limit": 1})[1])   # similarity.rs:94-100
         assert body["primary_keys"] == {"id": [4 - off]} and body["distances"] == [-1.0] and body["similarity_scores"] == [1.5]
+        # inf * 0 = NaN for the rows orthogonal to the query: a NaN distance among the hits fails the request as
+        # Distance::try_from does (distance.rs:76-83 -> 500); whether a NaN hit survives the walk is not defined (it is not in
+        # usearch either), but the body is never invalid JSON
+        st, body = s.ann(raw=b'{"vector":[1e999,0,0],"limit":4}')
+        assert st in (200, 500)
+        if st == 200:
+            assert all(np.isfinite(x) for x in json.loads(body)["distances"])
+        assert json.loads(s.ann({"vector": t["query"], "limit": 1})[1])["primary_keys"] == {"id": [4 - off]}   # still serving
     finally:
         s.close()
 

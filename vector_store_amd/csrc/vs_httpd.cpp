@@ -851,7 +851,10 @@ struct Worker {
         if (it == conns.end() || it->second.gen != p->gen) return;  // the client went away
         Conn& c = it->second;
         c.busy = false;
-        if (p->status == VS_OK) queue_response(c, Response{200, true, ann_body(*p)}, p->keep_alive);
+        bool in_range = true;  // Distance::try_from (distance.rs:58-105): an out-of-range distance fails the request (usearch.rs:219)
+        for (size_t i = 0; i < p->found && p->status == VS_OK; ++i) in_range = in_range && vs_distance_valid(p->dist[i], p->s->metric, p->s->dim);
+        if (p->status == VS_OK && !in_range) queue_response(c, Response{500, false, "index.ann request error: ann: search failed (distance out of range)"}, p->keep_alive);
+        else if (p->status == VS_OK) queue_response(c, Response{200, true, ann_body(*p)}, p->keep_alive);
         else queue_response(c, Response{p->status == VS_ERR_DIMENSION ? 400 : 500, false, "index.ann request error: " + p->err}, p->keep_alive);
         const int fd = c.fd;
         if (flush(c)) pump(fd);  // a pipelined request may already be waiting

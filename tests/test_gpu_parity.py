@@ -616,3 +616,38 @@ def test_non_finite_inputs_do_not_hang_or_poison_the_index():
     assert len(set(k2.tolist()) & set(good_k.tolist())) >= 8
     tk, td, _ = ix.exact_search_batch(base[n:n + 1], 10)
     assert len(set(tk[0].tolist()) & set(good_k.tolist())) >= 8
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("metric", ["cos", "ip", "l2sq"])
+def test_nan_distances_rank_last_and_never_corrupt_a_walk(metric):
+    """A NaN distance used to break the (distance, slot) order of the LDS lists: ranks collided, holes kept stale slot ids
+    and the walk followed them out of bounds.  NaN now ranks as +inf.  Many non-finite queries, small (team kernel) and
+    large batches, large k, exact search: nothing faults, clean queries keep their answers."""
+    v = vs()
+    n, dim = 20000, 24
+    base = _dataset(n + 600, dim, 29)
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric], expansion_search=200)
+    ix.reserve(n + 64)
+    poisoned = base[:n].copy()
+    poisoned[::97, 5] = np.nan                        # ~200 stored vectors carry a NaN
+    poisoned[50::97, 7] = np.inf
+    ix.add_batch(np.arange(n, dtype=np.uint64), poisoned)
+    q = base[n:n + 600].copy()
+    q[::3, 1] = np.nan
+    q[1::3, 2] = np.inf
+    clean = np.arange(2, 600, 3)
+    ref_k, ref_d, _ = ix.search_batch(q[clean], 50)
+    for lo, hi in ((0, 600), (0, 7), (7, 64), (64, 300)):
+        k, d, f = ix.search_batch(q[lo:hi], 50)
+        assert (f <= 50).all() and all(k[i, :f[i]].max(initial=0) < n for i in range(hi - lo))
+        sel = [i for i in range(lo, hi) if i % 3 == 2]
+        pos = [clean.tolist().index(i) for i in sel]
+        assert np.array_equal(k[[i - lo for i in sel]], ref_k[pos])
+    ek, ed, ef_ = ix.exact_search_batch(q[:64], 50)
+    assert (ef_ <= 50).all() and all(ek[i, :ef_[i]].max(initial=0) < n for i in range(64))
+    bk, bd = ix.search(q[0], 2000)                     # exhaustive ranking with NaNs in the table
+    assert len(bk) == 2000 and len(set(bk.tolist())) == 2000
+    for i in range(0, 30):
+        ix.search(q[i], 10)                            # one-query entry point (team kernel, zero-copy results)
+

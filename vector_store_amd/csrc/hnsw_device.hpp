@@ -378,8 +378,12 @@ __device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup
 #pragma unroll
         for (int i = 0; i < I; ++i) acc = accumulate<AR>(acc, q.c[i], g.buf[u][i]);
         acc = group_sum(acc, ix.lanes);
-        if (g.slot[u] != kInvalid && li == 0)
-            u_dist[(((L + (uint32_t)u) * (uint32_t)TEAM + w) << vshift) + grp] = finalize<AR>(ix.metric, acc, q.aux, g.aux[u]);
+        if (g.slot[u] != kInvalid && li == 0) {
+            // NaN (a non-finite query or stored vector) would break the total order every list relies on -- ranks collide and
+            // leave holes with stale slot ids -- so it is ranked as +inf, behind everything finite
+            const float d = finalize<AR>(ix.metric, acc, q.aux, g.aux[u]);
+            u_dist[(((L + (uint32_t)u) * (uint32_t)TEAM + w) << vshift) + grp] = d == d ? d : __builtin_inff();
+        }
     }
 }
 
@@ -691,6 +695,7 @@ __device__ __forceinline__ uint32_t list_merge(Sh& sh, int cur, uint32_t sz, uin
     float* od = sh.lst_d[cur];
     uint32_t* os = sh.lst_s[cur];
     constexpr int R = EFCAP / kWave;
+    nd = nd == nd ? nd : __builtin_inff();  // see group_reduce: (distance, slot) must be a total order
     // own old entries -> registers
     float keep_d[R];
     uint32_t keep_s[R], keep_p[R], shift[R];

@@ -651,3 +651,19 @@ def test_nan_distances_rank_last_and_never_corrupt_a_walk(metric):
     for i in range(0, 30):
         ix.search(q[i], 10)                            # one-query entry point (team kernel, zero-copy results)
 
+
+
+def test_identical_vectors_stay_reachable():
+    """12,000 copies of one vector: every distance ties.  With ties ordered by slot in the link kernel the same 32
+    lowest slots stayed in every list and only 34 members were reachable; ties are now ordered pseudo-randomly per
+    target, and a top-100 query finds 100 distinct members at distance 0."""
+    v = vs()
+    dim, n = 40, 12000
+    same = np.tile(np.random.default_rng(3).standard_normal(dim).astype(np.float32), (n, 1))
+    for metric in ("cos", "l2sq"):
+        ix = v.HipUsearchIndex(dim, v.METRICS[metric], expansion_search=128)
+        ix.reserve(n)
+        ix.add_batch(np.arange(n, dtype=np.uint64), same)
+        k, d, f = ix.search_batch(same[:200], 100)
+        assert (f == 100).all() and all(len(set(r.tolist())) == 100 for r in k)
+        assert np.abs(d).max() <= 1e-6

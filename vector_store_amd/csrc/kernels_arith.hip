@@ -303,7 +303,10 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
         float ed = sh.t_d[e];
         uint32_t es = sh.t_s[e];
         uint32_t rank = 0;
-        for (uint32_t f = 0; f < total; ++f) rank += key_less(sh.t_d[f], sh.t_s[f], ed, es) ? 1u : 0u;
+        // ties: a pseudo-random order per target (a fixed "lowest slot first" keeps the same old members of a group of
+        // exact duplicates in every list and leaves the later ones without incoming links)
+        const uint32_t salt = target * 0x9E3779B1u;
+        for (uint32_t f = 0; f < total; ++f) rank += key_less(sh.t_d[f], (sh.t_s[f] ^ salt) * 0x85EBCA6Bu, ed, (es ^ salt) * 0x85EBCA6Bu) ? 1u : 0u;
         sh.lst_d[0][rank] = ed;
         sh.lst_s[0][rank] = es;
     }

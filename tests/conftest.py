@@ -24,3 +24,23 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _gpu_warmup():
+    """On a GPU box: pay the cold-start costs (HIP init, loading the engine's code objects, first allocations) once,
+    before any test with a deadline runs -- on a fresh box they take tens of seconds."""
+    if _has_gpu():
+        try:
+            import numpy as np
+
+            import vector_store_amd as vs
+            ix = vs.HipUsearchIndex(8, vs.L2SQ)
+            ix.reserve(64)
+            ix.add_batch(np.arange(32, dtype=np.uint64), np.random.default_rng(0).standard_normal((32, 8)).astype(np.float32))
+            ix.search(np.zeros(8, dtype=np.float32), 3)
+            ix.exact_search_batch(np.zeros((1, 8), dtype=np.float32), 3)
+        except Exception:  # the tests themselves will say what is wrong
+            pass
+    yield
+

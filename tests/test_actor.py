@@ -20,7 +20,7 @@ def test_actor_library_exports_its_header():
     assert declared == {s for s in exported if s.startswith("vs_actor_")} and len(declared) == 13
 
 
-def wait_for_count(actor, expected, timeout=10.0):
+def wait_for_count(actor, expected, timeout=120.0):  # generous: the first GPU call of a fresh box loads 30 MB of code objects
     t0 = time.time()
     while actor.count() != expected:
         assert time.time() - t0 < timeout, (actor.count(), expected)
@@ -46,7 +46,7 @@ def test_add_or_replace_size_ann():
     wait_for_count(a, 3)
     t0 = time.time()
     while a.ann(p, [2.2, -2.2, 2.2], 1)[0].tolist() != [3]:
-        assert time.time() - t0 < 10
+        assert time.time() - t0 < 120
     a.remove_vector(p, 3)
     wait_for_count(a, 2)
     keys, d = a.ann(p, [2.2, -2.2, 2.2], 1)
@@ -140,6 +140,6 @@ def test_local_index_growth_and_partitions():
     a.remove_partition(1)
     t0 = time.time()
     while a.partitions() != 2:
-        assert time.time() - t0 < 10
+        assert time.time() - t0 < 120
     assert len(a.ann(1, data[1], 1)[0]) == 0 and a.count() == 2600 - 500
     a.stop()

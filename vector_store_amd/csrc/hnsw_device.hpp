@@ -430,6 +430,7 @@ template <bool ON>
 struct SelArrays {  // heuristic output (insert / link kernels only)
     uint32_t sel_s[64];
     float sel_d[64];
+    uint32_t tie_salt;  // insert kernel: order among equal distances is pseudo-random per new node (see key_less_in)
 };
 template <>
 struct SelArrays<false> {};
@@ -464,6 +465,21 @@ struct BeamShared : SelArrays<SEL>, TeamBox<TM> {
     uint32_t u_slot[64];
     float u_dist[64];
 };
+
+// The order of a kernel's candidate list.  Search (and everything that reports results): (distance, slot).  Insert: among
+// EQUAL distances a pseudo-random order per new node -- with "lowest slot first" every node of a sub-batch (they all see
+// the same frozen graph) picks the same members of a group of exact duplicates, whose later copies then get no links
+// at all; multiplying by an odd constant is a bijection on the 30 slot bits, so this is still a strict total order.
+template <class Sh>
+__device__ __forceinline__ bool key_less_in(const Sh& sh, float ad, uint32_t as, float bd, uint32_t bs) {
+    if constexpr (Sh::kSel) {
+        const uint32_t ta = (((as & kSlotMask) ^ sh.tie_salt) * 0x85EBCA6Bu) & kSlotMask;
+        const uint32_t tb = (((bs & kSlotMask) ^ sh.tie_salt) * 0x85EBCA6Bu) & kSlotMask;
+        return ad < bd || (ad == bd && ta < tb);
+    } else {
+        return key_less(ad, as, bd, bs);
+    }
+}
 
 // LDS hand-over between the lanes of the walking wave.  One wave per workgroup: the workgroup barrier (free).
 // Team: only a wave-level ordering point -- the helper waves are parked at the team barrier and must not be released.
@@ -717,12 +733,12 @@ __device__ __forceinline__ uint32_t list_merge(Sh& sh, int cur, uint32_t sz, uin
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool valid = (uint32_t)lane + (uint32_t)r * kWave < sz;
-            const bool less = valid && key_less(keep_d[r], keep_s[r], dj, sj);
+            const bool less = valid && key_less_in(sh, keep_d[r], keep_s[r], dj, sj);
             below += (uint32_t)__popcll(__ballot(less));
             shift[r] += (valid && !less) ? 1u : 0u;
         }
         if ((uint32_t)lane == j) r_old = below;
-        r_new += ((uint32_t)lane < m && key_less(dj, sj, nd, ns)) ? 1u : 0u;
+        r_new += ((uint32_t)lane < m && key_less_in(sh, dj, sj, nd, ns)) ? 1u : 0u;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -842,7 +858,7 @@ __device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>&
             uint32_t lo = 0, hi = admit ? sz : 0;
             while (lo < hi) {
                 uint32_t mid = (lo + hi) >> 1;
-                if (key_less(sh.lst_d[cur][mid], sh.lst_s[cur][mid], nd, ns)) lo = mid + 1; else hi = mid;
+                if (key_less_in(sh, sh.lst_d[cur][mid], sh.lst_s[cur][mid], nd, ns)) lo = mid + 1; else hi = mid;
             }
             if (admit && lo < sz && (sh.lst_s[cur][lo] & kSlotMask) == (ns & kSlotMask) && sh.lst_d[cur][lo] == nd) admit = false;
         }

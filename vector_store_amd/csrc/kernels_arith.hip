@@ -102,6 +102,7 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_insert_kernel(InsertArgs a) {
     const int level = a.levels[b];
     Query<AR, I> q;
     query_from_row<AR, I>(ix, slot, q, lane);
+    if (threadIdx.x == 0) sh.tie_salt = slot * 0x9E3779B1u;  // read by wave 0 only, after its first wsync
     if constexpr (TEAM > 1) {
         const uint32_t w = threadIdx.x >> 6;
         if (w != 0) {

@@ -194,3 +194,34 @@ def test_search_http_client_against_the_native_server(tmp_path):
         assert st == {"status": "SERVING", "count": 30000, "build_progress": 100.0}
     finally:
         s.close()
+
+
+def test_server_survives_rude_clients(tmp_path):
+    """Half-sent requests, abrupt closes while a query is in flight, garbage, oversized headers: the server keeps serving."""
+    s, t, _ = _serve_kat(tmp_path, "B11_filter_30", "l2sq")
+    try:
+        body = json.dumps({"vector": t["query"], "limit": 5}).encode()
+        head = f"POST /api/v1/indexes/ks/idx/ann HTTP/1.1\r\nhost: x\r\ncontent-type: application/json\r\ncontent-length: {len(body)}\r\n\r\n".encode()
+        for i in range(60):
+            c = socket.create_connection(("127.0.0.1", s.port), timeout=5)
+            kind = i % 6
+            if kind == 0:
+                c.sendall(head[: len(head) // 2])                  # half a header, then gone
+            elif kind == 1:
+                c.sendall(head + body[: len(body) // 2])           # half a body
+            elif kind == 2:
+                c.sendall(head + body)                             # complete request, closed before the answer
+            elif kind == 3:
+                c.sendall(b"\x00\xff garbage \r\n\r\n")
+            elif kind == 4:
+                c.sendall(b"GET /" + b"a" * 70000 + b" HTTP/1.1\r\n")   # oversized request line
+            else:
+                c.sendall((head + body) * 3)                       # three pipelined requests, read only the first
+                c.recv(4096)
+            c.close()
+        for _ in range(5):
+            st, out = s.ann({"vector": t["query"], "limit": 5})
+            assert st == 200 and len(json.loads(out)["primary_keys"]["id"]) == 5
+        assert s.proc.poll() is None
+    finally:
+        s.close()

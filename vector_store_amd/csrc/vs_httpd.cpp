@@ -37,6 +37,7 @@
 
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cinttypes>
 #include <cmath>
 #include <condition_variable>
@@ -382,6 +383,7 @@ struct BadRequest : std::runtime_error {
 };
 
 constexpr uint64_t kRowMask = (1ull << 48) - 1;
+constexpr int kIdleSeconds = 120;  // keep-alive connections idle for longer are closed (reqwest's pool default is 90 s)
 
 struct Test {
     enum Op { Eq, In, Lt, Le, Gt, Ge } op;
@@ -499,6 +501,7 @@ struct Conn {
     size_t out_off = 0;
     bool busy = false;   // a request is with the engine
     bool close_after = false;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();  // last byte received
 };
 
 struct Pending {  // one query in flight
@@ -862,8 +865,17 @@ struct Worker {
 
     void run() {
         epoll_event evs[256];
+        auto swept = std::chrono::steady_clock::now();
         for (;;) {
-            int n = epoll_wait(ep, evs, 256, -1);
+            int n = epoll_wait(ep, evs, 256, 1000);
+            const auto now = std::chrono::steady_clock::now();
+            if (now - swept > std::chrono::seconds(5)) {  // connections that sent nothing for kIdleSeconds (half requests, dead peers)
+                swept = now;
+                std::vector<int> idle;
+                for (auto& kv : conns)
+                    if (!kv.second.busy && kv.second.out.empty() && now - kv.second.last > std::chrono::seconds(kIdleSeconds)) idle.push_back(kv.first);
+                for (int fd : idle) close_conn(fd);
+            }
             for (int i = 0; i < n; ++i) {
                 int fd = evs[i].data.fd;
                 if (fd == lfd) {
@@ -907,6 +919,7 @@ struct Worker {
                         for (;;) {
                             ssize_t r = ::recv(fd, buf, sizeof buf, 0);
                             if (r > 0) {
+                                c.last = std::chrono::steady_clock::now();
                                 c.in.append(buf, (size_t)r);
                                 if ((size_t)r < sizeof buf) break;
                             } else if (r == 0) {

@@ -149,3 +149,27 @@ def test_link_kernel_with_accepted_rows_in_lds_builds_the_same_graph(monkeypatch
             assert np.array_equal(a["adj0"], g["adj0"]), (kind, metric, dim)
             assert np.array_equal(a["upper"], g["upper"])
             assert a["entry_slot"] == g["entry_slot"] and a["max_level"] == g["max_level"]
+
+
+def test_four_wave_team_tier_equals_single_wave_kernel(monkeypatch):
+    """257..768 queries on the device take teams of 4 waves (two per CU); VS_HNSW_TEAM=mid forces that kernel."""
+    v = vs()
+    n, dim = 6000, 768
+    base, q = _data(n, dim, 71), _data(512, dim, 72)
+    monkeypatch.setenv("VS_HNSW_TEAM", "never")
+    a = v.HipUsearchIndex(dim, v.COS, expansion_search=150)
+    a.reserve(n)
+    a.add_batch(np.arange(n, dtype=np.uint64), base)
+    monkeypatch.setenv("VS_HNSW_TEAM", "mid")
+    b = v.HipUsearchIndex(dim, v.COS, expansion_search=150)
+    b.import_graph(a.export_graph())
+    monkeypatch.delenv("VS_HNSW_TEAM")
+    c = v.HipUsearchIndex(dim, v.COS, expansion_search=150)   # default policy: 400 queries -> the 4-wave tier
+    c.import_graph(a.export_graph())
+    for ef in (64, 150):
+        for ix in (a, b, c):
+            ix.set_expansion_search(ef)
+        ka, da, fa = a.search_batch(q[:400], 10)
+        for other in (b, c):
+            ko, do, fo = other.search_batch(q[:400], 10)
+            assert np.array_equal(ka, ko) and np.array_equal(da.view(np.uint32), do.view(np.uint32)) and np.array_equal(fa, fo)

@@ -417,7 +417,7 @@ struct Engine {
         if (const char* cr = std::getenv("VS_HNSW_CHUNK")) chunk_rows = (uint32_t)std::max(1024, std::atoi(cr));                      // build experiments
         if (const char* sb = std::getenv("VS_HNSW_MAX_SUBBATCH")) max_sub_batch = (uint32_t)std::max(1, std::atoi(sb));
         max_sub_batch = std::min(max_sub_batch, chunk_rows);
-        if (const char* t = std::getenv("VS_HNSW_TEAM")) team_mode = !std::strcmp(t, "always") ? 1 : !std::strcmp(t, "never") ? 2 : team_mode;
+        if (const char* t = std::getenv("VS_HNSW_TEAM")) team_mode = !std::strcmp(t, "always") ? 1 : !std::strcmp(t, "never") ? 2 : !std::strcmp(t, "mid") ? 3 : team_mode;
         M = o.connectivity ? (uint32_t)o.connectivity : 16;  // usearch default_connectivity
         if (M < 2 || M > 32) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 32]");
         M0 = 2 * M;
@@ -865,7 +865,11 @@ struct Engine {
         a.ef = ef;
         a.has_removed = removed.load() ? 1u : 0u;
         a.stress_small_table = stress_small_table ? 1u : 0u;
-        a.team = (team_mode == 1 || (team_mode == 0 && std::max(nq, load) <= team_max_nq)) ? (uint32_t)kSearchTeam : 1u;
+        const size_t on_device = std::max(nq, load);
+        a.team = (team_mode == 1 || (team_mode == 0 && on_device <= team_max_nq)) ? (uint32_t)kSearchTeam
+                 : (team_mode == 0 && on_device <= 3 * team_max_nq)               ? (uint32_t)kSearchTeamMid  // measured: 4 waves win up to ~800
+                 : (team_mode == 3)                                               ? (uint32_t)kSearchTeamMid
+                                                                                  : 1u;
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;
@@ -1133,7 +1137,7 @@ class SearchService {
                 e->search_device(s.h_q, nb, k, s.h_k, s.h_d, s.h_f, s.st, load);
             else
                 e->search_device(s.d_q, nb, k, s.d_k, s.d_d, s.d_f, s.st, load);
-            const bool team = e->team_mode == 1 || (e->team_mode == 0 && std::max(nb, load) <= e->team_max_nq);
+            const bool team = e->team_mode == 1 || e->team_mode == 3 || (e->team_mode == 0 && std::max(nb, load) <= 3 * e->team_max_nq);  // 8- or 4-wave teams
             n_batches += 1;
             n_queries += nb;
             if (team) {

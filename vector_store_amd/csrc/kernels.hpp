@@ -12,6 +12,7 @@ namespace vs {
 enum : int { ST_SEARCH_EVALS = 0, ST_SEARCH_HOPS, ST_QUERIES, ST_ADD_EVALS, ST_ADD_HOPS, ST_ADDED, ST_OVERFLOW, ST_LINK_EVALS, ST_COUNT };  // ST_LINK_EVALS: the part of ST_ADD_EVALS spent in hnsw_link_kernel
 
 constexpr int kSearchTeam = 8;  // 512-thread workgroups: one team per CU at the kernel's register footprint
+constexpr int kSearchTeamMid = 4;  // search only: two teams per CU, for 257..768 queries on the device
 
 struct SearchArgs {
     IndexView ix;
@@ -20,7 +21,7 @@ struct SearchArgs {
     uint32_t nq, k, ef;
     uint32_t has_removed;         // some members carry the free key: the beam keeps ef LIVE entries
     uint32_t stress_small_table;  // test hook: 256-bucket visited table (iters == 1 only) to force overflow
-    uint32_t team;                // waves per query: 1, or kSearchTeam for batches too small to fill the chip
+    uint32_t team;                // waves per query: 1, kSearchTeamMid or kSearchTeam for batches too small to fill the chip
     uint64_t* out_keys;    // nq x k, padded with kFreeKey
     float* out_dist;       // nq x k, padded with +inf
     uint32_t* out_found;   // nq

@@ -326,6 +326,14 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
 template <int AR, int I>
 static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
     dim3 grid(a.nq), block(64);
+    if (a.team == kSearchTeamMid && a.ef <= 256 && !a.stress_small_table) {
+        dim3 tblock(64 * kSearchTeamMid);
+        if (a.ef <= 128)
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, kSearchTeamMid>), grid, tblock, 0, s, a);
+        else
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, kSearchTeamMid>), grid, tblock, 0, s, a);
+        return hipGetLastError();
+    }
     if (a.team == kSearchTeam && a.ef <= 256 && !a.stress_small_table) {
         dim3 tblock(64 * kSearchTeam);
         if (a.ef <= 128)

@@ -124,7 +124,7 @@ def test_search_matches_oracle_on_same_graph(metric, dim, n):
         base = base / np.linalg.norm(base, axis=1, keepdims=True)
     o = OracleIndex(dim, m)
     o.reserve(n)
-    o.add_batch(np.arange(n, dtype=np.uint64) * 3 + 7, base, threads=4)
+    o.add_batch(np.arange(n, dtype=np.uint64) * 3 + 7, base, threads=1)
     g = o.export_graph()
     ix = v.HipUsearchIndex(dim, v.METRICS[metric])
     ix.import_graph(g)
@@ -530,7 +530,7 @@ def test_wide_beam_up_to_512(metric, dim):
     data = _dataset(n + 32, dim, 333)
     o = OracleIndex(dim, oracle.METRICS[metric])
     o.reserve(n)
-    o.add_batch(np.arange(n, dtype=np.uint64), data[:n], threads=4)
+    o.add_batch(np.arange(n, dtype=np.uint64), data[:n], threads=1)
     ix = v.HipUsearchIndex(dim, v.METRICS[metric])
     ix.import_graph(o.export_graph())
     for ef, k in ((300, 100), (64, 500)):

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void exact_dist_kernel(IndexView ix, const flo
 // scores equal the VALU kernel's).  This is the one place of the path that really is a dense contraction
 // (exact search, ground truth, the q = 256 batched inner-product configuration); the graph walk is a gather.
 // Dot-product family only (cos / ip / every i8 metric); l2sq and hamming keep the (a-b)^2 VALU kernel.
-// 4 waves, each a 64 x 64 quadrant = 2 x 2 MFMA tiles (64 accumulator registers); K staged 32 deep through LDS.
+// 4 waves, each a 64 x 64 quadrant = 2 x 2 MFMA tiles (64 accumulator registers); K staged 16 deep through two LDS buffers.
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kMfmaKC = 16;
 

@@ -67,7 +67,9 @@ typedef struct vs_hnsw_options {
     int reserved;     /* 0; test hooks: bit 0 = tiny visited table in search (forces the overflow path),
                          bit 1 = exact search on the VALU tile kernel instead of MFMA,
                          bit 2 = always serve a query with a team of wavefronts, bit 3 = never (default: batches
-                         of at most one team per CU) */
+                         of at most one team per CU),
+                         bit 4 = usearch-order walk (two structures, exact tie order) for every search of this index (default:
+                         i8 / b1 storage only), bit 5 = always the global-bitmap instance of that walk */
 } vs_hnsw_options;
 
 /* -- lifecycle: usearch::Index::new (usearch.rs:172), drop ------------------------------- */

@@ -309,20 +309,38 @@ struct TopBuffer {
     }
 };
 
-// max_heap_gt on negated distances == min-heap on distance.
+// usearch max_heap_gt<candidate_t> holding NEGATED distances == a min-heap on distance [UPSTREAM, from memory].
+// usearch does not use std::push_heap / std::pop_heap: it carries its own array heap
+//   emplace: append, shift_up(last)        shift_up(i):   while i && less(parent, i): swap, i = parent
+//   pop:     swap(first, last), shrink,    shift_down(i): child = right iff less(left, right) else left;
+//            shift_down(0)                                swap and descend iff less(i, child), else stop
+// with less(a, b) = (-a.d) < (-b.d) = a.d > b.d.  Which of several EQUAL distances is popped first is decided by this
+// exact sequence of swaps (the order is not a function of (distance, slot)), so the GPU engine emulates the same
+// array heap step for step (vector_store_amd/csrc/walk_device.hpp) and tie-heavy metrics (Hamming, i8) return
+// identical ids.  (Round 1 used std::push_heap / pop_heap here, libstdc++'s bottom-up variant: same set of results on
+// tie-free data, a different order among equal distances.)
 struct NextHeap {
     std::vector<Cand> v;
-    static bool cmp(const Cand& a, const Cand& b) { return a.d > b.d; }
+    static bool less(const Cand& a, const Cand& b) { return a.d > b.d; }
     void clear() { v.clear(); }
     bool empty() const { return v.empty(); }
     const Cand& top() const { return v.front(); }
     void push(Cand c) {
         v.push_back(c);
-        std::push_heap(v.begin(), v.end(), cmp);
+        size_t i = v.size() - 1;
+        for (; i && less(v[(i - 1) / 2], v[i]); i = (i - 1) / 2) std::swap(v[(i - 1) / 2], v[i]);
     }
     void pop() {
-        std::pop_heap(v.begin(), v.end(), cmp);
+        std::swap(v.front(), v.back());
         v.pop_back();
+        const size_t n = v.size();
+        for (size_t i = 0; 2 * i + 1 < n;) {
+            const size_t l = 2 * i + 1, r = 2 * i + 2;
+            const size_t c = (r < n && less(v[l], v[r])) ? r : l;
+            if (!less(v[i], v[c])) break;
+            std::swap(v[i], v[c]);
+            i = c;
+        }
     }
 };
 

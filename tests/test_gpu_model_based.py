@@ -41,10 +41,15 @@ def test_random_operation_sequences(metric, quant, seed):
             assert len(set(gk.tolist())) == len(gk)
             # filtered: keys whose row index is even
             fk, fd = ix.filtered_search(q, 5, lambda key: (key & 0xFFFF) % 2 == 0)
+            o.set_expansion_search(64)
             ek, ed = o.filtered_search(q, 5, lambda key: (key & 0xFFFF) % 2 == 0)
+            o.set_expansion_search(max(k, 64))
             assert all((int(x) & 0xFFFF) % 2 == 0 for x in fk)
             assert len(fk) == min(5, sum(1 for x in model if (x & 0xFFFF) % 2 == 0))
             assert np.all(fd[:-1] <= fd[1:])
+            # the predicate gates admission inside the traversal: same result set and order as the CPU algorithm
+            assert np.allclose(fd, ed, rtol=1e-5, atol=1e-5)
+            assert fk.tolist() == ek.tolist(), (fk, ek, fd, ed)
 
     for phase in range(12):
         op = rng.choice(["add", "add", "remove", "update", "grow"])

@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <random>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <chrono>
@@ -293,6 +294,25 @@ struct Lease {
     WorkCtx* operator->() { return ctx.get(); }
 };
 
+// Workspace of the usearch-order walk kernels (kernels_walk.hip), one per (device, stream): launches on one stream
+// run one after the other and may share it; hipFree synchronises the device, so growing it is safe.
+struct WalkRes {
+    DeviceBuf lds_space;  // LDS-visited instances: the part of `next` beyond LDS, per workgroup
+    DeviceBuf g_space;    // global-bitmap instances: bitmap + visited log + heap, per workgroup
+    DeviceBuf retry;      // [count u32, 63 pad words | query ids]
+    DeviceBuf allow;      // filtered search: the allow-bitmap of the query
+    std::mutex mu;        // held while a call sizes the buffers and enqueues its launches
+    size_t g_layout[3] = {0, 0, 0};  // (bitmap words, stride, bytes) the bitmaps of g_space are known to be zero for
+};
+static WalkRes& walk_res(int dev, hipStream_t st) {
+    static std::mutex mu;
+    static std::unordered_map<uint64_t, std::unique_ptr<WalkRes>> all;  // leaked with the process
+    std::lock_guard<std::mutex> g(mu);
+    auto& r = all[((uint64_t)(uintptr_t)st << 8) ^ (uint64_t)(uint32_t)dev];
+    if (!r) r.reset(new WalkRes());
+    return *r;
+}
+
 // Sub-batches stay below 1/16 of the graph they are inserted into (nodes of one sub-batch do
 // not see each other during their search phase); capped at one staging chunk = 16 rounds of the chip's
 // 2048 resident waves, so the last, partly filled round costs ~3 % (8192: 4 rounds, ~12 %; measured at
@@ -315,6 +335,9 @@ struct Engine {
     int nt_policy = 0;                // 0 = by table size; VS_HNSW_NT_ROWS=1 / 0 forces non-temporal row loads on / off
     uint32_t link_cache_rows = 0;     // accepted rows the link kernel's re-selection keeps in LDS (set in init)
     uint32_t chunk_rows = kChunk;
+    int order_mode = 0;               // 0 = usearch-order walk for the tie-heavy metrics (i8, b1), fused list otherwise;
+                                      // 1 = always the usearch-order walk (reserved bit 4); 2 = never (A/B measurements only)
+    bool force_global_walk = false;   // reserved bit 5 (tests): every search takes the global-bitmap walk instance
     int team_mode = 0;                // 0 = by batch size; reserved bit 2 = always a team per query, bit 3 = never
     uint32_t team_max_nq = 256;       // batches up to one team per CU take the team kernel
     int scalar = VS_SCALAR_F32;
@@ -344,6 +367,10 @@ struct Engine {
     std::deque<uint32_t> free_slots;  // usearch ring_gt: FIFO
     std::vector<uint8_t> h_levels;
     std::vector<uint32_t> h_upper_off;
+    std::vector<uint64_t> h_keys;  // key of every slot (kFreeKey: removed / unused): what a filter's allow-bitmap is built from
+    // Searches read the arena pointers (view()) and launch under a shared lock; whatever may MOVE an arena (reserve,
+    // growth of `upper` in the middle of an ingest) drains the device and swaps pointers under the exclusive lock.
+    mutable std::shared_mutex view_mu;
     std::default_random_engine level_rng;  // same stream as a 1-thread usearch context (oracle orc_level_stream)
     double inv_log_m = 0;
     std::atomic<uint32_t> entry_slot{0};
@@ -414,6 +441,10 @@ struct Engine {
         stress_small_table = (o.reserved & 1) != 0;
         exact_valu = (o.reserved & 2) ? 1 : 0;
         team_mode = (o.reserved & 4) ? 1 : (o.reserved & 8) ? 2 : 0;
+        order_mode = (o.reserved & 16) ? 1 : 0;
+        force_global_walk = (o.reserved & 32) != 0;
+        if (const char* fw = std::getenv("VS_HNSW_WALK")) force_global_walk = !std::strcmp(fw, "global");
+        if (const char* om = std::getenv("VS_HNSW_ORDER")) order_mode = !std::strcmp(om, "usearch") ? 1 : !std::strcmp(om, "fused") ? 2 : order_mode;
         if (const char* cr = std::getenv("VS_HNSW_CHUNK")) chunk_rows = (uint32_t)std::max(1024, std::atoi(cr));                      // build experiments
         if (const char* sb = std::getenv("VS_HNSW_MAX_SUBBATCH")) max_sub_batch = (uint32_t)std::max(1, std::atoi(sb));
         max_sub_batch = std::min(max_sub_batch, chunk_rows);
@@ -491,6 +522,7 @@ struct Engine {
         if (cap < slots) fail(VS_ERR_INVALID_ARGUMENT, "can't reserve less than the current size");
         if (cap >= (1ull << 30)) fail(VS_ERR_UNSUPPORTED, "capacity must be below 2^30 slots per index");
         if (cap == capacity) return;
+        std::unique_lock<std::shared_mutex> vg(view_mu);
         HIP_OK(hipDeviceSynchronize());
         // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
         // coexist with the old ones while rows are copied across.
@@ -509,17 +541,25 @@ struct Engine {
         regrow(ar_levels, d_levels, capacity, cap, 0);
         h_levels.resize(cap, 0);
         h_upper_off.resize(cap, kInvalid);
+        h_keys.resize(cap, kFreeKey);
         capacity = cap;
         capacity_atomic = cap;
-        ensure_upper(cap / 8 + 64);
+        // expected upper-level blocks: cap / (M - 1) (sum over l >= 1 of M^-l); sized with a margin here, where moving
+        // an arena is free, so that an ingest almost never has to (ensure_upper still can, under the exclusive lock)
+        ensure_upper_locked((size_t)((double)cap / (double)(M - 1) * 1.25) + 1024);
     }
 
-    void ensure_upper(size_t blocks) {
+    void ensure_upper_locked(size_t blocks) {  // view_mu held exclusively
         if (blocks <= upper_cap) return;
         HIP_OK(hipDeviceSynchronize());
         size_t ncap = std::max(blocks, upper_cap * 2);
         regrow(ar_upper, d_upper, upper_cap * M, ncap * M, 0xFF);
         upper_cap = ncap;
+    }
+    void ensure_upper(size_t blocks) {
+        if (blocks <= upper_cap) return;
+        std::unique_lock<std::shared_mutex> vg(view_mu);  // no search may hold the old pointer (advisor finding, round 1)
+        ensure_upper_locked(blocks);
     }
 
     int32_t draw_level() {  // usearch choose_random_level_
@@ -730,6 +770,7 @@ struct Engine {
                 std::lock_guard<std::mutex> kg(key_mu);
                 for (uint32_t i = 0; i < m; ++i) lookup.emplace(key_v[i], slot_v[i]);
             }
+            for (uint32_t i = 0; i < m; ++i) h_keys[slot_v[i]] = key_v[i];
             live += m;
             if (!staged) committed += m;  // staged vectors were counted when add_one accepted them
         }
@@ -833,6 +874,7 @@ struct Engine {
         }
         const uint64_t free_key = kFreeKey;
         HIP_OK(hipMemcpy(d_keys + slot, &free_key, 8, hipMemcpyHostToDevice));
+        h_keys[slot] = kFreeKey;
         free_slots.push_back(slot);
         ++removed;
         --live;
@@ -841,21 +883,100 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ search
+    // Which kernel serves a search (usearch: expansion = max(expansion_search, wanted)):
+    //   fused-list kernel (hnsw_search_kernel)   float metrics, beam <= 512, index within the LDS tags' reach;
+    //   usearch-order walk, LDS visited table     i8 / b1 (ties are the rule there) or order_mode 1, beam <= 512;
+    //   usearch-order walk, global visited bitmap filtered search, beams 513..10,240, indexes beyond the LDS tags.
+    bool usearch_order() const { return order_mode == 1 || (order_mode == 0 && (scalar == VS_SCALAR_I8 || scalar == VS_SCALAR_B1)); }
     void check_search(size_t k, uint32_t& ef) const {
         if (k == 0) fail(VS_ERR_INVALID_ARGUMENT, "k must be > 0");
-        ef = (uint32_t)std::max<size_t>(ef_search.load(), k);  // usearch: expansion = max(expansion_search, wanted)
-        if (ef > kMaxBeam)
-            fail(VS_ERR_UNSUPPORTED, "k / expansion_search above 512 needs the exhaustive path (use exact search)");
-        if (slots > (1ull << visited_domain_bits(ef)))
-            fail(VS_ERR_UNSUPPORTED, "index too large for the LDS visited table of this beam width");
+        ef = (uint32_t)std::min<size_t>(std::max<size_t>(ef_search.load(), k), 0x7FFFFFFFu);
+        if (ef > kMaxWalkBeam)
+            fail(VS_ERR_UNSUPPORTED, "k / expansion_search above 10240 needs the exhaustive path (vs_hnsw_search)");
     }
+    bool beyond_lds_tags(uint32_t ef) const { return slots > (1ull << visited_domain_bits(std::min<uint32_t>(ef, kMaxBeam))); }
 
     // `load`: queries that will be on the device together with this batch (other pipeline slots included);
     // the team kernel only pays while the chip has idle CUs.
+    // allow: device bitmap(s) over slots for filtered search (allow_stride words apart, 0 = one for the whole batch).
     void search_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
-                       hipStream_t st, size_t load = 0) {
+                       hipStream_t st, size_t load = 0, const uint32_t* allow = nullptr, uint32_t allow_stride = 0) {
         uint32_t ef;
         check_search(k, ef);
+        if (!nq) return;
+        std::shared_lock<std::shared_mutex> vg(view_mu);
+        const bool global = allow || ef > kMaxBeam || beyond_lds_tags(ef) || force_global_walk;
+        if (global || usearch_order()) {
+            WalkArgs a;
+            a.ix = view();
+            a.queries = d_q;
+            a.q_stride = dim;
+            a.nq = (uint32_t)nq;
+            a.k = (uint32_t)k;
+            a.ef = ef;
+            a.has_removed = removed.load() ? 1u : 0u;
+            a.allow = allow;
+            a.allow_stride = allow_stride;
+            a.qlist = nullptr;
+            a.qcount = nullptr;
+            a.retry_list = nullptr;
+            a.retry_count = nullptr;
+            a.out_keys = d_keys_out;
+            a.out_dist = d_dist_out;
+            a.out_found = d_found;
+            a.stats = d_stats;
+            WalkRes& wr = walk_res(device, st);
+            std::lock_guard<std::mutex> wl(wr.mu);
+            const uint32_t g_inst = ef <= 512 ? WALK_GLOBAL_512 : ef <= 2048 ? WALK_GLOBAL_2048 : WALK_GLOBAL_10240;
+            // workspace of a global-bitmap launch of `grid` workgroups; the bitmaps must be zero on entry (the kernel
+            // leaves them zero), so a change of layout re-zeroes the block
+            auto global_space = [&](WalkArgs& w, uint32_t inst, uint32_t want_grid, bool deep_heap) {
+                w.bitmap_words = (uint32_t)((slots + 31) / 32);
+                w.vlog_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(slots, 1u << 16));
+                w.heap_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(slots, deep_heap ? (1u << 20) : (1u << 16)));
+                w.space_stride = walk_space_stride(w.bitmap_words, w.vlog_cap, w.heap_cap);
+                const uint32_t budget_grid = (uint32_t)std::max<size_t>(16, (4ull << 30) / w.space_stride);
+                uint32_t grid = 0;
+                HIP_OK(launch_walk(w, iters, inst, std::min(want_grid, budget_grid), st, &grid));
+                const size_t bytes = (size_t)grid * w.space_stride;
+                const bool grown = bytes > wr.g_space.bytes;
+                w.space = (char*)wr.g_space.ensure(bytes);
+                if (grown || wr.g_layout[0] != w.bitmap_words || wr.g_layout[1] != w.space_stride || wr.g_layout[2] < bytes) {
+                    HIP_OK(hipMemsetAsync(w.space, 0, bytes, st));
+                    wr.g_layout[0] = w.bitmap_words;
+                    wr.g_layout[1] = w.space_stride;
+                    wr.g_layout[2] = bytes;
+                }
+                return grid;
+            };
+            if (global) {
+                const uint32_t grid = global_space(a, g_inst, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
+                HIP_OK(launch_walk(a, iters, g_inst, grid, st, nullptr));
+                return;
+            }
+            // LDS visited table; queries that exhaust it (or the heap workspace) go to a global-bitmap launch behind
+            const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : WALK_LDS_512;
+            a.bitmap_words = 0;
+            a.vlog_cap = 0;
+            a.heap_cap = 8192;
+            a.space_stride = walk_space_stride(0, 0, a.heap_cap);
+            uint32_t grid = 0;
+            HIP_OK(launch_walk(a, iters, inst, 1u << 20, st, &grid));
+            a.space = (char*)wr.lds_space.ensure((size_t)grid * a.space_stride);
+            uint32_t* retry = (uint32_t*)wr.retry.ensure((64 + nq) * 4);
+            HIP_OK(hipMemsetAsync(retry, 0, 4, st));
+            a.retry_count = retry;
+            a.retry_list = retry + 64;
+            WalkArgs r = a;  // the retry launch: same queries, same outputs, global bitmap, only the listed queries
+            r.qlist = a.retry_list;
+            r.qcount = a.retry_count;
+            r.retry_list = nullptr;
+            r.retry_count = nullptr;
+            const uint32_t rgrid = global_space(r, WALK_GLOBAL_512, 64, true);
+            HIP_OK(launch_walk(a, iters, inst, grid, st, nullptr));
+            HIP_OK(launch_walk(r, iters, WALK_GLOBAL_512, rgrid, st, nullptr));
+            return;
+        }
         SearchArgs a;
         a.ix = view();
         a.queries = d_q;
@@ -880,6 +1001,7 @@ struct Engine {
     void exact_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
                       hipStream_t st, WorkCtx& w) {
         if (k == 0 || k > 256) fail(VS_ERR_UNSUPPORTED, "exact search supports 1 <= k <= 256");
+        std::shared_lock<std::shared_mutex> vg(view_mu);
         ExactArgs a;
         a.ix = view();
         a.queries = d_q;
@@ -895,7 +1017,9 @@ struct Engine {
         HIP_OK(launch_exact(a, scratch, st));
     }
 
-    void search_host(const float* q, size_t nq, size_t k, uint64_t* keys, float* dist, size_t* found, bool exact) {
+    // allow (host, optional): one allow-bitmap over slots for the whole batch (filtered search).
+    void search_host(const float* q, size_t nq, size_t k, uint64_t* keys, float* dist, size_t* found, bool exact,
+                     const std::vector<uint32_t>* allow = nullptr) {
         if (!nq) return;
         use_device();
         Lease w(device);
@@ -905,16 +1029,21 @@ struct Engine {
         float* d_d = (float*)w->c.ensure(nq * k * 4);
         uint32_t* d_f = (uint32_t*)w->d.ensure(nq * 4);
         HIP_OK(hipMemcpyAsync(d_q, q, nq * dim * 4, hipMemcpyHostToDevice, st));
-        if (exact)
+        if (exact) {
             exact_device(d_q, nq, k, d_k, d_d, d_f, st, *w.ctx);
-        else
+        } else if (allow) {
+            uint32_t* d_allow = (uint32_t*)w->e.ensure(allow->size() * 4);
+            HIP_OK(hipMemcpyAsync(d_allow, allow->data(), allow->size() * 4, hipMemcpyHostToDevice, st));
+            search_device(d_q, nq, k, d_k, d_d, d_f, st, 0, d_allow, 0);
+        } else {
             search_device(d_q, nq, k, d_k, d_d, d_f, st);
+        }
         std::vector<uint32_t> f32(nq);
         HIP_OK(hipMemcpyAsync(keys, d_k, nq * k * 8, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(dist, d_d, nq * k * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(f32.data(), d_f, nq * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
-        for (size_t i = 0; i < nq; ++i) found[i] = f32[i];
+        for (size_t i = 0; i < nq; ++i) found[i] = f32[i] == kWalkFailed ? (size_t)-1 : f32[i];  // (size_t)-1: rank exhaustively
     }
 
     // One query per FFI call (reference usearch.rs:212): handled by the per-device SearchService below.
@@ -938,6 +1067,7 @@ struct Engine {
             hipStream_t st = w->stream;
             n = e.slots;
             if (!n) return;
+            std::shared_lock<std::shared_mutex> vg(e.view_mu);
             float* d_q = (float*)w->a.ensure((size_t)e.dim * 4);
             HIP_OK(hipMemcpyAsync(d_q, q, (size_t)e.dim * 4, hipMemcpyHostToDevice, st));
             float* d_d = (float*)w->f.ensure((n + e.dim + 64) * 4);
@@ -951,6 +1081,7 @@ struct Engine {
             d_keys_sorted = rank;  // the unsorted ranks are dead: reuse as the key output
             d_dist_sorted = d_d;   // likewise the raw distances
             HIP_OK(launch_rank_emit(ix, sorted, (uint32_t)n, d_keys_sorted, d_dist_sorted, st));
+            HIP_OK(hipStreamSynchronize(st));  // nothing reads the arenas after the lock is gone
         }
         // members [from, from + count) of the ascending order; removed members (free key) mark the end
         void fetch(size_t from, size_t count, uint64_t* keys, float* dist) {
@@ -961,33 +1092,60 @@ struct Engine {
         }
     };
 
-    // usearch filtered_search (reference usearch.rs:224-248): the predicate is host state
-    // (a table read-lock + restriction evaluation, usearch.rs:1118-1124), so it cannot run in
-    // the kernel.  Over-fetch with a doubling beam; when even the widest LDS beam does not
-    // yield k admitted keys, rank every member exhaustively -- all matches are then found,
-    // as the reference tests require (vs_index.rs:1119-1158: 9 of 30 with limit 100).
-    size_t filtered(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist) {
+    // usearch filtered_search (reference usearch.rs:224-248; wrapper filtered_ann :1107-1154): the predicate gates
+    // admission to `top` INSIDE the traversal, rejected nodes are still expanded.  The predicate is host state (a table
+    // read-lock + restriction evaluation, usearch.rs:1118-1124) and cannot run in the kernel, so it is evaluated once
+    // per live member into an allow-bitmap over slots (in parallel above 256k members), which the usearch-order walk
+    // tests at admission (walk_device.hpp): same result set, same order as the CPU algorithm on the same graph.
+    // Beams beyond the widest walk instance, or a walk that outgrows its workspace, fall back to ranking every
+    // member exhaustively (exact; all matches are found, as vs_index.rs:1119-1158 requires: 9 of 30 with limit 100).
+    std::vector<uint32_t> allow_bitmap(vs_hnsw_predicate pred, void* pctx) {
+        size_t n;
+        {
+            std::lock_guard<std::mutex> g(mod_mu);  // searches do not overlap adds / reserve (usearch.rs:590-612): h_keys is stable
+            n = slots;
+        }
+        const size_t words = (n + 31) / 32;
+        std::vector<uint32_t> bits(words ? words : 1, 0u);
+        auto run = [&](size_t w0, size_t w1) {
+            for (size_t w = w0; w < w1; ++w) {
+                uint32_t v = 0;
+                const size_t s1 = std::min(n, (w + 1) * 32);
+                for (size_t s = w * 32; s < s1; ++s) {
+                    const uint64_t key = h_keys[s];
+                    if (key != kFreeKey && pred(key, pctx)) v |= 1u << (s & 31);
+                }
+                bits[w] = v;
+            }
+        };
+        const size_t threads = n >= (1u << 18) ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        if (threads <= 1) {
+            run(0, words);
+        } else {
+            std::vector<std::thread> th;
+            const size_t per = (words + threads - 1) / threads;
+            for (size_t t = 0; t < threads; ++t)
+                th.emplace_back(run, std::min(words, t * per), std::min(words, (t + 1) * per));
+            for (auto& x : th) x.join();
+        }
+        return bits;
+    }
+
+    size_t rank_all(const float* q, size_t k, uint64_t* keys, float* dist) {  // exhaustive ranking, no predicate
+        struct All {
+            static int yes(uint64_t, void*) { return 1; }
+        };
+        return filtered(q, k, &All::yes, nullptr, keys, dist, true);
+    }
+
+    size_t filtered(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, bool exhaustive = false) {
         const size_t n_live = live.load();
         if (!n_live) return 0;
-        size_t fetch = std::max<size_t>(k, ef_search.load());
-        for (;;) {
-            if (fetch > kMaxBeam || fetch >= n_live) break;
-            std::vector<uint64_t> kk(fetch);
-            std::vector<float> dd(fetch);
+        if (!exhaustive && std::max<size_t>(k, ef_search.load()) <= kMaxWalkBeam) {
+            const std::vector<uint32_t> bits = allow_bitmap(pred, pctx);
             size_t f = 0;
-            search_host(q, 1, fetch, kk.data(), dd.data(), &f, false);
-            size_t out = 0;
-            for (size_t i = 0; i < f && out < k; ++i)
-                if (pred(kk[i], pctx)) {
-                    keys[out] = kk[i];
-                    dist[out] = dd[i];
-                    ++out;
-                }
-            if (out == k) return out;
-            // the share that passed predicts the beam that would yield k: go there directly, or straight to the
-            // exhaustive ranking when no LDS beam can (a graph walk per doubling step costs more than ranking)
-            const size_t projected = out ? (size_t)(1.5 * (double)k * (double)f / (double)out) + 1 : kMaxBeam + 1;
-            fetch = std::max(fetch * 2, projected);
+            search_host(q, 1, k, keys, dist, &f, false, &bits);
+            if (f != (size_t)-1) return f;
         }
         // Walk the members in ascending (distance, slot) order and ask the predicate lazily: about k / selectivity calls
         // instead of one per member (the reference's predicate takes a table read-lock per call).
@@ -1393,16 +1551,18 @@ int vs_hnsw_search(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* k
         h->e.flush_pending();
         uint32_t ef;
         *found = 0;
-        if (k > vs::kMaxBeam || std::max<size_t>(k, h->e.ef_search.load()) > vs::kMaxBeam) {
-            // beyond the LDS beam: exhaustive ranking (exact, superset of what the beam would find)
-            struct All {
-                static int yes(uint64_t, void*) { return 1; }
-            };
-            need(k > 0, "k must be > 0");
-            *found = h->e.filtered(q, k, &All::yes, nullptr, keys, dist);
+        need(k > 0, "k must be > 0");
+        const size_t beam = std::max<size_t>(k, h->e.ef_search.load());
+        if (beam > vs::kMaxWalkBeam) {  // beyond the widest walk: exhaustive ranking (exact, a superset of any beam's answer)
+            *found = h->e.rank_all(q, k, keys, dist);
             return;
         }
         h->e.check_search(k, ef);
+        if (beam > vs::kMaxBeam || h->e.beyond_lds_tags(ef)) {  // wide beams / huge indexes: the global-bitmap walk, own launch
+            h->e.search_host(q, 1, k, keys, dist, found, false);
+            if (*found == (size_t)-1) *found = h->e.rank_all(q, k, keys, dist);
+            return;
+        }
         rc = h->e.search_one(q, k, keys, dist, found);
     });
     return g != VS_OK ? g : rc;
@@ -1438,7 +1598,13 @@ int vs_hnsw_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim, size
         need(h && (nq == 0 || (q && keys && dist && found)), "null argument");
         check_dim(h, dim);
         h->e.flush_pending();
+        if (std::max<size_t>(k, h->e.ef_search.load()) > vs::kMaxWalkBeam) {
+            for (size_t i = 0; i < nq; ++i) found[i] = h->e.rank_all(q + i * dim, k, keys + i * k, dist + i * k);
+            return;
+        }
         h->e.search_host(q, nq, k, keys, dist, found, false);
+        for (size_t i = 0; i < nq; ++i)
+            if (found[i] == (size_t)-1) found[i] = h->e.rank_all(q + i * dim, k, keys + i * k, dist + i * k);
     });
 }
 int vs_hnsw_exact_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim, size_t k, uint64_t* keys, float* dist,
@@ -1590,6 +1756,7 @@ int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const void* vectors, const int32_
         for (size_t s = 0; s < n; ++s) {
             e.h_levels[s] = (uint8_t)levels[s];
             e.h_upper_off[s] = upper_off[s];
+            e.h_keys[s] = keys[s];
             if (keys[s] != vs::kFreeKey) {
                 e.lookup.emplace(keys[s], (uint32_t)s);
                 ++live;

@@ -604,7 +604,6 @@ __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
     const uint32_t c1 = (sh.vis_cnt[b1 >> 2] >> s1) & 0xFFu;
     bool found = bucket_has(sh, b1, c1, tag);
     uint32_t b = b1, sb = s1, cb = c1, stored = tag;
-    bool full = c1 >= 8u;
     if (CH == 2) {
         const uint32_t alt = ((tag * 0x5BD1u) >> 3) & (uint32_t)(NB - 1);
         const uint32_t b2 = b1 ^ alt;
@@ -612,7 +611,6 @@ __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
             const uint32_t s2 = (b2 & 3u) * 8u;
             const uint32_t c2 = (sh.vis_cnt[b2 >> 2] >> s2) & 0xFFu;
             found |= bucket_has(sh, b2, c2, tag | 0x8000u);
-            full = full && c2 >= 8u;
             if (c2 < c1) {
                 b = b2;
                 sb = s2;
@@ -622,7 +620,11 @@ __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
         }
     }
     constexpr uint32_t ovf_cap = (uint32_t)kOvf - 2u;
-    if (!found && full) {  // every candidate bucket is full: later members live in the overflow list
+    if (!found) {
+        // Members that found their bucket full live in the overflow list.  With two choices a member can land there
+        // while its OTHER bucket still has room (several lanes of one hop pick the same nearly-full bucket from the
+        // counts they read before any of them inserted), so the list is searched whenever it is not empty, not only
+        // when both buckets are full -- else such a member is evaluated, and listed, twice.
         uint32_t oc = sh.ovf_cnt < ovf_cap ? sh.ovf_cnt : ovf_cap;
         for (uint32_t j = 0; j < oc; ++j) found |= sh.vis_ovf[j] == slot;
     }

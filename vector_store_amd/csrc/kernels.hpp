@@ -50,7 +50,41 @@ struct LinkArgs {
     unsigned long long* stats;
 };
 
-// per-arithmetic launchers (explicitly specialised in kernels_arith.hip, one object per arithmetic)
+// The usearch-order walk (walk_device.hpp / kernels_walk.hip): persistent workgroups, one WalkSpace each.
+enum : uint32_t { WALK_LDS_128 = 0, WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512, WALK_GLOBAL_2048, WALK_GLOBAL_10240,
+                  WALK_LDS_128_TINY /* test hook: 256-bucket visited table (1-chunk rows only), forces the retry path */ };
+constexpr uint32_t kWalkFailed = 0xFFFFFFFFu;  // out_found: the walk outgrew its workspace, the query was not answered
+constexpr uint32_t kMaxWalkBeam = 10240;       // widest `top` of the walk instances
+
+struct WalkArgs {
+    IndexView ix;
+    const float* queries;  // nq x q_stride floats
+    uint32_t q_stride;
+    uint32_t nq, k, ef;
+    uint32_t has_removed;
+    const uint32_t* allow;   // filtered search: bit s = slot s may be a result; nullptr = every live member
+    uint32_t allow_stride;   // words between the bitmaps of consecutive queries (0: one bitmap for the batch)
+    const uint32_t* qlist;   // retry instance: serve queries qlist[0 .. *qcount) instead of 0 .. nq
+    const uint32_t* qcount;
+    uint32_t* retry_list;    // LDS instances: queries whose visited table or heap ran out are appended here ...
+    uint32_t* retry_count;   // ... and served by a global-bitmap instance launched behind (nullptr: flag kWalkFailed)
+    char* space;             // grid x space_stride bytes: [bitmap_words u32 | vlog_cap u32 | heap_cap uint2] per workgroup
+    size_t space_stride;
+    uint32_t bitmap_words, vlog_cap, heap_cap;
+    uint64_t* out_keys;
+    float* out_dist;
+    uint32_t* out_found;
+    unsigned long long* stats;
+};
+inline size_t walk_space_stride(uint32_t bitmap_words, uint32_t vlog_cap, uint32_t heap_cap) {
+    return (((size_t)bitmap_words + vlog_cap) * 4 + (size_t)heap_cap * 8 + 255) / 256 * 256;
+}
+
+// per-arithmetic launchers (explicitly specialised in kernels_arith.hip / kernels_walk.hip, one object per arithmetic)
+// launch_walk: grid = min(queries, resident workgroups, grid_cap); grid_out != nullptr only reports that grid.
+template <int AR> hipError_t launch_walk_ar(const WalkArgs& a, uint32_t iters, uint32_t instance, uint32_t grid_cap, hipStream_t s,
+                                            uint32_t* grid_out);
+hipError_t launch_walk(const WalkArgs& a, uint32_t iters, uint32_t instance, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out);
 template <int AR> hipError_t launch_search_ar(const SearchArgs& a, uint32_t iters, hipStream_t s);
 template <int AR> hipError_t launch_insert_ar(const InsertArgs& a, uint32_t iters, hipStream_t s);
 template <int AR> hipError_t launch_link_ar(const LinkArgs& a, uint32_t iters, hipStream_t s);

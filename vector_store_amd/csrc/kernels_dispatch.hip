@@ -44,6 +44,12 @@ hipError_t launch_search(const SearchArgs& a, uint32_t iters, hipStream_t s) {
     VS_DISPATCH(launch_search_ar, (a, iters, s))
 }
 
+hipError_t launch_walk(const WalkArgs& a, uint32_t iters, uint32_t instance, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out) {
+    if (!grid_out && !a.qlist && a.nq == 0) return hipSuccess;
+    if (!search_supported(iters, 1) || a.ef < 1 || a.ef > kMaxWalkBeam) return hipErrorInvalidValue;
+    VS_DISPATCH(launch_walk_ar, (a, iters, instance, grid_cap, s, grid_out))
+}
+
 hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     if (!search_supported(iters, a.ef_add) || a.ef_add > 256) return hipErrorInvalidValue;

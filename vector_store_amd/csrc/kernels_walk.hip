@@ -1,0 +1,144 @@
+// kernels_walk.hip -- hnsw_walk_kernel for ONE arithmetic (-DVS_AR=0..7): the usearch-order search
+// (walk_device.hpp) behind usearch::Index::search / filtered_search as the reference calls them
+// (crates/vector-store/src/vs_index/usearch.rs:210-212, :233-236).
+//
+// Instances per arithmetic and row layout:
+//   LDS visited table  (EFCAP 128 / 256 / 512)     -- tie-heavy metrics (i8, Hamming) and "usearch order" indexes at the
+//                                                      usual beams; a query whose table or heap runs out is handed to
+//   global visited bitmap (EFCAP 512 / 2048 / 10240) -- the retry instance; filtered search (allow-bitmap tested at admission
+//                                                      to `top`, rejected nodes still expanded); beams of 513..10,240
+//                                                      (the reference passes any `limit` through, httproutes.rs:842-847);
+//                                                      indexes beyond what the LDS tags can tell apart.
+// Workgroups are persistent: workgroup b serves queries b, b + grid, ... and owns one WalkSpace.
+#include "kernels.hpp"
+#include "walk_device.hpp"
+
+#ifndef VS_AR
+#error "compile with -DVS_AR=<arithmetic>"
+#endif
+
+namespace vs {
+
+template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, bool VISG>
+__global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
+    using Sh = WalkShared<EFCAP, LCAP, NB, CH, VISG>;
+    __shared__ Sh sh;
+    const IndexView& ix = a.ix;
+    const int lane = lane_id();
+    WalkSpace ws;
+    {
+        char* base = a.space + (size_t)blockIdx.x * a.space_stride;
+        ws.bitmap = reinterpret_cast<uint32_t*>(base);
+        ws.vlog = ws.bitmap + a.bitmap_words;
+        ws.heap = reinterpret_cast<uint2*>(ws.vlog + a.vlog_cap);
+        ws.bitmap_words = a.bitmap_words;
+        ws.vlog_cap = a.vlog_cap;
+        ws.heap_cap = a.heap_cap;
+    }
+    const uint32_t total = a.qlist ? *a.qcount : a.nq;
+    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint32_t qi = a.qlist ? a.qlist[t] : t;
+        uint64_t* ok = a.out_keys + (size_t)qi * a.k;
+        float* od = a.out_dist + (size_t)qi * a.k;
+        if (ix.max_level < 0) {
+            for (uint32_t i = lane; i < a.k; i += kWave) {
+                ok[i] = kFreeKey;
+                od[i] = __builtin_inff();
+            }
+            if (lane == 0) a.out_found[qi] = 0;
+            continue;
+        }
+        Query<AR, I> q;
+        query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
+        Counters cnt = {0, 0, 0};
+        const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
+        bool exhausted = false;
+        const uint32_t* allow = a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
+        const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, allow, cnt, lane, exhausted);
+        if (exhausted) {
+            if (lane == 0) {
+                if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;  // the global-bitmap instance takes it
+                else a.out_found[qi] = kWalkFailed;                                // workspace too small: the host ranks exhaustively
+            }
+            __syncthreads();
+            continue;
+        }
+        // top.shrink(wanted): `top` holds admitted, live members only
+        const uint32_t found = sz < a.k ? sz : a.k;
+        for (uint32_t i = lane; i < a.k; i += kWave) {
+            const bool in = i < found;
+            ok[i] = in ? ix.keys[sh.lst_s[i]] : kFreeKey;
+            od[i] = in ? sh.lst_d[i] : __builtin_inff();
+        }
+        if (lane == 0) {
+            a.out_found[qi] = found;
+            atomicAdd(&a.stats[ST_SEARCH_EVALS], cnt.evals);
+            atomicAdd(&a.stats[ST_SEARCH_HOPS], cnt.hops);
+            atomicAdd(&a.stats[ST_QUERIES], 1ull);
+        }
+        __syncthreads();
+    }
+}
+
+template <class K>
+static uint32_t resident_workgroups(K kernel, int device) {  // workgroups of `kernel` the chip holds at once
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    return (uint32_t)per_cu * (uint32_t)cus;
+}
+
+template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, bool VISG>
+static hipError_t walk_launch(const WalkArgs& a, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out) {
+    auto kernel = hnsw_walk_kernel<AR, I, EFCAP, LCAP, NB, CH, VISG>;
+    static uint32_t resident = 0;  // per instance; the engine serves one device model
+    if (!resident) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        resident = resident_workgroups(kernel, dev);
+    }
+    uint32_t want = a.qlist ? grid_cap : a.nq;
+    uint32_t g = want < resident ? want : resident;
+    g = g < grid_cap ? g : grid_cap;
+    if (grid_out) {  // sizing query only
+        *grid_out = g ? g : 1;
+        return hipSuccess;
+    }
+    if (!g) return hipSuccess;
+    hipLaunchKernelGGL(kernel, dim3(g), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+constexpr int kWalkHeapLds = 512;
+
+template <int AR, int I>
+static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out) {
+    switch (instance) {
+        case WALK_LDS_128: return walk_launch<AR, I, 128, kWalkHeapLds, 1024, 1, false>(a, grid_cap, s, grid_out);
+        case WALK_LDS_256: return walk_launch<AR, I, 256, kWalkHeapLds, 1024, 2, false>(a, grid_cap, s, grid_out);
+        case WALK_LDS_512: return walk_launch<AR, I, 512, kWalkHeapLds, 2048, 2, false>(a, grid_cap, s, grid_out);
+        case WALK_GLOBAL_512: return walk_launch<AR, I, 512, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
+        case WALK_GLOBAL_2048: return walk_launch<AR, I, 2048, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
+        case WALK_GLOBAL_10240: return walk_launch<AR, I, 10240, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
+        case WALK_LDS_128_TINY:
+            if constexpr (I == 1) return walk_launch<AR, 1, 128, kWalkHeapLds, 256, 1, false>(a, grid_cap, s, grid_out);
+            return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <>
+hipError_t launch_walk_ar<VS_AR>(const WalkArgs& a, uint32_t iters, uint32_t instance, uint32_t grid_cap, hipStream_t s,
+                                 uint32_t* grid_out) {
+    switch (iters) {
+        case 1: return walk_ef<VS_AR, 1>(a, instance, grid_cap, s, grid_out);
+        case 2: return walk_ef<VS_AR, 2>(a, instance, grid_cap, s, grid_out);
+        case 3: return walk_ef<VS_AR, 3>(a, instance, grid_cap, s, grid_out);
+        case 4: return walk_ef<VS_AR, 4>(a, instance, grid_cap, s, grid_out);
+        case 6: return walk_ef<VS_AR, 6>(a, instance, grid_cap, s, grid_out);
+        case 8: return walk_ef<VS_AR, 8>(a, instance, grid_cap, s, grid_out);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace vs

@@ -1,0 +1,340 @@
+// walk_device.hpp -- the usearch-ORDER walk: search_to_find_in_base_ / search_to_insert_ with usearch's two
+// structures kept apart, step for step as oracle/cpu_hnsw.cpp restates them (reference call sites
+// crates/vector-store/src/vs_index/usearch.rs:210-212 search, :233-236 filtered_search):
+//
+//   top   sorted_buffer_gt: ascending by distance, a new entry goes IN FRONT of equal ones (lower_bound), bounded by
+//         ef, predicate-gated (only admitted members live here);
+//   next  max_heap_gt on negated distances: the array heap, emulated swap for swap (shift_up / shift_down), because
+//         which of several EQUAL distances pops first is a property of that exact heap, not of (distance, slot);
+//   the radius is re-read after every single admission, in adjacency order, as the CPU loop does.
+//
+// hnsw_device.hpp's fused list (one sorted list with "expanded" bits) is equivalent to this only while no two
+// distances tie; this walk is what serves the tie-heavy metrics (Hamming, i8), filtered search (rejected nodes are
+// expanded but never enter `top`, so `next` is unbounded), beams beyond the fused kernel's 512 entries, and any index
+// when the caller asks for usearch's order.  Ids are then bit-identical to the oracle's on the same graph.
+//
+// One wavefront walks; the data-parallel parts (visited test-and-set of the <= 64 neighbours, the distances, the list
+// merge) use all lanes, the sequential parts (admission against the moving radius, the heap) are wave-uniform scalar
+// code over LDS.
+#pragma once
+#include "hnsw_device.hpp"
+
+namespace vs {
+
+// Global workspace of ONE workgroup (one query at a time).
+struct WalkSpace {
+    uint32_t* bitmap;  // visited bits for the whole slot range (only kernels with a global visited set); all zero between queries
+    uint32_t* vlog;    // slots marked during the current query, so that only their words are cleared afterwards
+    uint2* heap;       // `next` beyond the part that lives in LDS: (distance bits, slot)
+    uint32_t bitmap_words, vlog_cap, heap_cap;
+};
+
+template <bool ON, int NB>
+struct VisitedLds {
+    alignas(16) uint16_t vis_tag[NB * 8];
+    uint32_t vis_cnt[NB / 4];
+    uint32_t vis_ovf[kOvf - 2];
+    uint32_t ovf_cnt;
+    uint32_t overflowed;
+};
+template <int NB>
+struct VisitedLds<false, NB> {};
+
+// EFCAP: capacity of `top`; LCAP: entries of `next` kept in LDS (the first levels of the heap -- every pop walks from the
+// root, the deep levels are touched once per pop); VISG: visited set = bitmap in global memory (no limit on the index
+// size or on the number of visited nodes) instead of the LDS tag table of hnsw_device.hpp.
+template <int EFCAP, int LCAP, int NB, int CH, bool VISG, int TM = 1, bool NT = false, bool SEL = false>
+struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB> {
+    static constexpr bool kNT = NT;
+    static constexpr int kChoices = CH;
+    static constexpr int kEfCap = EFCAP;
+    static constexpr int kNB = NB;
+    static constexpr int kTeam = TM;
+    static constexpr bool kSel = SEL;
+    static constexpr int kHeapLds = LCAP;
+    static constexpr bool kVisGlobal = VISG;
+    float lst_d[EFCAP];
+    uint32_t lst_s[EFCAP];
+    uint2 hp[LCAP];
+    uint32_t u_slot[64];
+    float u_dist[64];
+};
+
+// ---- `next`: usearch max_heap_gt, entries (distance, slot), less(a, b) = a.d > b.d ----------------------------------
+// Every lane runs the same scalar code on wave-uniform values; LDS reads broadcast, lane 0 writes.  LDS (and the
+// vector-memory path) keep one wave's accesses in order, so no barrier is needed between the steps.
+template <class Sh>
+__device__ __forceinline__ uint2 heap_get(const Sh& sh, const WalkSpace& ws, uint32_t i) {
+    if (i < (uint32_t)Sh::kHeapLds) return sh.hp[i];
+    return ws.heap[i - (uint32_t)Sh::kHeapLds];
+}
+template <class Sh>
+__device__ __forceinline__ void heap_set(Sh& sh, const WalkSpace& ws, uint32_t i, uint2 e, int lane) {
+    if (lane == 0) {
+        if (i < (uint32_t)Sh::kHeapLds) sh.hp[i] = e;
+        else ws.heap[i - (uint32_t)Sh::kHeapLds] = e;
+    }
+}
+
+// emplace + shift_up: the new entry climbs while its parent is strictly farther.
+template <class Sh>
+__device__ __forceinline__ void heap_push(Sh& sh, const WalkSpace& ws, uint32_t& hn, float d, uint32_t slot, int lane) {
+    uint32_t i = hn++;
+    while (i) {
+        const uint32_t p = (i - 1u) >> 1;
+        const uint2 e = heap_get(sh, ws, p);
+        if (!(__uint_as_float(e.x) > d)) break;
+        heap_set(sh, ws, i, e, lane);
+        i = p;
+    }
+    heap_set(sh, ws, i, make_uint2(__float_as_uint(d), slot), lane);
+}
+
+// pop: swap(first, last), shrink, shift_down(0): the larger child is the right one only when the left one is strictly
+// farther ("less(left, right)"), and the entry sinks only while it is strictly farther than that child.
+template <class Sh>
+__device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& hn, int lane) {
+    const uint32_t n = --hn;
+    if (n == 0) return;
+    const uint2 last = heap_get(sh, ws, n);
+    const float ld = __uint_as_float(last.x);
+    uint32_t i = 0;
+    for (;;) {
+        const uint32_t l = 2u * i + 1u;
+        if (l >= n) break;
+        uint2 ec = heap_get(sh, ws, l);
+        uint32_t c = l;
+        if (l + 1u < n) {
+            const uint2 er = heap_get(sh, ws, l + 1u);
+            if (__uint_as_float(ec.x) > __uint_as_float(er.x)) {
+                ec = er;
+                c = l + 1u;
+            }
+        }
+        if (!(ld > __uint_as_float(ec.x))) break;
+        heap_set(sh, ws, i, ec, lane);
+        i = c;
+    }
+    heap_set(sh, ws, i, last, lane);
+}
+
+// ---- visited ---------------------------------------------------------------------------------------------------------
+// Per-lane test-and-set.  LDS table: hnsw_device.hpp; when that table is exhausted the walk cannot stay exact
+// (a node evaluated twice would be pushed twice), so `exhausted` is raised and the kernel hands the query to the
+// global-bitmap instance.
+template <class Sh>
+__device__ __forceinline__ bool walk_visit(Sh& sh, const WalkSpace& ws, uint32_t slot) {
+    if constexpr (Sh::kVisGlobal) {
+        const uint32_t bit = 1u << (slot & 31u);
+        return (atomicOr(&ws.bitmap[slot >> 5], bit) & bit) != 0u;
+    } else {
+        return visited_test_and_set(sh, slot);
+    }
+}
+
+// The walk.  On return `top` is sh.lst_d / sh.lst_s [0, size) -- ascending, exactly the oracle's order -- and the
+// size is returned.  self: slot that is never a result (search_to_insert_ of an update), or kInvalid.
+// tomb: some members carry the free key (never results); allow: optional bitmap over slots (filtered_search).
+template <int AR, int I, class Sh>
+__device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& ws, const Query<AR, I>& q, uint32_t start, int level,
+                                 uint32_t ef, uint32_t self, bool tomb, const uint32_t* allow, Counters& cnt, int lane,
+                                 bool& exhausted) {
+    uint32_t vcount = 0;  // entries of ws.vlog (global visited set only)
+    bool vlog_lost = false;
+    exhausted = false;
+    if constexpr (!Sh::kVisGlobal) {
+        visited_clear(sh, lane);
+        wsync<Sh>();
+    }
+    auto allowed = [&](uint32_t s) -> bool {
+        bool ok = true;
+        if (tomb) ok = ix.keys[s] != kFreeKey;
+        if (allow) ok = ok && ((allow[s >> 5] >> (s & 31u)) & 1u) != 0u;
+        return ok;
+    };
+    auto mark = [&](uint32_t n) -> bool {  // true: n is new to the visited set (and, for the bitmap, logged)
+        const bool fresh = n != kInvalid && !walk_visit(sh, ws, n);
+        if constexpr (Sh::kVisGlobal) {
+            const uint64_t fm = __ballot(fresh);
+            const uint32_t c = (uint32_t)__popcll(fm);
+            if (vcount + c <= ws.vlog_cap) {
+                if (fresh) ws.vlog[vcount + mbcnt(fm)] = n;
+            } else {
+                vlog_lost = true;  // too many to log: the whole bitmap is cleared at the end
+            }
+            vcount += c;
+        }
+        return fresh;
+    };
+    // visits.set(start); visits.set(self)
+    (void)mark(lane == 0 ? start : (lane == 1 && self != start) ? self : kInvalid);
+    if (lane == 0) sh.u_slot[0] = start;
+    wsync<Sh>();
+    eval_shared<AR, I>(ix, q, sh, 1, lane);
+    cnt.evals += 1;
+    const float d0 = sh.u_dist[0];
+    uint32_t hn = 0, sz = 0;
+    heap_push(sh, ws, hn, d0, start, lane);
+    if (start != self && allowed(start)) {
+        if (lane == 0) {
+            sh.lst_d[0] = d0;
+            sh.lst_s[0] = start;
+        }
+        sz = 1;
+    }
+    wsync<Sh>();
+    while (hn) {
+        const uint2 ce = sh.hp[0];
+        const float cd = __uint_as_float(ce.x);
+        const uint32_t cs = ce.y;
+        if (sz == ef && cd > sh.lst_d[sz - 1]) break;  // `candidate.distance > radius && top.size() == top_limit`
+        // the adjacency row is on its way while the heap is repaired
+        uint32_t cap;
+        const uint32_t* row = adjacency(ix, cs, level, cap);
+        const uint32_t n = (uint32_t)lane < cap ? row[lane] : kInvalid;
+        heap_pop(sh, ws, hn, lane);
+        cnt.hops += 1;
+        if (cs == self) continue;
+        const bool fresh = mark(n);
+        const uint64_t fmask = __ballot(fresh);
+        const uint32_t m = (uint32_t)__popcll(fmask);
+        if constexpr (!Sh::kVisGlobal) {
+            if (sh.overflowed) {  // wave-uniform (LDS flag set by any lane of this hop)
+                exhausted = true;
+                break;
+            }
+        }
+        if (fresh) sh.u_slot[mbcnt(fmask)] = n;
+        wsync<Sh>();
+        if (m == 0) continue;
+        eval_shared<AR, I>(ix, q, sh, m, lane);
+        cnt.evals += m;
+        float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
+        uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
+        const uint64_t okmask = __ballot((uint32_t)lane < m && allowed(ns));
+        // ---- admission, one neighbour at a time in adjacency order (wave-uniform scalar code) ----
+        // T: old entries of `top` that survive; alive: new entries that are in `top` at the end; pushed: new entries of `next`
+        uint64_t pushed = 0, alive = 0;
+        uint32_t T = sz, cur = sz;
+        const uint64_t all_m = m >= 64u ? ~0ull : ((1ull << m) - 1ull);
+        if (sz + m <= ef) {  // `top` cannot fill up during this hop: everything is admitted
+            pushed = all_m;
+            alive = okmask;
+            cur = sz + (uint32_t)__popcll(alive);
+        } else {
+            // once full the radius only shrinks: what is not below it now never will be
+            uint64_t cand = sz == ef ? __ballot((uint32_t)lane < m && nd < sh.lst_d[sz - 1]) : all_m;
+            float tail_d = T ? sh.lst_d[T - 1] : -__builtin_inff();
+            float max_d = -__builtin_inff();  // worst of the alive new entries: largest distance, the OLDEST among equals
+            uint32_t max_j = 0, a_cnt = 0;
+            for (; cand; cand &= cand - 1ull) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(cand);
+                const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), (int)j));
+                // the worst entry of `top` right now: old entries are older than new ones, so they lose ties
+                const bool worst_is_old = T && (a_cnt == 0 || tail_d >= max_d);
+                if (cur == ef && !(dj < (worst_is_old ? tail_d : max_d))) continue;  // `top.size() < top_limit || d < radius`
+                pushed |= 1ull << j;
+                if (!((okmask >> j) & 1ull)) continue;
+                if (cur == ef) {  // top.insert at the limit drops the last (worst) entry
+                    if (worst_is_old) {
+                        --T;
+                        tail_d = T ? sh.lst_d[T - 1] : -__builtin_inff();
+                    } else {
+                        alive &= ~(1ull << max_j);
+                        --a_cnt;
+                        max_d = -__builtin_inff();
+                        for (uint64_t r = alive; r; r &= r - 1ull) {
+                            const uint32_t i = (uint32_t)__builtin_ctzll(r);
+                            const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), (int)i));
+                            if (di > max_d) {
+                                max_d = di;
+                                max_j = i;
+                            }
+                        }
+                    }
+                } else {
+                    ++cur;
+                }
+                alive |= 1ull << j;
+                ++a_cnt;
+                if (dj > max_d) {
+                    max_d = dj;
+                    max_j = j;
+                }
+            }
+        }
+        // ---- next.insert for every admitted neighbour, in order ----
+        for (uint64_t r = pushed; r; r &= r - 1ull) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(r);
+            if (hn >= (uint32_t)Sh::kHeapLds + ws.heap_cap) {  // `next` outgrew its workspace
+                exhausted = true;
+                break;
+            }
+            heap_push(sh, ws, hn, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), (int)j)),
+                      (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)j), lane);
+        }
+        if (exhausted) break;
+        // ---- top: merge the alive new entries into the surviving T old ones, in place ----
+        const uint32_t a = (uint32_t)__popcll(alive);
+        if (a == 0) continue;
+        wsync<Sh>();
+        if ((alive >> lane) & 1ull) {
+            const uint32_t r = mbcnt(alive);
+            sh.u_dist[r] = nd;
+            sh.u_slot[r] = ns;
+        }
+        wsync<Sh>();
+        nd = (uint32_t)lane < a ? sh.u_dist[lane] : __builtin_inff();
+        ns = (uint32_t)lane < a ? sh.u_slot[lane] : kInvalid;
+        // rank among the old entries: the first one that is not strictly closer (a new entry precedes equal old ones)
+        uint32_t lo = 0, hi = (uint32_t)lane < a ? T : 0u;
+        while (__ballot(lo < hi)) {
+            if (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sh.lst_d[mid] < nd) lo = mid + 1u; else hi = mid;
+            }
+        }
+        // rank among the new ones: closer first, the NEWER first among equals
+        uint32_t rn = 0, pmin = T;
+        for (uint32_t i = 0; i < a; ++i) {
+            const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), (int)i));
+            const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)i);
+            rn += (di < nd || (di == nd && i > (uint32_t)lane)) ? 1u : 0u;
+            pmin = li < pmin ? li : pmin;
+        }
+        // old entries from the first insertion point on move up by the number of new entries that precede them;
+        // highest chunk first, so nothing is overwritten before it has been read
+        if (T > pmin) {
+            for (int c = (int)((T - 1u) >> 6); c >= (int)(pmin >> 6); --c) {
+                const uint32_t p = (uint32_t)c * 64u + (uint32_t)lane;
+                const bool act = p >= pmin && p < T;
+                const float od = act ? sh.lst_d[p] : 0.f;
+                const uint32_t os = act ? sh.lst_s[p] : 0u;
+                uint32_t shift = 0;
+                for (uint32_t i = 0; i < a; ++i)
+                    shift += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), (int)i)) <= od ? 1u : 0u;
+                if (act && shift) {
+                    sh.lst_d[p + shift] = od;
+                    sh.lst_s[p + shift] = os;
+                }
+            }
+        }
+        if ((uint32_t)lane < a) {
+            sh.lst_d[lo + rn] = nd;
+            sh.lst_s[lo + rn] = ns;
+        }
+        sz = T + a;
+        wsync<Sh>();
+    }
+    if constexpr (Sh::kVisGlobal) {  // leave the bitmap all zero for the next query of this workgroup
+        if (vlog_lost) {
+            for (uint32_t w = (uint32_t)lane; w < ws.bitmap_words; w += kWave) ws.bitmap[w] = 0u;
+        } else {
+            for (uint32_t i = (uint32_t)lane; i < vcount; i += kWave) ws.bitmap[ws.vlog[i] >> 5] = 0u;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached L2 before the next query's atomics
+    }
+    return sz;
+}
+
+}  // namespace vs

@@ -925,6 +925,7 @@ struct Engine {
             a.out_dist = d_dist_out;
             a.out_found = d_found;
             a.stats = d_stats;
+            a.debug = nullptr;
             WalkRes& wr = walk_res(device, st);
             std::lock_guard<std::mutex> wl(wr.mu);
             const uint32_t g_inst = ef <= 512 ? WALK_GLOBAL_512 : ef <= 2048 ? WALK_GLOBAL_2048 : WALK_GLOBAL_10240;
@@ -949,8 +950,11 @@ struct Engine {
                 }
                 return grid;
             };
+            uint32_t* retry = (uint32_t*)wr.retry.ensure((64 + nq) * 4);  // [0] retried queries, [1] / [2] work counters, [64..] their ids
+            HIP_OK(hipMemsetAsync(retry, 0, 256, st));
             if (global) {
                 const uint32_t grid = global_space(a, g_inst, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
+                a.work_counter = retry + 1;
                 HIP_OK(launch_walk(a, iters, g_inst, grid, st, nullptr));
                 return;
             }
@@ -963,18 +967,42 @@ struct Engine {
             uint32_t grid = 0;
             HIP_OK(launch_walk(a, iters, inst, 1u << 20, st, &grid));
             a.space = (char*)wr.lds_space.ensure((size_t)grid * a.space_stride);
-            uint32_t* retry = (uint32_t*)wr.retry.ensure((64 + nq) * 4);
-            HIP_OK(hipMemsetAsync(retry, 0, 4, st));
             a.retry_count = retry;
             a.retry_list = retry + 64;
+            a.work_counter = retry + 1;
             WalkArgs r = a;  // the retry launch: same queries, same outputs, global bitmap, only the listed queries
             r.qlist = a.retry_list;
             r.qcount = a.retry_count;
             r.retry_list = nullptr;
             r.retry_count = nullptr;
+            r.work_counter = retry + 2;
             const uint32_t rgrid = global_space(r, WALK_GLOBAL_512, 64, true);
+            static const bool walk_debug = std::getenv("VS_HNSW_WALK_DEBUG") != nullptr;  // measurement aid: per-query walk sizes to stderr
+            uint32_t* d_dbg = nullptr;
+            if (walk_debug) {
+                HIP_OK(hipMalloc((void**)&d_dbg, nq * 48));
+                HIP_OK(hipMemsetAsync(d_dbg, 0, nq * 48, st));
+                a.debug = r.debug = d_dbg;
+            }
             HIP_OK(launch_walk(a, iters, inst, grid, st, nullptr));
             HIP_OK(launch_walk(r, iters, WALK_GLOBAL_512, rgrid, st, nullptr));
+            if (walk_debug) {
+                std::vector<uint32_t> h(nq * 12);
+                uint32_t retried = 0;
+                HIP_OK(hipMemcpyAsync(h.data(), d_dbg, nq * 48, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipMemcpyAsync(&retried, retry, 4, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                (void)hipFree(d_dbg);
+                for (int c = 0; c < 12; ++c) {
+                    std::vector<uint32_t> v(nq);
+                    for (size_t i = 0; i < nq; ++i) v[i] = h[i * 12 + c];
+                    std::sort(v.begin(), v.end());
+                    static const char* names[12] = {"max_next", "evals", "hops", "pushed", "clk/16 startup", "clk/16 pop", "clk/16 visited",
+                                                    "clk/16 distances", "clk/16 admission", "clk/16 pushes", "clk/16 merge", "clk/16 -"};
+                    fprintf(stderr, "[walk] %s: p50 %u p90 %u p99 %u max %u\n", names[c], v[nq / 2], v[nq * 9 / 10], v[nq * 99 / 100], v[nq - 1]);
+                }
+                fprintf(stderr, "[walk] ef %u grid %u retried %u of %zu\n", ef, grid, retried, nq);
+            }
             return;
         }
         SearchArgs a;

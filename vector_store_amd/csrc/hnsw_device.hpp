@@ -455,6 +455,7 @@ struct BeamShared : SelArrays<SEL>, TeamBox<TM> {
     static constexpr int kNB = NB;
     static constexpr int kTeam = TM;
     static constexpr bool kSel = SEL;
+    static constexpr uint32_t kOvfCap = (uint32_t)kOvf - 2u;  // entries of vis_ovf
     float lst_d[1][EFCAP];  // one buffer: list_merge works in place
     uint32_t lst_s[1][EFCAP];
     alignas(16) uint16_t vis_tag[NB * 8];
@@ -619,7 +620,7 @@ __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
             }
         }
     }
-    constexpr uint32_t ovf_cap = (uint32_t)kOvf - 2u;
+    constexpr uint32_t ovf_cap = Sh::kOvfCap;
     if (!found) {
         // Members that found their bucket full live in the overflow list.  With two choices a member can land there
         // while its OTHER bucket still has room (several lanes of one hop pick the same nearly-full bucket from the

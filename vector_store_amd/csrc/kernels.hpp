@@ -68,6 +68,8 @@ struct WalkArgs {
     const uint32_t* qcount;
     uint32_t* retry_list;    // LDS instances: queries whose visited table or heap ran out are appended here ...
     uint32_t* retry_count;   // ... and served by a global-bitmap instance launched behind (nullptr: flag kWalkFailed)
+    uint32_t* work_counter;  // zero at launch: workgroups draw the next query from it (a workgroup that becomes resident
+                             // late -- the occupancy query can be one per CU too high -- then simply finds nothing left)
     char* space;             // grid x space_stride bytes: [bitmap_words u32 | vlog_cap u32 | heap_cap uint2] per workgroup
     size_t space_stride;
     uint32_t bitmap_words, vlog_cap, heap_cap;
@@ -75,6 +77,7 @@ struct WalkArgs {
     float* out_dist;
     uint32_t* out_found;
     unsigned long long* stats;
+    uint32_t* debug;         // nullptr, or nq x 12 words: largest `next`, nodes evaluated, hops, admitted, 8 phase clocks (VS_HNSW_WALK_DEBUG)
 };
 inline size_t walk_space_stride(uint32_t bitmap_words, uint32_t vlog_cap, uint32_t heap_cap) {
     return (((size_t)bitmap_words + vlog_cap) * 4 + (size_t)heap_cap * 8 + 255) / 256 * 256;

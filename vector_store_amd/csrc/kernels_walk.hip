@@ -9,7 +9,7 @@
 //                                                      to `top`, rejected nodes still expanded); beams of 513..10,240
 //                                                      (the reference passes any `limit` through, httproutes.rs:842-847);
 //                                                      indexes beyond what the LDS tags can tell apart.
-// Workgroups are persistent: workgroup b serves queries b, b + grid, ... and owns one WalkSpace.
+// Workgroups are persistent: each owns one WalkSpace and draws queries from a shared counter until none is left.
 #include "kernels.hpp"
 #include "walk_device.hpp"
 
@@ -36,7 +36,11 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
         ws.heap_cap = a.heap_cap;
     }
     const uint32_t total = a.qlist ? *a.qcount : a.nq;
-    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.work_counter, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= total) break;
         const uint32_t qi = a.qlist ? a.qlist[t] : t;
         uint64_t* ok = a.out_keys + (size_t)qi * a.k;
         float* od = a.out_dist + (size_t)qi * a.k;
@@ -54,7 +58,8 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
         const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
         bool exhausted = false;
         const uint32_t* allow = a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
-        const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, allow, cnt, lane, exhausted);
+        const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, allow, cnt, lane, exhausted,
+                                         a.debug ? a.debug + (size_t)qi * 12 : nullptr);
         if (exhausted) {
             if (lane == 0) {
                 if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;  // the global-bitmap instance takes it
@@ -109,7 +114,10 @@ static hipError_t walk_launch(const WalkArgs& a, uint32_t grid_cap, hipStream_t 
     return hipGetLastError();
 }
 
-constexpr int kWalkHeapLds = 512;
+#ifndef VS_WALK_LCAP
+#define VS_WALK_LCAP 512
+#endif
+constexpr int kWalkHeapLds = VS_WALK_LCAP;  // entries of `next` in LDS (LDS instances); deeper levels live in global memory
 
 template <int AR, int I>
 static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out) {

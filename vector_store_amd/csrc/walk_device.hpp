@@ -19,6 +19,21 @@
 #pragma once
 #include "hnsw_device.hpp"
 
+// -DVS_WALK_PROFILE: shader-clock stamps around the phases of a hop, summed per query into WalkArgs::debug[4..11]
+// (measurement builds only; scripts/probe/walk_profile.sh).
+#ifdef VS_WALK_PROFILE
+#define WALK_STAMP(slot)                                         \
+    do {                                                         \
+        const uint64_t now__ = __builtin_amdgcn_s_memtime();     \
+        prof[slot] += now__ - prof_t;                            \
+        prof_t = now__;                                          \
+    } while (0)
+#else
+#define WALK_STAMP(slot) \
+    do {                 \
+    } while (0)
+#endif
+
 namespace vs {
 
 // Global workspace of ONE workgroup (one query at a time).
@@ -29,11 +44,12 @@ struct WalkSpace {
     uint32_t bitmap_words, vlog_cap, heap_cap;
 };
 
+constexpr int kWalkOvf = 62;  // overflow list of the walk's visited table (the 128-entry `top` instance then fits 7 per CU)
 template <bool ON, int NB>
 struct VisitedLds {
     alignas(16) uint16_t vis_tag[NB * 8];
     uint32_t vis_cnt[NB / 4];
-    uint32_t vis_ovf[kOvf - 2];
+    uint32_t vis_ovf[kWalkOvf];
     uint32_t ovf_cnt;
     uint32_t overflowed;
 };
@@ -53,9 +69,11 @@ struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB> {
     static constexpr bool kSel = SEL;
     static constexpr int kHeapLds = LCAP;
     static constexpr bool kVisGlobal = VISG;
+    static constexpr bool kHeapSpill = VISG;
+    static constexpr uint32_t kOvfCap = (uint32_t)kWalkOvf;  // `next` may outgrow LDS into WalkSpace::heap (LDS instances hand the query over instead)
     float lst_d[EFCAP];
     uint32_t lst_s[EFCAP];
-    uint2 hp[LCAP];
+    uint2 hp[LCAP + 1];  // + 1: the right child of the last parent is read unconditionally
     uint32_t u_slot[64];
     float u_dist[64];
 };
@@ -63,23 +81,41 @@ struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB> {
 // ---- `next`: usearch max_heap_gt, entries (distance, slot), less(a, b) = a.d > b.d ----------------------------------
 // Every lane runs the same scalar code on wave-uniform values; LDS reads broadcast, lane 0 writes.  LDS (and the
 // vector-memory path) keep one wave's accesses in order, so no barrier is needed between the steps.
+// Heap indices, sizes and entries are wave-uniform; entries read from LDS are passed through v_readfirstlane so that
+// the compiler keeps the whole sift loop on the scalar unit (s_cmp / s_cbranch, no exec-mask bookkeeping): the loops
+// are latency chains of LDS reads, and executed as vector code each level cost ~4x as many cycles.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 template <class Sh>
 __device__ __forceinline__ uint2 heap_get(const Sh& sh, const WalkSpace& ws, uint32_t i) {
-    if (i < (uint32_t)Sh::kHeapLds) return sh.hp[i];
-    return ws.heap[i - (uint32_t)Sh::kHeapLds];
+    uint2 e;
+    if constexpr (Sh::kHeapSpill) {
+        i = uni(i);  // a scalar branch between two loads, not one flat load that waits for every outstanding row load
+        if (i < (uint32_t)Sh::kHeapLds) e = sh.hp[i];
+        else e = ws.heap[i - (uint32_t)Sh::kHeapLds];
+    } else {
+        e = sh.hp[i];
+    }
+    return make_uint2(uni(e.x), uni(e.y));
 }
 template <class Sh>
 __device__ __forceinline__ void heap_set(Sh& sh, const WalkSpace& ws, uint32_t i, uint2 e, int lane) {
-    if (lane == 0) {
-        if (i < (uint32_t)Sh::kHeapLds) sh.hp[i] = e;
-        else ws.heap[i - (uint32_t)Sh::kHeapLds] = e;
+    if constexpr (Sh::kHeapSpill) {
+        i = uni(i);
+        if (i < (uint32_t)Sh::kHeapLds) {
+            if (lane == 0) sh.hp[i] = e;
+        } else if (lane == 0) {
+            ws.heap[i - (uint32_t)Sh::kHeapLds] = e;
+        }
+    } else {
+        if (lane == 0) sh.hp[i] = e;  // one lane: 64 lanes storing to one address would be a 32-way bank conflict
     }
 }
 
 // emplace + shift_up: the new entry climbs while its parent is strictly farther.
 template <class Sh>
 __device__ __forceinline__ void heap_push(Sh& sh, const WalkSpace& ws, uint32_t& hn, float d, uint32_t slot, int lane) {
-    uint32_t i = hn++;
+    uint32_t i = uni(hn);
+    hn = i + 1u;
     while (i) {
         const uint32_t p = (i - 1u) >> 1;
         const uint2 e = heap_get(sh, ws, p);
@@ -92,9 +128,11 @@ __device__ __forceinline__ void heap_push(Sh& sh, const WalkSpace& ws, uint32_t&
 
 // pop: swap(first, last), shrink, shift_down(0): the larger child is the right one only when the left one is strictly
 // farther ("less(left, right)"), and the entry sinks only while it is strictly farther than that child.
+// Both children are read at once (one LDS latency per level); a right child beyond the heap is ignored.
 template <class Sh>
 __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& hn, int lane) {
-    const uint32_t n = --hn;
+    const uint32_t n = uni(hn) - 1u;
+    hn = n;
     if (n == 0) return;
     const uint2 last = heap_get(sh, ws, n);
     const float ld = __uint_as_float(last.x);
@@ -102,14 +140,19 @@ __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& 
     for (;;) {
         const uint32_t l = 2u * i + 1u;
         if (l >= n) break;
-        uint2 ec = heap_get(sh, ws, l);
+        uint2 ec, er;
+        if constexpr (Sh::kHeapSpill) {
+            ec = heap_get(sh, ws, l);
+            er = l + 1u < n ? heap_get(sh, ws, l + 1u) : ec;
+        } else {
+            const uint2 a = sh.hp[l], b = sh.hp[l + 1u];
+            ec = make_uint2(uni(a.x), uni(a.y));
+            er = make_uint2(uni(b.x), uni(b.y));
+        }
         uint32_t c = l;
-        if (l + 1u < n) {
-            const uint2 er = heap_get(sh, ws, l + 1u);
-            if (__uint_as_float(ec.x) > __uint_as_float(er.x)) {
-                ec = er;
-                c = l + 1u;
-            }
+        if (l + 1u < n && __uint_as_float(ec.x) > __uint_as_float(er.x)) {
+            ec = er;
+            c = l + 1u;
         }
         if (!(ld > __uint_as_float(ec.x))) break;
         heap_set(sh, ws, i, ec, lane);
@@ -138,7 +181,13 @@ __device__ __forceinline__ bool walk_visit(Sh& sh, const WalkSpace& ws, uint32_t
 template <int AR, int I, class Sh>
 __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& ws, const Query<AR, I>& q, uint32_t start, int level,
                                  uint32_t ef, uint32_t self, bool tomb, const uint32_t* allow, Counters& cnt, int lane,
-                                 bool& exhausted) {
+                                 bool& exhausted, uint32_t* debug = nullptr) {
+    uint32_t dbg_max_hn = 0, dbg_pushed = 0;
+#ifdef VS_WALK_PROFILE
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prof_t = __builtin_amdgcn_s_memtime();
+#endif
+    start = uni(start);   // wave-uniform by construction; said so, the loop control below stays on the scalar unit
     uint32_t vcount = 0;  // entries of ws.vlog (global visited set only)
     bool vlog_lost = false;
     exhausted = false;
@@ -175,7 +224,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
     const float d0 = sh.u_dist[0];
     uint32_t hn = 0, sz = 0;
     heap_push(sh, ws, hn, d0, start, lane);
-    if (start != self && allowed(start)) {
+    if (start != self && uni(allowed(start) ? 1u : 0u)) {
         if (lane == 0) {
             sh.lst_d[0] = d0;
             sh.lst_s[0] = start;
@@ -183,23 +232,39 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         sz = 1;
     }
     wsync<Sh>();
+    // Adjacency prefetch: once the candidate is popped, the new root of `next` is the runner-up; its row is loaded while
+    // this hop's vectors stream in and is used when that node is indeed expanded next (nothing closer was pushed).
+    uint32_t pf_slot = kInvalid, pf_n = kInvalid;
+    WALK_STAMP(0);  // start-up: clear, first evaluation
     while (hn) {
-        const uint2 ce = sh.hp[0];
+        sz = uni(sz);  // wave-uniform by construction (see `start`)
+        const uint2 ce = heap_get(sh, ws, 0);
         const float cd = __uint_as_float(ce.x);
         const uint32_t cs = ce.y;
-        if (sz == ef && cd > sh.lst_d[sz - 1]) break;  // `candidate.distance > radius && top.size() == top_limit`
-        // the adjacency row is on its way while the heap is repaired
-        uint32_t cap;
-        const uint32_t* row = adjacency(ix, cs, level, cap);
-        const uint32_t n = (uint32_t)lane < cap ? row[lane] : kInvalid;
+        if (sz == ef && cd > __uint_as_float(uni(__float_as_uint(sh.lst_d[sz - 1])))) break;  // `candidate.distance > radius && top.size() == top_limit`
+        uint32_t n;
+        if (cs == pf_slot) {
+            n = pf_n;
+        } else {  // on its way while the heap is repaired
+            uint32_t cap;
+            const uint32_t* row = adjacency(ix, cs, level, cap);
+            n = (uint32_t)lane < cap ? row[lane] : kInvalid;
+        }
         heap_pop(sh, ws, hn, lane);
         cnt.hops += 1;
+        pf_slot = hn ? heap_get(sh, ws, 0).y : kInvalid;
+        if (pf_slot != kInvalid) {
+            uint32_t cap2;
+            const uint32_t* row2 = adjacency(ix, pf_slot, level, cap2);
+            pf_n = (uint32_t)lane < cap2 ? row2[lane] : kInvalid;
+        }
         if (cs == self) continue;
+        WALK_STAMP(1);  // candidate, pop, prefetch issue
         const bool fresh = mark(n);
         const uint64_t fmask = __ballot(fresh);
         const uint32_t m = (uint32_t)__popcll(fmask);
         if constexpr (!Sh::kVisGlobal) {
-            if (sh.overflowed) {  // wave-uniform (LDS flag set by any lane of this hop)
+            if (uni(sh.overflowed)) {  // wave-uniform (LDS flag set by any lane of this hop)
                 exhausted = true;
                 break;
             }
@@ -207,8 +272,10 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         if (fresh) sh.u_slot[mbcnt(fmask)] = n;
         wsync<Sh>();
         if (m == 0) continue;
+        WALK_STAMP(2);  // visited test-and-set, compaction
         eval_shared<AR, I>(ix, q, sh, m, lane);
         cnt.evals += m;
+        WALK_STAMP(3);  // distances
         float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
         uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
         const uint64_t okmask = __ballot((uint32_t)lane < m && allowed(ns));
@@ -224,7 +291,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         } else {
             // once full the radius only shrinks: what is not below it now never will be
             uint64_t cand = sz == ef ? __ballot((uint32_t)lane < m && nd < sh.lst_d[sz - 1]) : all_m;
-            float tail_d = T ? sh.lst_d[T - 1] : -__builtin_inff();
+            float tail_d = T ? __uint_as_float(uni(__float_as_uint(sh.lst_d[T - 1]))) : -__builtin_inff();
             float max_d = -__builtin_inff();  // worst of the alive new entries: largest distance, the OLDEST among equals
             uint32_t max_j = 0, a_cnt = 0;
             for (; cand; cand &= cand - 1ull) {
@@ -238,7 +305,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
                 if (cur == ef) {  // top.insert at the limit drops the last (worst) entry
                     if (worst_is_old) {
                         --T;
-                        tail_d = T ? sh.lst_d[T - 1] : -__builtin_inff();
+                        tail_d = T ? __uint_as_float(uni(__float_as_uint(sh.lst_d[T - 1]))) : -__builtin_inff();
                     } else {
                         alive &= ~(1ull << max_j);
                         --a_cnt;
@@ -263,10 +330,11 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
                 }
             }
         }
+        WALK_STAMP(4);  // admission
         // ---- next.insert for every admitted neighbour, in order ----
         for (uint64_t r = pushed; r; r &= r - 1ull) {
             const uint32_t j = (uint32_t)__builtin_ctzll(r);
-            if (hn >= (uint32_t)Sh::kHeapLds + ws.heap_cap) {  // `next` outgrew its workspace
+            if (hn >= (uint32_t)Sh::kHeapLds + (Sh::kHeapSpill ? ws.heap_cap : 0u)) {  // `next` outgrew its workspace
                 exhausted = true;
                 break;
             }
@@ -274,9 +342,58 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
                       (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)j), lane);
         }
         if (exhausted) break;
+        WALK_STAMP(5);  // pushes
+        dbg_max_hn = hn > dbg_max_hn ? hn : dbg_max_hn;
+        dbg_pushed += (uint32_t)__popcll(pushed);
         // ---- top: merge the alive new entries into the surviving T old ones, in place ----
         const uint32_t a = (uint32_t)__popcll(alive);
         if (a == 0) continue;
+        if constexpr (Sh::kEfCap <= 512) {
+            // small `top`: every lane holds its R = EFCAP / 64 old entries in registers; ranks by ballot + popcount, no
+            // dependent LDS chain (a binary search costs log2(ef) LDS latencies), one scatter at the end
+            constexpr int R = Sh::kEfCap / kWave;
+            float keep_d[R];
+            uint32_t keep_s[R], shift[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+                keep_d[r] = p < T ? sh.lst_d[p] : __builtin_inff();
+                keep_s[r] = p < T ? sh.lst_s[p] : 0u;
+                shift[r] = 0;
+            }
+            const bool mine = ((alive >> lane) & 1ull) != 0ull;
+            uint32_t lo = 0, rn = 0;
+            for (uint64_t rem = alive; rem; rem &= rem - 1ull) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(rem);
+                const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), (int)i));
+                uint32_t below = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool valid = (uint32_t)lane + (uint32_t)r * kWave < T;
+                    below += (uint32_t)__popcll(__ballot(valid && keep_d[r] < di));  // a new entry precedes equal old ones
+                    shift[r] += (valid && di <= keep_d[r]) ? 1u : 0u;
+                }
+                if ((uint32_t)lane == i) lo = below;
+                rn += (mine && (di < nd || (di == nd && i > (uint32_t)lane))) ? 1u : 0u;  // closer first, the NEWER first among equals
+            }
+            __builtin_amdgcn_wave_barrier();  // every read of the old list is in registers
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+                if (p < T && shift[r]) {
+                    sh.lst_d[p + shift[r]] = keep_d[r];
+                    sh.lst_s[p + shift[r]] = keep_s[r];
+                }
+            }
+            if (mine) {
+                sh.lst_d[lo + rn] = nd;
+                sh.lst_s[lo + rn] = ns;
+            }
+            sz = T + a;
+            wsync<Sh>();
+            WALK_STAMP(6);  // merge into top
+            continue;
+        }
         wsync<Sh>();
         if ((alive >> lane) & 1ull) {
             const uint32_t r = mbcnt(alive);
@@ -325,6 +442,15 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         }
         sz = T + a;
         wsync<Sh>();
+    }
+    if (debug && lane == 0) {
+        debug[0] = dbg_max_hn;
+        debug[1] = (uint32_t)cnt.evals;
+        debug[2] = (uint32_t)cnt.hops;
+        debug[3] = dbg_pushed;
+#ifdef VS_WALK_PROFILE
+        for (int i = 0; i < 8; ++i) debug[4 + i] = (uint32_t)(prof[i] >> 4);
+#endif
     }
     if constexpr (Sh::kVisGlobal) {  // leave the bitmap all zero for the next query of this workgroup
         if (vlog_lost) {

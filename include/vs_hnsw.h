@@ -69,7 +69,8 @@ typedef struct vs_hnsw_options {
                          bit 2 = always serve a query with a team of wavefronts, bit 3 = never (default: batches
                          of at most one team per CU),
                          bit 4 = usearch-order walk (two structures, exact tie order) for every search of this index (default:
-                         i8 / b1 storage only), bit 5 = always the global-bitmap instance of that walk */
+                         i8 / b1 storage only), bit 5 = always the global-bitmap instance of that walk,
+                         bit 6 = wide visited tags (the instances for indexes above 2^25 / 2^26 slots) on a small index */
 } vs_hnsw_options;
 
 /* -- lifecycle: usearch::Index::new (usearch.rs:172), drop ------------------------------- */

@@ -9,23 +9,25 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _setup(n, ef):
+def _setup(n, ef, dim=768, metric="cos"):
     import torch
 
     import vector_store_amd as vs
     from bench import make_data
 
     dev = torch.device("cuda:0")
-    base = make_data(n, 768, "lowrank", 1234, dev, 24)
-    q = make_data(2000, 768, "lowrank", 4321, dev, 24)
-    ix = vs.HipUsearchIndex(768, vs.COS, expansion_search=ef)
+    base = make_data(n, dim, "lowrank", 1234, dev, 24)
+    q = make_data(2000, dim, "lowrank", 4321, dev, 24)
+    if metric == "ip":  # base L2-normalised
+        base /= base.norm(dim=1, keepdim=True)
+    ix = vs.HipUsearchIndex(dim, vs.METRICS[metric], expansion_search=ef)
     ix.reserve(n)
-    ix.add_batch_device(np.arange(n, dtype=np.uint64), base.data_ptr(), n, 768)
+    ix.add_batch_device(np.arange(n, dtype=np.uint64), base.data_ptr(), n, dim)
     return vs, torch, ix, base, q
 
 
-def _check(n, ef):
-    vs, torch, ix, base, q = _setup(n, ef)
+def _check(n, ef, dim=768, metric="cos"):
+    vs, torch, ix, base, q = _setup(n, ef, dim, metric)
     k = 10
     assert ix.size() == n
     qh = q.cpu().numpy()
@@ -34,7 +36,7 @@ def _check(n, ef):
     assert (found == k).all()
     assert (np.diff(dist, axis=1) >= 0).all()
     assert all(len(set(row.tolist())) == k for row in keys)
-    assert keys.max() < n and dist.min() >= 0.0 and dist.max() <= 2.0
+    assert keys.max() < n and dist.min() >= (0.0 if metric != "ip" else -1e30) and (metric != "cos" or dist.max() <= 2.0)
     st = ix.stats()
     assert st["visited_overflow"] == 0
     # recall@10 against the exact search, and exact search is idempotent
@@ -50,7 +52,8 @@ def _check(n, ef):
     probe = base[:: n // 500][:500].cpu().numpy()
     want = np.arange(0, n, n // 500, dtype=np.uint64)[:500]
     sk, sd, _ = ix.search_batch(probe, 1)
-    assert (sk[:, 0] == want).mean() >= 0.99 and np.abs(sd[:, 0]).max() <= 1e-5
+    if metric != "ip":  # (inner product: a longer query-aligned vector may beat the vector itself)
+        assert (sk[:, 0] == want).mean() >= 0.99 and np.abs(sd[:, 0]).max() <= (1e-5 if metric == "cos" else 1e-3)
     # small batches (team kernel) and the one-query entry point agree with the big batch
     for lo in (0, 700):
         k2, d2, _ = ix.search_batch(qh[lo:lo + 100], k)
@@ -83,3 +86,77 @@ def test_headline_10m_x_768_cosine():
     if free < 100 * 2**30:
         pytest.skip("needs 100 GiB of free HBM")
     _check(10_000_000, 208)
+
+
+def test_configs2_10m_x_1536_l2():
+    """BASELINE configs[2]: 10M x dim=1536 L2 (OpenAI-large-style), graph + 61 GB of vectors resident in HBM."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 180 * 2**30:
+        pytest.skip("needs 180 GiB of free HBM (61 GB of vectors, as much again for the generator's copy)")
+    _check(10_000_000, 320, dim=1536, metric="l2sq")
+
+
+def test_configs4_batched_q256_10m_x_768_inner_product():
+    """BASELINE configs[4]: batches of q = 256 over 10M x 768 inner product: the MFMA block-distance path (exact) against the
+    graph walk on the same index -- the walk reaches the recall the metric is quoted at, its distances are the exact
+    path's, and the exact path is idempotent and equal batch by batch."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2**30:
+        pytest.skip("needs 100 GiB of free HBM")
+    vs, torch, ix, base, q = _setup(10_000_000, 256, 768, "ip")
+    qh = q.cpu().numpy()[:512]
+    tk, td, tf = ix.exact_search_batch(qh[:256], 10)          # one q = 256 batch
+    tk2, td2, _ = ix.exact_search_batch(qh[:512], 10)          # two of them
+    assert (tf == 10).all() and np.array_equal(tk, tk2[:256]) and np.array_equal(td, td2[:256])
+    assert (np.diff(td, axis=1) >= 0).all() and all(len(set(r.tolist())) == 10 for r in tk)
+    # float64 check of the MFMA distances on a sample of (query, hit) pairs
+    rows = torch.from_numpy(tk[:32].astype(np.int64).ravel()).cuda()
+    ref = 1.0 - (base[rows].double().reshape(32, 10, 768) * q[:32].double()[:, None, :]).sum(-1).cpu().numpy()
+    assert np.allclose(td[:32], ref, rtol=1e-5, atol=1e-5)
+    wk, wd, wf = ix.search_batch(qh[:512], 10)
+    recall = np.mean([len(set(tk2[i].tolist()) & set(wk[i].tolist())) / 10 for i in range(512)])
+    assert recall >= 0.95, recall
+    same = wk[:, 0] == tk2[:, 0]
+    assert same.mean() > 0.9 and np.allclose(wd[same, 0], td2[same, 0], rtol=1e-5, atol=1e-5)
+
+
+def test_one_index_beyond_2_pow_26_members():
+    """The reference grows an index by +1,000,000 for ever (usearch.rs:440-443, 655-665).  The plain visited tags tell
+    2^26 slots apart (2^25 with two choices); beyond that the wide-tag instances of the insert and search kernels take
+    over, and the usearch-order walk uses its global bitmap -- one handle over 70M members: members stored past slot
+    2^26 are found by their own vector, results stay sorted and duplicate-free."""
+    import torch
+
+    import vector_store_amd as vs
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs 60 GiB of free HBM")
+    n, dim, chunk = 70_000_000, 8, 10_000_000
+    ix = vs.HipUsearchIndex(dim, vs.L2SQ, quantization=vs.F16, expansion_search=64)
+    ix.reserve(n)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    keep = {}
+    for c0 in range(0, n, chunk):
+        block = torch.randn((chunk, dim), generator=g, device="cuda", dtype=torch.float32)
+        ix.add_batch_device(np.arange(c0, c0 + chunk, dtype=np.uint64), block.data_ptr(), chunk, dim)
+        keep[c0] = block[:: chunk // 100][:100].cpu().numpy()
+        del block
+    assert ix.size() == n
+    assert ix.stats()["added"] == n - 1
+    for c0 in (0, 30_000_000, 60_000_000):             # the last block lives entirely above slot 2^26 = 67,108,864 ... almost:
+        probe = keep[c0]
+        want = np.arange(c0, c0 + chunk, chunk // 100, dtype=np.uint64)[:100]
+        k, d, f = ix.search_batch(probe, 10)
+        assert (f == 10).all() and (np.diff(d, axis=1) >= 0).all() and all(len(set(r.tolist())) == 10 for r in k)
+        hit = np.mean([want[i] in k[i] for i in range(100)])
+        assert hit >= 0.9, (c0, hit)                    # f16 storage of 8-d vectors: the vector itself or an equal-distance twin
+    probe = torch.randn((100, dim), generator=g, device="cuda").cpu().numpy()
+    top = 69_999_999
+    k, d, f = ix.search_batch(probe, 10)
+    assert k.max() <= top and (f == 10).all()
+    kw, dw = ix.search(probe[0], 1000)                  # a wide walk (global bitmap) on the same index
+    assert len(kw) == 1000 and len(set(kw.tolist())) == 1000 and (np.diff(dw) >= 0).all()
+    assert set(k[0].tolist()) <= set(kw.tolist()[:200])

@@ -113,6 +113,11 @@ def test_wire_format_status_codes_and_scores(tmp_path):
         assert st == 200 and [np.float32(x) for x in json.loads(body)["distances"]] == [np.finfo(np.float32).max] * 3   # ... saturated (lib.rs:397-409)
         assert json.loads(body)["similarity_scores"] == [0.0, 0.0, 0.0]
         assert s.get("/api/v1/nothing")[0] == 404
+        # an absurd limit is clamped to the members the index holds: 200 with every member, the server stays up
+        for huge in (4611686018427387904, 10 ** 9, 2 ** 63 - 1):
+            st, body = s.ann({"vector": [0.0], "limit": huge})
+            assert st == 200 and len(json.loads(body)["distances"]) == 3, (huge, st, body)
+        assert json.loads(s.get("/api/v1/status")[1]) == "SERVING"
         # keep-alive: several requests on one connection, answers in order
         c = http.client.HTTPConnection("127.0.0.1", s.port, timeout=30)
         for q, want in (([0.0], 0), ([1.2], 1), ([2.9], 2)):

@@ -190,6 +190,61 @@ def test_usearch_order_walk_is_bit_identical_on_exactly_representable_data(metri
     compare()
 
 
+def test_configs0_10k_x_128_cosine_top10():
+    """BASELINE configs[0] (10k random f32 vectors, dim 128, cosine, top-10: the CPU-runnable plumbing case) through
+    the HIP path: SURVEY.md section 8d's generator (numpy PCG64 standard_normal, seeds 1234 / 4321), M = 16,
+    ef_add = 128, ef_search = 64; the oracle builds the graph, both search it."""
+    v = vs()
+    n, dim, nq, k = 10_000, 128, 1000, 10
+    base = np.random.Generator(np.random.PCG64(1234)).standard_normal((n, dim), dtype=np.float32)
+    q = np.random.Generator(np.random.PCG64(4321)).standard_normal((nq, dim), dtype=np.float32)
+    o = OracleIndex(dim, oracle.COS, 16, 128, 64)
+    o.reserve(n)
+    o.add_batch(np.arange(n, dtype=np.uint64), base, threads=1)
+    ix = v.HipUsearchIndex(dim, v.COS, 16, 128, 64)
+    ix.import_graph(o.export_graph())
+    gk, gd, gf = ix.search_batch(q, k)
+    ok_, od_, of_ = o.search_batch(q, k, threads=8)
+    ties = 0
+    for i in range(nq):
+        assert gf[i] == of_[i] == k
+        ties += assert_same_results(gk[i], gd[i], ok_[i], od_[i], _oracle_dist("cos", q[i], base, lambda key: key), what=i)
+    assert ties <= 10, ties
+    # and built by the engine itself: recall against the exact search is what the CPU algorithm reaches on its own graph
+    ix2 = v.HipUsearchIndex(dim, v.COS, 16, 128, 64)
+    ix2.reserve(n)
+    ix2.add_batch(np.arange(n, dtype=np.uint64), base)
+    tk, _, _ = ix2.exact_search_batch(q, k)
+    k2, _, _ = ix2.search_batch(q, k)
+    rec_gpu = np.mean([len(set(tk[i].tolist()) & set(k2[i].tolist())) / k for i in range(nq)])
+    rec_cpu = np.mean([len(set(tk[i].tolist()) & set(ok_[i].tolist())) / k for i in range(nq)])
+    assert rec_gpu >= rec_cpu - 0.03, (rec_gpu, rec_cpu)
+
+
+def test_wide_visited_tags_build_and_search_like_plain_ones():
+    """options.reserved bit 6 runs the wide-tag instances (indexes above 2^25 / 2^26 slots) on a small index: the visited
+    set is exact either way, so the graph and every answer must be bit-identical to the plain-tag build."""
+    v = vs()
+    n, dim = 40000, 64
+    data = _dataset(n + 200, dim, 61)
+    out = []
+    for hook in (0, 64):
+        ix = v.HipUsearchIndex(dim, v.COS, expansion_add=200, _stress=hook)   # expansion_add 200: the two-choice table
+        ix.reserve(n)
+        ix.add_batch(np.arange(n, dtype=np.uint64), data[:n])
+        g = ix.export_graph()
+        res = []
+        for ef in (64, 200, 400):
+            ix.set_expansion_search(ef)
+            res.append(ix.search_batch(data[n:], 10))
+        assert ix.stats()["visited_overflow"] == 0
+        out.append((g, res))
+    (g0, r0), (g1, r1) = out
+    assert np.array_equal(g0["adj0"], g1["adj0"]) and np.array_equal(g0["upper"], g1["upper"])
+    for a, b in zip(r0, r1):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_evals_and_hops_match_oracle_counters():
     """The engine counts E_q / H_q exactly as the CPU restatement does."""
     v = vs()

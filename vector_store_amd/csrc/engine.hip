@@ -337,6 +337,7 @@ struct Engine {
     uint32_t chunk_rows = kChunk;
     int order_mode = 0;               // 0 = usearch-order walk for the tie-heavy metrics (i8, b1), fused list otherwise;
                                       // 1 = always the usearch-order walk (reserved bit 4); 2 = never (A/B measurements only)
+    bool force_wide_tags = false;     // reserved bit 6 (tests): wide visited tags although the index is small
     bool force_global_walk = false;   // reserved bit 5 (tests): every search takes the global-bitmap walk instance
     int team_mode = 0;                // 0 = by batch size; reserved bit 2 = always a team per query, bit 3 = never
     uint32_t team_max_nq = 256;       // batches up to one team per CU take the team kernel
@@ -443,6 +444,7 @@ struct Engine {
         team_mode = (o.reserved & 4) ? 1 : (o.reserved & 8) ? 2 : 0;
         order_mode = (o.reserved & 16) ? 1 : 0;
         force_global_walk = (o.reserved & 32) != 0;
+        force_wide_tags = (o.reserved & 64) != 0;
         if (const char* fw = std::getenv("VS_HNSW_WALK")) force_global_walk = !std::strcmp(fw, "global");
         if (const char* om = std::getenv("VS_HNSW_ORDER")) order_mode = !std::strcmp(om, "usearch") ? 1 : !std::strcmp(om, "fused") ? 2 : order_mode;
         if (const char* cr = std::getenv("VS_HNSW_CHUNK")) chunk_rows = (uint32_t)std::max(1024, std::atoi(cr));                      // build experiments
@@ -521,6 +523,9 @@ struct Engine {
         use_device();
         if (cap < slots) fail(VS_ERR_INVALID_ARGUMENT, "can't reserve less than the current size");
         if (cap >= (1ull << 30)) fail(VS_ERR_UNSUPPORTED, "capacity must be below 2^30 slots per index");
+        // the insert kernel's visited table must tell every slot apart (wide tags: 2^30 at expansion_add <= 128, 2^29 above)
+        if (cap > (1ull << visited_domain_bits(ef_add, true)))
+            fail(VS_ERR_UNSUPPORTED, "capacity above 2^29 slots needs expansion_add <= 128 (or several shards, include/vs_shards.h)");
         if (cap == capacity) return;
         std::unique_lock<std::shared_mutex> vg(view_mu);
         HIP_OK(hipDeviceSynchronize());
@@ -742,6 +747,7 @@ struct Engine {
                 ia.n = take;
                 ia.ef_add = ef_add;
                 ia.team = (team_mode == 1 || (team_mode == 0 && take <= team_max_nq)) ? (uint32_t)kSearchTeam : 1u;
+                ia.wide_tags = (slots > (1ull << visited_domain_bits(ef_add)) || force_wide_tags) ? 1u : 0u;
                 ia.req_base = req_off[pos];
                 ia.req_key = rk_in;
                 ia.req_val = rv_in;
@@ -894,7 +900,10 @@ struct Engine {
         if (ef > kMaxWalkBeam)
             fail(VS_ERR_UNSUPPORTED, "k / expansion_search above 10240 needs the exhaustive path (vs_hnsw_search)");
     }
-    bool beyond_lds_tags(uint32_t ef) const { return slots > (1ull << visited_domain_bits(std::min<uint32_t>(ef, kMaxBeam))); }
+    bool needs_global_walk(uint32_t ef) const {
+        return ef > kMaxBeam || force_global_walk || beyond_lds_tags(ef, true) || (beyond_lds_tags(ef) && usearch_order());
+    }
+    bool beyond_lds_tags(uint32_t ef, bool wide = false) const { return slots > (1ull << visited_domain_bits(std::min<uint32_t>(ef, kMaxBeam), wide)); }
 
     // `load`: queries that will be on the device together with this batch (other pipeline slots included);
     // the team kernel only pays while the chip has idle CUs.
@@ -905,7 +914,8 @@ struct Engine {
         check_search(k, ef);
         if (!nq) return;
         std::shared_lock<std::shared_mutex> vg(view_mu);
-        const bool global = allow || ef > kMaxBeam || beyond_lds_tags(ef) || force_global_walk;
+        // plain tags -> wide tags (fused kernel only) -> global bitmap, as the index outgrows what each can tell apart
+        const bool global = allow || needs_global_walk(ef);
         if (global || usearch_order()) {
             WalkArgs a;
             a.ix = view();
@@ -1014,6 +1024,7 @@ struct Engine {
         a.ef = ef;
         a.has_removed = removed.load() ? 1u : 0u;
         a.stress_small_table = stress_small_table ? 1u : 0u;
+        a.wide_tags = (beyond_lds_tags(ef) || force_wide_tags) ? 1u : 0u;
         const size_t on_device = std::max(nq, load);
         a.team = (team_mode == 1 || (team_mode == 0 && on_device <= team_max_nq)) ? (uint32_t)kSearchTeam
                  : (team_mode == 0 && on_device <= 3 * team_max_nq)               ? (uint32_t)kSearchTeamMid  // measured: 4 waves win up to ~800
@@ -1586,7 +1597,7 @@ int vs_hnsw_search(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* k
             return;
         }
         h->e.check_search(k, ef);
-        if (beam > vs::kMaxBeam || h->e.beyond_lds_tags(ef)) {  // wide beams / huge indexes: the global-bitmap walk, own launch
+        if (h->e.needs_global_walk(ef)) {  // wide beams / huge indexes: the global-bitmap walk, own launch
             h->e.search_host(q, 1, k, keys, dist, found, false);
             if (*found == (size_t)-1) *found = h->e.rank_all(q, k, keys, dist);
             return;

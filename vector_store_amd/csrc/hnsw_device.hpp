@@ -446,9 +446,19 @@ struct TeamBox {
 template <>
 struct TeamBox<1> {};
 
+// Wide tags: 4 more tag bits per visited entry (one dword of nibbles per bucket), for indexes whose slot ids the
+// 15 / 16-bit tags cannot tell apart: 2^26 -> 2^30 slots (one choice), 2^25 -> 2^29 (two choices).  +4 B per bucket.
+template <bool WIDE, int NB>
+struct VisitedHi {
+    uint32_t vis_hi[NB];
+};
+template <int NB>
+struct VisitedHi<false, NB> {};
+
 // EFCAP=128, NB=1024, no SelArrays: 20,480 B -> 8 single-wave workgroups per CU (160 KiB LDS).
-template <int EFCAP, int NB, bool SEL = false, int CH = 1, int TM = 1, bool NT = false>
-struct BeamShared : SelArrays<SEL>, TeamBox<TM> {
+template <int EFCAP, int NB, bool SEL = false, int CH = 1, int TM = 1, bool NT = false, bool WT = false>
+struct BeamShared : SelArrays<SEL>, TeamBox<TM>, VisitedHi<WT, NB> {
+    static constexpr bool kWideTags = WT;
     static constexpr bool kNT = NT;  // walk evaluations load vector rows non-temporally (IndexView::nt_rows, host-chosen)
     static constexpr int kChoices = CH;
     static constexpr int kEfCap = EFCAP;
@@ -558,17 +568,20 @@ __device__ __forceinline__ void team_release(Sh& sh, int lane) {  // walker: no 
     }
 }
 
-template <int NB, int CH = 1>
+template <int NB, int CH = 1, bool WT = false>
 struct VisitedCfg {
     static constexpr int log2nb = NB == 256 ? 8 : NB == 512 ? 9 : NB == 1024 ? 10 : NB == 2048 ? 11 : 12;
     static constexpr uint32_t tag_bits = CH == 2 ? 15 : 16;  // two-choice: bit 15 marks "stored in its alternate bucket"
-    static constexpr uint32_t domain_bits = tag_bits + log2nb;
+    static constexpr uint32_t hi_bits = WT ? 4 : 0;          // wide tags: kept in vis_hi, one nibble per entry
+    static constexpr uint32_t domain_bits = tag_bits + hi_bits + log2nb;
     static constexpr uint32_t domain_mask = (1u << domain_bits) - 1u;
 };
 
 template <class Sh>
 __device__ __forceinline__ void visited_clear(Sh& sh, int lane) {
     for (int i = lane; i < Sh::kNB / 4; i += kWave) sh.vis_cnt[i] = 0;
+    if constexpr (Sh::kWideTags)
+        for (int i = lane; i < Sh::kNB; i += kWave) sh.vis_hi[i] = 0;  // nibbles are OR-ed in
     if (lane == 0) {
         sh.ovf_cnt = 0;
         sh.overflowed = 0;
@@ -577,15 +590,19 @@ __device__ __forceinline__ void visited_clear(Sh& sh, int lane) {
 
 // Tags of one bucket that match `want` among its first min(cnt, 8) entries.
 template <class Sh>
-__device__ __forceinline__ bool bucket_has(const Sh& sh, uint32_t b, uint32_t cnt, uint32_t want) {
+__device__ __forceinline__ bool bucket_has(const Sh& sh, uint32_t b, uint32_t cnt, uint32_t want, uint32_t want_hi) {
     const uint4 t4 = *reinterpret_cast<const uint4*>(&sh.vis_tag[b * 8]);
     const uint32_t w[4] = {t4.x, t4.y, t4.z, t4.w};
     const uint32_t n = cnt < 8u ? cnt : 8u;
+    uint32_t hw = 0;
+    if constexpr (Sh::kWideTags) hw = sh.vis_hi[b];
     bool found = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         uint32_t tj = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-        found |= ((uint32_t)j < n) && tj == want;
+        bool eq = tj == want;
+        if constexpr (Sh::kWideTags) eq = eq && ((hw >> (4 * j)) & 15u) == want_hi;
+        found |= ((uint32_t)j < n) && eq;
     }
     return found;
 }
@@ -597,13 +614,14 @@ __device__ __forceinline__ bool bucket_has(const Sh& sh, uint32_t b, uint32_t cn
 template <class Sh>
 __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
     constexpr int NB = Sh::kNB, CH = Sh::kChoices;
-    using C = VisitedCfg<NB, CH>;
+    using C = VisitedCfg<NB, CH, Sh::kWideTags>;
     const uint32_t m = (slot * 0x9E3779B1u) & C::domain_mask;
-    const uint32_t b1 = m >> C::tag_bits;
+    const uint32_t b1 = m >> (C::tag_bits + C::hi_bits);
     const uint32_t tag = m & ((1u << C::tag_bits) - 1u);
+    const uint32_t hi = (m >> C::tag_bits) & ((1u << C::hi_bits) - 1u);
     const uint32_t s1 = (b1 & 3u) * 8u;
     const uint32_t c1 = (sh.vis_cnt[b1 >> 2] >> s1) & 0xFFu;
-    bool found = bucket_has(sh, b1, c1, tag);
+    bool found = bucket_has(sh, b1, c1, tag, hi);
     uint32_t b = b1, sb = s1, cb = c1, stored = tag;
     if (CH == 2) {
         const uint32_t alt = ((tag * 0x5BD1u) >> 3) & (uint32_t)(NB - 1);
@@ -611,7 +629,7 @@ __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
         if (b2 != b1) {
             const uint32_t s2 = (b2 & 3u) * 8u;
             const uint32_t c2 = (sh.vis_cnt[b2 >> 2] >> s2) & 0xFFu;
-            found |= bucket_has(sh, b2, c2, tag | 0x8000u);
+            found |= bucket_has(sh, b2, c2, tag | 0x8000u, hi);
             if (c2 < c1) {
                 b = b2;
                 sb = s2;
@@ -634,6 +652,7 @@ __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
     uint32_t pos = cb >= 8u ? 8u : (atomicAdd(&sh.vis_cnt[b >> 2], 1u << sb) >> sb) & 0xFFu;
     if (pos < 8u) {
         sh.vis_tag[b * 8 + pos] = (uint16_t)stored;
+        if constexpr (Sh::kWideTags) atomicOr(&sh.vis_hi[b], hi << (4u * pos));
         return false;
     }
     uint32_t o = atomicAdd(&sh.ovf_cnt, 1u);

@@ -22,6 +22,7 @@ struct SearchArgs {
     uint32_t has_removed;         // some members carry the free key: the beam keeps ef LIVE entries
     uint32_t stress_small_table;  // test hook: 256-bucket visited table (iters == 1 only) to force overflow
     uint32_t team;                // waves per query: 1, kSearchTeamMid or kSearchTeam for batches too small to fill the chip
+    uint32_t wide_tags;           // index beyond the plain visited tags' reach (2^25 / 2^26 slots): the wide-tag instance
     uint64_t* out_keys;    // nq x k, padded with kFreeKey
     float* out_dist;       // nq x k, padded with +inf
     uint32_t* out_found;   // nq
@@ -35,6 +36,7 @@ struct InsertArgs {
     const uint32_t* req_off;  // n: first request index of node b (levels*(M) requests, one block per level)
     uint32_t n, ef_add;
     uint32_t team;            // waves per new node: 1, or kSearchTeam for sub-batches too small to fill the chip
+    uint32_t wide_tags;       // see SearchArgs
     uint32_t req_base;        // req_off[first node of this sub-batch]
     uint64_t* req_key;        // (level << 32) | target, ~0 = unused
     uint64_t* req_val;        // (float bits of d(source,target) << 32) | source
@@ -98,8 +100,8 @@ bool search_supported(uint32_t iters, uint32_t ef);
 hipError_t launch_search(const SearchArgs& a, uint32_t iters, hipStream_t s);
 hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s);
 hipError_t launch_link(const LinkArgs& a, uint32_t iters, hipStream_t s);
-// bits of slot ids the visited table of the kernel chosen for `ef` can distinguish
-uint32_t visited_domain_bits(uint32_t ef);
+// bits of slot ids the visited table of the kernel chosen for `ef` can distinguish (wide: the 4-extra-tag-bit instance)
+uint32_t visited_domain_bits(uint32_t ef, bool wide = false);
 
 // f32 rows (dim floats, src_stride apart) -> storage rows (cast as usearch does, zero padded) + aux;
 // rows given by slots[] or first + i

@@ -24,9 +24,10 @@ namespace vs {
 // batches -- wave 0 walks exactly as before, every wave evaluates its share of each hop's neighbours, so a lone
 // query has TEAM times the loads in flight; results are identical (same distances, same order of decisions).
 // NT: vector rows loaded non-temporally (tables far larger than the caches; chosen by the host, IndexView::nt_rows).
-template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1, bool NT = false>
+// WT: wide visited tags, for indexes of more than 2^25 / 2^26 slots (one handle over everything 288 GB hold).
+template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1, bool NT = false, bool WT = false>
 __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
-    using Sh = BeamShared<EFCAP, NB, false, CH, TEAM, NT>;
+    using Sh = BeamShared<EFCAP, NB, false, CH, TEAM, NT, WT>;
     __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
 
 // TEAM > 1: small sub-batches (the first geometric steps of a build, streaming adds between searches) get a
 // workgroup of TEAM waves per new node, as the search kernel does for small query batches; same decisions, same graph.
-template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1, bool NT = false>
+template <int AR, int I, int EFCAP, int NB, int CH, int TEAM = 1, bool NT = false, bool WT = false>
 __global__ __launch_bounds__(64 * TEAM) void hnsw_insert_kernel(InsertArgs a) {
-    using Sh = BeamShared<EFCAP, NB, true, CH, TEAM, NT>;
+    using Sh = BeamShared<EFCAP, NB, true, CH, TEAM, NT, WT>;
     __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
@@ -326,6 +327,15 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
 template <int AR, int I>
 static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
     dim3 grid(a.nq), block(64);
+    if (a.wide_tags) {  // huge index: always far beyond the caches (non-temporal rows), one wave per query
+        if (a.ef <= 128)
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, 1, true, true>), grid, block, 0, s, a);
+        else if (a.ef <= 256)
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, 1, true, true>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 512, 2048, 2, 1, true, true>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if (a.team == kSearchTeamMid && a.ef <= 256 && !a.stress_small_table) {
         dim3 tblock(64 * kSearchTeamMid);
         if (a.ef <= 128)
@@ -363,6 +373,13 @@ static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
 template <int AR, int I>
 static hipError_t insert_ef(const InsertArgs& a, hipStream_t s) {
     dim3 grid(a.n), block(64);
+    if (a.wide_tags) {
+        if (a.ef_add <= 128)
+            hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 128, 1024, 1, 1, true, true>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 256, 1024, 2, 1, true, true>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if (a.team == kSearchTeam) {
         dim3 tblock(64 * kSearchTeam);
         if (a.ef_add <= 128)

@@ -39,6 +39,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cinttypes>
+#include <cerrno>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -191,9 +192,13 @@ class JsonParser {
             v.kind = JVal::Num;
             v.num = std::strtod(t.c_str(), &end);
             if (end != t.c_str() + t.size() || t == "-") throw JsonError("bad number");
-            if (integral && t.size() <= 18) {
-                v.is_int = true;
-                v.i = std::strtoll(t.c_str(), nullptr, 10);
+            if (integral && t.size() <= 20) {  // every int64 (serde reads `limit` as a usize: 2^62 is a valid request)
+                errno = 0;
+                const long long i = std::strtoll(t.c_str(), nullptr, 10);
+                if (errno != ERANGE) {
+                    v.is_int = true;
+                    v.i = i;
+                }
             }
             return v;
         }
@@ -384,6 +389,7 @@ struct BadRequest : std::runtime_error {
 
 constexpr uint64_t kRowMask = (1ull << 48) - 1;
 constexpr int kIdleSeconds = 120;  // keep-alive connections idle for longer are closed (reqwest's pool default is 90 s)
+constexpr size_t kMaxBuffered = (64u << 20) + (1u << 20);  // unread request bytes one connection may hold (one maximal body + headers)
 
 struct Test {
     enum Op { Eq, In, Lt, Le, Gt, Ge } op;
@@ -764,7 +770,10 @@ struct Worker {
                         if (flt->kind != JVal::Obj) throw BadRequest("filter must be an object");
                         p->tests = compile_filter(*flt, s.pk);
                     }
-                    p->k = limit;
+                    // The engine never returns more than the members it holds, so `limit` is clamped to that before anything is
+                    // sized by it: an absurd limit (2^62) must cost a 200 with `count` hits, not a bad_alloc on the event loop
+                    // (advisor finding, round 1: one unauthenticated request took the server down).
+                    p->k = std::min<size_t>(limit, std::max<size_t>(1, vs_hnsw_size(s.h)));
                 } catch (const BadRequest& e) {
                     return reply(400, false, e.what());
                 }
@@ -842,7 +851,13 @@ struct Worker {
                 break;
             }
             if (c.in.size() < he + 4 + clen) break;  // body still arriving
-            bool deferred = handle(c, method, path, c.in.data() + he + 4, clen, keep);
+            bool deferred = false;
+            try {
+                deferred = handle(c, method, path, c.in.data() + he + 4, clen, keep);
+            } catch (const std::exception& e) {  // nothing may unwind into the event loop: answer 500 and go on
+                c.busy = false;
+                queue_response(c, Response{500, false, std::string("internal error: ") + e.what()}, false);
+            }
             c.in.erase(0, he + 4 + clen);
             if (deferred) break;
         }
@@ -850,6 +865,12 @@ struct Worker {
     }
 
     void complete(std::unique_ptr<Pending> p) {
+        try {
+            complete_unguarded(std::move(p));
+        } catch (const std::exception&) {  // a response that cannot be built (out of memory) drops that answer, not the server
+        }
+    }
+    void complete_unguarded(std::unique_ptr<Pending> p) {
         auto it = conns.find(p->fd);
         if (it == conns.end() || it->second.gen != p->gen) return;  // the client went away
         Conn& c = it->second;
@@ -920,6 +941,10 @@ struct Worker {
                             ssize_t r = ::recv(fd, buf, sizeof buf, 0);
                             if (r > 0) {
                                 c.last = std::chrono::steady_clock::now();
+                                if (c.in.size() + (size_t)r > kMaxBuffered) {  // a pipelined flood while a request is in flight
+                                    closed = true;
+                                    break;
+                                }
                                 c.in.append(buf, (size_t)r);
                                 if ((size_t)r < sizeof buf) break;
                             } else if (r == 0) {

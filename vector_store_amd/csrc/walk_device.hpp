@@ -69,6 +69,7 @@ struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB> {
     static constexpr bool kSel = SEL;
     static constexpr int kHeapLds = LCAP;
     static constexpr bool kVisGlobal = VISG;
+    static constexpr bool kWideTags = false;  // indexes beyond the plain tags' reach take the global-bitmap instance
     static constexpr bool kHeapSpill = VISG;
     static constexpr uint32_t kOvfCap = (uint32_t)kWalkOvf;  // `next` may outgrow LDS into WalkSpace::heap (LDS instances hand the query over instead)
     float lst_d[EFCAP];

@@ -203,7 +203,7 @@ def main():
         else:
             dist.init_process_group(a.backend)
     import vector_store_amd as vs  # after torch: one HIP runtime per process
-    from vector_store_amd import sharded
+    from vector_store_amd import ranks, sharded
 
     def barrier():
         if dist is not None:
@@ -220,10 +220,15 @@ def main():
     build_info = {"vectors_per_s": n / build_s, "seconds": build_s, "vectors": n,
                   "evals_per_add": st["add_evals"] / max(st["added"], 1)}
     se = Searcher(ix, queries, k)
+    finish = lambda: None  # pipelined steppers: completes the batch still in flight
     if shard_mode:
-        gs = sharded.ShardedSearcher(ix, queries, k, dist, vs)
+        # native path (libvs_ranks: one ncclAllGather per batch on its own stream, overlapped with the next walk);
+        # the torch.distributed twin only where RCCL is not the backend (gloo smoke tests)
+        gs = (ranks.RankedSearcher(ix, queries, k, dist, n * world) if a.backend == "nccl"
+              else sharded.ShardedSearcher(ix, queries, k, dist, vs))
         truth = gs.exact()
         step = gs.step
+        finish = getattr(gs, "flush", finish)
         result_keys = lambda: gs.keys.cpu().numpy()
     else:
         truth, _ = se.exact()
@@ -237,6 +242,7 @@ def main():
     def probe(ef):
         ix.set_expansion_search(ef)
         step()
+        finish()
         torch.cuda.synchronize()
         r = recall_at_k(truth, result_keys())
         if dist is not None:
@@ -270,6 +276,7 @@ def main():
     # ---- timed region: W warmup steps, then exactly K steps between barrier + synchronize
     for _ in range(a.warmup):
         step()
+    finish()
     torch.cuda.synchronize()
     ix.stats(reset=True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -280,6 +287,7 @@ def main():
         ev[i][0].record()
         step()
         ev[i][1].record()
+    finish()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -330,9 +338,12 @@ def main():
             six, sbuild = build_index(vs, sbase, skeys, a.metric, quantization=a.quantization)
             six.set_expansion_search(ef)
             sq = make_data(nq, dim, a.dist, 4321, dev, a.rank)
-            gs = sharded.ShardedSearcher(six, sq, k, dist, vs)
+            gs = (ranks.RankedSearcher(six, sq, k, dist, n * world) if a.backend == "nccl"
+                  else sharded.ShardedSearcher(six, sq, k, dist, vs))
+            sfinish = getattr(gs, "flush", lambda: None)
             struth = gs.exact()
             gs.step()
+            sfinish()
             torch.cuda.synchronize()
             srec = recall_at_k(struth, gs.keys.cpu().numpy())
             barrier()
@@ -340,12 +351,13 @@ def main():
             ts = time.perf_counter()
             for _ in range(max(a.steps // 2, 1)):
                 gs.step()
+            sfinish()
             torch.cuda.synchronize()
             barrier()
             tel = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
             dist.all_reduce(tel, op=dist.ReduceOp.MAX)
             out["sharded"] = {"index_vectors_total": n * world, "queries_per_s": nq * max(a.steps // 2, 1) / float(tel.item()),
-                              "recall_at_10": round(srec, 4), "collective": "RCCL all_gather of per-shard top-k + vs_topk_merge_device",
+                              "recall_at_10": round(srec, 4), "collective": "one ncclAllGather (RCCL, libvs_ranks) of packed per-shard top-k per batch + topk_merge_kernel, overlapped with the next walk",
                               "build_vectors_per_s_per_gpu": n / sbuild}
             del six, sbase
         except Exception as e:  # the replica number stands on its own

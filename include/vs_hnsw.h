@@ -162,6 +162,11 @@ VS_API int vs_hnsw_import_graph(vs_hnsw* index, size_t slots, const void* vector
 VS_API int vs_topk_merge_device(const uint64_t* d_part_keys, const float* d_part_dists, size_t parts, size_t nq, size_t k,
                          uint64_t* d_keys, float* d_dists, uint32_t* d_found, void* hip_stream);
 
+/* The same merge over `parts` packed blocks of block_bytes each (a multiple of 16), block p = [nq x k keys u64 | nq x k
+ * distances f32 | padding]: the receive buffer of the ONE ncclAllGather per batch of include/vs_ranks.h. */
+VS_API int vs_topk_merge_packed_device(const void* d_blocks, size_t parts, size_t block_bytes, size_t nq, size_t k,
+                                uint64_t* d_keys, float* d_dists, uint32_t* d_found, void* hip_stream);
+
 /* -- small host helpers that the reference keeps next to the wrapper ---------------------- */
 /* f32_to_b1x8 (usearch.rs:1179-1205): out has ceil(n/8) bytes. */
 VS_API void vs_f32_to_b1x8(const float* v, size_t n, uint8_t* out);

@@ -25,6 +25,17 @@ def test_c_abi_exports_every_declared_symbol():
     assert vs.version() and isinstance(vs.version(), str)
     for sym in declared:
         getattr(vs.lib(), sym)
+    # every other header of include/ against its library (actor, in-process shards, one-process-per-GPU ranks)
+    for hdr, so in (("vs_actor.h", "libvs_actor.so"), ("vs_shards.h", "libvs_shards.so"), ("vs_ranks.h", "libvs_ranks.so")):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        want = set(re.findall(r"^VS_API [^;(]*?\b(vs_[a-z0-9_]+)\(", text, flags=re.M))
+        assert want, hdr
+        out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "vector_store_amd", so)], text=True)
+        have = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+        assert want <= have, (hdr, want - have)
+        assert {x for x in have if x.startswith("vs_")} == want, (hdr, have - want)
+    from vector_store_amd import ranks
+    assert ranks.lib().vs_ranks_create  # loads (librccl resolves) without a GPU
 
 
 def test_host_helpers_match_reference_kats():

@@ -1,0 +1,93 @@
+"""libvs_ranks (include/vs_ranks.h): key-range shards, one process per GPU, ONE ncclAllGather per batch + merge.
+world = 1 runs on any box (communicator-free path, same pack / merge / stream plumbing); world = 2 spawns two ranks over
+RCCL when the box has two GPUs (BASELINE.json configs[3] shrunk to what a test may take)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_world_of_one_equals_the_plain_search():
+    import torch
+
+    import vector_store_amd as vs
+    from vector_store_amd import ranks
+    n, dim, nq, k = 50000, 96, 512, 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    base = torch.randn((n, dim), generator=g, device="cuda")
+    q = torch.randn((nq, dim), generator=g, device="cuda")
+    ix = vs.HipUsearchIndex(dim, vs.COS, expansion_search=128)
+    ix.reserve(n)
+    ix.add_batch_device(np.arange(n, dtype=np.uint64), base.data_ptr(), n, dim)
+    want_k, want_d, want_f = ix.search_batch(q.cpu().numpy(), k)
+    rs = ranks.RankedSearcher(ix, q, k, None, n)
+    assert rs.ranks.key_range() == (0, n) and rs.ranks.owner(n - 1) == 0
+    rs.step_sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(rs.keys.cpu().numpy().view(np.uint64), want_k) and np.array_equal(rs.dists.cpu().numpy(), want_d)
+    for _ in range(5):      # pipelined: two batches in flight, results one step behind
+        rs.step()
+    rs.flush()
+    assert np.array_equal(rs.keys.cpu().numpy().view(np.uint64), want_k) and np.array_equal(rs.dists.cpu().numpy(), want_d)
+    truth = rs.exact()
+    tk, _, _ = ix.exact_search_batch(q.cpu().numpy(), k)
+    assert np.array_equal(truth.view(np.uint64), tk)
+    # ownership filter of the ingest path
+    extra = torch.randn((10, dim), generator=g, device="cuda").cpu().numpy()
+    ix.reserve(n + 10)
+    assert rs.ranks.add_batch(np.arange(n, n + 10, dtype=np.uint64), extra) == 10
+
+
+def test_packed_merge_equals_the_two_array_merge():
+    import torch
+
+    import vector_store_amd as vs
+    parts, nq, k = 5, 333, 7
+    rng = np.random.default_rng(4)
+    d = np.sort(rng.random((parts, nq, k)).astype(np.float32), axis=2)
+    keys = rng.integers(0, 1 << 60, size=(parts, nq, k), dtype=np.uint64)
+    d[2, :, 4:] = np.inf
+    keys[2, :, 4:] = 0xFFFFFFFFFFFFFFFF
+    block = (nq * k * 12 + 15) // 16 * 16
+    packed = np.zeros((parts, block), dtype=np.uint8)
+    for p in range(parts):
+        packed[p, : nq * k * 8] = keys[p].reshape(-1).view(np.uint8)
+        packed[p, nq * k * 8: nq * k * 12] = d[p].reshape(-1).view(np.uint8)
+    dp = torch.from_numpy(packed).cuda()
+    dk, dd = torch.from_numpy(keys.view(np.int64)).cuda(), torch.from_numpy(d).cuda()
+    outs = []
+    for packed_form in (False, True):
+        ok_ = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        od = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        of = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        if packed_form:
+            assert vs.lib().vs_topk_merge_packed_device(dp.data_ptr(), parts, block, nq, k, ok_.data_ptr(), od.data_ptr(), of.data_ptr(), s) == 0
+        else:
+            vs.topk_merge_device(dk.data_ptr(), dd.data_ptr(), parts, nq, k, ok_.data_ptr(), od.data_ptr(), of.data_ptr(), s)
+        torch.cuda.synchronize()
+        outs.append((ok_.cpu().numpy(), od.cpu().numpy(), of.cpu().numpy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_two_ranks_over_rccl():
+    """bench.py --gpus 2 --mode shard: two processes, two GPUs, nccl backend, libvs_ranks on the data path."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "shard", "--vectors", "200000", "--nq", "2000",
+         "--steps", "4", "--warmup", "1", "--ef", "128", "--cpu-seconds", "0"], env=env, text=True, timeout=900, cwd=ROOT)
+    import json
+    rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["mode"] == "shard" and rec["config"]["index_vectors_total"] == 400000
+    assert rec["recall_at_10"] >= 0.9 and rec["value"] > 0

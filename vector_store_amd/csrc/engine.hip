@@ -1820,6 +1820,17 @@ int vs_topk_merge_device(const uint64_t* d_part_keys, const float* d_part_dists,
     });
 }
 
+int vs_topk_merge_packed_device(const void* d_blocks, size_t parts, size_t block_bytes, size_t nq, size_t k, uint64_t* d_keys,
+                                float* d_dists, uint32_t* d_found, void* stream) {
+    return guarded([&] {
+        need(d_blocks && d_keys && d_dists, "null argument");
+        need(block_bytes % 16 == 0 && block_bytes >= nq * k * 12, "blocks must be 16-byte multiples of at least nq * k * 12 bytes");
+        const char* base = (const char*)d_blocks;
+        HIP_OK(vs::launch_topk_merge((const uint64_t*)base, (const float*)(base + nq * k * 8), (uint32_t)parts, (uint32_t)nq, (uint32_t)k,
+                                     d_keys, d_dists, d_found, (hipStream_t)stream, block_bytes / 8, block_bytes / 4));
+    });
+}
+
 // reference vs_index/usearch.rs:1179-1205
 void vs_f32_to_b1x8(const float* v, size_t n, uint8_t* out) {
     const size_t nb = (n + 7) / 8;

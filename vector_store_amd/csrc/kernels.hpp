@@ -138,7 +138,8 @@ hipError_t launch_distance_row(const IndexView& ix, const float* d_query, uint32
                                float* host_out);
 
 hipError_t launch_topk_merge(const uint64_t* part_keys, const float* part_dist, uint32_t parts, uint32_t nq, uint32_t k,
-                             uint64_t* out_keys, float* out_dist, uint32_t* out_found, hipStream_t s);
+                             uint64_t* out_keys, float* out_dist, uint32_t* out_found, hipStream_t s, size_t key_stride = 0,
+                             size_t dist_stride = 0);  // strides in elements between consecutive parts; 0 = nq * k
 
 // radix sort of (key, value) pairs by key bits [0, end_bit); temp sized by sort_temp_bytes()
 size_t sort_temp_bytes(size_t n);

@@ -695,9 +695,11 @@ hipError_t launch_rank_emit(const IndexView& ix, const uint64_t* sorted, uint32_
 }
 
 // ---------------------------------------------------------------- multi-GPU top-k merge (after the RCCL all-gather)
+// key_stride / dist_stride: elements between the lists of consecutive parts (nq * k for two plain arrays; for the packed
+// all-gather blocks [keys | distances] of include/vs_ranks.h both arrays advance by one block per part).
 __global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t* part_keys, const float* part_dist, uint32_t parts,
-                                                        uint32_t nq, uint32_t k, uint64_t* out_keys, float* out_dist,
-                                                        uint32_t* out_found) {
+                                                        uint32_t nq, uint32_t k, size_t key_stride, size_t dist_stride,
+                                                        uint64_t* out_keys, float* out_dist, uint32_t* out_found) {
     __shared__ SelectShared sh;
     const int lane = lane_id();
     const uint32_t q = blockIdx.x;
@@ -708,9 +710,9 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t* part_key
         uint32_t c = c0 + lane;
         bool ok = c < total;
         uint32_t p = ok ? c / k : 0, j = ok ? c % k : 0;
-        size_t src = ((size_t)p * nq + q) * k + j;
-        float d = ok ? part_dist[src] : __builtin_inff();
-        ok = ok && part_keys[src] != kFreeKey;
+        const size_t in_part = (size_t)q * k + j;
+        float d = ok ? part_dist[(size_t)p * dist_stride + in_part] : __builtin_inff();
+        ok = ok && part_keys[(size_t)p * key_stride + in_part] != kFreeKey;
         if (ok && sz == k) ok = key_less(d, c, sh.lst_d[cur][k - 1], sh.lst_s[cur][k - 1]);
         uint64_t mask = __ballot(ok);
         if (!mask) continue;
@@ -732,8 +734,7 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t* part_key
         float d = __builtin_inff();
         if (i < sz) {
             uint32_t c = sh.lst_s[cur][i];
-            size_t src = ((size_t)(c / k) * nq + q) * k + (c % k);
-            key = part_keys[src];
+            key = part_keys[(size_t)(c / k) * key_stride + (size_t)q * k + (c % k)];
             d = sh.lst_d[cur][i];
         }
         out_keys[(size_t)q * k + i] = key;
@@ -743,11 +744,14 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t* part_key
 }
 
 hipError_t launch_topk_merge(const uint64_t* part_keys, const float* part_dist, uint32_t parts, uint32_t nq, uint32_t k,
-                             uint64_t* out_keys, float* out_dist, uint32_t* out_found, hipStream_t s) {
+                             uint64_t* out_keys, float* out_dist, uint32_t* out_found, hipStream_t s, size_t key_stride,
+                             size_t dist_stride) {
     if (!nq) return hipSuccess;
     if (k == 0 || k > 256 || (size_t)parts * k >= 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(64), 0, s, part_keys, part_dist, parts, nq, k, out_keys, out_dist,
-                       out_found);
+    if (!key_stride) key_stride = (size_t)nq * k;
+    if (!dist_stride) dist_stride = (size_t)nq * k;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(64), 0, s, part_keys, part_dist, parts, nq, k, key_stride, dist_stride,
+                       out_keys, out_dist, out_found);
     return hipGetLastError();
 }
 

@@ -1,0 +1,229 @@
+// ranks.cpp -- libvs_ranks.so: key-range shards, one process per GPU, per-shard top-k exchanged by ONE RCCL
+// ncclAllGather per batch and merged on every rank (include/vs_ranks.h; BASELINE.json configs[3]).
+#include "../../include/vs_ranks.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+thread_local std::string g_err;
+constexpr uint64_t kIdxMask = (1ull << 48) - 1;
+
+struct Fail {
+    int code;
+    std::string msg;
+};
+#define HIP_OK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) throw Fail{VS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)}; \
+    } while (0)
+#define NCCL_OK(expr)                                                                            \
+    do {                                                                                         \
+        ncclResult_t e__ = (expr);                                                               \
+        if (e__ != ncclSuccess) throw Fail{VS_ERR_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(e__)}; \
+    } while (0)
+#define VS_OK_OR_THROW(expr)                                              \
+    do {                                                                  \
+        int e__ = (expr);                                                 \
+        if (e__ != VS_OK) throw Fail{e__, std::string(vs_hnsw_last_error())}; \
+    } while (0)
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return VS_OK;
+    } catch (const Fail& x) {
+        g_err = x.msg;
+        return x.code;
+    } catch (const std::exception& x) {
+        g_err = x.what();
+        return VS_ERR_DEVICE;
+    }
+}
+}  // namespace
+
+struct vs_ranks {
+    vs_hnsw* shard = nullptr;
+    int rank = 0, world = 1;
+    uint64_t total_rows = 0, per = 1;
+    ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    struct Slot {
+        char* gathered = nullptr;  // world x block bytes; this rank's block is written by its walk, in place
+        uint32_t* local_found = nullptr;
+        size_t bytes = 0, found_n = 0;
+        hipEvent_t walked = nullptr, merged = nullptr;
+    } slot[2];
+
+    void ensure(Slot& s, size_t block, size_t nq) {
+        const size_t want = block * (size_t)world;
+        if (want > s.bytes) {
+            if (s.gathered) HIP_OK(hipFree(s.gathered));
+            s.gathered = nullptr;
+            HIP_OK(hipMalloc((void**)&s.gathered, want + want / 4));
+            s.bytes = want + want / 4;
+        }
+        if (nq > s.found_n) {
+            if (s.local_found) HIP_OK(hipFree(s.local_found));
+            s.local_found = nullptr;
+            HIP_OK(hipMalloc((void**)&s.local_found, (nq + nq / 4) * 4));
+            s.found_n = nq + nq / 4;
+        }
+        if (!s.walked) {
+            HIP_OK(hipEventCreateWithFlags(&s.walked, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&s.merged, hipEventDisableTiming));
+        }
+    }
+
+    // walk (or exact search) on `st` into this rank's block -> all-gather + merge on comm_stream
+    void submit(int si, bool exact, const float* d_q, size_t nq, size_t dim, size_t k, uint64_t* d_keys, float* d_dist,
+                uint32_t* d_found, hipStream_t st) {
+        if (si < 0 || si > 1) throw Fail{VS_ERR_INVALID_ARGUMENT, "slot must be 0 or 1"};
+        if (!nq || !k) throw Fail{VS_ERR_INVALID_ARGUMENT, "empty batch"};
+        Slot& s = slot[si];
+        const size_t block = (nq * k * 12 + 15) / 16 * 16;  // [keys u64 | distances f32], 16-byte aligned blocks
+        if (s.merged) HIP_OK(hipStreamWaitEvent(st, s.merged, 0));  // this slot's previous merge has read the blocks the walk is about to rewrite
+        ensure(s, block, nq);
+        char* mine = s.gathered + (size_t)rank * block;
+        if (exact)
+            VS_OK_OR_THROW(vs_hnsw_exact_search_batch_device(shard, d_q, nq, dim, k, (uint64_t*)mine, (float*)(mine + nq * k * 8),
+                                                             s.local_found, st));
+        else
+            VS_OK_OR_THROW(vs_hnsw_search_batch_device(shard, d_q, nq, dim, k, (uint64_t*)mine, (float*)(mine + nq * k * 8),
+                                                       s.local_found, st));
+        HIP_OK(hipEventRecord(s.walked, st));
+        HIP_OK(hipStreamWaitEvent(comm_stream, s.walked, 0));
+        if (world > 1) NCCL_OK(ncclAllGather(mine, s.gathered, block, ncclChar, comm, comm_stream));  // in place: sendbuff = recvbuff + rank * count
+        VS_OK_OR_THROW(vs_topk_merge_packed_device(s.gathered, (size_t)world, block, nq, k, d_keys, d_dist, d_found, comm_stream));
+        HIP_OK(hipEventRecord(s.merged, comm_stream));
+    }
+};
+
+extern "C" {
+
+const char* vs_ranks_last_error(void) { return g_err.c_str(); }
+
+int vs_ranks_unique_id(uint8_t id[VS_RANKS_ID_BYTES]) {
+    return guarded([&] {
+        static_assert(sizeof(ncclUniqueId) == VS_RANKS_ID_BYTES, "ncclUniqueId size");
+        ncclUniqueId u;
+        NCCL_OK(ncclGetUniqueId(&u));
+        std::memcpy(id, &u, sizeof u);
+    });
+}
+
+int vs_ranks_create(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_RANKS_ID_BYTES], uint64_t total_rows, vs_ranks** out) {
+    return guarded([&] {
+        if (!shard || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id))
+            throw Fail{VS_ERR_INVALID_ARGUMENT, "invalid argument"};
+        vs_ranks* r = new vs_ranks();
+        r->shard = shard;
+        r->rank = rank;
+        r->world = world;
+        r->total_rows = total_rows ? total_rows : 1;
+        r->per = (r->total_rows + (uint64_t)world - 1) / (uint64_t)world;
+        try {
+            HIP_OK(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+            if (world > 1) {
+                ncclUniqueId u;
+                std::memcpy(&u, id, sizeof u);
+                NCCL_OK(ncclCommInitRank(&r->comm, world, u, rank));
+            }
+        } catch (...) {
+            vs_ranks_free(r);
+            throw;
+        }
+        *out = r;
+    });
+}
+
+void vs_ranks_free(vs_ranks* r) {
+    if (!r) return;
+    if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
+    for (auto& s : r->slot) {
+        if (s.gathered) (void)hipFree(s.gathered);
+        if (s.local_found) (void)hipFree(s.local_found);
+        if (s.walked) (void)hipEventDestroy(s.walked);
+        if (s.merged) (void)hipEventDestroy(s.merged);
+    }
+    if (r->comm) (void)ncclCommDestroy(r->comm);
+    if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
+    delete r;
+}
+
+int vs_ranks_owner(const vs_ranks* r, uint64_t key) {
+    if (!r) return -1;
+    const uint64_t o = (key & kIdxMask) / r->per;
+    return (int)(o < (uint64_t)r->world ? o : (uint64_t)r->world - 1);
+}
+
+void vs_ranks_range(const vs_ranks* r, uint64_t* first_row, uint64_t* end_row) {
+    if (!r) return;
+    const uint64_t lo = std::min(r->total_rows, (uint64_t)r->rank * r->per);
+    if (first_row) *first_row = lo;
+    if (end_row) *end_row = std::min(r->total_rows, lo + r->per);
+}
+
+int vs_ranks_add_batch(vs_ranks* r, const uint64_t* keys, const float* vectors, size_t n, size_t dim, size_t* added) {
+    return guarded([&] {
+        if (!r || (n && (!keys || !vectors))) throw Fail{VS_ERR_INVALID_ARGUMENT, "null argument"};
+        std::vector<uint64_t> mk;
+        std::vector<float> mv;
+        bool all = true;
+        for (size_t i = 0; i < n; ++i) all = all && vs_ranks_owner(r, keys[i]) == r->rank;
+        if (all) {  // the usual case: the caller already routes by range
+            if (n) VS_OK_OR_THROW(vs_hnsw_add_batch(r->shard, keys, vectors, n, dim));
+            if (added) *added = n;
+            return;
+        }
+        for (size_t i = 0; i < n; ++i)
+            if (vs_ranks_owner(r, keys[i]) == r->rank) {
+                mk.push_back(keys[i]);
+                mv.insert(mv.end(), vectors + i * dim, vectors + (i + 1) * dim);
+            }
+        if (!mk.empty()) VS_OK_OR_THROW(vs_hnsw_add_batch(r->shard, mk.data(), mv.data(), mk.size(), dim));
+        if (added) *added = mk.size();
+    });
+}
+
+int vs_ranks_search_submit(vs_ranks* r, int slot, const float* d_q, size_t nq, size_t dim, size_t k, uint64_t* d_keys, float* d_dist,
+                           uint32_t* d_found, void* stream) {
+    return guarded([&] {
+        if (!r || !d_q || !d_keys || !d_dist) throw Fail{VS_ERR_INVALID_ARGUMENT, "null argument"};
+        r->submit(slot, false, d_q, nq, dim, k, d_keys, d_dist, d_found, (hipStream_t)stream);
+    });
+}
+
+int vs_ranks_wait(vs_ranks* r, int slot, void* stream) {
+    return guarded([&] {
+        if (!r || slot < 0 || slot > 1) throw Fail{VS_ERR_INVALID_ARGUMENT, "invalid argument"};
+        if (r->slot[slot].merged) HIP_OK(hipStreamWaitEvent((hipStream_t)stream, r->slot[slot].merged, 0));
+    });
+}
+
+int vs_ranks_search_batch_device(vs_ranks* r, const float* d_q, size_t nq, size_t dim, size_t k, uint64_t* d_keys, float* d_dist,
+                                 uint32_t* d_found, void* stream) {
+    return guarded([&] {
+        if (!r || !d_q || !d_keys || !d_dist) throw Fail{VS_ERR_INVALID_ARGUMENT, "null argument"};
+        r->submit(0, false, d_q, nq, dim, k, d_keys, d_dist, d_found, (hipStream_t)stream);
+        HIP_OK(hipStreamWaitEvent((hipStream_t)stream, r->slot[0].merged, 0));
+    });
+}
+
+int vs_ranks_exact_search_batch_device(vs_ranks* r, const float* d_q, size_t nq, size_t dim, size_t k, uint64_t* d_keys,
+                                       float* d_dist, uint32_t* d_found, void* stream) {
+    return guarded([&] {
+        if (!r || !d_q || !d_keys || !d_dist) throw Fail{VS_ERR_INVALID_ARGUMENT, "null argument"};
+        r->submit(0, true, d_q, nq, dim, k, d_keys, d_dist, d_found, (hipStream_t)stream);
+        HIP_OK(hipStreamWaitEvent((hipStream_t)stream, r->slot[0].merged, 0));
+    });
+}
+
+}  // extern "C"

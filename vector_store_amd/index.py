@@ -95,6 +95,7 @@ def lib():
     L.vs_hnsw_export_graph.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.vs_hnsw_import_graph.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz, C.c_int32, C.c_uint32]
     L.vs_topk_merge_device.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp]
+    L.vs_topk_merge_packed_device.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp, vp]
     L.vs_f32_to_b1x8.argtypes = [vp, sz, vp]
     L.vs_distance_valid.argtypes = [f32, C.c_int, sz]
     L.vs_similarity_score.restype = f32

@@ -164,6 +164,93 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, extra_host=None):
     return out, keys
 
 
+def side_records(vs, dev, dim, metric, k, rank0_only=True):
+    """How "QPS at recall@10 >= 0.95" depends on the synthetic generator, at 1M x dim: the survey's
+    own i.i.d. Gaussian (numpy PCG64 standard_normal, seeds 1234 / 4321) and its clustered variant (256 centres,
+    sigma 0.2, seed 99) as side records, plus the intrinsic dimension of the default low-rank generator swept over
+    16 / 24 / 48.  Each record: recall@10 and QPS (10,000 resident queries per launch) at ef 128 / 256 / 512."""
+    n, nq = 1_000_000, 10_000
+    out = []
+
+    def numpy_normal(rows, seed):
+        return np.random.Generator(np.random.PCG64(seed)).standard_normal((rows, dim), dtype=np.float32)
+
+    variants = [("gaussian_pcg64", None), ("clustered_pcg64", None), ("lowrank16", 16), ("lowrank24", 24), ("lowrank48", 48)]
+    for name, rank in variants:
+        t0 = time.perf_counter()
+        if name == "gaussian_pcg64":
+            base = torch.from_numpy(numpy_normal(n, 1234)).to(dev)
+            q = torch.from_numpy(numpy_normal(nq, 4321)).to(dev)
+        elif name == "clustered_pcg64":
+            centres = np.random.Generator(np.random.PCG64(99)).standard_normal((256, dim), dtype=np.float32)
+            g1, g2 = np.random.Generator(np.random.PCG64(1234)), np.random.Generator(np.random.PCG64(4321))
+            c = torch.from_numpy(centres).to(dev)
+            base = c[torch.from_numpy(g1.integers(0, 256, n)).to(dev)] + 0.2 * torch.from_numpy(g1.standard_normal((n, dim), dtype=np.float32)).to(dev)
+            q = c[torch.from_numpy(g2.integers(0, 256, nq)).to(dev)] + 0.2 * torch.from_numpy(g2.standard_normal((nq, dim), dtype=np.float32)).to(dev)
+        else:
+            base = make_data(n, dim, "lowrank", 1234, dev, rank)
+            q = make_data(nq, dim, "lowrank", 4321, dev, rank)
+        keys = np.arange(n, dtype=np.uint64)
+        ix, build_s = build_index(vs, base, keys, metric)
+        se = Searcher(ix, q, k)
+        truth, _ = se.exact()
+        rec = {"data": name, "vectors": n, "build_vectors_per_s": n / build_s, "points": []}
+        for ef in (128, 256, 512):
+            ix.set_expansion_search(ef)
+            se.step()
+            torch.cuda.synchronize()
+            r = recall_at_k(truth, se.keys.cpu().numpy())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                se.step()
+            e1.record()
+            torch.cuda.synchronize()
+            rec["points"].append({"ef": ef, "recall_at_10": round(r, 4), "queries_per_s": nq * 3 / (e0.elapsed_time(e1) * 1e-3)})
+            if r >= 0.95:
+                break
+        rec["seconds"] = round(time.perf_counter() - t0, 1)
+        out.append(rec)
+        del ix, se, base, q
+        torch.cuda.empty_cache()
+    return out
+
+
+def boundary_record(ix, queries_host, truth, k, seconds):
+    """What a drop-in caller gets THROUGH the C ABI on this very index (reference call pattern): one query per
+    vs_hnsw_search call from num_workers() + 1 blocking threads (usearch.rs:203-222, worker.rs:44-118), and the
+    non-blocking entry point with 16 x 256 queries in flight; the reference's loop and histogram
+    (crates/benchmark/src/main.rs:435-604) as libvs_callers.so runs them."""
+    import ctypes as C
+
+    class Res(C.Structure):
+        _fields_ = [("seconds", C.c_double), ("queries", C.c_uint64), ("qps", C.c_double), ("latency_min_ns", C.c_int64),
+                    ("latency_max_ns", C.c_int64)] + [(f"p{p:02d}_ns", C.c_int64) for p in (1, 10, 25, 50, 75, 90, 99)] + [
+                    ("recall_avg", C.c_double), ("errors", C.c_uint64), ("launches", C.c_uint64), ("team_launches", C.c_uint64)]
+
+    L = C.CDLL(os.path.join(ROOT, "vector_store_amd", "libvs_callers.so"))
+    L.vs_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint,
+                                 C.c_double, C.POINTER(Res)]
+    q = np.ascontiguousarray(queries_host, dtype=np.float32)
+    t = np.ascontiguousarray(truth, dtype=np.uint64)
+    cores = effective_cores()
+    out = {"cores": cores}
+
+    def ms(ns):
+        return None if ns >= 2 ** 62 else round(ns / 1e6, 3)
+
+    for name, threads, inflight in (("blocking_callers", cores + 1, 1), ("async_in_flight", 16, 256)):
+        r = Res()
+        rc = L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, t.ctypes.data, threads, inflight, seconds, C.byref(r))
+        out[name] = {"threads": threads, "in_flight_per_thread": inflight, "queries_per_s": r.qps, "seconds": r.seconds,
+                     "latency_min_ms": round(r.latency_min_ns / 1e6, 3), "p50_ms": ms(r.p50_ns), "p90_ms": ms(r.p90_ns),
+                     "p99_ms": ms(r.p99_ns), "recall_at_10": round(r.recall_avg, 4), "errors": int(r.errors), "status": rc,
+                     "kernel_launches": int(r.launches), "team_kernel_launches": int(r.team_launches)}
+    out["note"] = ("one query per C-ABI call; percentiles on the reference's histogram (10,000 buckets over 1..100 ms: anything "
+                   "faster reads 1.0 ms); latency_min_ms is the raw minimum")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +270,8 @@ def main():
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall seconds of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-build-vectors", type=int, default=20_000, help="vectors the cpu_baseline leg inserts into the full-size index (0 = skip)")
+    ap.add_argument("--boundary-seconds", type=float, default=3.0, help="seconds per leg of the through-the-C-ABI record (0 = skip)")
+    ap.add_argument("--no-side-records", action="store_true", help="skip the generator side records (gaussian / clustered / rank sweep at 1M)")
     ap.add_argument("--no-sharded-leg", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0")
@@ -218,7 +307,9 @@ def main():
     ix, build_s = build_index(vs, base, keys, a.metric, quantization=a.quantization)
     st = ix.stats(reset=True)
     build_info = {"vectors_per_s": n / build_s, "seconds": build_s, "vectors": n,
-                  "evals_per_add": st["add_evals"] / max(st["added"], 1)}
+                  "evals_per_add": st["add_evals"] / max(st["added"], 1),
+                  "insert_evals_per_add": (st["add_evals"] - st["link_evals"]) / max(st["added"], 1),  # hnsw_insert_kernel's share
+                  "hops_per_add": st["add_hops"] / max(st["added"], 1)}
     se = Searcher(ix, queries, k)
     finish = lambda: None  # pipelined steppers: completes the batch still in flight
     if shard_mode:
@@ -320,13 +411,21 @@ def main():
                      "visited_overflow": st["visited_overflow"]},
         "build": build_info,
     }
-    # PMC-measured HBM bytes per launch for this exact workload (profiles/*traffic.json, see profiles/README.md)
+    # PMC-measured HBM bytes per launch for this exact workload (profiles/*traffic.json, see profiles/README.md).  A record
+    # is only used while the kernel sources it was measured on are the ones in the tree; otherwise traffic stays null and
+    # traffic_source says which record went stale.
     import glob
+    from scripts.summarise_profiles import kernel_sources_sha16
+    sha_now = kernel_sources_sha16()
+    out["roofline"]["traffic_source"] = None
     for tr in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
         try:
             rec = json.load(open(tr))
             if rec.get("workload") == out["config"]["workload"]:
-                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                fresh = rec.get("kernel_sources_sha16") == sha_now
+                out["roofline"]["traffic_source"] = {"file": os.path.relpath(tr, ROOT), "kernel_sources_sha16": rec.get("kernel_sources_sha16"),
+                                                     "current_kernel_sources_sha16": sha_now, "stale": not fresh}
+                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"] if fresh else None
         except Exception:
             pass
 
@@ -362,6 +461,20 @@ def main():
             del six, sbase
         except Exception as e:  # the replica number stands on its own
             out["sharded"] = {"error": repr(e)}
+
+    # ---- through the boundary: what a drop-in caller of the trait gets on this index (N=1 only)
+    if world == 1 and a.boundary_seconds > 0:
+        try:
+            out["boundary"] = boundary_record(ix, queries.cpu().numpy(), truth, k, a.boundary_seconds)
+        except Exception as e:
+            out["boundary"] = {"error": repr(e)}
+
+    # ---- the same metric on the survey's own generators, and across the default generator's intrinsic dimension (N=1 only)
+    if world == 1 and not a.no_side_records and a.quantization == "f32":
+        try:
+            out["generators_at_1m"] = side_records(vs, dev, dim, a.metric, k)
+        except Exception as e:
+            out["generators_at_1m"] = {"error": repr(e)}
 
     # ---- CPU baseline: rank 0, N=1 only, bounded
     if world == 1 and a.cpu_seconds > 0:

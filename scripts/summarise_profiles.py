@@ -14,9 +14,22 @@ Writes  <tag>_kernel_stats.csv           (rocprofv3 --stats, verbatim)
 import argparse
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["hnsw_device.hpp", "walk_device.hpp", "kernels_arith.hip", "kernels_walk.hip", "kernels_misc.hip", "kernels.hpp"]
+
+
+def kernel_sources_sha16():
+    """What a traffic record is valid for: the kernel sources it was measured on (bench.py recomputes this and reports a
+    record as stale -- roofline.traffic null -- when they have changed since)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "vector_store_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def find(d, suffix):
@@ -24,13 +37,13 @@ def find(d, suffix):
     return hits[0] if hits else None
 
 
-def search_rows(path, counter):
-    """Counter rows of the hnsw_search kernel with the bench batch's grid (the largest grid seen)."""
+def search_rows(path, counter, kernel="hnsw_search_kernel"):
+    """Counter rows of one kernel's launches with its largest grid (search: the bench batch; insert: full sub-batches)."""
     rows = []
     with open(path, newline="") as f:
         r = csv.DictReader(f)
         for row in r:
-            if "hnsw_search_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 rows.append(row)
         fields = r.fieldnames
     if not rows:
@@ -86,7 +99,61 @@ def main():
                     rec["workload"] = b["config"]["workload"]
                     rec["algorithmic_bytes_per_launch"] = b["roofline"]["bytes_per_query"] * nq
                     rec["ratio_traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
+        rec["kernel_sources_sha16"] = kernel_sources_sha16()
         json.dump(rec, open(os.path.join(a.out, f"{a.tag}_traffic.json"), "w"), indent=1)
+    # the other two hot kernels of the same run: the build's insert kernel (HBM-bound) and the exact path's MFMA tile kernel
+    bench = None
+    if a.bench_json and os.path.exists(a.bench_json):
+        for line in open(a.bench_json):
+            if line.strip().startswith("{"):
+                bench = json.loads(line)
+    stats = {}
+    ks = find(a.stats_dir, "_kernel_stats.csv") if a.stats_dir else None
+    if ks:
+        for row in csv.DictReader(open(ks, newline="")):
+            stats[row["Name"]] = row
+    for kernel, label in (("hnsw_insert_kernel", "insert"), ("exact_dist_mfma_kernel", "mfma")):
+        raw2, kname = {}, None
+        for name, d in (("FETCH_SIZE", a.fetch_dir), ("WRITE_SIZE", a.write_dir)):
+            cc = find(d, "_counter_collection.csv") if d else None
+            if not cc:
+                continue
+            _, rows = search_rows(cc, name, kernel)
+            if rows:
+                raw2[name] = sum(float(x["Counter_Value"]) for x in rows) / len(rows)
+                raw2[name + "_launches"] = len(rows)
+                raw2[name + "_ms"] = sum(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows) / len(rows) / 1e6
+                raw2["grid"] = int(rows[0]["Grid_Size"])
+                kname = rows[0]["Kernel_Name"]
+        if "FETCH_SIZE" not in raw2 or "WRITE_SIZE" not in raw2:
+            continue
+        rec = {"kernel": kname, "launches_averaged": raw2["FETCH_SIZE_launches"], "grid_threads": raw2["grid"],
+               "raw": {"FETCH_SIZE_KB_per_launch": raw2["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": raw2["WRITE_SIZE"]},
+               "hbm_bytes_per_launch": 2 * raw2["FETCH_SIZE"] * 1024 + raw2["WRITE_SIZE"] * 1024,
+               "kernel_sources_sha16": kernel_sources_sha16()}
+        rec["full_grid_launch_ms_in_the_pmc_pass"] = raw2["FETCH_SIZE_ms"]
+        st = stats.get(kname)
+        if st:
+            rec["rocprof_average_ms_all_launches"] = float(st["AverageNs"]) / 1e6
+            rec["rocprof_max_ms"] = float(st["MaxNs"]) / 1e6
+        if bench and label == "insert" and "build" in bench:
+            b = bench["build"]
+            nodes = raw2["grid"] // 64
+            row_b = bench["roofline"]["bytes_per_query"] and (bench["roofline"]["bytes_per_query"] - bench["roofline"]["hops_per_query"] * 132
+                                                              - int(bench["config"]["workload"].split("x")[1].split()[0]) * 4) / bench["roofline"]["evals_per_query"]
+            if "insert_evals_per_add" in b:
+                rec["algorithmic_bytes_per_launch"] = nodes * (b["insert_evals_per_add"] * row_b + b["hops_per_add"] * 132)
+                rec["ratio_traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
+                rec["achieved_TBps"] = rec["algorithmic_bytes_per_launch"] / (raw2["FETCH_SIZE_ms"] * 1e-3) / 1e12
+                rec["frac_of_8TBps"] = rec["achieved_TBps"] / 8.0
+        if bench and label == "mfma":
+            dim = int(bench["config"]["workload"].split("x")[1].split()[0])
+            tiles = raw2["grid"] // 256  # 128 x 128 score tiles, one 256-thread workgroup each
+            rec["flops_per_launch"] = 2.0 * tiles * 128 * 128 * dim
+            rec["achieved_TFLOPs"] = rec["flops_per_launch"] / (raw2["FETCH_SIZE_ms"] * 1e-3) / 1e12
+            rec["frac_of_157_TFLOPs_f32_mfma"] = rec["achieved_TFLOPs"] / 157.3
+            rec["algorithmic_bytes_per_launch"] = (tiles ** 0.5 * 128 * 2) * dim * 4  # lower bound: a square block of rows + queries once
+        json.dump(rec, open(os.path.join(a.out, f"{a.tag}_traffic_{label}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -195,3 +195,20 @@ def test_gpu_build_recall_and_exact(kind, metric):
         overlap = np.mean([len(set(fk[i].tolist()) & set(tk[i].tolist())) / k for i in range(len(q))])
         assert overlap >= (0.95 if kind == "f16" else 0.85), overlap
     assert ix.stats()["visited_overflow"] == 0
+
+
+@pytest.mark.timeout(60)
+@pytest.mark.parametrize("kind", ["i8", "b1", "f32"])
+def test_walk_on_an_empty_index_returns_nothing(kind):
+    """reference tests/integration/vs_index.rs:1919-1951 (empty => empty) through the usearch-order walk, batch and
+    single-query entry points (a round-2 build spun for ever here: the work-fetch loop lost its convergence point)."""
+    v = vs()
+    ix = v.HipUsearchIndex(20, v.COS, quantization=v.SCALARS[kind], _stress=16)
+    ix.reserve(100)
+    q = np.ones((3, 20), dtype=np.float32)
+    k, d, f = ix.search_batch(q, 5)
+    assert f.tolist() == [0, 0, 0]
+    assert len(ix.search(q[0], 5)[0]) == 0
+    assert len(ix.filtered_search(q[0], 5, lambda key: True)[0]) == 0
+    ix.add(7, q[0])
+    assert ix.search(q[0], 5)[0].tolist() == [7]

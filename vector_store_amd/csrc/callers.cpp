@@ -1,0 +1,155 @@
+// callers.cpp -- libvs_callers.so (include/vs_callers.h): the reference's search load loop
+// (crates/benchmark/src/main.rs:435-525) over the C ABI of the engine, blocking or with queries in flight.
+#include "../../include/vs_callers.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <random>
+#include <thread>
+#include <unordered_set>
+#include <vector>
+
+#include "bench_util.hpp"
+
+using vsb::SearchMeasure;
+using Clock = std::chrono::steady_clock;
+
+namespace {
+double recall_of(const uint64_t* truth, size_t k, const uint64_t* found, size_t n) {
+    size_t hit = 0;
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < k; ++j)
+            if (truth[j] == found[i]) {
+                ++hit;
+                break;
+            }
+    return k ? (double)hit / (double)k : 0.0;
+}
+}  // namespace
+
+extern "C" int vs_callers_run(vs_hnsw* h, const float* queries, size_t nq, size_t dim, size_t k, const uint64_t* truth,
+                              unsigned threads, unsigned inflight, double seconds, vs_callers_result* out) {
+    if (!h || !queries || !nq || !k || !threads || !out) return VS_ERR_INVALID_ARGUMENT;
+    if (!inflight) inflight = 1;
+    std::atomic<bool> stop{false};
+    std::vector<SearchMeasure> per(threads);
+    std::vector<uint64_t> errors(threads, 0);
+    for (auto& m : per) m.with_recall = truth != nullptr;
+    uint64_t sv0[4] = {0, 0, 0, 0}, sv1[4] = {0, 0, 0, 0};
+    (void)vs_search_service_stats(sv0);
+    auto t0 = Clock::now();
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; ++t)
+        th.emplace_back([&, t] {
+            std::mt19937_64 g(t * 7919 + 13);
+            if (inflight == 1) {  // one blocking call per query: a thread of the reference's worker pool
+                std::vector<uint64_t> keys(k);
+                std::vector<float> dist(k);
+                while (!stop.load(std::memory_order_relaxed)) {
+                    const size_t qi = g() % nq;
+                    size_t found = 0;
+                    auto s = Clock::now();
+                    int rc = vs_hnsw_search(h, queries + qi * dim, dim, k, keys.data(), dist.data(), &found);
+                    int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
+                    if (rc != VS_OK) {
+                        ++errors[t];
+                        break;
+                    }
+                    per[t].record(ns, truth ? recall_of(truth + qi * k, k, keys.data(), found) : 0.0);
+                }
+                return;
+            }
+            struct Slot {  // the non-blocking entry point, `inflight` queries outstanding per worker
+                std::vector<uint64_t> keys;
+                std::vector<float> dist;
+                size_t found = 0, qi = 0;
+                bool busy = false, done = true;
+                Clock::time_point start;
+                int status = 0;
+                std::mutex* mu;
+                std::condition_variable* cv;
+            };
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<Slot> slots(inflight);
+            for (auto& sl : slots) {
+                sl.keys.resize(k);
+                sl.dist.resize(k);
+                sl.mu = &mu;
+                sl.cv = &cv;
+            }
+            auto done = [](void* ctx, int status) {
+                Slot* sl = (Slot*)ctx;
+                std::lock_guard<std::mutex> lk(*sl->mu);
+                sl->status = status;
+                sl->done = true;
+                sl->cv->notify_one();
+            };
+            size_t outstanding = 0;
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                bool stopping = stop.load(std::memory_order_relaxed);
+                for (auto& sl : slots) {
+                    if (!sl.done) continue;
+                    if (sl.busy) {  // a completed query
+                        int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - sl.start).count();
+                        if (sl.status != VS_OK) ++errors[t];
+                        else per[t].record(ns, truth ? recall_of(truth + sl.qi * k, k, sl.keys.data(), sl.found) : 0.0);
+                        sl.busy = false;
+                        --outstanding;
+                    }
+                    if (stopping) continue;
+                    sl.qi = g() % nq;
+                    sl.done = false;
+                    sl.busy = true;
+                    sl.start = Clock::now();
+                    ++outstanding;
+                    lk.unlock();
+                    int rc = vs_hnsw_search_async(h, queries + sl.qi * dim, dim, k, sl.keys.data(), sl.dist.data(), &sl.found, done, &sl);
+                    lk.lock();
+                    if (rc != VS_OK) {
+                        ++errors[t];
+                        sl.done = true;
+                        sl.busy = false;
+                        --outstanding;
+                        stopping = true;
+                        stop = true;
+                    }
+                }
+                if (stopping && outstanding == 0) break;
+                cv.wait(lk, [&] {
+                    for (auto& sl : slots)
+                        if (sl.done && sl.busy) return true;
+                    return stop.load() && outstanding == 0;
+                });
+            }
+        });
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    stop = true;
+    for (auto& x : th) x.join();
+    const double wall = std::chrono::duration<double>(Clock::now() - t0).count();
+    (void)vs_search_service_stats(sv1);
+    SearchMeasure all;
+    all.with_recall = truth != nullptr;
+    for (auto& m : per) all.append(m);
+    out->seconds = wall;
+    out->queries = all.count;
+    out->qps = all.count / wall;
+    out->latency_min_ns = all.count ? all.latency_min : 0;
+    out->latency_max_ns = all.latency_max;
+    out->p01_ns = all.histogram.percentile(1);
+    out->p10_ns = all.histogram.percentile(10);
+    out->p25_ns = all.histogram.percentile(25);
+    out->p50_ns = all.histogram.percentile(50);
+    out->p75_ns = all.histogram.percentile(75);
+    out->p90_ns = all.histogram.percentile(90);
+    out->p99_ns = all.histogram.percentile(99);
+    out->recall_avg = truth && all.count ? all.recall_sum / (double)all.count : -1.0;
+    out->errors = 0;
+    for (uint64_t e : errors) out->errors += e;
+    out->launches = sv1[0] - sv0[0];
+    out->team_launches = sv1[2] - sv0[2];
+    return VS_OK;
+}

@@ -337,6 +337,9 @@ struct Engine {
     uint32_t chunk_rows = kChunk;
     int order_mode = 0;               // 0 = usearch-order walk for the tie-heavy metrics (i8, b1), fused list otherwise;
                                       // 1 = always the usearch-order walk (reserved bit 4); 2 = never (A/B measurements only)
+    bool tie_newest = true;           // build: equal distances ordered as usearch's sorted buffer orders them (newest first; in a
+                                      // re-selected row: later members first, the new link last).  VS_HNSW_TIE=random: pseudo-random
+                                      // per node (round 1), kept for A/B -- on 50x duplicated data it costs 0.20 of the tied recall
     bool force_wide_tags = false;     // reserved bit 6 (tests): wide visited tags although the index is small
     bool force_global_walk = false;   // reserved bit 5 (tests): every search takes the global-bitmap walk instance
     int team_mode = 0;                // 0 = by batch size; reserved bit 2 = always a team per query, bit 3 = never
@@ -396,6 +399,8 @@ struct Engine {
     std::atomic<size_t> queued{0};               // pending + being flushed
     std::atomic<size_t> committed{0};            // live members + staged adds: what capacity is checked against
     std::mutex key_mu;                           // guards `lookup` membership (adds validate against it concurrently)
+    std::mutex poison_mu;
+    std::string poison;                          // set when a deferred insertion failed: every later call reports it
 
     void use_device() const { HIP_OK(hipSetDevice(device)); }
 
@@ -445,6 +450,7 @@ struct Engine {
         order_mode = (o.reserved & 16) ? 1 : 0;
         force_global_walk = (o.reserved & 32) != 0;
         force_wide_tags = (o.reserved & 64) != 0;
+        if (const char* tn = std::getenv("VS_HNSW_TIE")) tie_newest = std::strcmp(tn, "random") != 0;
         if (const char* fw = std::getenv("VS_HNSW_WALK")) force_global_walk = !std::strcmp(fw, "global");
         if (const char* om = std::getenv("VS_HNSW_ORDER")) order_mode = !std::strcmp(om, "usearch") ? 1 : !std::strcmp(om, "fused") ? 2 : order_mode;
         if (const char* cr = std::getenv("VS_HNSW_CHUNK")) chunk_rows = (uint32_t)std::max(1024, std::atoi(cr));                      // build experiments
@@ -747,6 +753,7 @@ struct Engine {
                 ia.n = take;
                 ia.ef_add = ef_add;
                 ia.team = (team_mode == 1 || (team_mode == 0 && take <= team_max_nq)) ? (uint32_t)kSearchTeam : 1u;
+                ia.tie_newest = tie_newest ? 1u : 0u;
                 ia.wide_tags = (slots > (1ull << visited_domain_bits(ef_add)) || force_wide_tags) ? 1u : 0u;
                 ia.req_base = req_off[pos];
                 ia.req_key = rk_in;
@@ -761,6 +768,7 @@ struct Engine {
                     la.req_val = rv_out;
                     la.total = total_req;
                     la.cache_rows = link_cache_rows;
+                    la.tie_newest = tie_newest ? 1u : 0u;
                     la.stats = d_stats;
                     HIP_OK(launch_link(la, iters, st));
                 }
@@ -792,6 +800,13 @@ struct Engine {
     static constexpr size_t kFlushThreshold = 4096;
 
     int add_one(uint64_t key, const float* v) {
+        {
+            std::lock_guard<std::mutex> pg(poison_mu);
+            if (!poison.empty()) {
+                g_err = poison;
+                return VS_ERR_DEVICE;
+            }
+        }
         std::unique_lock<std::mutex> lk(pend_mu);
         if (key == kFreeKey) {
             g_err = error_text(VS_ERR_INVALID_ARGUMENT);
@@ -841,6 +856,20 @@ struct Engine {
             rc = VS_ERR_DEVICE;
             g_err = e.what();
         }
+        if (rc != VS_OK) {
+            // The staged vectors are lost although their vs_hnsw_add calls returned VS_OK, and add_batch may have stopped
+            // between the host bookkeeping and the GPU work: the index is not trustworthy any more.  It says so to every
+            // later call (a device failure is not recoverable in this process anyway) instead of reporting a false
+            // "Reserve capacity" to an unrelated caller (advisor finding, round 1).
+            size_t lost = 0;
+            {
+                std::lock_guard<std::mutex> kg(key_mu);
+                for (uint64_t k : take.keys) lost += lookup.count(k) ? 0 : 1;
+            }
+            committed -= std::min(lost, committed.load());
+            std::lock_guard<std::mutex> pg(poison_mu);
+            if (poison.empty()) poison = "index unusable after a failed insertion of " + std::to_string(lost) + " staged vectors: " + g_err;
+        }
         lk.lock();
         for (uint64_t k : take.keys) flushing_keys.erase(k);
         queued -= take.keys.size();
@@ -849,6 +878,10 @@ struct Engine {
 
     // Barrier used by every operation that observes the index.
     void flush_pending() {
+        {
+            std::lock_guard<std::mutex> pg(poison_mu);
+            if (!poison.empty()) fail(VS_ERR_DEVICE, poison);
+        }
         {
             std::unique_lock<std::mutex> lk(pend_mu);
             int rc = flush_locked(lk);

@@ -431,6 +431,7 @@ struct SelArrays {  // heuristic output (insert / link kernels only)
     uint32_t sel_s[64];
     float sel_d[64];
     uint32_t tie_salt;  // insert kernel: order among equal distances is pseudo-random per new node (see key_less_in)
+    uint32_t tie_newest;  // 1: usearch's own order instead -- a newly found entry precedes the equal ones already listed
 };
 template <>
 struct SelArrays<false> {};
@@ -755,12 +756,17 @@ __device__ __forceinline__ uint32_t list_merge(Sh& sh, int cur, uint32_t sz, uin
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool valid = (uint32_t)lane + (uint32_t)r * kWave < sz;
-            const bool less = valid && key_less_in(sh, keep_d[r], keep_s[r], dj, sj);
+            bool less;
+            if constexpr (Sh::kSel) less = valid && (sh.tie_newest ? keep_d[r] < dj : key_less_in(sh, keep_d[r], keep_s[r], dj, sj));
+            else less = valid && key_less_in(sh, keep_d[r], keep_s[r], dj, sj);
             below += (uint32_t)__popcll(__ballot(less));
             shift[r] += (valid && !less) ? 1u : 0u;
         }
         if ((uint32_t)lane == j) r_old = below;
-        r_new += ((uint32_t)lane < m && key_less_in(sh, dj, sj, nd, ns)) ? 1u : 0u;
+        bool before;  // new element j precedes this lane's new element
+        if constexpr (Sh::kSel) before = sh.tie_newest ? (dj < nd || (dj == nd && j > (uint32_t)lane)) : key_less_in(sh, dj, sj, nd, ns);
+        else before = key_less_in(sh, dj, sj, nd, ns);
+        r_new += ((uint32_t)lane < m && before) ? 1u : 0u;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -877,12 +883,20 @@ __device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>&
             if (sz == ef) admit = admit && nd < sh.lst_d[cur][ef - 1];
         }
         if (sh.overflowed) {  // wave-uniform; see visited_test_and_set: re-evaluated nodes are dropped here
+            bool positional = false;
+            if constexpr (Sh::kSel) positional = sh.tie_newest != 0;
             uint32_t lo = 0, hi = admit ? sz : 0;
             while (lo < hi) {
                 uint32_t mid = (lo + hi) >> 1;
-                if (key_less_in(sh, sh.lst_d[cur][mid], sh.lst_s[cur][mid], nd, ns)) lo = mid + 1; else hi = mid;
+                const bool lt = positional ? sh.lst_d[cur][mid] < nd : key_less_in(sh, sh.lst_d[cur][mid], sh.lst_s[cur][mid], nd, ns);
+                if (lt) lo = mid + 1; else hi = mid;
             }
-            if (admit && lo < sz && (sh.lst_s[cur][lo] & kSlotMask) == (ns & kSlotMask) && sh.lst_d[cur][lo] == nd) admit = false;
+            if (positional) {  // equal distances are not ordered by slot: scan the run
+                for (; admit && lo < sz && sh.lst_d[cur][lo] == nd; ++lo)
+                    if ((sh.lst_s[cur][lo] & kSlotMask) == (ns & kSlotMask)) admit = false;
+            } else if (admit && lo < sz && (sh.lst_s[cur][lo] & kSlotMask) == (ns & kSlotMask) && sh.lst_d[cur][lo] == nd) {
+                admit = false;
+            }
         }
         uint64_t amask = __ballot(admit);
         uint32_t ma = (uint32_t)__popcll(amask);

@@ -37,6 +37,7 @@ struct InsertArgs {
     uint32_t n, ef_add;
     uint32_t team;            // waves per new node: 1, or kSearchTeam for sub-batches too small to fill the chip
     uint32_t wide_tags;       // see SearchArgs
+    uint32_t tie_newest;      // order among equal distances: 0 pseudo-random per node, 1 usearch's (newest first)
     uint32_t req_base;        // req_off[first node of this sub-batch]
     uint64_t* req_key;        // (level << 32) | target, ~0 = unused
     uint64_t* req_val;        // (float bits of d(source,target) << 32) | source
@@ -49,6 +50,7 @@ struct LinkArgs {
     const uint64_t* req_val;
     uint32_t total;
     uint32_t cache_rows;      // accepted neighbours whose rows the re-selection keeps in LDS (0 = none)
+    uint32_t tie_newest;      // see InsertArgs (here: later list members first, new links last, as sorted_buffer_gt orders them)
     unsigned long long* stats;
 };
 

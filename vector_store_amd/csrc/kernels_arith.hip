@@ -103,7 +103,10 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_insert_kernel(InsertArgs a) {
     const int level = a.levels[b];
     Query<AR, I> q;
     query_from_row<AR, I>(ix, slot, q, lane);
-    if (threadIdx.x == 0) sh.tie_salt = slot * 0x9E3779B1u;  // read by wave 0 only, after its first wsync
+    if (threadIdx.x == 0) {  // read by wave 0 only, after its first wsync
+        sh.tie_salt = slot * 0x9E3779B1u;
+        sh.tie_newest = a.tie_newest;
+    }
     if constexpr (TEAM > 1) {
         const uint32_t w = threadIdx.x >> 6;
         if (w != 0) {
@@ -250,74 +253,94 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
     const uint64_t key = a.req_key[r];
     if (key == ~0ull) return;
     if (r > 0 && a.req_key[r - 1] == key) return;  // not the head of its (level, target) group
-    uint32_t n_new;
-    {
-        uint32_t idx = r + (uint32_t)lane;
-        bool same = idx < a.total && a.req_key[idx] == key;
-        uint64_t mask = __ballot(same);
-        n_new = ~mask ? (uint32_t)__builtin_ctzll(~mask) : kMaxNewPerTarget;
-    }
     const uint32_t target = (uint32_t)key;
     const int level = (int)(key >> 32);
     uint32_t cap;
     uint32_t* row = const_cast<uint32_t*>(adjacency(ix, target, level, cap));
-    uint32_t src = kInvalid;
-    float src_d = 0.f;
-    if ((uint32_t)lane < n_new) {
-        uint64_t v = a.req_val[r + lane];
-        src = (uint32_t)v;
-        src_d = __uint_as_float((uint32_t)(v >> 32));
-    }
-    // existing links; a link to a source being (re)inserted is superseded by the new request
-    uint32_t ex = (uint32_t)lane < cap ? row[lane] : kInvalid;
-    for (uint32_t j = 0; j < n_new; ++j) {
-        uint32_t sj = (uint32_t)__shfl((int)src, (int)j);
-        if (ex == sj) ex = kInvalid;
-    }
-    uint64_t emask = __ballot(ex != kInvalid);
-    const uint32_t cnt = (uint32_t)__popcll(emask);
-    if (ex != kInvalid) sh.u_slot[mbcnt(emask)] = ex;
-    __syncthreads();
-    if (cnt + n_new <= cap) {  // usearch: close_header.push_back(new_slot)
-        const bool is_new = lane >= (int)cnt && lane < (int)(cnt + n_new);
-        const uint32_t from_new = (uint32_t)__shfl((int)src, is_new ? lane - (int)cnt : 0);
-        if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < cnt ? sh.u_slot[lane] : (is_new ? from_new : kInvalid);
-        return;
-    }
-    // usearch: top = {new} U existing, all measured from `close_slot`; refine_(connectivity_max)
     Counters c = {0, 0, 0};
-    Query<AR, I> q;
-    query_from_row<AR, I>(ix, target, q, lane);
-    eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, cnt, lane);
-    __syncthreads();
-    c.evals += cnt;
-    const uint32_t total = cnt + n_new;  // <= 32 + 64
-    if ((uint32_t)lane < cnt) {
-        sh.t_d[lane] = sh.u_dist[lane];
-        sh.t_s[lane] = sh.u_slot[lane];
+    // A group of more than 64 requests (hub targets: clustered or duplicate-heavy data) is taken 64 at a time, each round
+    // against the row the round before left -- as if the sources had arrived in that order (usearch's reconnect runs once
+    // per arriving source); before, requests 65.. of a group were dropped (advisor finding, round 1).
+    for (uint32_t base = r;; base += kMaxNewPerTarget) {
+        uint32_t n_new;
+        {
+            uint32_t idx = base + (uint32_t)lane;
+            bool same = idx < a.total && a.req_key[idx] == key;
+            uint64_t mask = __ballot(same);
+            n_new = ~mask ? (uint32_t)__builtin_ctzll(~mask) : kMaxNewPerTarget;
+        }
+        if (n_new == 0) break;
+        uint32_t src = kInvalid;
+        float src_d = 0.f;
+        if ((uint32_t)lane < n_new) {
+            uint64_t v = a.req_val[base + lane];
+            src = (uint32_t)v;
+            src_d = __uint_as_float((uint32_t)(v >> 32));
+        }
+        // existing links; a link to a source being (re)inserted is superseded by the new request
+        uint32_t ex = (uint32_t)lane < cap ? row[lane] : kInvalid;
+        for (uint32_t j = 0; j < n_new; ++j) {
+            uint32_t sj = (uint32_t)__shfl((int)src, (int)j);
+            if (ex == sj) ex = kInvalid;
+        }
+        uint64_t emask = __ballot(ex != kInvalid);
+        const uint32_t cnt = (uint32_t)__popcll(emask);
+        __syncthreads();
+        if (ex != kInvalid) sh.u_slot[mbcnt(emask)] = ex;
+        __syncthreads();
+        if (cnt + n_new <= cap) {  // usearch: close_header.push_back(new_slot)
+            const bool is_new = lane >= (int)cnt && lane < (int)(cnt + n_new);
+            const uint32_t from_new = (uint32_t)__shfl((int)src, is_new ? lane - (int)cnt : 0);
+            if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < cnt ? sh.u_slot[lane] : (is_new ? from_new : kInvalid);
+        } else {
+            // usearch: top = {new} U existing, all measured from `close_slot`; refine_(connectivity_max)
+            Query<AR, I> q;
+            query_from_row<AR, I>(ix, target, q, lane);
+            eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, cnt, lane);
+            __syncthreads();
+            c.evals += cnt;
+            const uint32_t total = cnt + n_new;  // <= 32 + 64
+            if ((uint32_t)lane < cnt) {
+                sh.t_d[lane] = sh.u_dist[lane];
+                sh.t_s[lane] = sh.u_slot[lane];
+            }
+            if ((uint32_t)lane < n_new) {
+                sh.t_d[cnt + lane] = src_d;
+                sh.t_s[cnt + lane] = src;
+            }
+            __syncthreads();
+            for (uint32_t e = (uint32_t)lane; e < total; e += kWave) {  // rank sort, ascending
+                float ed = sh.t_d[e];
+                uint32_t es = sh.t_s[e];
+                uint32_t rank = 0;
+                if (a.tie_newest) {
+                    // usearch builds this list with top.insert(new), then top.insert(existing...) in adjacency order, each
+                    // going IN FRONT of equal ones: among equal distances the later members of the row come first, the
+                    // new link last
+                    const uint32_t te = e < cnt ? cnt - 1u - e : e;
+                    for (uint32_t f = 0; f < total; ++f) {
+                        const uint32_t tf = f < cnt ? cnt - 1u - f : f;
+                        rank += (sh.t_d[f] < ed || (sh.t_d[f] == ed && tf < te)) ? 1u : 0u;
+                    }
+                } else {
+                    // A/B only (VS_HNSW_TIE=random): a pseudo-random order per target among equal distances
+                    const uint32_t salt = target * 0x9E3779B1u;
+                    for (uint32_t f = 0; f < total; ++f)
+                        rank += key_less(sh.t_d[f], (sh.t_s[f] ^ salt) * 0x85EBCA6Bu, ed, (es ^ salt) * 0x85EBCA6Bu) ? 1u : 0u;
+                }
+                sh.lst_d[0][rank] = ed;
+                sh.lst_s[0][rank] = es;
+            }
+            __syncthreads();
+            extern __shared__ uint4 link_rowbuf[];
+            uint32_t nsel = a.cache_rows ? refine_cached<AR, I>(ix, sh, link_rowbuf, a.cache_rows, total, cap, c, lane)
+                                         : refine<AR, I>(ix, sh, 0, total, cap, c, lane);
+            if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < nsel ? sh.sel_s[lane] : kInvalid;
+        }
+        if (n_new < kMaxNewPerTarget) break;
+        __syncthreads();
     }
-    if ((uint32_t)lane < n_new) {
-        sh.t_d[cnt + lane] = src_d;
-        sh.t_s[cnt + lane] = src;
-    }
-    __syncthreads();
-    for (uint32_t e = (uint32_t)lane; e < total; e += kWave) {  // rank sort, ascending (distance, slot)
-        float ed = sh.t_d[e];
-        uint32_t es = sh.t_s[e];
-        uint32_t rank = 0;
-        // ties: a pseudo-random order per target (a fixed "lowest slot first" keeps the same old members of a group of
-        // exact duplicates in every list and leaves the later ones without incoming links)
-        const uint32_t salt = target * 0x9E3779B1u;
-        for (uint32_t f = 0; f < total; ++f) rank += key_less(sh.t_d[f], (sh.t_s[f] ^ salt) * 0x85EBCA6Bu, ed, (es ^ salt) * 0x85EBCA6Bu) ? 1u : 0u;
-        sh.lst_d[0][rank] = ed;
-        sh.lst_s[0][rank] = es;
-    }
-    __syncthreads();
-    extern __shared__ uint4 link_rowbuf[];
-    uint32_t nsel = a.cache_rows ? refine_cached<AR, I>(ix, sh, link_rowbuf, a.cache_rows, total, cap, c, lane)
-                                 : refine<AR, I>(ix, sh, 0, total, cap, c, lane);
-    if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < nsel ? sh.sel_s[lane] : kInvalid;
-    if (lane == 0) {
+    if (lane == 0 && c.evals) {
         atomicAdd(&a.stats[ST_ADD_EVALS], c.evals);
         atomicAdd(&a.stats[ST_LINK_EVALS], c.evals);
     }

@@ -36,22 +36,30 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
         ws.heap_cap = a.heap_cap;
     }
     const uint32_t total = a.qlist ? *a.qcount : a.nq;
+    if (ix.max_level < 0) {  // empty index: nothing to walk
+        for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+            const uint32_t qi = a.qlist ? a.qlist[t] : t;
+            for (uint32_t i = lane; i < a.k; i += kWave) {
+                a.out_keys[(size_t)qi * a.k + i] = kFreeKey;
+                a.out_dist[(size_t)qi * a.k + i] = __builtin_inff();
+            }
+            if (lane == 0) a.out_found[qi] = 0;
+        }
+        return;
+    }
+    __shared__ uint32_t next_query;
     for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(a.work_counter, 1u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        // The next query comes from a shared counter; it reaches the wave through LDS between two barriers.  (Lane 0's
+        // atomic followed by v_readfirstlane is NOT enough: on a path without a barrier the compiler peeled the other 63
+        // lanes into a loop of their own that never re-ran the atomic -- an endless loop on an empty index.)
+        if (lane == 0) next_query = atomicAdd(a.work_counter, 1u);
+        __syncthreads();
+        const uint32_t t = next_query;
+        __syncthreads();
         if (t >= total) break;
         const uint32_t qi = a.qlist ? a.qlist[t] : t;
         uint64_t* ok = a.out_keys + (size_t)qi * a.k;
         float* od = a.out_dist + (size_t)qi * a.k;
-        if (ix.max_level < 0) {
-            for (uint32_t i = lane; i < a.k; i += kWave) {
-                ok[i] = kFreeKey;
-                od[i] = __builtin_inff();
-            }
-            if (lane == 0) a.out_found[qi] = 0;
-            continue;
-        }
         Query<AR, I> q;
         query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
         Counters cnt = {0, 0, 0};

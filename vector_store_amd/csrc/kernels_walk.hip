@@ -130,9 +130,10 @@ constexpr int kWalkHeapLds = VS_WALK_LCAP;  // entries of `next` in LDS (LDS ins
 template <int AR, int I>
 static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out) {
     switch (instance) {
+        // `next` in LDS: 4 x the beam (largest heap seen at 1M x 768: 469 / 792 at beams of 128 / 256); beyond -> retry instance
         case WALK_LDS_128: return walk_launch<AR, I, 128, kWalkHeapLds, 1024, 1, false>(a, grid_cap, s, grid_out);
-        case WALK_LDS_256: return walk_launch<AR, I, 256, kWalkHeapLds, 1024, 2, false>(a, grid_cap, s, grid_out);
-        case WALK_LDS_512: return walk_launch<AR, I, 512, kWalkHeapLds, 2048, 2, false>(a, grid_cap, s, grid_out);
+        case WALK_LDS_256: return walk_launch<AR, I, 256, 2 * kWalkHeapLds, 1024, 2, false>(a, grid_cap, s, grid_out);
+        case WALK_LDS_512: return walk_launch<AR, I, 512, 4 * kWalkHeapLds, 2048, 2, false>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_512: return walk_launch<AR, I, 512, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_2048: return walk_launch<AR, I, 2048, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_10240: return walk_launch<AR, I, 10240, 1024, 256, 1, true>(a, grid_cap, s, grid_out);

@@ -113,53 +113,112 @@ __device__ __forceinline__ void heap_set(Sh& sh, const WalkSpace& ws, uint32_t i
 }
 
 // emplace + shift_up: the new entry climbs while its parent is strictly farther.
+// LDS-only heaps (LDS instances): the ancestors of the insertion point are known up front -- ((pos + 1) >> k) - 1 --, so
+// lane k loads ancestor k, one ballot says how far the entry climbs, and the entries on that stretch move down one
+// level each in ONE parallel store: one LDS round trip per push instead of one per level.
 template <class Sh>
 __device__ __forceinline__ void heap_push(Sh& sh, const WalkSpace& ws, uint32_t& hn, float d, uint32_t slot, int lane) {
-    uint32_t i = uni(hn);
-    hn = i + 1u;
-    while (i) {
-        const uint32_t p = (i - 1u) >> 1;
-        const uint2 e = heap_get(sh, ws, p);
-        if (!(__uint_as_float(e.x) > d)) break;
-        heap_set(sh, ws, i, e, lane);
-        i = p;
+    if constexpr (!Sh::kHeapSpill) {
+        const uint32_t pos = uni(hn);
+        hn = pos + 1u;
+        const uint32_t depth = 32u - (uint32_t)__builtin_clz(pos + 1u) - 1u;  // ancestors 1..depth (ancestor `depth` is the root)
+        const uint32_t k = (uint32_t)lane;
+        const bool on = k >= 1u && k <= depth;
+        const uint32_t anc = ((pos + 1u) >> (on ? k : 0u)) - 1u;
+        const uint2 e = on ? sh.hp[anc] : make_uint2(0u, 0u);
+        // climbs past ancestor k iff every ancestor 1..k is strictly farther: leading ones of the ballot from bit 1
+        const uint64_t far = __ballot(on && __uint_as_float(e.x) > d) >> 1;
+        const uint32_t climb = (uint32_t)__builtin_ctzll(~far);  // <= depth
+        if (on && k <= climb) sh.hp[((pos + 1u) >> (k - 1u)) - 1u] = e;  // ancestor k moves down to where ancestor k - 1 was
+        if (lane == 0) sh.hp[((pos + 1u) >> climb) - 1u] = make_uint2(__float_as_uint(d), slot);
+        return;
+    } else {
+        uint32_t i = uni(hn);
+        hn = i + 1u;
+        while (i) {
+            const uint32_t p = (i - 1u) >> 1;
+            const uint2 e = heap_get(sh, ws, p);
+            if (!(__uint_as_float(e.x) > d)) break;
+            heap_set(sh, ws, i, e, lane);
+            i = p;
+        }
+        heap_set(sh, ws, i, make_uint2(__float_as_uint(d), slot), lane);
     }
-    heap_set(sh, ws, i, make_uint2(__float_as_uint(d), slot), lane);
 }
 
 // pop: swap(first, last), shrink, shift_down(0): the larger child is the right one only when the left one is strictly
 // farther ("less(left, right)"), and the entry sinks only while it is strictly farther than that child.
-// Both children are read at once (one LDS latency per level); a right child beyond the heap is ignored.
+// LDS-only heaps: which child a node prefers does not depend on the sinking entry, so (1) every internal node's
+// preference is computed in parallel (lane i handles nodes i, i + 64, ...: ballots -> bit masks in scalar registers),
+// (2) the path of preferred children from the root to a leaf is followed on those bits with scalar code, (3) lane k loads
+// the k-th node of the path, one ballot says where the last entry stops, one parallel store moves the stretch up.
+// Three LDS round trips per pop instead of two per level.
 template <class Sh>
 __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& hn, int lane) {
     const uint32_t n = uni(hn) - 1u;
     hn = n;
     if (n == 0) return;
-    const uint2 last = heap_get(sh, ws, n);
-    const float ld = __uint_as_float(last.x);
-    uint32_t i = 0;
-    for (;;) {
-        const uint32_t l = 2u * i + 1u;
-        if (l >= n) break;
-        uint2 ec, er;
-        if constexpr (Sh::kHeapSpill) {
-            ec = heap_get(sh, ws, l);
-            er = l + 1u < n ? heap_get(sh, ws, l + 1u) : ec;
-        } else {
-            const uint2 a = sh.hp[l], b = sh.hp[l + 1u];
-            ec = make_uint2(uni(a.x), uni(a.y));
-            er = make_uint2(uni(b.x), uni(b.y));
+    if constexpr (!Sh::kHeapSpill) {
+        constexpr int RMAX = Sh::kHeapLds / 128;  // 64 internal nodes per ballot
+        const uint2 last = sh.hp[n];
+        const float ld = __uint_as_float(uni(last.x));
+        uint64_t pref[RMAX];  // bit i of pref[r]: node 64 r + i prefers its RIGHT child
+        const uint32_t internal = n >> 1;  // nodes with a left child below n: 2 i + 1 < n  <=>  i < n / 2 (n >= 1)
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            pref[r] = 0;
+            if ((uint32_t)r * 64u < internal) {
+                const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane, l = 2u * i + 1u;
+                const bool two = l + 1u < n;  // both children exist
+                const float dl = two ? __uint_as_float(sh.hp[l].x) : 0.f, dr = two ? __uint_as_float(sh.hp[l + 1u].x) : 0.f;
+                pref[r] = __ballot(two && dl > dr);
+            }
         }
-        uint32_t c = l;
-        if (l + 1u < n && __uint_as_float(ec.x) > __uint_as_float(er.x)) {
-            ec = er;
-            c = l + 1u;
+        // the path root -> leaf; lane k keeps node k of it (and node k - 1, where its entry may move to)
+        uint32_t p = 0, len = 0, mine = 0, above = 0;
+        for (;;) {
+            const uint32_t l = 2u * p + 1u;
+            if (l >= n) break;
+            uint64_t w = pref[0];
+#pragma unroll
+            for (int r = 1; r < RMAX; ++r) w = (p >> 6) == (uint32_t)r ? pref[r] : w;
+            const uint32_t c = l + (uint32_t)((w >> (p & 63u)) & 1ull);
+            ++len;
+            if ((uint32_t)lane == len) {
+                mine = c;
+                above = p;
+            }
+            p = c;
         }
-        if (!(ld > __uint_as_float(ec.x))) break;
-        heap_set(sh, ws, i, ec, lane);
-        i = c;
+        const bool on = (uint32_t)lane >= 1u && (uint32_t)lane <= len;
+        const uint2 e = on ? sh.hp[mine] : make_uint2(0u, 0u);
+        const uint64_t closer = __ballot(on && ld > __uint_as_float(e.x)) >> 1;  // bit k - 1: the last entry sinks past path node k
+        const uint32_t sink = (uint32_t)__builtin_ctzll(~closer);                // <= len
+        if (on && (uint32_t)lane <= sink) sh.hp[above] = e;                       // path node k moves up to node k - 1
+        // the last entry lands on path node `sink` (the root when it does not sink at all)
+        const uint32_t land = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)sink);
+        if (lane == 0) sh.hp[sink ? land : 0u] = make_uint2(last.x, last.y);
+        return;
+    } else {
+        const uint2 last = heap_get(sh, ws, n);
+        const float ld = __uint_as_float(last.x);
+        uint32_t i = 0;
+        for (;;) {
+            const uint32_t l = 2u * i + 1u;
+            if (l >= n) break;
+            uint2 ec = heap_get(sh, ws, l);
+            uint2 er = l + 1u < n ? heap_get(sh, ws, l + 1u) : ec;
+            uint32_t c = l;
+            if (l + 1u < n && __uint_as_float(ec.x) > __uint_as_float(er.x)) {
+                ec = er;
+                c = l + 1u;
+            }
+            if (!(ld > __uint_as_float(ec.x))) break;
+            heap_set(sh, ws, i, ec, lane);
+            i = c;
+        }
+        heap_set(sh, ws, i, last, lane);
     }
-    heap_set(sh, ws, i, last, lane);
 }
 
 // ---- visited ---------------------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["hnsw_device.hpp", "walk_device.hpp", "kernels_arith.hip", "kernels_walk.hip", "kernels_misc.hip", "kernels.hpp"]
+KERNEL_SOURCES = ["hnsw_device.hpp", "kernels_arith.hip", "kernels_misc.hip", "kernels.hpp"]  # what the fused search / insert / exact kernels are built from
 
 
 def kernel_sources_sha16():

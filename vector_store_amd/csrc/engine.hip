@@ -302,6 +302,8 @@ struct WalkRes {
     DeviceBuf retry;      // [count u32, 63 pad words | query ids]
     DeviceBuf allow;      // filtered search: the allow-bitmap of the query
     std::mutex mu;        // held while a call sizes the buffers and enqueues its launches
+    uint32_t* retry_seen = nullptr;  // pinned: [retried queries of the last small-table launch, its batch size]
+    bool retry_seen_valid = false;
     size_t g_layout[3] = {0, 0, 0};  // (bitmap words, stride, bytes) the bitmaps of g_space are known to be zero for
 };
 static WalkRes& walk_res(int dev, hipStream_t st) {
@@ -340,6 +342,7 @@ struct Engine {
     bool tie_newest = true;           // build: equal distances ordered as usearch's sorted buffer orders them (newest first; in a
                                       // re-selected row: later members first, the new link last).  VS_HNSW_TIE=random: pseudo-random
                                       // per node (round 1), kept for A/B -- on 50x duplicated data it costs 0.20 of the tied recall
+    std::atomic<bool> small_table_ok{true};  // usearch-order walk, beams <= 128: the half-size visited table is paying off
     bool force_wide_tags = false;     // reserved bit 6 (tests): wide visited tags although the index is small
     bool force_global_walk = false;   // reserved bit 5 (tests): every search takes the global-bitmap walk instance
     int team_mode = 0;                // 0 = by batch size; reserved bit 2 = always a team per query, bit 3 = never
@@ -1002,7 +1005,16 @@ struct Engine {
                 return;
             }
             // LDS visited table; queries that exhaust it (or the heap workspace) go to a global-bitmap launch behind
-            const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : WALK_LDS_512;
+            // Beams up to 128 visit ~3,000 nodes: a 4,096-entry two-choice table holds them in half the LDS (11 instead of 6
+            // walks per CU).  Queries that outgrow it are retried exactly (global bitmap); should a data set make that
+            // common -- the previous launch's retry count is read back with every launch -- the index goes back to the
+            // 8,192-entry table for good.
+            if (wr.retry_seen_valid) {
+                if (wr.retry_seen[1] >= 64 && wr.retry_seen[0] * 20 > wr.retry_seen[1]) small_table_ok = false;  // > 5 % retried
+                wr.retry_seen_valid = false;
+            }
+            const bool small = ef <= 128 && small_table_ok.load() && slots <= (1ull << walk_small_table_bits()) && !stress_small_table;
+            const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : WALK_LDS_512;
             a.bitmap_words = 0;
             a.vlog_cap = 0;
             a.heap_cap = 8192;
@@ -1029,6 +1041,12 @@ struct Engine {
             }
             HIP_OK(launch_walk(a, iters, inst, grid, st, nullptr));
             HIP_OK(launch_walk(r, iters, WALK_GLOBAL_512, rgrid, st, nullptr));
+            if (small) {  // how many queries of this launch had to be retried: looked at by the next launch on this stream
+                if (!wr.retry_seen) HIP_OK(hipHostMalloc((void**)&wr.retry_seen, 8, hipHostMallocDefault));
+                wr.retry_seen[1] = (uint32_t)nq;
+                HIP_OK(hipMemcpyAsync(&wr.retry_seen[0], retry, 4, hipMemcpyDeviceToHost, st));
+                wr.retry_seen_valid = true;  // (read one launch later: by then the copy has long landed; a stale value only delays the switch)
+            }
             if (walk_debug) {
                 std::vector<uint32_t> h(nq * 12);
                 uint32_t retried = 0;

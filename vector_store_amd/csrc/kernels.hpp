@@ -56,7 +56,8 @@ struct LinkArgs {
 
 // The usearch-order walk (walk_device.hpp / kernels_walk.hip): persistent workgroups, one WalkSpace each.
 enum : uint32_t { WALK_LDS_128 = 0, WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512, WALK_GLOBAL_2048, WALK_GLOBAL_10240,
-                  WALK_LDS_128_TINY /* test hook: 256-bucket visited table (1-chunk rows only), forces the retry path */ };
+                  WALK_LDS_128_TINY /* test hook: 256-bucket visited table (1-chunk rows only), forces the retry path */,
+                  WALK_LDS_128_SMALL /* 512-bucket two-choice table (4,096 entries, slots < 2^24): 14.6 KB of LDS, 11 waves per CU */ };
 constexpr uint32_t kWalkFailed = 0xFFFFFFFFu;  // out_found: the walk outgrew its workspace, the query was not answered
 constexpr uint32_t kMaxWalkBeam = 10240;       // widest `top` of the walk instances
 
@@ -104,6 +105,7 @@ hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s);
 hipError_t launch_link(const LinkArgs& a, uint32_t iters, hipStream_t s);
 // bits of slot ids the visited table of the kernel chosen for `ef` can distinguish (wide: the 4-extra-tag-bit instance)
 uint32_t visited_domain_bits(uint32_t ef, bool wide = false);
+uint32_t walk_small_table_bits();  // slot bits WALK_LDS_128_SMALL can tell apart
 
 // f32 rows (dim floats, src_stride apart) -> storage rows (cast as usearch does, zero padded) + aux;
 // rows given by slots[] or first + i

@@ -22,6 +22,8 @@ bool search_supported(uint32_t iters, uint32_t ef) {
     return (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8) && ef >= 1 && ef <= 512;
 }
 
+uint32_t walk_small_table_bits() { return VisitedCfg<512, 2>::domain_bits; }
+
 uint32_t visited_domain_bits(uint32_t ef, bool wide) {
     if (wide) return ef <= 128 ? VisitedCfg<1024, 1, true>::domain_bits : ef <= 256 ? VisitedCfg<1024, 2, true>::domain_bits : VisitedCfg<2048, 2, true>::domain_bits;
     return ef <= 128 ? VisitedCfg<1024, 1>::domain_bits : ef <= 256 ? VisitedCfg<1024, 2>::domain_bits : VisitedCfg<2048, 2>::domain_bits;

@@ -137,6 +137,7 @@ static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_ca
         case WALK_GLOBAL_512: return walk_launch<AR, I, 512, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_2048: return walk_launch<AR, I, 2048, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_10240: return walk_launch<AR, I, 10240, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
+        case WALK_LDS_128_SMALL: return walk_launch<AR, I, 128, kWalkHeapLds, 512, 2, false>(a, grid_cap, s, grid_out);
         case WALK_LDS_128_TINY:
             if constexpr (I == 1) return walk_launch<AR, 1, 128, kWalkHeapLds, 256, 1, false>(a, grid_cap, s, grid_out);
             return hipErrorInvalidValue;

@@ -117,6 +117,9 @@ VS_API int vs_hnsw_filtered_search(vs_hnsw* index, const float* query, size_t di
 /* nq queries, row-major nq x dim; keys/distances are nq x k, found is nq. */
 VS_API int vs_hnsw_search_batch(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, uint64_t* keys,
                          float* distances, size_t* found);
+/* Device form: enqueued on hip_stream, nothing is synchronised.  k (or expansion_search) up to 10,240: beams beyond 512 take
+ * the wide walk, whose per-workgroup workspace is bounded -- a query that outgrows it (not observed; the host entry points
+ * then rank exhaustively) is flagged with d_found[i] = 0xFFFFFFFF instead of an answer. */
 VS_API int vs_hnsw_search_batch_device(vs_hnsw* index, const float* d_queries, size_t nq, size_t dim, size_t k,
                                 uint64_t* d_keys, float* d_distances, uint32_t* d_found, void* hip_stream);
 /* Exact brute-force top-k (usearch `exact` search; ground truth for recall). Device buffers. */
@@ -139,6 +142,10 @@ VS_API int vs_hnsw_memory_info(vs_hnsw* index, uint64_t out[4]);
 /* Single-query dispatcher (vs_hnsw_search / _async), process-wide: [0] kernel launches, [1] queries,
  * [2] launches and [3] queries that took the team kernel (8 wavefronts per query, lightly loaded device). */
 VS_API int vs_search_service_stats(uint64_t out[4]);
+
+/* Filtered search on indexes above 65,536 slots asks the predicate lazily (only for members a walk needs a verdict for, in
+ * rounds): [0] walk launches and [1] predicate calls spent that way so far. */
+VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
 
 /* -- graph export / import (flat layout; see oracle/cpu_hnsw.cpp orc_export_graph) ------- */
 typedef struct vs_hnsw_graph_info {

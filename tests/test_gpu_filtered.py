@@ -48,6 +48,11 @@ def test_filtered_search_equals_the_cpu_algorithm_at_100k(metric, kind, dim):
             assert len(fk) == len(ek) == k, (modulo, k, len(fk), len(ek))
             ties += assert_same_results(fk, fd, ek, ed, dist_of(i), exact=exact, what=(metric, kind, modulo, k, ef, i))
     assert ties <= 8, ties
+    # 100,000 members > 65,536: the predicate was asked lazily -- a few rounds per query, far fewer calls than one per member
+    fs = ix.filter_stats()
+    queries = 6 * nq
+    assert fs["lazy_rounds"] >= queries and fs["lazy_rounds"] <= 8 * queries, fs
+    assert fs["lazy_predicate_calls"] < 0.5 * n * queries, fs
     # a predicate nothing passes, one a single member passes, and one everything passes (== plain search)
     fk, fd = ix.filtered_search(q[0], 10, lambda key: False)
     assert len(fk) == 0

@@ -342,6 +342,8 @@ struct Engine {
     bool tie_newest = true;           // build: equal distances ordered as usearch's sorted buffer orders them (newest first; in a
                                       // re-selected row: later members first, the new link last).  VS_HNSW_TIE=random: pseudo-random
                                       // per node (round 1), kept for A/B -- on 50x duplicated data it costs 0.20 of the tied recall
+    bool eager_filter = false;               // VS_HNSW_FILTER=eager: always one predicate call per live member (the full bitmap)
+    std::atomic<uint64_t> lazy_rounds{0}, lazy_predicate_calls{0};  // filtered_lazy: rounds / predicate calls so far (tests)
     std::atomic<bool> small_table_ok{true};  // usearch-order walk, beams <= 128: the half-size visited table is paying off
     bool force_wide_tags = false;     // reserved bit 6 (tests): wide visited tags although the index is small
     bool force_global_walk = false;   // reserved bit 5 (tests): every search takes the global-bitmap walk instance
@@ -453,6 +455,7 @@ struct Engine {
         order_mode = (o.reserved & 16) ? 1 : 0;
         force_global_walk = (o.reserved & 32) != 0;
         force_wide_tags = (o.reserved & 64) != 0;
+        if (const char* ff = std::getenv("VS_HNSW_FILTER")) eager_filter = !std::strcmp(ff, "eager");
         if (const char* tn = std::getenv("VS_HNSW_TIE")) tie_newest = std::strcmp(tn, "random") != 0;
         if (const char* fw = std::getenv("VS_HNSW_WALK")) force_global_walk = !std::strcmp(fw, "global");
         if (const char* om = std::getenv("VS_HNSW_ORDER")) order_mode = !std::strcmp(om, "usearch") ? 1 : !std::strcmp(om, "fused") ? 2 : order_mode;
@@ -944,8 +947,15 @@ struct Engine {
     // `load`: queries that will be on the device together with this batch (other pipeline slots included);
     // the team kernel only pays while the chip has idle CUs.
     // allow: device bitmap(s) over slots for filtered search (allow_stride words apart, 0 = one for the whole batch).
+    struct LazyFilter {  // device side of a lazily evaluated predicate (WalkArgs::known ...)
+        const uint32_t* known = nullptr;
+        uint32_t* unknown_list = nullptr;
+        uint32_t* unknown_count = nullptr;
+        uint32_t cap = 0, budget = 0;
+    };
     void search_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
-                       hipStream_t st, size_t load = 0, const uint32_t* allow = nullptr, uint32_t allow_stride = 0) {
+                       hipStream_t st, size_t load = 0, const uint32_t* allow = nullptr, uint32_t allow_stride = 0,
+                       const LazyFilter* lazy = nullptr) {
         uint32_t ef;
         check_search(k, ef);
         if (!nq) return;
@@ -963,6 +973,11 @@ struct Engine {
             a.has_removed = removed.load() ? 1u : 0u;
             a.allow = allow;
             a.allow_stride = allow_stride;
+            a.known = lazy ? lazy->known : nullptr;
+            a.unknown_list = lazy ? lazy->unknown_list : nullptr;
+            a.unknown_count = lazy ? lazy->unknown_count : nullptr;
+            a.unknown_cap = lazy ? lazy->cap : 0u;
+            a.unknown_budget = lazy ? lazy->budget : 0u;
             a.qlist = nullptr;
             a.qcount = nullptr;
             a.retry_list = nullptr;
@@ -1221,6 +1236,70 @@ struct Engine {
         return bits;
     }
 
+    // Filtered search on a large index without asking the predicate for every member (the reference's predicate takes a
+    // table read-lock per call, usearch.rs:1118-1124; usearch itself only asks for the candidates a walk admits).  Rounds:
+    // the walk runs with the verdicts known so far (`known` / `allow` bitmaps), lists the slots whose verdict it needs and
+    // does not have -- taking them as rejected, which can only make it explore further --, the host evaluates the predicate
+    // for exactly those, and the walk runs again.  A round that lists nothing used only true verdicts: it IS the walk
+    // with the full predicate, so its result is exact.  The per-round budget doubles, predicate calls total a small
+    // multiple of what the final walk needs.  (size_t)-1: gave up (caller falls back to the full bitmap).
+    static constexpr size_t kLazyFilterAbove = 1u << 16;
+    size_t filtered_lazy(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist) {
+        use_device();
+        size_t n;
+        {
+            std::lock_guard<std::mutex> g(mod_mu);
+            n = slots;
+        }
+        const size_t words = (n + 31) / 32;
+        std::vector<uint32_t> known_h(words, 0u), allow_h(words, 0u);
+        const uint32_t cap = 1u << 17;
+        std::vector<uint32_t> list(cap);
+        Lease w(device);
+        hipStream_t st = w->stream;
+        float* d_q = (float*)w->a.ensure((size_t)dim * 4);
+        uint64_t* d_k = (uint64_t*)w->b.ensure(k * 8);
+        float* d_d = (float*)w->c.ensure(k * 4);
+        uint32_t* d_f = (uint32_t*)w->d.ensure(64);
+        uint32_t* d_bits = (uint32_t*)w->e.ensure(words * 8);              // [allow | known]
+        uint32_t* d_unknown = (uint32_t*)w->f.ensure(((size_t)cap + 64) * 4);  // [count, 63 pad | list]
+        HIP_OK(hipMemcpyAsync(d_q, q, (size_t)dim * 4, hipMemcpyHostToDevice, st));
+        for (int round = 0; round < 20; ++round) {
+            HIP_OK(hipMemcpyAsync(d_bits, allow_h.data(), words * 4, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(d_bits + words, known_h.data(), words * 4, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemsetAsync(d_unknown, 0, 4, st));
+            LazyFilter lf;
+            lf.known = d_bits + words;
+            lf.unknown_list = d_unknown + 64;
+            lf.unknown_count = d_unknown;
+            lf.cap = cap;
+            lf.budget = (uint32_t)std::min<size_t>(cap, (size_t)2048 << round);
+            search_device(d_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
+            uint32_t count = 0, found = 0;
+            HIP_OK(hipMemcpyAsync(&count, d_unknown, 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(&found, d_f, 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            if (count == 0) {
+                if (found == kWalkFailed) return (size_t)-1;
+                HIP_OK(hipMemcpy(keys, d_k, (size_t)found * 8, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(dist, d_d, (size_t)found * 4, hipMemcpyDeviceToHost));
+                lazy_rounds += (uint64_t)round + 1;
+                return found;
+            }
+            const uint32_t m = std::min(count, cap);
+            HIP_OK(hipMemcpy(list.data(), d_unknown + 64, (size_t)m * 4, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint32_t s = list[i];
+                if (s >= n || ((known_h[s >> 5] >> (s & 31)) & 1u)) continue;
+                known_h[s >> 5] |= 1u << (s & 31);
+                const uint64_t key = h_keys[s];
+                ++lazy_predicate_calls;
+                if (key != kFreeKey && pred(key, pctx)) allow_h[s >> 5] |= 1u << (s & 31);
+            }
+        }
+        return (size_t)-1;
+    }
+
     size_t rank_all(const float* q, size_t k, uint64_t* keys, float* dist) {  // exhaustive ranking, no predicate
         struct All {
             static int yes(uint64_t, void*) { return 1; }
@@ -1232,6 +1311,10 @@ struct Engine {
         const size_t n_live = live.load();
         if (!n_live) return 0;
         if (!exhaustive && std::max<size_t>(k, ef_search.load()) <= kMaxWalkBeam) {
+            if (slots > kLazyFilterAbove && !eager_filter) {
+                const size_t f = filtered_lazy(q, k, pred, pctx, keys, dist);
+                if (f != (size_t)-1) return f;
+            }
             const std::vector<uint32_t> bits = allow_bitmap(pred, pctx);
             size_t f = 0;
             search_host(q, 1, k, keys, dist, &f, false, &bits);
@@ -1771,6 +1854,13 @@ int vs_hnsw_memory_info(vs_hnsw* h, uint64_t out[4]) {
         }
         out[3] = vs::Arena::copied_bytes.load();
     });
+}
+
+int vs_hnsw_filter_stats(vs_hnsw* h, uint64_t out[2]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.lazy_rounds.load();
+    out[1] = h->e.lazy_predicate_calls.load();
+    return VS_OK;
 }
 
 int vs_hnsw_graph_info_get(vs_hnsw* h, vs_hnsw_graph_info* info) {

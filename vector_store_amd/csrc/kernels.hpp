@@ -69,6 +69,13 @@ struct WalkArgs {
     uint32_t has_removed;
     const uint32_t* allow;   // filtered search: bit s = slot s may be a result; nullptr = every live member
     uint32_t allow_stride;   // words between the bitmaps of consecutive queries (0: one bitmap for the batch)
+    // Lazy predicate (filtered search on large indexes): `known` says for which slots `allow` is valid.  A slot the walk
+    // needs but does not know yet is appended to unknown_list and taken as rejected; the host evaluates the predicate for
+    // the listed slots and launches again -- a launch that lists nothing was exact.  nullptr: `allow` is complete.
+    const uint32_t* known;
+    uint32_t* unknown_list;   // unknown_cap entries per query
+    uint32_t* unknown_count;  // one per query; the walk stops once it has listed unknown_budget slots
+    uint32_t unknown_cap, unknown_budget;
     const uint32_t* qlist;   // retry instance: serve queries qlist[0 .. *qcount) instead of 0 .. nq
     const uint32_t* qcount;
     uint32_t* retry_list;    // LDS instances: queries whose visited table or heap ran out are appended here ...

@@ -10,6 +10,8 @@
 //                                                      (the reference passes any `limit` through, httproutes.rs:842-847);
 //                                                      indexes beyond what the LDS tags can tell apart.
 // Workgroups are persistent: each owns one WalkSpace and draws queries from a shared counter until none is left.
+#include <atomic>
+
 #include "kernels.hpp"
 #include "walk_device.hpp"
 
@@ -67,7 +69,10 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
         bool exhausted = false;
         const uint32_t* allow = a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
         const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, allow, cnt, lane, exhausted,
-                                         a.debug ? a.debug + (size_t)qi * 12 : nullptr);
+                                         a.debug ? a.debug + (size_t)qi * 12 : nullptr,
+                                         a.known ? a.known + (size_t)qi * a.allow_stride : nullptr,
+                                         a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
+                                         a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget);
         if (exhausted) {
             if (lane == 0) {
                 if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;  // the global-bitmap instance takes it
@@ -104,11 +109,13 @@ static uint32_t resident_workgroups(K kernel, int device) {  // workgroups of `k
 template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, bool VISG>
 static hipError_t walk_launch(const WalkArgs& a, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out) {
     auto kernel = hnsw_walk_kernel<AR, I, EFCAP, LCAP, NB, CH, VISG>;
-    static uint32_t resident = 0;  // per instance; the engine serves one device model
+    static std::atomic<uint32_t> resident_cache{0};  // per instance; the engine serves one device model
+    uint32_t resident = resident_cache.load(std::memory_order_relaxed);
     if (!resident) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         resident = resident_workgroups(kernel, dev);
+        resident_cache.store(resident, std::memory_order_relaxed);
     }
     uint32_t want = a.qlist ? grid_cap : a.nq;
     uint32_t g = want < resident ? want : resident;

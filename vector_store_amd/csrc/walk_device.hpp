@@ -241,7 +241,9 @@ __device__ __forceinline__ bool walk_visit(Sh& sh, const WalkSpace& ws, uint32_t
 template <int AR, int I, class Sh>
 __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& ws, const Query<AR, I>& q, uint32_t start, int level,
                                  uint32_t ef, uint32_t self, bool tomb, const uint32_t* allow, Counters& cnt, int lane,
-                                 bool& exhausted, uint32_t* debug = nullptr) {
+                                 bool& exhausted, uint32_t* debug = nullptr, const uint32_t* known = nullptr,
+                                 uint32_t* unknown_list = nullptr, uint32_t* unknown_count = nullptr, uint32_t unknown_cap = 0,
+                                 uint32_t unknown_budget = 0) {
     uint32_t dbg_max_hn = 0, dbg_pushed = 0;
 #ifdef VS_WALK_PROFILE
     uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -255,10 +257,29 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         visited_clear(sh, lane);
         wsync<Sh>();
     }
-    auto allowed = [&](uint32_t s) -> bool {
-        bool ok = true;
-        if (tomb) ok = ix.keys[s] != kFreeKey;
-        if (allow) ok = ok && ((allow[s >> 5] >> (s & 31u)) & 1u) != 0u;
+    // May slot s be a result?  Wave-level (every lane calls it, `valid` says whether the lane holds a slot): with a lazy
+    // predicate the slots whose verdict is not known yet are listed for the host and count as rejected for this launch.
+    bool over_budget = false;
+    auto allowed = [&](uint32_t s, bool valid) -> bool {
+        bool ok = valid;
+        if (tomb) ok = ok && ix.keys[valid ? s : 0u] != kFreeKey;
+        if (allow) {
+            if (known) {
+                const bool kn = ok && ((known[s >> 5] >> (s & 31u)) & 1u) != 0u;
+                const bool unk = ok && !kn;  // (removed members need no verdict)
+                const uint64_t um = __ballot(unk);
+                if (um) {
+                    const uint32_t c = (uint32_t)__popcll(um);
+                    uint32_t base = 0;
+                    if (lane == (int)__builtin_ctzll(um)) base = atomicAdd(unknown_count, c);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(um));
+                    if (unk && base + mbcnt(um) < unknown_cap) unknown_list[base + mbcnt(um)] = s;
+                    if (base + c >= unknown_budget) over_budget = true;
+                }
+                ok = kn;
+            }
+            ok = ok && ((allow[(ok ? s : 0u) >> 5] >> (s & 31u)) & 1u) != 0u;
+        }
         return ok;
     };
     auto mark = [&](uint32_t n) -> bool {  // true: n is new to the visited set (and, for the bitmap, logged)
@@ -284,7 +305,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
     const float d0 = sh.u_dist[0];
     uint32_t hn = 0, sz = 0;
     heap_push(sh, ws, hn, d0, start, lane);
-    if (start != self && uni(allowed(start) ? 1u : 0u)) {
+    if (start != self && (__ballot(allowed(start, lane == 0)) & 1ull)) {
         if (lane == 0) {
             sh.lst_d[0] = d0;
             sh.lst_s[0] = start;
@@ -338,7 +359,14 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         WALK_STAMP(3);  // distances
         float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
         uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
-        const uint64_t okmask = __ballot((uint32_t)lane < m && allowed(ns));
+        // the verdict is only needed for neighbours that can still be admitted (usearch asks the predicate inside
+        // `if (top.size() < top_limit || d < radius)`): once `top` is full, those below the radius of the hop's start
+        const float radius0 = sz == ef ? __uint_as_float(uni(__float_as_uint(sh.lst_d[sz - 1]))) : __builtin_inff();
+        const uint64_t okmask = __ballot(allowed(ns, (uint32_t)lane < m && (sz < ef || nd < radius0)));
+        if (over_budget) {  // enough unknown slots listed for one round: the host evaluates them and launches again
+            exhausted = true;
+            break;
+        }
         // ---- admission, one neighbour at a time in adjacency order (wave-uniform scalar code) ----
         // T: old entries of `top` that survive; alive: new entries that are in `top` at the end; pushed: new entries of `next`
         uint64_t pushed = 0, alive = 0;

@@ -91,6 +91,7 @@ def lib():
     L.vs_hnsw_set_expansion_search.argtypes = [vp, sz]
     L.vs_hnsw_stats.argtypes = [vp, vp, C.c_int]
     L.vs_hnsw_memory_info.argtypes = [vp, vp]
+    L.vs_hnsw_filter_stats.argtypes = [vp, vp]
     L.vs_hnsw_graph_info_get.argtypes = [vp, C.POINTER(_GraphInfo)]
     L.vs_hnsw_export_graph.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.vs_hnsw_import_graph.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz, C.c_int32, C.c_uint32]
@@ -272,6 +273,11 @@ class HipUsearchIndex:
         out = np.zeros(4, dtype=np.uint64)
         _check(self.L.vs_hnsw_memory_info(self.h, _p(out)))
         return {n: int(v) for n, v in zip(["bytes", "in_place_bytes", "chunks", "copied_bytes"], out)}
+
+    def filter_stats(self) -> dict:
+        out = np.zeros(2, dtype=np.uint64)
+        _check(self.L.vs_hnsw_filter_stats(self.h, _p(out)))
+        return {"lazy_rounds": int(out[0]), "lazy_predicate_calls": int(out[1])}
 
     def graph_info(self) -> dict:
         gi = _GraphInfo()

@@ -216,6 +216,25 @@ def side_records(vs, dev, dim, metric, k, rank0_only=True):
     return out
 
 
+def make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, total_rows, backend):
+    """The native path (libvs_ranks: ncclAllGather issued by the library) when RCCL is the backend; the torch.distributed
+    twin for gloo smoke tests, with VS_RANKS=torch, or when the native communicator cannot be created (every rank
+    agrees on the choice through an all-reduce, so no rank is left waiting in a collective the others never enter)."""
+    import torch
+    native = backend == "nccl" and os.environ.get("VS_RANKS", "native") != "torch"
+    gs = None
+    if native:
+        try:
+            gs = ranks.RankedSearcher(ix, queries, k, dist, total_rows)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] libvs_ranks unavailable on rank {dist.get_rank()}: {e!r}", file=sys.stderr)
+        ok = torch.tensor([1 if gs is not None else 0], device=queries.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            gs = None
+    return gs if gs is not None else sharded.ShardedSearcher(ix, queries, k, dist, vs)
+
+
 def boundary_record(ix, queries_host, truth, k, seconds):
     """What a drop-in caller gets THROUGH the C ABI on this very index (reference call pattern): one query per
     vs_hnsw_search call from num_workers() + 1 blocking threads (usearch.rs:203-222, worker.rs:44-118), and the
@@ -315,8 +334,7 @@ def main():
     if shard_mode:
         # native path (libvs_ranks: one ncclAllGather per batch on its own stream, overlapped with the next walk);
         # the torch.distributed twin only where RCCL is not the backend (gloo smoke tests)
-        gs = (ranks.RankedSearcher(ix, queries, k, dist, n * world) if a.backend == "nccl"
-              else sharded.ShardedSearcher(ix, queries, k, dist, vs))
+        gs = make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, n * world, a.backend)
         truth = gs.exact()
         step = gs.step
         finish = getattr(gs, "flush", finish)
@@ -437,8 +455,7 @@ def main():
             six, sbuild = build_index(vs, sbase, skeys, a.metric, quantization=a.quantization)
             six.set_expansion_search(ef)
             sq = make_data(nq, dim, a.dist, 4321, dev, a.rank)
-            gs = (ranks.RankedSearcher(six, sq, k, dist, n * world) if a.backend == "nccl"
-                  else sharded.ShardedSearcher(six, sq, k, dist, vs))
+            gs = make_sharded_searcher(six, sq, k, dist, vs, ranks, sharded, n * world, a.backend)
             sfinish = getattr(gs, "flush", lambda: None)
             struth = gs.exact()
             gs.step()
@@ -455,7 +472,7 @@ def main():
             barrier()
             tel = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
             dist.all_reduce(tel, op=dist.ReduceOp.MAX)
-            out["sharded"] = {"index_vectors_total": n * world, "queries_per_s": nq * max(a.steps // 2, 1) / float(tel.item()),
+            out["sharded"] = {"path": type(gs).__name__, "index_vectors_total": n * world, "queries_per_s": nq * max(a.steps // 2, 1) / float(tel.item()),
                               "recall_at_10": round(srec, 4), "collective": "one ncclAllGather (RCCL, libvs_ranks) of packed per-shard top-k per batch + topk_merge_kernel, overlapped with the next walk",
                               "build_vectors_per_s_per_gpu": n / sbuild}
             del six, sbase

@@ -147,6 +147,11 @@ VS_API int vs_search_service_stats(uint64_t out[4]);
  * rounds): [0] walk launches and [1] predicate calls spent that way so far. */
 VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
 
+/* Exact search on float storage (cos / ip, k <= 64, >= 65,536 slots) nominates with split-bf16 MFMA tiles, re-scores the nominees
+ * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's
+ * certificate failed. */
+VS_API int vs_hnsw_exact_stats(vs_hnsw* index, uint64_t out[2]);
+
 /* -- graph export / import (flat layout; see oracle/cpu_hnsw.cpp orc_export_graph) ------- */
 typedef struct vs_hnsw_graph_info {
     size_t slots;        /* nodes ever allocated (including removed) */

@@ -826,3 +826,46 @@ def test_heavily_duplicated_data_builds_as_well_as_the_cpu_algorithm():
     cpu = tied(do, fo)
     assert (f == 10).all()
     assert gpu >= cpu - 0.03 and gpu >= 0.6, (gpu, cpu)
+
+
+@pytest.mark.parametrize("metric,quant", [("cos", "f32"), ("ip", "f32"), ("cos", "f16")])
+def test_exact_search_split_bf16_nomination_is_certified_or_falls_back(metric, quant):
+    """Exact search on large float indexes nominates with split-bf16 MFMA tiles (three bf16 products per f32 product), re-scores
+    the nominees in f32 and certifies the answer; a query whose certificate fails (a crowd of equal scores at the cut) sends
+    the batch to the f32-input MFMA path.  Same ids as that path either way; both cases are provoked."""
+    import os
+    v = vs()
+    n, dim, k = 80000, 96, 10
+    data = _dataset(n + 64, dim, 13)
+    base, q = data[:n].copy(), data[n:]
+    if metric == "ip":
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+    def build(env):
+        old = os.environ.pop("VS_HNSW_EXACT", None)
+        if env:
+            os.environ["VS_HNSW_EXACT"] = env
+        try:
+            ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS[quant])
+        finally:
+            os.environ.pop("VS_HNSW_EXACT", None)
+            if old:
+                os.environ["VS_HNSW_EXACT"] = old
+        ix.reserve(n)
+        ix.add_batch(np.arange(n, dtype=np.uint64), base)
+        return ix
+    fast, ref = build(None), build("f32")
+    fk, fd, ff = fast.exact_search_batch(q, k)
+    rk, rd, rf = ref.exact_search_batch(q, k)
+    st = fast.exact_stats()
+    assert st["block_batches"] >= 1 and st["block_fallbacks"] == 0 and ref.exact_stats()["block_batches"] == 0
+    assert (ff == k).all() and np.allclose(fd, rd, rtol=1e-5, atol=2e-5)
+    assert np.mean([fk[i].tolist() == rk[i].tolist() for i in range(len(q))]) >= 0.97      # f32 near-ties may swap
+    assert all(set(fk[i].tolist()) == set(rk[i].tolist()) or np.isclose(fd[i, -1], rd[i, -1], rtol=1e-5, atol=2e-5) for i in range(len(q)))
+    # 300 copies of one vector right at the query: the 64 nominees all tie with 236 rows outside -> no certificate -> f32 path
+    base[1000:1300] = q[0] / (np.linalg.norm(q[0]) if metric == "ip" else 1.0)
+    fast2, ref2 = build(None), build("f32")
+    fk, fd, ff = fast2.exact_search_batch(q[:4], k)
+    rk, rd, rf = ref2.exact_search_batch(q[:4], k)
+    assert fast2.exact_stats()["block_fallbacks"] == 1
+    assert np.array_equal(fk, rk) and np.array_equal(fd, rd)          # the very same kernels answered
+    assert set(fk[0].tolist()) <= set(range(1000, 1300))

@@ -342,6 +342,12 @@ struct Engine {
     bool tie_newest = true;           // build: equal distances ordered as usearch's sorted buffer orders them (newest first; in a
                                       // re-selected row: later members first, the new link last).  VS_HNSW_TIE=random: pseudo-random
                                       // per node (round 1), kept for A/B -- on 50x duplicated data it costs 0.20 of the tied recall
+    bool exact_f32_only = false;             // VS_HNSW_EXACT=f32: exact search on the f32-input MFMA path only (A/B, tests)
+    std::atomic<uint64_t> block_batches{0}, block_fallbacks{0};  // exact batches on the split-bf16 path / of them re-run in f32
+    std::mutex norm_mu;
+    float max_norm_value = 0.f;              // max |row| over rows [0, max_norm_slots) (inner product: scales the certificate)
+    size_t max_norm_slots = 0;
+    uint32_t* d_max_norm = nullptr;
     bool eager_filter = false;               // VS_HNSW_FILTER=eager: always one predicate call per live member (the full bitmap)
     std::atomic<uint64_t> lazy_rounds{0}, lazy_predicate_calls{0};  // filtered_lazy: rounds / predicate calls so far (tests)
     std::atomic<bool> small_table_ok{true};  // usearch-order walk, beams <= 128: the half-size visited table is paying off
@@ -436,6 +442,7 @@ struct Engine {
         (void)hipDeviceSynchronize();
         for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels}) a->release();
         if (d_stats) (void)hipFree(d_stats);
+        if (d_max_norm) (void)hipFree(d_max_norm);
     }
 
     void init(const vs_hnsw_options& o) {
@@ -456,6 +463,7 @@ struct Engine {
         force_global_walk = (o.reserved & 32) != 0;
         force_wide_tags = (o.reserved & 64) != 0;
         if (const char* ff = std::getenv("VS_HNSW_FILTER")) eager_filter = !std::strcmp(ff, "eager");
+        if (const char* xf = std::getenv("VS_HNSW_EXACT")) exact_f32_only = !std::strcmp(xf, "f32");
         if (const char* tn = std::getenv("VS_HNSW_TIE")) tie_newest = std::strcmp(tn, "random") != 0;
         if (const char* fw = std::getenv("VS_HNSW_WALK")) force_global_walk = !std::strcmp(fw, "global");
         if (const char* om = std::getenv("VS_HNSW_ORDER")) order_mode = !std::strcmp(om, "usearch") ? 1 : !std::strcmp(om, "fused") ? 2 : order_mode;
@@ -1103,6 +1111,26 @@ struct Engine {
         HIP_OK(launch_search(a, iters, st));
     }
 
+    // max |row| of the stored vectors (removed rows included: an upper bound is all the certificate needs); rows added since
+    // the last call are folded in.  view_mu is held (shared) by the caller.
+    float max_row_norm(const IndexView& ix, hipStream_t st) {
+        std::lock_guard<std::mutex> g(norm_mu);
+        if (!d_max_norm) {
+            HIP_OK(hipMalloc((void**)&d_max_norm, 4));
+            HIP_OK(hipMemset(d_max_norm, 0, 4));
+        }
+        const size_t n = slots;
+        if (n > max_norm_slots) {
+            HIP_OK(launch_row_norm_max(ix, (uint32_t)max_norm_slots, (uint32_t)(n - max_norm_slots), d_max_norm, st));
+            uint32_t bits = 0;
+            HIP_OK(hipMemcpyAsync(&bits, d_max_norm, 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            std::memcpy(&max_norm_value, &bits, 4);
+            max_norm_slots = n;
+        }
+        return max_norm_value;
+    }
+
     void exact_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
                       hipStream_t st, WorkCtx& w) {
         if (k == 0 || k > 256) fail(VS_ERR_UNSUPPORTED, "exact search supports 1 <= k <= 256");
@@ -1118,6 +1146,21 @@ struct Engine {
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;
+        // Large float indexes, cos / ip, k <= 64: nominate with the split-bf16 MFMA pass, re-score the nominees exactly,
+        // certify; only a batch with an uncertified query (dense ties at the cut) pays the f32 path as well.
+        if (block_search_supported(a.ix, a.k) && slots >= (1u << 16) && !a.use_valu && !exact_f32_only) {
+            const float mx = metric == VS_METRIC_IP ? max_row_norm(a.ix, st) : 1.f;
+            char* scratch = (char*)w.f.ensure(block_scratch_bytes((uint32_t)nq, dim) + 256);
+            uint32_t* d_unc = (uint32_t*)scratch;
+            HIP_OK(hipMemsetAsync(d_unc, 0, 4, st));
+            HIP_OK(launch_block_search(a, scratch + 256, mx, d_unc, st));
+            uint32_t unc = 0;
+            HIP_OK(hipMemcpyAsync(&unc, d_unc, 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            block_batches += 1;
+            if (unc == 0) return;
+            block_fallbacks += 1;
+        }
         void* scratch = w.f.ensure(exact_scratch_bytes((uint32_t)nq, (uint32_t)k, dim));
         HIP_OK(launch_exact(a, scratch, st));
     }
@@ -1860,6 +1903,13 @@ int vs_hnsw_filter_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.lazy_rounds.load();
     out[1] = h->e.lazy_predicate_calls.load();
+    return VS_OK;
+}
+
+int vs_hnsw_exact_stats(vs_hnsw* h, uint64_t out[2]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.block_batches.load();
+    out[1] = h->e.block_fallbacks.load();
     return VS_OK;
 }
 

@@ -142,6 +142,13 @@ struct ExactArgs {
 };
 size_t exact_scratch_bytes(uint32_t nq, uint32_t k, uint32_t dim);
 hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s);
+// The same answer through the split-bf16 MFMA nomination pass + exact f32 re-score (kernels_misc.hip "block search"):
+// float storage, cos / ip, k <= 64.  *d_uncertified (zeroed by the caller) counts the queries whose certificate failed:
+// non-zero after the stream has drained => run launch_exact instead.  max_row_norm: max |row| (inner product; 1 for cosine).
+bool block_search_supported(const IndexView& ix, uint32_t k);
+size_t block_scratch_bytes(uint32_t nq, uint32_t dim);
+hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_norm, uint32_t* d_uncertified, hipStream_t s);
+hipError_t launch_row_norm_max(const IndexView& ix, uint32_t first, uint32_t n, uint32_t* d_max_bits, hipStream_t s);
 
 // out[s] = distance(query, row s) for s in [0, n): one wave per row; result copied to host_out.
 // d_scratch: n + dim + 64 floats.

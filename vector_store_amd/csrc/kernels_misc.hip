@@ -423,7 +423,7 @@ using SelectShared = BeamShared<256, 256>;
 __global__ __launch_bounds__(64) void exact_select_kernel(IndexView ix, const float* D, uint32_t q0, uint32_t n0,
                                                           uint32_t n_all, uint32_t k, int first, int last, float* st_d,
                                                           uint32_t* st_s, uint32_t* st_n, uint64_t* out_keys,
-                                                          float* out_dist, uint32_t* out_found) {
+                                                          float* out_dist, uint32_t* out_found, int raw_slots = 0) {
     __shared__ SelectShared sh;
     const int lane = lane_id();
     const uint32_t ql = blockIdx.x, qg = q0 + ql;
@@ -489,7 +489,8 @@ __global__ __launch_bounds__(64) void exact_select_kernel(IndexView ix, const fl
         return;
     }
     for (uint32_t i = lane; i < k; i += kWave) {
-        out_keys[(size_t)qg * k + i] = i < sz ? ix.keys[sh.lst_s[cur][i] & kSlotMask] : kFreeKey;
+        const uint32_t slot = i < sz ? (sh.lst_s[cur][i] & kSlotMask) : 0u;
+        out_keys[(size_t)qg * k + i] = i < sz ? (raw_slots ? (uint64_t)slot : ix.keys[slot]) : kFreeKey;
         out_dist[(size_t)qg * k + i] = i < sz ? sh.lst_d[cur][i] : __builtin_inff();
     }
     if (lane == 0) out_found[qg] = sz;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(64) void exact_select_kernel(IndexView ix, const fl
 // Merges the S per-segment states of one query into its result.
 __global__ __launch_bounds__(64) void exact_finish_kernel(IndexView ix, uint32_t q0, uint32_t S, uint32_t k, const float* st_d,
                                                           const uint32_t* st_s, const uint32_t* st_n, uint64_t* out_keys,
-                                                          float* out_dist, uint32_t* out_found) {
+                                                          float* out_dist, uint32_t* out_found, int raw_slots = 0) {
     __shared__ SelectShared sh;
     const int lane = lane_id();
     const uint32_t qg = q0 + blockIdx.x;
@@ -521,7 +522,8 @@ __global__ __launch_bounds__(64) void exact_finish_kernel(IndexView ix, uint32_t
         }
     }
     for (uint32_t i = lane; i < k; i += kWave) {
-        out_keys[(size_t)qg * k + i] = i < sz ? ix.keys[sh.lst_s[0][i] & kSlotMask] : kFreeKey;
+        const uint32_t slot = i < sz ? (sh.lst_s[0][i] & kSlotMask) : 0u;
+        out_keys[(size_t)qg * k + i] = i < sz ? (raw_slots ? (uint64_t)slot : ix.keys[slot]) : kFreeKey;
         out_dist[(size_t)qg * k + i] = i < sz ? sh.lst_d[0][i] : __builtin_inff();
     }
     if (lane == 0) out_found[qg] = sz;
@@ -691,6 +693,313 @@ hipError_t launch_rank_keys(const IndexView& ix, const float* d, uint32_t n, uin
 hipError_t launch_rank_emit(const IndexView& ix, const uint64_t* sorted, uint32_t n, uint64_t* out_keys, float* out_dist, hipStream_t s) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(rank_emit_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ix, sorted, n, out_keys, out_dist);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- block search: split-bf16 MFMA candidates + exact re-score
+// The q x candidate-block contraction (BASELINE configs[4], ground truth for recall) at the bf16 matrix rate WITHOUT giving up
+// exactness.  Every f32 value is split x = hi + lo (two bf16, round-to-nearest: |x - hi - lo| <= 2^-18 |x|) and
+// q . c ~= qh.ch + qh.cl + ql.ch: three v_mfma_f32_32x32x16_bf16 (f32 accumulate) per 16 k -- 96 matrix cycles against 512 for
+// the f32-input MFMA.  The dropped ql.cl term and the residuals bound the error of a score by eps = 3e-5 |q| |c|.  The
+// approximate scores only NOMINATE: the C = 256 best rows per query are re-scored with exact f32 arithmetic, and the answer
+// is certified -- if the k-th exact score is below (C-th approximate score - eps), no row outside the nominees can beat it.
+// A query that fails the certificate (dense ties at the cut) is counted, and the host re-runs the f32 path.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr uint32_t kBlockC = 256;    // nominees per query
+constexpr int kBlockKC = 64;         // k staged per LDS buffer.  Measured at 10M x 768, q = 256 (whole search): 64 deep, one buffer, two
+                                     // barriers per stage 21.8 ms; 32 deep through two buffers (the f32 kernel's structure) 31.2 ms
+constexpr int kBlockLd = kBlockKC + 8;  // halfwords per LDS row: 144 B, 16-byte reads of 16 consecutive rows hit 64 distinct dwords
+
+// two f32 -> their (hi, lo) bf16 pairs, packed [x0 | x1 << 16]; the casts compile to v_cvt_pk_bf16_f32 (round to nearest even)
+__device__ __forceinline__ void split_bf16x2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+    const __bf16 l0 = (__bf16)(x0 - (float)h0), l1 = (__bf16)(x1 - (float)h1);
+    hi = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+    lo = (uint32_t)__builtin_bit_cast(unsigned short, l0) | ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+__device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
+    uint32_t h, l;
+    split_bf16x2(x, 0.f, h, l);
+    hi = h & 0xFFFFu;
+    lo = l & 0xFFFFu;
+}
+
+// qd (nq x kpad f32, the form the metric sees) -> qh / ql (nq x kpad bf16 bits) and |q|
+__global__ void split_queries_kernel(const float* qd, uint32_t nq, uint32_t kpad, uint16_t* qh, uint16_t* ql, float* qnorm) {
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    if (w >= nq) return;
+    float sq = 0.f;
+    for (uint32_t e = lane; e < kpad; e += kWave) {
+        const float x = qd[(size_t)w * kpad + e];
+        uint32_t h, l;
+        split_bf16(x, h, l);
+        qh[(size_t)w * kpad + e] = (uint16_t)h;
+        ql[(size_t)w * kpad + e] = (uint16_t)l;
+        sq = fmaf(x, x, sq);
+    }
+    for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) qnorm[w] = sqrtf(sq);
+}
+
+// 128 queries x 128 base rows per workgroup, 4 waves x (2 x 2) 32x32 tiles, K staged 32 deep (one LDS buffer, the next
+// stage's global loads in flight in registers while this one is multiplied).
+template <int SC>
+__global__ __launch_bounds__(256) void block_dist_bf16x3_kernel(IndexView ix, const uint16_t* qh, const uint16_t* ql, uint32_t kpad,
+                                                                const float* q_aux, uint32_t q0, uint32_t nq_blk, uint32_t n0,
+                                                                uint32_t n_blk, float* D) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[128][kBlockLd], Al[128][kBlockLd], Bh[128][kBlockLd], Bl[128][kBlockLd];
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t wy = w >> 1, wx = w & 1;
+    const uint32_t qt = blockIdx.x * 128, nt = blockIdx.y * 128;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // Staging, coalesced along the rows: 16 lanes read the 256 contiguous bytes a base row contributes to a stage (a wave-load
+    // = 4 rows, whole 128-byte lines), 8 lanes the 128 bytes of a pre-split query row.  The next stage's loads are in
+    // flight (in registers) while this stage is multiplied.
+    const uint32_t brow = t >> 4, bk = (t & 15) * 4;  // base: rows brow + 16 f, k bk..bk+3
+    const uint32_t arow = t >> 3, ak = (t & 7) * 8;   // queries: rows arow + 32 f, k ak..ak+7
+    uint4 ah[4], al[4], braw[8];
+    auto fetch = [&](uint32_t k0) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t r = arow + 32u * f;
+            ah[f] = al[f] = make_uint4(0u, 0u, 0u, 0u);
+            if (qt + r < nq_blk && k0 + ak < kpad) {
+                ah[f] = *reinterpret_cast<const uint4*>(qh + (size_t)(q0 + qt + r) * kpad + k0 + ak);
+                al[f] = *reinterpret_cast<const uint4*>(ql + (size_t)(q0 + qt + r) * kpad + k0 + ak);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const uint32_t r = brow + 16u * f;
+            braw[f] = load4_raw<SC>(ix, (size_t)(n0 + nt + r), k0 + bk, nt + r < n_blk && k0 + bk < kpad);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            *reinterpret_cast<uint4*>(&Ah[arow + 32 * f][ak]) = ah[f];
+            *reinterpret_cast<uint4*>(&Al[arow + 32 * f][ak]) = al[f];
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            float bv[4];
+            dequant4<SC>(braw[f], bv);
+            uint32_t h0, l0, h1, l1;
+            split_bf16x2(bv[0], bv[1], h0, l0);
+            split_bf16x2(bv[2], bv[3], h1, l1);
+            *reinterpret_cast<uint2*>(&Bh[brow + 16 * f][bk]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(&Bl[brow + 16 * f][bk]) = make_uint2(l0, l1);
+        }
+    };
+    fetch(0);
+    for (uint32_t k0 = 0; k0 < kpad; k0 += kBlockKC) {
+        __syncthreads();  // the previous stage has been multiplied
+        stage();
+        __syncthreads();
+        if (k0 + kBlockKC < kpad) fetch(k0 + kBlockKC);
+#pragma unroll
+        for (int ks = 0; ks < kBlockKC / 16; ++ks) {
+            const uint32_t kk = (uint32_t)ks * 16u + 8u * (lane >> 5), c = lane & 31;
+            bf16x8 fa_h[2], fa_l[2], fb_h[2], fb_l[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa_h[i] = *reinterpret_cast<const bf16x8*>(&Ah[wy * 64 + i * 32 + c][kk]);
+                fa_l[i] = *reinterpret_cast<const bf16x8*>(&Al[wy * 64 + i * 32 + c][kk]);
+                fb_h[i] = *reinterpret_cast<const bf16x8*>(&Bh[wx * 64 + i * 32 + c][kk]);
+                fb_l[i] = *reinterpret_cast<const bf16x8*>(&Bl[wx * 64 + i * 32 + c][kk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_l[i], fb_h[j], acc[i][j], 0, 0, 0);  // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h[i], fb_l[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h[i], fb_h[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    const bool aux = exact_needs_aux(ix);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t ni = nt + wx * 64 + j * 32 + (lane & 31);
+            const float ra = (aux && ni < n_blk) ? ix.aux[n0 + ni] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t qi = qt + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qi < nq_blk && ni < n_blk)
+                    D[(size_t)qi * kExactCH + ni] = finalize_exact(ix, acc[i][j][r], aux ? q_aux[q0 + qi] : 0.f, ra);
+            }
+        }
+}
+
+// exact f32 score of nominee c of query q: one wave per (query, nominee)
+__global__ __launch_bounds__(256) void block_rescore_kernel(IndexView ix, const float* qd, uint32_t kpad, const float* q_aux,
+                                                            uint32_t C, const uint64_t* cand_slot, const uint32_t* cand_found,
+                                                            float* exact_d) {
+    const uint32_t q = blockIdx.x, c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    if (c >= cand_found[q]) return;
+    const uint32_t slot = (uint32_t)cand_slot[(size_t)q * C + c];
+    float acc = 0.f;
+    for (uint32_t k = (uint32_t)lane * 4u; k < kpad; k += kWave * 4u) {
+        float v[4];
+        load4_dequant(ix, (size_t)slot, k, v);
+        const float4 a = *reinterpret_cast<const float4*>(qd + (size_t)q * kpad + k);
+        acc = fmaf(a.x, v[0], acc);
+        acc = fmaf(a.y, v[1], acc);
+        acc = fmaf(a.z, v[2], acc);
+        acc = fmaf(a.w, v[3], acc);
+    }
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    const bool aux = exact_needs_aux(ix);
+    if (lane == 0) exact_d[(size_t)q * C + c] = finalize_exact(ix, acc, aux ? q_aux[q] : 0.f, aux ? ix.aux[slot] : 0.f);
+}
+
+// per query: the nominees ordered by their exact scores, the k best out, and the certificate
+__global__ __launch_bounds__(64) void block_final_kernel(IndexView ix, uint32_t k, uint32_t C, const uint64_t* cand_slot, const float* cand_approx,
+                                                         const uint32_t* cand_found, const float* exact_d, const float* qnorm,
+                                                         float max_row_norm, uint64_t* out_keys, float* out_dist, uint32_t* out_found,
+                                                         uint32_t* uncertified) {
+    __shared__ float sd[kBlockC];
+    __shared__ uint32_t ss[kBlockC];
+    const uint32_t q = blockIdx.x;
+    const int lane = lane_id();
+    const uint32_t n = cand_found[q];
+    for (uint32_t i = lane; i < n; i += kWave) {
+        const float d = exact_d[(size_t)q * C + i];
+        sd[i] = d == d ? d : __builtin_inff();
+        ss[i] = (uint32_t)cand_slot[(size_t)q * C + i];
+    }
+    __syncthreads();
+    const uint32_t found = n < k ? n : k;
+    float kth = -__builtin_inff();
+    for (uint32_t i = lane; i < n; i += kWave) {  // rank by (score, slot): a strict total order
+        const float d = sd[i];
+        const uint32_t sl = ss[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += key_less(sd[j], ss[j], d, sl) ? 1u : 0u;
+        if (rank < k) {
+            out_keys[(size_t)q * k + rank] = ix.keys[sl];
+            out_dist[(size_t)q * k + rank] = d;
+        }
+        if (rank + 1 == found) kth = d;
+    }
+    for (uint32_t i = found + lane; i < k; i += kWave) {
+        out_keys[(size_t)q * k + i] = kFreeKey;
+        out_dist[(size_t)q * k + i] = __builtin_inff();
+    }
+    for (int o = 32; o; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
+    if (lane == 0) {
+        out_found[q] = found;
+        if (n == C) {  // rows outside the nominees exist: they score at least (worst nominated approximate score - eps)
+            // split residuals (3 x 2^-18) + worst-case f32 accumulation of both scores (2 x K x 2^-24), times |q| |c|
+            const float scale = ix.metric == COS ? 1.f : qnorm[q] * max_row_norm;
+            const float eps = (1.15e-5f + 1.2e-7f * (float)((ix.dim + 31u) & ~31u)) * 1.05f * scale + 1e-6f;
+            const float t = cand_approx[(size_t)q * C + C - 1];
+            if (!(kth < t - eps)) atomicAdd(uncertified, 1u);
+        }
+    }
+}
+
+// max |row| over rows [first, first + n) (inner product only: scales the certificate's eps); atomicMax on the f32 bits
+__global__ __launch_bounds__(256) void row_norm_max_kernel(IndexView ix, uint32_t first, uint32_t n, uint32_t kpad, uint32_t* max_bits) {
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    if (r >= n) return;
+    float sq = 0.f;
+    for (uint32_t k = (uint32_t)lane * 4u; k < kpad; k += kWave * 4u) {
+        float v[4];
+        load4_dequant(ix, (size_t)(first + r), k, v);
+        sq = fmaf(v[0], v[0], sq);
+        sq = fmaf(v[1], v[1], sq);
+        sq = fmaf(v[2], v[2], sq);
+        sq = fmaf(v[3], v[3], sq);
+    }
+    for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0 && sq == sq) atomicMax(max_bits, __float_as_uint(sqrtf(sq)));
+}
+
+bool block_search_supported(const IndexView& ix, uint32_t k) {
+    return (ix.scalar == SC_F32 || ix.scalar == SC_F16 || ix.scalar == SC_BF16) && (ix.metric == COS || ix.metric == IP) && k >= 1 &&
+           k * 4 <= kBlockC;
+}
+static uint32_t block_nominees(uint32_t k) {  // 4 k, at least 64: the margin the certificate lives on
+    uint32_t c = 64;
+    while (c < 4 * k) c *= 2;
+    return c;
+}
+
+size_t block_scratch_bytes(uint32_t nq, uint32_t dim) {
+    const size_t S = exact_segments(nq), kpad = (dim + 31u) & ~31u;
+    return (size_t)kExactQB * kExactCH * 4 + (size_t)nq * S * kBlockC * 8 + (size_t)nq * S * 4 + (size_t)nq * 8 +
+           (size_t)nq * kpad * 8 + (size_t)nq * kBlockC * 16 + (size_t)nq * 4 + 4096;
+}
+
+hipError_t launch_row_norm_max(const IndexView& ix, uint32_t first, uint32_t n, uint32_t* d_max_bits, hipStream_t s) {
+    if (!n) return hipSuccess;
+    const uint32_t kpad = (ix.dim + 31u) & ~31u;
+    hipLaunchKernelGGL(row_norm_max_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ix, first, n, kpad, d_max_bits);
+    return hipGetLastError();
+}
+
+// d_uncertified: one zeroed word; after the stream has drained, non-zero means: re-run with launch_exact.
+hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_norm, uint32_t* d_uncertified, hipStream_t s) {
+    if (a.nq == 0) return hipSuccess;
+    if (!block_search_supported(a.ix, a.k) || a.slots == 0) return hipErrorInvalidValue;
+    const uint32_t kpad = (a.ix.dim + 31u) & ~31u;  // the stage depth of the tile kernel
+    const uint32_t S = exact_segments(a.nq), C = block_nominees(a.k);
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    float* D = (float*)take((size_t)kExactQB * kExactCH * 4);
+    float* st_d = (float*)take((size_t)a.nq * S * kBlockC * 4);
+    uint32_t* st_s = (uint32_t*)take((size_t)a.nq * S * kBlockC * 4);
+    uint32_t* st_n = (uint32_t*)take((size_t)a.nq * S * 4);
+    float* q_aux = (float*)take((size_t)a.nq * 4);
+    float* qnorm = (float*)take((size_t)a.nq * 4);
+    float* qd = (float*)take((size_t)a.nq * kpad * 4);
+    uint16_t* qh = (uint16_t*)take((size_t)a.nq * kpad * 2);
+    uint16_t* ql = (uint16_t*)take((size_t)a.nq * kpad * 2);
+    uint64_t* cand_slot = (uint64_t*)take((size_t)a.nq * kBlockC * 8);
+    float* cand_approx = (float*)take((size_t)a.nq * kBlockC * 4);
+    float* exact_d = (float*)take((size_t)a.nq * kBlockC * 4);
+    uint32_t* cand_found = (uint32_t*)take((size_t)a.nq * 4);
+    hipError_t e = prepare_queries(a.ix, a.queries, a.q_stride, a.nq, kpad, qd, q_aux, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(split_queries_kernel, dim3((a.nq + 3) / 4), dim3(256), 0, s, qd, a.nq, kpad, qh, ql, qnorm);
+    for (uint32_t q0 = 0; q0 < a.nq; q0 += kExactQB) {
+        const uint32_t nqb = a.nq - q0 < kExactQB ? a.nq - q0 : kExactQB;
+        for (uint32_t n0 = 0; n0 < a.slots; n0 += kExactCH) {
+            const uint32_t nb = a.slots - n0 < kExactCH ? a.slots - n0 : kExactCH;
+            const dim3 mg((nqb + 127) / 128, (nb + 127) / 128);
+            switch (a.ix.scalar) {
+                case SC_F32: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F32>), mg, dim3(256), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
+                case SC_F16: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F16>), mg, dim3(256), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
+                default: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_BF16>), mg, dim3(256), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
+            }
+            const int first = n0 == 0, last = n0 + kExactCH >= a.slots;
+            hipLaunchKernelGGL(exact_select_kernel, dim3(nqb, S), dim3(64), 0, s, a.ix, D, q0, n0, nb, C, first, last, st_d, st_s,
+                               st_n, cand_slot, cand_approx, cand_found, 1);
+        }
+        if (S > 1)
+            hipLaunchKernelGGL(exact_finish_kernel, dim3(nqb), dim3(64), 0, s, a.ix, q0, S, C, st_d, st_s, st_n, cand_slot, cand_approx,
+                               cand_found, 1);
+    }
+    hipLaunchKernelGGL(block_rescore_kernel, dim3(a.nq, C / 4), dim3(256), 0, s, a.ix, qd, kpad, q_aux, C, cand_slot, cand_found, exact_d);
+    hipLaunchKernelGGL(block_final_kernel, dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, qnorm,
+                       max_row_norm, a.out_keys, a.out_dist, a.out_found, d_uncertified);
     return hipGetLastError();
 }
 

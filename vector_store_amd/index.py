@@ -92,6 +92,7 @@ def lib():
     L.vs_hnsw_stats.argtypes = [vp, vp, C.c_int]
     L.vs_hnsw_memory_info.argtypes = [vp, vp]
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
+    L.vs_hnsw_exact_stats.argtypes = [vp, vp]
     L.vs_hnsw_graph_info_get.argtypes = [vp, C.POINTER(_GraphInfo)]
     L.vs_hnsw_export_graph.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.vs_hnsw_import_graph.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz, C.c_int32, C.c_uint32]
@@ -278,6 +279,11 @@ class HipUsearchIndex:
         out = np.zeros(2, dtype=np.uint64)
         _check(self.L.vs_hnsw_filter_stats(self.h, _p(out)))
         return {"lazy_rounds": int(out[0]), "lazy_predicate_calls": int(out[1])}
+
+    def exact_stats(self) -> dict:
+        out = np.zeros(2, dtype=np.uint64)
+        _check(self.L.vs_hnsw_exact_stats(self.h, _p(out)))
+        return {"block_batches": int(out[0]), "block_fallbacks": int(out[1])}
 
     def graph_info(self) -> dict:
         gi = _GraphInfo()

@@ -742,33 +742,32 @@ __global__ void split_queries_kernel(const float* qd, uint32_t nq, uint32_t kpad
     if (lane == 0) qnorm[w] = sqrtf(sq);
 }
 
-// 128 queries x 128 base rows per workgroup, 4 waves x (2 x 2) 32x32 tiles, K staged 32 deep (one LDS buffer, the next
-// stage's global loads in flight in registers while this one is multiplied).
+// 128 queries x 128 base rows per workgroup of EIGHT waves, each a 64 x 32 part (2 MFMA tiles: 32 accumulator registers), K
+// staged 64 deep through one LDS buffer with the next stage's global loads in flight in registers.  Eight waves at ~110
+// registers put 4 waves on every SIMD (two workgroups per CU by LDS): twice the latency cover of the 4-wave form, whose
+// 64 accumulator + 64 prefetch registers allowed only 2 per SIMD (configs[4]: 20.9 ms per batch with that form).
 template <int SC>
-__global__ __launch_bounds__(256) void block_dist_bf16x3_kernel(IndexView ix, const uint16_t* qh, const uint16_t* ql, uint32_t kpad,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void block_dist_bf16x3_kernel(IndexView ix, const uint16_t* qh, const uint16_t* ql, uint32_t kpad,
                                                                 const float* q_aux, uint32_t q0, uint32_t nq_blk, uint32_t n0,
                                                                 uint32_t n_blk, float* D) {
     __shared__ __attribute__((aligned(16))) uint16_t Ah[128][kBlockLd], Al[128][kBlockLd], Bh[128][kBlockLd], Bl[128][kBlockLd];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t wy = w >> 1, wx = w & 1;
+    const uint32_t wy = w >> 2, wx = w & 3;  // wave (wy, wx): query rows 64 wy .. +63, base rows 32 wx .. +31
     const uint32_t qt = blockIdx.x * 128, nt = blockIdx.y * 128;
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     // Staging, coalesced along the rows: 16 lanes read the 256 contiguous bytes a base row contributes to a stage (a wave-load
-    // = 4 rows, whole 128-byte lines), 8 lanes the 128 bytes of a pre-split query row.  The next stage's loads are in
-    // flight (in registers) while this stage is multiplied.
-    const uint32_t brow = t >> 4, bk = (t & 15) * 4;  // base: rows brow + 16 f, k bk..bk+3
-    const uint32_t arow = t >> 3, ak = (t & 7) * 8;   // queries: rows arow + 32 f, k ak..ak+7
-    uint4 ah[4], al[4], braw[8];
+    // = 4 rows, whole 128-byte lines), 8 lanes the 128 bytes of a pre-split query row.
+    const uint32_t brow = t >> 4, bk = (t & 15) * 4;  // base: rows brow + 32 f, k bk..bk+3
+    const uint32_t arow = t >> 3, ak = (t & 7) * 8;   // queries: rows arow + 64 f, k ak..ak+7
+    uint4 ah[2], al[2], braw[4];
     auto fetch = [&](uint32_t k0) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const uint32_t r = arow + 32u * f;
+        for (int f = 0; f < 2; ++f) {
+            const uint32_t r = arow + 64u * f;
             ah[f] = al[f] = make_uint4(0u, 0u, 0u, 0u);
             if (qt + r < nq_blk && k0 + ak < kpad) {
                 ah[f] = *reinterpret_cast<const uint4*>(qh + (size_t)(q0 + qt + r) * kpad + k0 + ak);
@@ -776,26 +775,26 @@ __global__ __launch_bounds__(256) void block_dist_bf16x3_kernel(IndexView ix, co
             }
         }
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            const uint32_t r = brow + 16u * f;
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t r = brow + 32u * f;
             braw[f] = load4_raw<SC>(ix, (size_t)(n0 + nt + r), k0 + bk, nt + r < n_blk && k0 + bk < kpad);
         }
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            *reinterpret_cast<uint4*>(&Ah[arow + 32 * f][ak]) = ah[f];
-            *reinterpret_cast<uint4*>(&Al[arow + 32 * f][ak]) = al[f];
+        for (int f = 0; f < 2; ++f) {
+            *reinterpret_cast<uint4*>(&Ah[arow + 64 * f][ak]) = ah[f];
+            *reinterpret_cast<uint4*>(&Al[arow + 64 * f][ak]) = al[f];
         }
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
+        for (int f = 0; f < 4; ++f) {
             float bv[4];
             dequant4<SC>(braw[f], bv);
             uint32_t h0, l0, h1, l1;
             split_bf16x2(bv[0], bv[1], h0, l0);
             split_bf16x2(bv[2], bv[3], h1, l1);
-            *reinterpret_cast<uint2*>(&Bh[brow + 16 * f][bk]) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(&Bl[brow + 16 * f][bk]) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2*>(&Bh[brow + 32 * f][bk]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(&Bl[brow + 32 * f][bk]) = make_uint2(l0, l1);
         }
     };
     fetch(0);
@@ -807,37 +806,27 @@ __global__ __launch_bounds__(256) void block_dist_bf16x3_kernel(IndexView ix, co
 #pragma unroll
         for (int ks = 0; ks < kBlockKC / 16; ++ks) {
             const uint32_t kk = (uint32_t)ks * 16u + 8u * (lane >> 5), c = lane & 31;
-            bf16x8 fa_h[2], fa_l[2], fb_h[2], fb_l[2];
+            const bf16x8 fb_h = *reinterpret_cast<const bf16x8*>(&Bh[wx * 32 + c][kk]);
+            const bf16x8 fb_l = *reinterpret_cast<const bf16x8*>(&Bl[wx * 32 + c][kk]);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa_h[i] = *reinterpret_cast<const bf16x8*>(&Ah[wy * 64 + i * 32 + c][kk]);
-                fa_l[i] = *reinterpret_cast<const bf16x8*>(&Al[wy * 64 + i * 32 + c][kk]);
-                fb_h[i] = *reinterpret_cast<const bf16x8*>(&Bh[wx * 64 + i * 32 + c][kk]);
-                fb_l[i] = *reinterpret_cast<const bf16x8*>(&Bl[wx * 64 + i * 32 + c][kk]);
+                const bf16x8 fa_h = *reinterpret_cast<const bf16x8*>(&Ah[wy * 64 + i * 32 + c][kk]);
+                const bf16x8 fa_l = *reinterpret_cast<const bf16x8*>(&Al[wy * 64 + i * 32 + c][kk]);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_l, fb_h, acc[i], 0, 0, 0);  // small terms first
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h, fb_l, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h, fb_h, acc[i], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_l[i], fb_h[j], acc[i][j], 0, 0, 0);  // small terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h[i], fb_l[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h[i], fb_h[j], acc[i][j], 0, 0, 0);
-                }
         }
     }
     const bool aux = exact_needs_aux(ix);
+    const uint32_t ni = nt + wx * 32 + (lane & 31);  // C/D layout: column on the lane, rows in the registers
+    const float ra = (aux && ni < n_blk) ? ix.aux[n0 + ni] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t ni = nt + wx * 64 + j * 32 + (lane & 31);
-            const float ra = (aux && ni < n_blk) ? ix.aux[n0 + ni] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t qi = qt + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (qi < nq_blk && ni < n_blk)
-                    D[(size_t)qi * kExactCH + ni] = finalize_exact(ix, acc[i][j][r], aux ? q_aux[q0 + qi] : 0.f, ra);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t qi = qt + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (qi < nq_blk && ni < n_blk) D[(size_t)qi * kExactCH + ni] = finalize_exact(ix, acc[i][r], aux ? q_aux[q0 + qi] : 0.f, ra);
         }
 }
 
@@ -985,9 +974,9 @@ hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_
             const uint32_t nb = a.slots - n0 < kExactCH ? a.slots - n0 : kExactCH;
             const dim3 mg((nqb + 127) / 128, (nb + 127) / 128);
             switch (a.ix.scalar) {
-                case SC_F32: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F32>), mg, dim3(256), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
-                case SC_F16: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F16>), mg, dim3(256), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
-                default: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_BF16>), mg, dim3(256), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
+                case SC_F32: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F32>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
+                case SC_F16: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F16>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
+                default: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_BF16>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
             }
             const int first = n0 == 0, last = n0 + kExactCH >= a.slots;
             hipLaunchKernelGGL(exact_select_kernel, dim3(nqb, S), dim3(64), 0, s, a.ix, D, q0, n0, nb, C, first, last, st_d, st_s,

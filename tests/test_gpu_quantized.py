@@ -212,3 +212,51 @@ def test_walk_on_an_empty_index_returns_nothing(kind):
     assert len(ix.filtered_search(q[0], 5, lambda key: True)[0]) == 0
     ix.add(7, q[0])
     assert ix.search(q[0], 5)[0].tolist() == [7]
+
+
+@pytest.mark.timeout(120)
+def test_concurrent_callers_on_the_walk_get_the_serial_answers():
+    """num_workers() + 1 threads call search (single-query dispatcher), search_batch (own streams) and filtered_search
+    concurrently on an i8 index: every answer equals the one computed serially -- the walk kernels' per-stream workspaces
+    (heap spill, retry list, bitmaps) are not shared between launches in flight."""
+    import threading
+    v = vs()
+    n, dim, k = 120000, 64, 10
+    data = _data(n + 256, dim, 71)
+    ix = v.HipUsearchIndex(dim, v.L2SQ, quantization=v.I8)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), data[:n])
+    q = data[n:]
+    want_k, want_d, _ = ix.search_batch(q, k)
+    pred = lambda key: key % 3 == 0
+    want_f = [ix.filtered_search(q[i], k, pred)[0].tolist() for i in range(8)]
+    errs = []
+
+    def single(t):
+        try:
+            for i in range(t, 256, 17):
+                kk, dd = ix.search(q[i], k)
+                assert kk.tolist() == want_k[i].tolist() and dd.tolist() == want_d[i].tolist(), ("single", i)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    def batch(t):
+        try:
+            for _ in range(4):
+                kk, dd, _ = ix.search_batch(q[t * 16:(t + 1) * 16 + 40], k)
+                assert np.array_equal(kk, want_k[t * 16:(t + 1) * 16 + 40]), ("batch", t)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    def filt(t):
+        try:
+            for i in range(8):
+                assert ix.filtered_search(q[i], k, pred)[0].tolist() == want_f[i], ("filtered", i)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=single, args=(t,)) for t in range(9)] + [threading.Thread(target=batch, args=(t,)) for t in range(6)] + \
+         [threading.Thread(target=filt, args=(t,)) for t in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs[:3]

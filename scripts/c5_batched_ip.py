@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4]: batched search, q = 256, 10M x 768 inner product (base L2-normalised).
-Times (a) the exact MFMA block-distance path (exact_dist_mfma_kernel + exact_select_kernel) and (b) the HNSW walk on
+Times (a) the exact block-distance path (split-bf16 MFMA nomination + f32 re-score + certificate; VS_HNSW_EXACT=f32: the f32-input MFMA
+path of round 1) and (b) the HNSW walk on
 the same 256-query batches, with recall of (b) against (a).  Prints one JSON line."""
 import json
 import os

@@ -223,6 +223,8 @@ def make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, total_rows, 
     import torch
     native = backend == "nccl" and os.environ.get("VS_RANKS", "native") != "torch"
     gs = None
+    if dist is None:
+        return ranks.RankedSearcher(ix, queries, k, None, total_rows)
     if native:
         try:
             gs = ranks.RankedSearcher(ix, queries, k, dist, total_rows)
@@ -318,7 +320,7 @@ def main():
             dist.barrier()
 
     n, dim, nq, k = a.n, a.dim, a.nq, a.k
-    shard_mode = a.mode == "shard" and world > 1
+    shard_mode = a.mode == "shard"  # (at N = 1: the same code path over a world of one -- no collective, same pack / merge / pipeline)
     # replica: same base on every rank, own queries; shard: own base (key range r*n..), same queries
     base = make_data(n, dim, a.dist, 1234 + (rank if shard_mode else 0), dev, a.rank)
     queries = make_data(nq, dim, a.dist, 4321 + (0 if shard_mode else rank), dev, a.rank)
@@ -420,7 +422,7 @@ def main():
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.quantization, "data": "synthetic",
         "config": {"workload": f"{n}x{dim} {a.metric} top-{k} per GPU, {nq} queries/step, M=16 ef_add=128 ef_search={ef}" + ("" if a.quantization == "f32" else f" {a.quantization}"),
-                   "distribution": a.dist + (f"{a.rank}" if a.dist == "lowrank" else ""), "mode": a.mode if world > 1 else "single",
+                   "distribution": a.dist + (f"{a.rank}" if a.dist == "lowrank" else ""), "mode": a.mode if (world > 1 or shard_mode) else "single",
                    "index_vectors_total": n * (world if shard_mode else 1)},
         "recall_at_10": round(recall, 4), "ef_search": ef, "ef_sweep": sweep,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

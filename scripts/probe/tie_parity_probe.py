@@ -14,4 +14,5 @@ for kind, metric, dim in (("b1", "hamming", 256), ("b1", "hamming", 64), ("i8", 
         gk, gd, gf = ix.search_batch(q, k)
         ok, od, of = o.search_batch(q, k, threads=8)
         bad = sum(not (gf[i] == of[i] and np.array_equal(gd[i, :gf[i]], od[i, :of[i]])) for i in range(len(q)))
-        print(f"{kind} {metric} dim {dim} ef {ef} k {k}: queries whose distance list differs from the oracle's: {bad}/1000", flush=True)
+        bad_ids = sum(not (gf[i] == of[i] and np.array_equal(gk[i, :gf[i]], ok[i, :of[i]])) for i in range(len(q)))
+        print(f"{kind} {metric} dim {dim} ef {ef} k {k}: queries whose distance list / id list differs from the oracle's: {bad} / {bad_ids} of 1000", flush=True)

@@ -493,7 +493,12 @@ struct Engine {
         iters = 0;
         uint32_t max_lg = 6;
         if (const char* ml = std::getenv("VS_HNSW_MAX_LANES_LOG2")) max_lg = std::min<uint32_t>(6, (uint32_t)std::atoi(ml));  // layout experiments
-        for (uint32_t lg = 0; lg <= max_lg; ++lg)
+        // b1 rows of 64+ bytes: at least 4 lanes per row (768 bits: 4 x 2 chunks, rows padded to one 128-byte line, instead of
+        // 2 x 3) -- one chunk pair per lane keeps the walk kernel at 114 instead of 191 registers (measured: walk +8 %, fused
+        // list unchanged; Hamming distances are integers, so the layout cannot change a result)
+        uint32_t min_lg = (scalar == VS_SCALAR_B1 && chunks >= 4) ? 2 : 0;
+        if (const char* ml = std::getenv("VS_HNSW_MIN_LANES_LOG2")) min_lg = std::min<uint32_t>(max_lg, (uint32_t)std::atoi(ml));  // layout experiments
+        for (uint32_t lg = min_lg; lg <= max_lg; ++lg)
             for (uint32_t it : ok_iters) {
                 const uint32_t cap = (1u << lg) * it;
                 if (cap < chunks) continue;
@@ -1037,13 +1042,14 @@ struct Engine {
                 wr.retry_seen_valid = false;
             }
             const bool small = ef <= 128 && small_table_ok.load() && slots <= (1ull << walk_small_table_bits()) && !stress_small_table;
-            const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : WALK_LDS_512;
+            const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : ef <= kWalk320MaxBeam ? WALK_LDS_320 : WALK_LDS_512;
             a.bitmap_words = 0;
             a.vlog_cap = 0;
             a.heap_cap = 8192;
             a.space_stride = walk_space_stride(0, 0, a.heap_cap);
             uint32_t grid = 0;
-            HIP_OK(launch_walk(a, iters, inst, 1u << 20, st, &grid));
+            static const uint32_t grid_limit = std::getenv("VS_HNSW_WALK_GRID") ? (uint32_t)std::max(1, std::atoi(std::getenv("VS_HNSW_WALK_GRID"))) : (1u << 20);  // residency experiments
+            HIP_OK(launch_walk(a, iters, inst, grid_limit, st, &grid));
             a.space = (char*)wr.lds_space.ensure((size_t)grid * a.space_stride);
             a.retry_count = retry;
             a.retry_list = retry + 64;

@@ -13,6 +13,9 @@
 #include <atomic>
 
 #include "kernels.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include "walk_device.hpp"
 
 #ifndef VS_AR
@@ -103,6 +106,13 @@ static uint32_t resident_workgroups(K kernel, int device) {  // workgroups of `k
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    if (const char* pc = std::getenv("VS_HNSW_WALK_PER_CU")) per_cu = std::max(1, std::atoi(pc));  // residency experiments
+    if (std::getenv("VS_HNSW_WALK_DEBUG")) {
+        hipFuncAttributes fa{};
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel));
+        fprintf(stderr, "[walk] occupancy: %d workgroups per CU x %d CUs (registers %d, LDS %zu B, scratch %zu B)\n", per_cu, cus, fa.numRegs,
+                fa.sharedSizeBytes, fa.localSizeBytes);
+    }
     return (uint32_t)per_cu * (uint32_t)cus;
 }
 
@@ -139,8 +149,13 @@ static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_ca
     switch (instance) {
         // `next` in LDS: 4 x the beam (largest heap seen at 1M x 768: 469 / 792 at beams of 128 / 256); beyond -> retry instance
         case WALK_LDS_128: return walk_launch<AR, I, 128, kWalkHeapLds, 1024, 1, false>(a, grid_cap, s, grid_out);
-        case WALK_LDS_256: return walk_launch<AR, I, 256, 2 * kWalkHeapLds, 1024, 2, false>(a, grid_cap, s, grid_out);
-        case WALK_LDS_512: return walk_launch<AR, I, 512, 4 * kWalkHeapLds, 2048, 2, false>(a, grid_cap, s, grid_out);
+        // 796 entries of `next` (largest seen at a beam of 256: 792; beyond -> retry instance): 26,612 B of LDS, what still
+        // fits 6 per CU (LDS is handed out in 2 KiB steps: 26 KiB x 6 = 156 KiB)
+        case WALK_LDS_256: return walk_launch<AR, I, 256, 796, 1024, 2, false>(a, grid_cap, s, grid_out);
+        // beams of 257..288: 990 entries of `next`, 28,664 B of LDS, 5 per CU
+        case WALK_LDS_320: return walk_launch<AR, I, 320, 990, 1024, 2, false>(a, grid_cap, s, grid_out);
+        // 1,690 entries of `next` (largest seen at a beam of 512: 1,341): 53,220 B of LDS, what still fits 3 per CU
+        case WALK_LDS_512: return walk_launch<AR, I, 512, 1690, 2048, 2, false>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_512: return walk_launch<AR, I, 512, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_2048: return walk_launch<AR, I, 2048, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_10240: return walk_launch<AR, I, 10240, 1024, 256, 1, true>(a, grid_cap, s, grid_out);

@@ -159,7 +159,7 @@ __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& 
     hn = n;
     if (n == 0) return;
     if constexpr (!Sh::kHeapSpill) {
-        constexpr int RMAX = Sh::kHeapLds / 128;  // 64 internal nodes per ballot
+        constexpr int RMAX = (Sh::kHeapLds + 127) / 128;  // 64 internal nodes per ballot
         const uint2 last = sh.hp[n];
         const float ld = __uint_as_float(uni(last.x));
         uint64_t pref[RMAX];  // bit i of pref[r]: node 64 r + i prefers its RIGHT child

@@ -753,7 +753,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ __attribute__((aligned(16))) uint16_t Ah[128][kBlockLd], Al[128][kBlockLd], Bh[128][kBlockLd], Bl[128][kBlockLd];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t wy = w >> 2, wx = w & 3;  // wave (wy, wx): query rows 64 wy .. +63, base rows 32 wx .. +31
-    const uint32_t qt = blockIdx.x * 128, nt = blockIdx.y * 128;
+    // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (each with its own L2), so the query tiles of ONE row
+    // block are made consecutive workgroups of ONE XCD -- the second one finds the rows in that L2 instead of fetching
+    // them from HBM again (measured with 2 query tiles: 2.36 x the algorithmic bytes per launch before).
+    const uint32_t q_tiles = (nq_blk + 127u) / 128u;
+    const uint32_t in_xcd = blockIdx.x >> 3;
+    const uint32_t qt = (in_xcd % q_tiles) * 128, nt = ((in_xcd / q_tiles) * 8u + (blockIdx.x & 7u)) * 128;
+    if (nt >= n_blk) return;
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -972,7 +978,7 @@ hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_
         const uint32_t nqb = a.nq - q0 < kExactQB ? a.nq - q0 : kExactQB;
         for (uint32_t n0 = 0; n0 < a.slots; n0 += kExactCH) {
             const uint32_t nb = a.slots - n0 < kExactCH ? a.slots - n0 : kExactCH;
-            const dim3 mg((nqb + 127) / 128, (nb + 127) / 128);
+            const dim3 mg(((nqb + 127) / 128) * (((nb + 127) / 128 + 7) / 8 * 8));  // row blocks rounded up to the 8 XCDs
             switch (a.ix.scalar) {
                 case SC_F32: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F32>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
                 case SC_F16: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F16>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;

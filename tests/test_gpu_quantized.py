@@ -136,7 +136,7 @@ def test_integer_metrics_return_the_oracles_ids_at_100k(kind, metric, dim):
                 assert_same_results(gk[i, : gf[i]], gd[i, : gf[i]], ok_[i, : of_[i]], od_[i, : of_[i]], exact=True,
                                     what=(kind, metric, dim, ef, k, i))
 
-    compare(((64, 10), (100, 50), (128, 100), (256, 10), (512, 100), (1000, 1000)))
+    compare(((64, 10), (100, 50), (128, 100), (256, 10), (257, 10), (288, 100), (300, 30), (512, 100), (1000, 1000)))
     for key in range(0, n, 4):
         assert ix.remove(key)
         assert o.remove(key)
@@ -146,6 +146,35 @@ def test_integer_metrics_return_the_oracles_ids_at_100k(kind, metric, dim):
         o.set_expansion_search(64)
         assert_same_results(*ix.search(q[i], 10), *o.search(q[i], 10), exact=True)
     assert ix.stats()["visited_overflow"] == 0
+
+
+@pytest.mark.parametrize("kind,metric,dim", [("i8", "l2sq", 32), ("b1", "hamming", 256)])
+def test_walk_whose_candidate_heap_outgrows_lds_is_retried_exactly(kind, metric, dim):
+    """Removed members are expanded and pushed to `next` but never enter `top`: with 15 of 16 members removed `top` fills
+    slowly while `next` grows far beyond the part of it an LDS instance holds (512 / 796 / 990 / 1,690 entries), so the
+    kernel hands those queries to the global-bitmap instance launched behind it.  Same ids as the CPU restatement either way."""
+    v = vs()
+    n, nq = 60000, 200
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS[kind])
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    o = OracleIndex(dim, oracle.METRICS[metric], quantization=oracle.SCALARS[kind])
+    o.import_graph(ix.export_graph())
+    for key in range(n):
+        if key % 16:
+            assert ix.remove(key)
+            assert o.remove(key)
+    for ef, k in ((128, 10), (256, 100), (288, 100), (512, 200)):
+        ix.set_expansion_search(ef)
+        o.set_expansion_search(ef)
+        gk, gd, gf = ix.search_batch(q, k)
+        ok_, od_, of_ = o.search_batch(q, k, threads=8)
+        for i in range(nq):
+            assert gf[i] == of_[i]
+            assert_same_results(gk[i, : gf[i]], gd[i, : gf[i]], ok_[i, : of_[i]], od_[i, : of_[i]], exact=True, what=(kind, ef, k, i))
 
 
 @pytest.mark.parametrize("kind", ["f16", "bf16", "i8", "b1"])

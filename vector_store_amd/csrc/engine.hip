@@ -302,7 +302,7 @@ struct WalkRes {
     DeviceBuf retry;      // [count u32, 63 pad words | query ids]
     DeviceBuf allow;      // filtered search: the allow-bitmap of the query
     std::mutex mu;        // held while a call sizes the buffers and enqueues its launches
-    uint32_t* retry_seen = nullptr;  // pinned: [retried queries of the last small-table launch, its batch size]
+    uint32_t* retry_seen = nullptr;  // pinned: [retried queries of the last LDS-instance launch, its batch size, its instance]
     bool retry_seen_valid = false;
     size_t g_layout[3] = {0, 0, 0};  // (bitmap words, stride, bytes) the bitmaps of g_space are known to be zero for
 };
@@ -350,6 +350,7 @@ struct Engine {
     uint32_t* d_max_norm = nullptr;
     bool eager_filter = false;               // VS_HNSW_FILTER=eager: always one predicate call per live member (the full bitmap)
     std::atomic<uint64_t> lazy_rounds{0}, lazy_predicate_calls{0};  // filtered_lazy: rounds / predicate calls so far (tests)
+    std::atomic<bool> lds_walk_bad[16] = {};  // per walk instance: more than a quarter of a batch outgrew its LDS structures -> global-bitmap instance at once
     std::atomic<bool> small_table_ok{true};  // usearch-order walk, beams <= 128: the half-size visited table is paying off
     bool force_wide_tags = false;     // reserved bit 6 (tests): wide visited tags although the index is small
     bool force_global_walk = false;   // reserved bit 5 (tests): every search takes the global-bitmap walk instance
@@ -1008,7 +1009,7 @@ struct Engine {
             auto global_space = [&](WalkArgs& w, uint32_t inst, uint32_t want_grid, bool deep_heap) {
                 w.bitmap_words = (uint32_t)((slots + 31) / 32);
                 w.vlog_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(slots, 1u << 16));
-                w.heap_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(slots, deep_heap ? (1u << 20) : (1u << 16)));
+                w.heap_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(slots, deep_heap ? (1u << 18) : (1u << 16)));
                 w.space_stride = walk_space_stride(w.bitmap_words, w.vlog_cap, w.heap_cap);
                 const uint32_t budget_grid = (uint32_t)std::max<size_t>(16, (4ull << 30) / w.space_stride);
                 uint32_t grid = 0;
@@ -1026,7 +1027,18 @@ struct Engine {
             };
             uint32_t* retry = (uint32_t*)wr.retry.ensure((64 + nq) * 4);  // [0] retried queries, [1] / [2] work counters, [64..] their ids
             HIP_OK(hipMemsetAsync(retry, 0, 256, st));
-            if (global) {
+            // How the previous launch on this stream fared: the half-size table goes back to the full one when > 5 % of a
+            // batch outgrew it; an instance most of whose queries outgrow its LDS structures (structureless data: `next`
+            // holds thousands of equal-distance entries) is skipped from then on -- the retry launch is exact but narrow.
+            if (wr.retry_seen_valid) {
+                const uint32_t seen = wr.retry_seen[0], of = wr.retry_seen[1], which = wr.retry_seen[2] & 15u;
+                if (of >= 64 && which == WALK_LDS_128_SMALL && seen * 20 > of) small_table_ok = false;
+                else if (of >= 64 && which != WALK_LDS_128_SMALL && which != WALK_LDS_128_TINY && seen * 4 > of) lds_walk_bad[which] = true;
+                wr.retry_seen_valid = false;
+            }
+            const bool small = ef <= 128 && small_table_ok.load() && slots <= (1ull << walk_small_table_bits()) && !stress_small_table;
+            const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : ef <= kWalk320MaxBeam ? WALK_LDS_320 : WALK_LDS_512;
+            if (global || lds_walk_bad[inst].load()) {
                 const uint32_t grid = global_space(a, g_inst, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
                 a.work_counter = retry + 1;
                 HIP_OK(launch_walk(a, iters, g_inst, grid, st, nullptr));
@@ -1037,12 +1049,6 @@ struct Engine {
             // walks per CU).  Queries that outgrow it are retried exactly (global bitmap); should a data set make that
             // common -- the previous launch's retry count is read back with every launch -- the index goes back to the
             // 8,192-entry table for good.
-            if (wr.retry_seen_valid) {
-                if (wr.retry_seen[1] >= 64 && wr.retry_seen[0] * 20 > wr.retry_seen[1]) small_table_ok = false;  // > 5 % retried
-                wr.retry_seen_valid = false;
-            }
-            const bool small = ef <= 128 && small_table_ok.load() && slots <= (1ull << walk_small_table_bits()) && !stress_small_table;
-            const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : ef <= kWalk320MaxBeam ? WALK_LDS_320 : WALK_LDS_512;
             a.bitmap_words = 0;
             a.vlog_cap = 0;
             a.heap_cap = 8192;
@@ -1060,7 +1066,7 @@ struct Engine {
             r.retry_list = nullptr;
             r.retry_count = nullptr;
             r.work_counter = retry + 2;
-            const uint32_t rgrid = global_space(r, WALK_GLOBAL_512, 64, true);
+            const uint32_t rgrid = global_space(r, WALK_GLOBAL_512, 256, true);
             static const bool walk_debug = std::getenv("VS_HNSW_WALK_DEBUG") != nullptr;  // measurement aid: per-query walk sizes to stderr
             uint32_t* d_dbg = nullptr;
             if (walk_debug) {
@@ -1070,9 +1076,10 @@ struct Engine {
             }
             HIP_OK(launch_walk(a, iters, inst, grid, st, nullptr));
             HIP_OK(launch_walk(r, iters, WALK_GLOBAL_512, rgrid, st, nullptr));
-            if (small) {  // how many queries of this launch had to be retried: looked at by the next launch on this stream
-                if (!wr.retry_seen) HIP_OK(hipHostMalloc((void**)&wr.retry_seen, 8, hipHostMallocDefault));
+            {  // how many queries of this launch had to be retried: looked at by the next launch on this stream
+                if (!wr.retry_seen) HIP_OK(hipHostMalloc((void**)&wr.retry_seen, 16, hipHostMallocDefault));
                 wr.retry_seen[1] = (uint32_t)nq;
+                wr.retry_seen[2] = inst;
                 HIP_OK(hipMemcpyAsync(&wr.retry_seen[0], retry, 4, hipMemcpyDeviceToHost, st));
                 wr.retry_seen_valid = true;  // (read one launch later: by then the copy has long landed; a stale value only delays the switch)
             }

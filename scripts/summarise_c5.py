@@ -14,7 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarise_profiles import kernel_sources_sha16  # noqa: E402
 
-KERNELS = ("block_dist_bf16x3_kernel", "exact_select_kernel", "exact_finish_kernel", "block_rescore_kernel", "block_final_kernel",
+KERNELS = ("block_dist_bf16x3_kernel", "block_merge_kernel", "exact_select_kernel", "exact_finish_kernel", "block_rescore_kernel", "block_final_kernel",
            "split_queries_kernel", "exact_dist_mfma_kernel")
 
 

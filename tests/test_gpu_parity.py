@@ -869,3 +869,27 @@ def test_exact_search_split_bf16_nomination_is_certified_or_falls_back(metric, q
     assert fast2.exact_stats()["block_fallbacks"] == 1
     assert np.array_equal(fk, rk) and np.array_equal(fd, rd)          # the very same kernels answered
     assert set(fk[0].tolist()) <= set(range(1000, 1300))
+    # Row blocks after the first pass on only the scores at or below each query's threshold.  (a) members of the second block
+    # removed: never results; (b) rows stored farthest-first from one query: its second block beats everything seen before,
+    # the per-query buffer overflows and the batch is answered by the f32 path -- same ids either way.
+    base = data[:n].copy()
+    if metric == "ip":
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+    fast3, ref3 = build(None), build("f32")
+    gone = list(range(65536, n, 3))
+    for key in gone:
+        assert fast3.remove(key) and ref3.remove(key)
+    fk, fd, ff = fast3.exact_search_batch(q, k)
+    rk, rd, rf = ref3.exact_search_batch(q, k)
+    assert fast3.exact_stats()["block_fallbacks"] == 0 and not (set(fk.ravel().tolist()) & set(gone))
+    assert np.allclose(fd, rd, rtol=1e-5, atol=2e-5)
+    assert all(set(fk[i].tolist()) == set(rk[i].tolist()) or np.isclose(fd[i, -1], rd[i, -1], rtol=1e-5, atol=2e-5) for i in range(len(q)))
+    qn = q[0] / np.linalg.norm(q[0])
+    order = np.argsort(-(1.0 - (base @ qn) / (np.linalg.norm(base, axis=1) if metric == "cos" else 1.0)), kind="stable")
+    base = base[order]
+    fast4, ref4 = build(None), build("f32")
+    fk, fd, ff = fast4.exact_search_batch(q[:8], k)
+    rk, rd, rf = ref4.exact_search_batch(q[:8], k)
+    assert fast4.exact_stats()["block_fallbacks"] == 1
+    assert np.array_equal(fk, rk) and np.array_equal(fd, rd)
+    assert fk[0].min() >= n - 64                                       # the nearest rows are the last ones stored

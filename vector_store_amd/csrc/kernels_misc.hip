@@ -706,6 +706,7 @@ hipError_t launch_rank_emit(const IndexView& ix, const uint64_t* sorted, uint32_
 // A query that fails the certificate (dense ties at the cut) is counted, and the host re-runs the f32 path.
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr uint32_t kBlockC = 256;    // nominees per query
+constexpr uint32_t kBlockCandCap = 4096;  // scores per query a row block may pass on to the nominee list (after the first block)
 constexpr int kBlockKC = 64;         // k staged per LDS buffer.  Measured at 10M x 768, q = 256 (whole search): 64 deep, one buffer, two
                                      // barriers per stage 21.8 ms; 32 deep through two buffers (the f32 kernel's structure) 31.2 ms
 constexpr int kBlockLd = kBlockKC + 8;  // halfwords per LDS row: 144 B, 16-byte reads of 16 consecutive rows hit 64 distinct dwords
@@ -749,8 +750,10 @@ __global__ void split_queries_kernel(const float* qd, uint32_t nq, uint32_t kpad
 template <int SC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void block_dist_bf16x3_kernel(IndexView ix, const uint16_t* qh, const uint16_t* ql, uint32_t kpad,
                                                                 const float* q_aux, uint32_t q0, uint32_t nq_blk, uint32_t n0,
-                                                                uint32_t n_blk, float* D) {
+                                                                uint32_t n_blk, float* D, const float* thr, uint2* cand,
+                                                                uint32_t* cand_cnt, uint32_t cand_cap) {
     __shared__ __attribute__((aligned(16))) uint16_t Ah[128][kBlockLd], Al[128][kBlockLd], Bh[128][kBlockLd], Bl[128][kBlockLd];
+    __shared__ float thr_s[128];  // the tile's queries' thresholds (read in the epilogue; the K loop's barriers publish them)
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t wy = w >> 2, wx = w & 3;  // wave (wy, wx): query rows 64 wy .. +63, base rows 32 wx .. +31
     // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (each with its own L2), so the query tiles of ONE row
@@ -760,6 +763,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t in_xcd = blockIdx.x >> 3;
     const uint32_t qt = (in_xcd % q_tiles) * 128, nt = ((in_xcd / q_tiles) * 8u + (blockIdx.x & 7u)) * 128;
     if (nt >= n_blk) return;
+    if (thr && t < 128) thr_s[t] = qt + t < nq_blk ? thr[qt + t] : -__builtin_inff();
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -832,8 +836,73 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const uint32_t qi = qt + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (qi < nq_blk && ni < n_blk) D[(size_t)qi * kExactCH + ni] = finalize_exact(ix, acc[i][r], aux ? q_aux[q0 + qi] : 0.f, ra);
+            if (qi < nq_blk && ni < n_blk) {
+                const float d = finalize_exact(ix, acc[i][r], aux ? q_aux[q0 + qi] : 0.f, ra);
+                if (thr) {  // every row block after the first: only scores that can still enter the query's nominee list leave the tile
+                    if (d <= thr_s[qi - qt]) {
+                        const uint32_t at = atomicAdd(&cand_cnt[qi], 1u);
+                        if (at < cand_cap) cand[(size_t)qi * cand_cap + at] = make_uint2(__float_as_uint(d), n0 + ni);
+                    }
+                } else {
+                    D[(size_t)qi * kExactCH + ni] = d;
+                }
+            }
         }
+}
+
+// Row blocks after the first: the tile kernel appended the few scores at or below each query's threshold (the worst score on
+// its full nominee list) to a per-query buffer; one wave per query merges them into the list -- same (score, slot) order as
+// exact_select_kernel, so the nominees are the same -- and publishes the new threshold.  A buffer that overflowed (rows stored
+// in an order that keeps improving on everything seen before) raises `uncertified`: the host re-runs the batch on the f32 path.
+__global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt,
+                                                         const uint2* cand, uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr,
+                                                         uint32_t* uncertified) {
+    __shared__ SelectShared sh;
+    const int lane = lane_id();
+    const uint32_t ql = blockIdx.x, qg = q0 + ql;
+    uint32_t n = cand_cnt[ql];
+    uint32_t sz = list_n[qg];
+    for (uint32_t i = lane; i < sz; i += kWave) {
+        sh.lst_d[0][i] = list_d[(size_t)qg * C + i];
+        sh.lst_s[0][i] = (uint32_t)list_slot[(size_t)qg * C + i];
+    }
+    __syncthreads();
+    if (lane == 0) cand_cnt[ql] = 0;
+    if (n > cand_cap) {
+        if (lane == 0) atomicAdd(uncertified, 1u);
+        n = cand_cap;
+    }
+    for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const uint2 e = i < n ? cand[(size_t)ql * cand_cap + i] : make_uint2(0u, 0u);
+        const float d = __uint_as_float(e.x);
+        const uint32_t slot = e.y;
+        bool ok = i < n;
+        if (ok && sz == C) ok = key_less(d, slot, sh.lst_d[0][C - 1], sh.lst_s[0][C - 1]);
+        ok = ok && ix.keys[ok ? slot : 0] != kFreeKey;
+        const uint64_t mask = __ballot(ok);
+        if (!mask) continue;
+        const uint32_t ma = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (ok) {
+            const uint32_t r = mbcnt(mask);
+            sh.u_dist[r] = d;
+            sh.u_slot[r] = slot;
+        }
+        __syncthreads();
+        const float nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
+        const uint32_t ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
+        sz = list_merge(sh, 0, sz, C, nd, ns, ma, lane);
+        __syncthreads();
+    }
+    for (uint32_t i = lane; i < sz; i += kWave) {
+        list_d[(size_t)qg * C + i] = sh.lst_d[0][i];
+        list_slot[(size_t)qg * C + i] = (uint64_t)(sh.lst_s[0][i] & kSlotMask);
+    }
+    if (lane == 0) {
+        list_n[qg] = sz;
+        thr[ql] = sz == C ? sh.lst_d[0][C - 1] : __builtin_inff();
+    }
 }
 
 // exact f32 score of nominee c of query q: one wave per (query, nominee)
@@ -976,21 +1045,36 @@ hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_
     hipLaunchKernelGGL(split_queries_kernel, dim3((a.nq + 3) / 4), dim3(256), 0, s, qd, a.nq, kpad, qh, ql, qnorm);
     for (uint32_t q0 = 0; q0 < a.nq; q0 += kExactQB) {
         const uint32_t nqb = a.nq - q0 < kExactQB ? a.nq - q0 : kExactQB;
+        // The first row block goes through the score block D and the segmented select pass, which leaves each query's nominee
+        // list (cand_*); from then on that list's worst score is a threshold few scores pass (C per query over the second
+        // block, fewer later), so the tiles append those to per-query buffers -- kept where D was: it is free by then -- and
+        // one wave per query merges them: no 67 MB score block per launch, no pass over it.
+        uint2* cand = reinterpret_cast<uint2*>(D);
+        uint32_t* cand_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(D) + (size_t)kExactQB * kBlockCandCap * 8);
+        float* thr = reinterpret_cast<float*>(cand_cnt + kExactQB);
         for (uint32_t n0 = 0; n0 < a.slots; n0 += kExactCH) {
             const uint32_t nb = a.slots - n0 < kExactCH ? a.slots - n0 : kExactCH;
             const dim3 mg(((nqb + 127) / 128) * (((nb + 127) / 128 + 7) / 8 * 8));  // row blocks rounded up to the 8 XCDs
+            const bool first = n0 == 0;
+            const float* t = first ? nullptr : thr;
             switch (a.ix.scalar) {
-                case SC_F32: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F32>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
-                case SC_F16: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F16>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
-                default: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_BF16>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D); break;
+                case SC_F32: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F32>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D, t, cand, cand_cnt, kBlockCandCap); break;
+                case SC_F16: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_F16>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D, t, cand, cand_cnt, kBlockCandCap); break;
+                default: hipLaunchKernelGGL((block_dist_bf16x3_kernel<SC_BF16>), mg, dim3(512), 0, s, a.ix, qh, ql, kpad, q_aux, q0, nqb, n0, nb, D, t, cand, cand_cnt, kBlockCandCap); break;
             }
-            const int first = n0 == 0, last = n0 + kExactCH >= a.slots;
-            hipLaunchKernelGGL(exact_select_kernel, dim3(nqb, S), dim3(64), 0, s, a.ix, D, q0, n0, nb, C, first, last, st_d, st_s,
-                               st_n, cand_slot, cand_approx, cand_found, 1);
+            if (first) {
+                hipLaunchKernelGGL(exact_select_kernel, dim3(nqb, S), dim3(64), 0, s, a.ix, D, q0, n0, nb, C, 1, 1, st_d, st_s, st_n, cand_slot,
+                                   cand_approx, cand_found, 1);
+                if (S > 1)
+                    hipLaunchKernelGGL(exact_finish_kernel, dim3(nqb), dim3(64), 0, s, a.ix, q0, S, C, st_d, st_s, st_n, cand_slot, cand_approx,
+                                       cand_found, 1);
+                if (n0 + kExactCH >= a.slots) break;
+                e = hipMemsetAsync(cand_cnt, 0, (size_t)kExactQB * 4, s);  // D is free from here on
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(block_merge_kernel, dim3(nqb), dim3(64), 0, s, a.ix, q0, C, kBlockCandCap, cand_cnt, cand, cand_slot, cand_approx,
+                               cand_found, thr, d_uncertified);
         }
-        if (S > 1)
-            hipLaunchKernelGGL(exact_finish_kernel, dim3(nqb), dim3(64), 0, s, a.ix, q0, S, C, st_d, st_s, st_n, cand_slot, cand_approx,
-                               cand_found, 1);
     }
     hipLaunchKernelGGL(block_rescore_kernel, dim3(a.nq, C / 4), dim3(256), 0, s, a.ix, qd, kpad, q_aux, C, cand_slot, cand_found, exact_d);
     hipLaunchKernelGGL(block_final_kernel, dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, qnorm,

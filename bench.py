@@ -416,6 +416,9 @@ def main():
     total_q = nq * a.steps * (1 if shard_mode else world)
     value = total_q / elapsed
 
+    # i8 / b1 indexes (and VS_HNSW_ORDER=usearch) are served by the usearch-order walk, everything else by the fused-list kernel
+    order = os.environ.get("VS_HNSW_ORDER", "")
+    search_kernel_name = "hnsw_walk_kernel" if (order == "usearch" or (a.quantization in ("i8", "b1") and order != "fused")) else "hnsw_search_kernel"
     out = {
         "metric": "QPS at recall@10>=0.95 (HNSW search, inputs resident in HBM)",
         "value": value, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -426,7 +429,7 @@ def main():
                    "index_vectors_total": n * (world if shard_mode else 1)},
         "recall_at_10": round(recall, 4), "ef_search": ef, "ef_sweep": sweep,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "hnsw_search_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": search_kernel_name,
                      "kernel_ms": kernel_ms, "bytes_per_query": b_q, "evals_per_query": e_q, "hops_per_query": h_q,
                      "visited_overflow": st["visited_overflow"]},
         "build": build_info,

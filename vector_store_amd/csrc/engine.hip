@@ -304,6 +304,7 @@ struct WalkRes {
     std::mutex mu;        // held while a call sizes the buffers and enqueues its launches
     uint32_t* retry_seen = nullptr;  // pinned: [retried queries of the last LDS-instance launch, its batch size, its instance]
     bool retry_seen_valid = false;
+    const void* retry_seen_owner = nullptr;  // the index that launch searched (streams are shared between indexes)
     size_t g_layout[3] = {0, 0, 0};  // (bitmap words, stride, bytes) the bitmaps of g_space are known to be zero for
 };
 static WalkRes& walk_res(int dev, hipStream_t st) {
@@ -1030,12 +1031,12 @@ struct Engine {
             // How the previous launch on this stream fared: the half-size table goes back to the full one when > 5 % of a
             // batch outgrew it; an instance most of whose queries outgrow its LDS structures (structureless data: `next`
             // holds thousands of equal-distance entries) is skipped from then on -- the retry launch is exact but narrow.
-            if (wr.retry_seen_valid) {
+            if (wr.retry_seen_valid && wr.retry_seen_owner == this) {
                 const uint32_t seen = wr.retry_seen[0], of = wr.retry_seen[1], which = wr.retry_seen[2] & 15u;
                 if (of >= 64 && which == WALK_LDS_128_SMALL && seen * 20 > of) small_table_ok = false;
                 else if (of >= 64 && which != WALK_LDS_128_SMALL && which != WALK_LDS_128_TINY && seen * 4 > of) lds_walk_bad[which] = true;
-                wr.retry_seen_valid = false;
             }
+            wr.retry_seen_valid = false;
             const bool small = ef <= 128 && small_table_ok.load() && slots <= (1ull << walk_small_table_bits()) && !stress_small_table;
             const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : ef <= kWalk320MaxBeam ? WALK_LDS_320 : WALK_LDS_512;
             if (global || lds_walk_bad[inst].load()) {
@@ -1080,6 +1081,7 @@ struct Engine {
                 if (!wr.retry_seen) HIP_OK(hipHostMalloc((void**)&wr.retry_seen, 16, hipHostMallocDefault));
                 wr.retry_seen[1] = (uint32_t)nq;
                 wr.retry_seen[2] = inst;
+                wr.retry_seen_owner = this;
                 HIP_OK(hipMemcpyAsync(&wr.retry_seen[0], retry, 4, hipMemcpyDeviceToHost, st));
                 wr.retry_seen_valid = true;  // (read one launch later: by then the copy has long landed; a stale value only delays the switch)
             }

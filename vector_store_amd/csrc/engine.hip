@@ -1054,9 +1054,13 @@ struct Engine {
             a.vlog_cap = 0;
             a.heap_cap = 8192;
             a.space_stride = walk_space_stride(0, 0, a.heap_cap);
+            // batches too small to fill the chip (lone callers): a team of waves per query, as the fused-list kernel does
+            const bool team_walk = inst != WALK_LDS_512 && inst != WALK_LDS_128_TINY &&
+                                   (team_mode == 1 || (team_mode == 0 && std::max(nq, load) <= team_max_nq));
+            const uint32_t launch_inst = team_walk ? (inst | kWalkTeamFlag) : inst;
             uint32_t grid = 0;
             static const uint32_t grid_limit = std::getenv("VS_HNSW_WALK_GRID") ? (uint32_t)std::max(1, std::atoi(std::getenv("VS_HNSW_WALK_GRID"))) : (1u << 20);  // residency experiments
-            HIP_OK(launch_walk(a, iters, inst, grid_limit, st, &grid));
+            HIP_OK(launch_walk(a, iters, launch_inst, grid_limit, st, &grid));
             a.space = (char*)wr.lds_space.ensure((size_t)grid * a.space_stride);
             a.retry_count = retry;
             a.retry_list = retry + 64;
@@ -1075,7 +1079,7 @@ struct Engine {
                 HIP_OK(hipMemsetAsync(d_dbg, 0, nq * 48, st));
                 a.debug = r.debug = d_dbg;
             }
-            HIP_OK(launch_walk(a, iters, inst, grid, st, nullptr));
+            HIP_OK(launch_walk(a, iters, launch_inst, grid, st, nullptr));
             HIP_OK(launch_walk(r, iters, WALK_GLOBAL_512, rgrid, st, nullptr));
             {  // how many queries of this launch had to be retried: looked at by the next launch on this stream
                 if (!wr.retry_seen) HIP_OK(hipHostMalloc((void**)&wr.retry_seen, 16, hipHostMallocDefault));

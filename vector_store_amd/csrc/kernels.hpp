@@ -59,6 +59,7 @@ enum : uint32_t { WALK_LDS_128 = 0, WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512,
                   WALK_LDS_128_TINY /* test hook: 256-bucket visited table (1-chunk rows only), forces the retry path */,
                   WALK_LDS_128_SMALL /* 512-bucket two-choice table (4,096 entries, slots < 2^24): 14.6 KB of LDS, 10 walks per CU */,
                   WALK_LDS_320 /* beams of 257..288 (`top` of 320): the 256 instance's visited table, 5 walks per CU instead of 3 */ };
+constexpr uint32_t kWalkTeamFlag = 0x100;      // instance | flag: one workgroup of kSearchTeam waves per query (LDS instances up to 320, unfiltered)
 constexpr uint32_t kWalk320MaxBeam = 288;      // ~23.6 evaluations per beam entry: 6,800 of the table's 8,192 entries
 constexpr uint32_t kWalkFailed = 0xFFFFFFFFu;  // out_found: the walk outgrew its workspace, the query was not answered
 constexpr uint32_t kMaxWalkBeam = 10240;       // widest `top` of the walk instances

@@ -101,6 +101,74 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
     }
 }
 
+// Small batches (lone callers: the reference issues one query per FFI call): one workgroup of TEAM waves per query, as
+// hnsw_search_kernel does -- wave 0 walks exactly as above, every wave evaluates its share of each hop's neighbours, so a
+// lone walk has TEAM times the row loads in flight.  Same decisions, same ids.  LDS instances only; a query that outgrows
+// its structures goes to the retry list like any other.
+template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, int TEAM>
+__global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_kernel(WalkArgs a) {
+    using Sh = WalkShared<EFCAP, LCAP, NB, CH, false, TEAM>;
+    __shared__ Sh sh;
+    const IndexView& ix = a.ix;
+    const int lane = lane_id();
+    const uint32_t qi = blockIdx.x, w = threadIdx.x >> 6;
+    uint64_t* ok = a.out_keys + (size_t)qi * a.k;
+    float* od = a.out_dist + (size_t)qi * a.k;
+    if (ix.max_level < 0) {  // empty index
+        if (w == 0) {
+            for (uint32_t i = lane; i < a.k; i += kWave) {
+                ok[i] = kFreeKey;
+                od[i] = __builtin_inff();
+            }
+            if (lane == 0) a.out_found[qi] = 0;
+        }
+        return;
+    }
+    Query<AR, I> q;
+    query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
+    if (w != 0) {
+        team_helper_loop<AR, I>(ix, q, sh, lane, w);
+        return;
+    }
+    WalkSpace ws = {nullptr, nullptr, nullptr, 0u, 0u, 0u};  // LDS instance: nothing lives in global memory
+    Counters cnt = {0, 0, 0};
+    const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
+    bool exhausted = false;
+    const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, nullptr, cnt, lane, exhausted);
+    team_release(sh, lane);
+    wsync<Sh>();
+    if (exhausted) {
+        if (lane == 0) {
+            if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;
+            else a.out_found[qi] = kWalkFailed;
+        }
+        return;
+    }
+    const uint32_t found = sz < a.k ? sz : a.k;
+    for (uint32_t i = lane; i < a.k; i += kWave) {
+        const bool in = i < found;
+        ok[i] = in ? ix.keys[sh.lst_s[i]] : kFreeKey;
+        od[i] = in ? sh.lst_d[i] : __builtin_inff();
+    }
+    if (lane == 0) {
+        a.out_found[qi] = found;
+        atomicAdd(&a.stats[ST_SEARCH_EVALS], cnt.evals);
+        atomicAdd(&a.stats[ST_SEARCH_HOPS], cnt.hops);
+        atomicAdd(&a.stats[ST_QUERIES], 1ull);
+    }
+}
+
+template <int AR, int I, int EFCAP, int LCAP, int NB, int CH>
+static hipError_t walk_team_launch(const WalkArgs& a, hipStream_t s, uint32_t* grid_out) {
+    if (grid_out) {
+        *grid_out = a.nq ? a.nq : 1;
+        return hipSuccess;
+    }
+    if (!a.nq || a.qlist || a.allow) return a.nq ? hipErrorInvalidValue : hipSuccess;
+    hipLaunchKernelGGL((hnsw_walk_team_kernel<AR, I, EFCAP, LCAP, NB, CH, kSearchTeam>), dim3(a.nq), dim3(64 * kSearchTeam), 0, s, a);
+    return hipGetLastError();
+}
+
 template <class K>
 static uint32_t resident_workgroups(K kernel, int device) {  // workgroups of `kernel` the chip holds at once
     int per_cu = 0, cus = 0;
@@ -160,6 +228,11 @@ static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_ca
         case WALK_GLOBAL_2048: return walk_launch<AR, I, 2048, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_10240: return walk_launch<AR, I, 10240, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_LDS_128_SMALL: return walk_launch<AR, I, 128, kWalkHeapLds, 512, 2, false>(a, grid_cap, s, grid_out);
+        // team forms (small batches) of the instances above
+        case WALK_LDS_128 | kWalkTeamFlag: return walk_team_launch<AR, I, 128, kWalkHeapLds, 1024, 1>(a, s, grid_out);
+        case WALK_LDS_128_SMALL | kWalkTeamFlag: return walk_team_launch<AR, I, 128, kWalkHeapLds, 512, 2>(a, s, grid_out);
+        case WALK_LDS_256 | kWalkTeamFlag: return walk_team_launch<AR, I, 256, 796, 1024, 2>(a, s, grid_out);
+        case WALK_LDS_320 | kWalkTeamFlag: return walk_team_launch<AR, I, 320, 990, 1024, 2>(a, s, grid_out);
         case WALK_LDS_128_TINY:
             if constexpr (I == 1) return walk_launch<AR, 1, 128, kWalkHeapLds, 256, 1, false>(a, grid_cap, s, grid_out);
             return hipErrorInvalidValue;

@@ -135,7 +135,7 @@ def test_search_matches_oracle_on_same_graph(metric, dim, n):
     ix.import_graph(g)
     assert ix.size() == n
     ties = rows = 0
-    for ef, k in ((64, 10), (128, 10), (200, 100)):
+    for ef, k in ((64, 10), (128, 10), (200, 100), (400, 100)):  # (the 64 queries of a batch take the team kernels, 512-entry one included)
         o.set_expansion_search(ef)
         ix.set_expansion_search(ef)
         gk, gd, gf = ix.search_batch(q, k)

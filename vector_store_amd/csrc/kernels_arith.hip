@@ -367,12 +367,14 @@ static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, kSearchTeamMid>), grid, tblock, 0, s, a);
         return hipGetLastError();
     }
-    if (a.team == kSearchTeam && a.ef <= 256 && !a.stress_small_table) {
+    if (a.team == kSearchTeam && !a.stress_small_table) {
         dim3 tblock(64 * kSearchTeam);
         if (a.ef <= 128)
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, kSearchTeam>), grid, tblock, 0, s, a);
-        else
+        else if (a.ef <= 256)
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, kSearchTeam>), grid, tblock, 0, s, a);
+        else  // beams of 257..512 (configs[2] needs 304): lone callers get the team there too
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 512, 2048, 2, kSearchTeam>), grid, tblock, 0, s, a);
         return hipGetLastError();
     }
     const bool nt = a.ix.nt_rows != 0;

@@ -44,7 +44,7 @@ def test_team_kernel_equals_single_wave_kernel(kind, metric, dim):
     n = 6000
     base = _data(n, dim, 5)
     q = _data(300, dim, 6)
-    for ef in (64, 200):
+    for ef in (64, 200, 300):  # 300: the 512-entry fused-list team kernel; i8 / b1: the team forms of the usearch-order walk
         a, b = _pair(v, dim, m, kind, base, ef)
         a.stats(reset=True), b.stats(reset=True)
         ka, da, fa = a.search_batch(q, 10)

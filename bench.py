@@ -4,27 +4,43 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (hnsw_search, one wavefront per query) over one batch of
-`--nq` synthetic queries that are already resident in HBM.  Workload at N=1 = the configuration
-BASELINE.json's metric is quoted on: 10M x 768 cosine, top-10, one GPU (31 GB of vectors + 1.4 GB of graph
-in HBM); ef_search = the smallest beam width (coarse sweep 64,96,...,256,320,...,512, then bisection in steps of 8) reaching recall@10 >= 0.95 against the exact
-brute-force ground truth computed on the GPU.  `--vectors 1000000` is configs[1] (ef_search 128).
+`--gpus N` is authoritative.  Started WITHOUT a torch.distributed environment and N > 1, this process -- before it touches
+a GPU -- starts the N ranks itself (a child `python -m torch.distributed.run` on 127.0.0.1, one rank per GPU), relays
+rank 0's JSON line and exits with the children's status; it refuses (exit 2) when the box shows fewer than N GPUs.
+Started by a launcher, every rank checks WORLD_SIZE == N and exits 2 otherwise.  `--dry-run` only brings the ranks up,
+has them agree on who they are over the chosen backend and prints that (CPU test of the launcher: gloo).
 
-Multi-GPU (`--mode replica`, default): the reference scales by replication -- every vector-store
-process holds the whole index -- so each rank builds a full replica and
-serves its own query stream; no data-path collective; scaling "weak"; value = all ranks' queries
-per second.  With N>1 a sharded leg (key-range shards, per-shard top-k all-gathered over RCCL and
-merged by vs_topk_merge_device) is also run and reported under "sharded" (`--mode shard` makes it
-the timed path).
+A "step" is one pass of the hot path (hnsw_search, one wavefront per query) over one batch of `--nq` synthetic queries
+that are already resident in HBM; `--query-batches` (4) distinct batches rotate through the steps, so no step replays the
+previous one's rows.  Workload at N=1 = the configuration BASELINE.json's metric is quoted on: 10M x 768 cosine, top-10,
+one GPU (31 GB of vectors + 1.4 GB of graph in HBM); ef_search = the smallest beam width (coarse sweep 64,96,...,256,
+320,...,512, then bisection in steps of 8) reaching recall@10 >= 0.95 against the exact brute-force ground truth computed
+on the GPU.  `--vectors 1000000` is configs[1] (ef_search 128).
 
-Synthetic data: `--dist lowrank` (default) = 24-d Gaussian latent mapped by a fixed random 24 x dim
-matrix plus 0.05 isotropic noise: embedding-like local intrinsic dimension, on which HNSW reaches
-the recall target at the reference's beam widths.  `--dist gaussian` is the i.i.d. generator of
-SURVEY.md section 8d, on which no graph index reaches useful recall at dim 768.
+The N=1 default run also times, as `configs` side records with their own roofline blocks, BASELINE.json's configs[1]
+(1M x 768 cos, ef_search 128), configs[4] (q = 256 batches over 10M x 768 inner product: the MFMA block-distance path)
+and -- when the device has >= 180 GiB free -- configs[2] (10M x 1536 L2); `--configs` picks them.  The cpu_baseline
+leg times the CPU restatement on the SAME graph and compares its ids with the GPU's for every query of the batch
+(`cpu_baseline.id_parity`); a violation (ids that differ where the oracle sees no f32 near-tie) makes the run exit 3.
+
+Multi-GPU (`--mode replica`, default): the reference scales by replication -- every vector-store process holds the whole
+index -- so each rank builds a full replica and serves its own query stream; no data-path
+collective; scaling "weak"; value = all ranks' queries per second.  With N>1 two sharded legs (SURVEY.md section 8e:
+key-range shards, per-shard top-k all-gathered by ONE ncclAllGather per batch issued by libvs_ranks over RCCL, merged by
+topk_merge_kernel) are also run and reported under "sharded": `weak` (--vectors per GPU, index = N x that) and
+`fixed_total` (--vectors / N per GPU: the same index as N = 1, cut into N key ranges).  `--mode shard` makes the weak
+sharded form the timed path.  `rccl_ranks` is ncclCommCount of the library's communicator.
+
+Synthetic data: `--dist lowrank` (default) = 24-d Gaussian latent mapped by a fixed random 24 x dim matrix plus 0.05
+isotropic noise: embedding-like local intrinsic dimension, on which HNSW reaches the recall target at the reference's
+beam widths.  `--dist gaussian` is the i.i.d. generator of SURVEY.md section 8d, on which no graph index reaches useful
+recall at dim 768.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,8 +51,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
-ADJ_BYTES = 132        # level-0 adjacency record, 4 + 32*4
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline figure is not used)
+ADJ_BYTES = 132             # level-0 adjacency record, 4 + 32*4
 
 
 def make_data(n, dim, kind, seed, device, rank=24):
@@ -73,20 +90,25 @@ def recall_at_k(truth: np.ndarray, got: np.ndarray) -> float:
 
 
 class Searcher:
-    """Device-resident query batch + output buffers; one call = one step of the hot path."""
+    """Device-resident query batches + output buffers; one call = one step of the hot path.  `batches` rotate through
+    the steps (step i searches batch i mod B); batch 0 is the one recall and parity are measured on."""
 
-    def __init__(self, ix, queries, k):
-        self.ix, self.q, self.k = ix, queries, k
-        nq = queries.shape[0]
-        dev = queries.device
+    def __init__(self, ix, batches, k):
+        self.ix, self.k = ix, k
+        self.batches = batches if isinstance(batches, (list, tuple)) else [batches]
+        self.q = self.batches[0]
+        nq, dev = self.q.shape[0], self.q.device
         self.keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
         self.dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
         self.found = torch.empty((nq,), dtype=torch.int32, device=dev)
+        self.turn = 0
 
-    def step(self):
+    def step(self, batch=None):
+        q = self.batches[self.turn % len(self.batches)] if batch is None else self.batches[batch]
+        if batch is None:
+            self.turn += 1
         s = torch.cuda.current_stream().cuda_stream
-        self.ix.search_batch_device(self.q.data_ptr(), self.q.shape[0], self.k, self.keys.data_ptr(),
-                                    self.dist.data_ptr(), self.found.data_ptr(), s)
+        self.ix.search_batch_device(q.data_ptr(), q.shape[0], self.k, self.keys.data_ptr(), self.dist.data_ptr(), self.found.data_ptr(), s)
 
     def exact(self):
         s = torch.cuda.current_stream().cuda_stream
@@ -129,17 +151,48 @@ def effective_cores() -> int:
     return n
 
 
-def cpu_baseline(ix, queries_host, k, ef, seconds, extra_host=None):
+def timed_steps(step, finish, steps):
+    """`steps` steps between two HIP events each, on torch's current stream = the stream the kernels are launched on;
+    returns (mean ms per launch by the events, wall seconds of the whole region)."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    finish()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])), wall
+
+
+def hbm_roofline(ix, st, nq, dim, kernel_ms, kernel_name):
+    """B_q = E_q * row_bytes + H_q * 132 + dim * 4 (E_q, H_q counted in-kernel), one launch = nq queries."""
+    e_q = st["search_evals"] / max(st["queries"], 1)
+    h_q = st["search_hops"] / max(st["queries"], 1)
+    b_q = e_q * ix.bytes_per_vector() + h_q * ADJ_BYTES + dim * 4
+    achieved = b_q * nq / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": kernel_name, "kernel_ms": kernel_ms, "bytes_per_query": b_q, "evals_per_query": e_q, "hops_per_query": h_q,
+            "visited_overflow": st["visited_overflow"]}
+
+
+def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_host=None):
     """The CPU restatement of the usearch algorithm (oracle/, kind "port") on the host cores of this box, on the
     SAME graph: searches one query per call from T threads (reference usearch.rs:212), then -- the build half of the
-    metric -- inserts `extra_host` further vectors into that full-size index from T threads (usearch.rs:194-196)."""
+    metric -- inserts `extra_host` further vectors into that full-size index from T threads (usearch.rs:194-196).
+    id_parity: the oracle's (keys, distances) for EVERY query of the batch against the GPU's, position by position, with
+    the bar of tests/parity_util.py (counted here instead of asserted)."""
     import oracle
+    from tests.parity_util import count_parity
     o = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef, quantization=ix.scalar)
     slots = ix.graph_info()["slots"]
     extra = 0 if extra_host is None else len(extra_host)
     o.reserve(slots + extra)
     g = ix.export_graph(vectors_out=o.vector_arena(slots))  # straight into the oracle's arena
     o.import_graph(g)
+    slot_of_key = None if np.array_equal(g["keys"], np.arange(slots, dtype=np.uint64)) else {int(kk): i for i, kk in enumerate(g["keys"])}
     del g
     o.set_expansion_search(ef)
     threads = effective_cores()
@@ -147,7 +200,7 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, extra_host=None):
     o.search_batch(queries_host[: min(nq, 4 * threads)], k, threads=threads)  # page in, create contexts
     done, t0 = 0, time.perf_counter()
     while True:
-        keys, _, _ = o.search_batch(queries_host, k, threads=threads)
+        keys, dists, found = o.search_batch(queries_host, k, threads=threads)
         done += nq
         el = time.perf_counter() - t0
         if el >= seconds:
@@ -155,6 +208,13 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, extra_host=None):
     out = {"value": done / el, "unit": "queries/s", "cores": threads, "kind": "port",
            "sample": f"{done} queries ({done // nq} passes over the bench batch) in {el:.1f}s on the GPU-built graph, "
                      f"ef_search={ef}, usearch-algorithm CPU restatement (not the usearch binary)"}
+
+    def oracle_distance(qi, key):  # the oracle's own distance from query qi to the member the ENGINE returned
+        s = int(key) if slot_of_key is None else slot_of_key.get(int(key), -1)
+        return float("nan") if s < 0 or s >= slots else o.distance_to_slot(queries_host[qi], s)
+
+    exact = ix.scalar in (oracle.I8, oracle.B1)
+    out["id_parity"] = count_parity(gpu_keys, gpu_dist, keys, dists, found, oracle_distance, exact=exact)
     if extra:
         t0 = time.perf_counter()
         o.add_batch(np.arange(slots, slots + extra, dtype=np.uint64) + np.uint64(1 << 40), extra_host, threads=threads)
@@ -164,23 +224,24 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, extra_host=None):
     return out, keys
 
 
-def side_records(vs, dev, dim, metric, k, rank0_only=True):
+def numpy_normal(rows, dim, seed):
+    return np.random.Generator(np.random.PCG64(seed)).standard_normal((rows, dim), dtype=np.float32)
+
+
+def side_records(vs, dev, dim, metric, k):
     """How "QPS at recall@10 >= 0.95" depends on the synthetic generator, at 1M x dim: the survey's
     own i.i.d. Gaussian (numpy PCG64 standard_normal, seeds 1234 / 4321) and its clustered variant (256 centres,
     sigma 0.2, seed 99) as side records, plus the intrinsic dimension of the default low-rank generator swept over
-    16 / 24 / 48.  Each record: recall@10 and QPS (10,000 resident queries per launch) at ef 128 / 256 / 512."""
+    16 / 24 / 48.  Each record: recall@10 and QPS (10,000 resident queries per launch) at ef 128 / 256 / 512.
+    The lowrank24 variant at ef 128 IS BASELINE.json's configs[1]: it is returned separately with its roofline block."""
     n, nq = 1_000_000, 10_000
-    out = []
-
-    def numpy_normal(rows, seed):
-        return np.random.Generator(np.random.PCG64(seed)).standard_normal((rows, dim), dtype=np.float32)
-
+    out, c2 = [], None
     variants = [("gaussian_pcg64", None), ("clustered_pcg64", None), ("lowrank16", 16), ("lowrank24", 24), ("lowrank48", 48)]
     for name, rank in variants:
         t0 = time.perf_counter()
         if name == "gaussian_pcg64":
-            base = torch.from_numpy(numpy_normal(n, 1234)).to(dev)
-            q = torch.from_numpy(numpy_normal(nq, 4321)).to(dev)
+            base = torch.from_numpy(numpy_normal(n, dim, 1234)).to(dev)
+            q = torch.from_numpy(numpy_normal(nq, dim, 4321)).to(dev)
         elif name == "clustered_pcg64":
             centres = np.random.Generator(np.random.PCG64(99)).standard_normal((256, dim), dtype=np.float32)
             g1, g2 = np.random.Generator(np.random.PCG64(1234)), np.random.Generator(np.random.PCG64(4321))
@@ -200,28 +261,127 @@ def side_records(vs, dev, dim, metric, k, rank0_only=True):
             se.step()
             torch.cuda.synchronize()
             r = recall_at_k(truth, se.keys.cpu().numpy())
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                se.step()
-            e1.record()
-            torch.cuda.synchronize()
-            rec["points"].append({"ef": ef, "recall_at_10": round(r, 4), "queries_per_s": nq * 3 / (e0.elapsed_time(e1) * 1e-3)})
+            ix.stats(reset=True)
+            steps = 5 if name == "lowrank24" else 3
+            kernel_ms, _ = timed_steps(se.step, lambda: None, steps)
+            rec["points"].append({"ef": ef, "recall_at_10": round(r, 4), "queries_per_s": nq / (kernel_ms * 1e-3)})
+            if name == "lowrank24" and ef == 128 and metric == "cos":
+                st = ix.stats(reset=True)
+                c2 = {"config": "configs[1]", "workload": f"{n}x{dim} cos top-{k}, {nq} queries/step, M=16 ef_add=128 ef_search=128",
+                      "distribution": "lowrank24", "queries_per_s": nq / (kernel_ms * 1e-3), "recall_at_10": round(r, 4), "steps": steps,
+                      "build_vectors_per_s": n / build_s,
+                      "roofline": hbm_roofline(ix, st, nq, dim, kernel_ms, "hnsw_search_kernel")}
             if r >= 0.95:
                 break
         rec["seconds"] = round(time.perf_counter() - t0, 1)
         out.append(rec)
         del ix, se, base, q
         torch.cuda.empty_cache()
+    return out, c2
+
+
+def config_c5(vs, dev, n, dim, k, dist_kind, rank):
+    """BASELINE.json configs[4]: batched search, q = 256, 10M x 768 inner product over unit vectors -- the one dense
+    contraction of the path (exact block search: split-bf16 MFMA nomination, f32 re-score, certificate).  Bound: bf16 MFMA.
+    achieved = ISSUED bf16 flops (3 split products per f32 product, 2*q*n*dim each) / batch time, the batch timed whole
+    (tile kernel + selection + re-score) with HIP events on the launch stream; the HBM floor is reported beside it."""
+    nq, batches = 256, 8
+    t0 = time.perf_counter()
+    base = make_data(n, dim, dist_kind, 1234, dev, rank)
+    base /= base.norm(dim=1, keepdim=True)
+    q = make_data(nq * batches, dim, dist_kind, 4321, dev, rank)
+    q /= q.norm(dim=1, keepdim=True)
+    ix = vs.HipUsearchIndex(dim, vs.IP, expansion_search=200)
+    ix.reserve(n)
+    tb = time.perf_counter()
+    ix.add_batch_device(np.arange(n, dtype=np.uint64), base.data_ptr(), n, dim)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - tb
+    del base
+    tk = torch.empty((nq * batches, k), dtype=torch.int64, device=dev)
+    wk = torch.empty_like(tk)
+    od = torch.empty((nq * batches, k), dtype=torch.float32, device=dev)
+    of = torch.empty((nq * batches,), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    turn = [0]
+
+    def exact():
+        o = (turn[0] % batches) * nq
+        turn[0] += 1
+        ix.exact_search_batch_device(q[o:].data_ptr(), nq, k, tk[o:].data_ptr(), od[o:].data_ptr(), of[o:].data_ptr(), s)
+
+    def walk():
+        o = (turn[0] % batches) * nq
+        turn[0] += 1
+        ix.search_batch_device(q[o:].data_ptr(), nq, k, wk[o:].data_ptr(), od[o:].data_ptr(), of[o:].data_ptr(), s)
+
+    exact()
+    turn[0] = 0
+    x0 = ix.exact_stats()
+    exact_ms, _ = timed_steps(exact, lambda: None, batches)
+    x1 = ix.exact_stats()
+    walk()
+    turn[0] = 0
+    walk_ms, _ = timed_steps(walk, lambda: None, batches)
+    rec = recall_at_k(tk.cpu().numpy(), wk.cpu().numpy())
+    flops = 2.0 * nq * n * dim
+    issued = 3.0 * flops / (exact_ms * 1e-3) / 1e12
+    out = {"config": "configs[4]", "workload": f"{n}x{dim} ip (unit vectors), batches of {nq} queries, top-{k}", "distribution": dist_kind + (str(rank) if dist_kind == "lowrank" else ""),
+           "ms_per_batch": exact_ms, "queries_per_s": nq / exact_ms * 1e3, "batches_timed": batches,
+           "block_search_batches": x1["block_batches"] - x0["block_batches"], "f32_fallback_batches": x1["block_fallbacks"] - x0["block_fallbacks"],
+           "roofline": {"bound": "mfma", "achieved": issued, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / BF16_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "block_dist_bf16x3_kernel (+ selection, f32 re-score, certificate: the whole batch is timed)",
+                        "f32_equivalent_tflops": flops / (exact_ms * 1e-3) / 1e12,
+                        "hbm_floor": {"bytes_per_batch": float(n) * dim * 4, "achieved_gbs": float(n) * dim * 4 / (exact_ms * 1e-3) / 1e9, "frac_of_8tbs": float(n) * dim * 4 / (exact_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+           "hnsw_walk_ef200": {"ms_per_batch": walk_ms, "queries_per_s": nq / walk_ms * 1e3, "recall_at_10_vs_exact": round(rec, 4)},
+           "build_vectors_per_s": n / build_s, "seconds": round(time.perf_counter() - t0, 1)}
+    del ix, q
+    torch.cuda.empty_cache()
+    return out
+
+
+def config_c3(vs, dev, n, k, dist_kind, rank, target):
+    """BASELINE.json configs[2]: 10M x 1536 L2 (OpenAI-large-style), single GPU, graph resident in HBM (61 GB of vectors)."""
+    dim, nq = 1536, 10_000
+    t0 = time.perf_counter()
+    base = make_data(n, dim, dist_kind, 1234, dev, rank)
+    q = make_data(nq, dim, dist_kind, 4321, dev, rank)
+    ix, build_s = build_index(vs, base, np.arange(n, dtype=np.uint64), "l2sq")
+    del base
+    torch.cuda.empty_cache()
+    se = Searcher(ix, q, k)
+    truth, _ = se.exact()
+    sweep, chosen = [], None
+    for ef in (256, 288, 304, 320, 384, 448, 512):
+        ix.set_expansion_search(ef)
+        se.step(0)
+        torch.cuda.synchronize()
+        r = recall_at_k(truth, se.keys.cpu().numpy())
+        sweep.append({"ef": ef, "recall": round(r, 4)})
+        if r >= target:
+            chosen = (ef, r)
+            break
+    ef, r = chosen if chosen else (sweep[-1]["ef"], sweep[-1]["recall"])
+    ix.stats(reset=True)
+    steps = 5
+    kernel_ms, _ = timed_steps(se.step, lambda: None, steps)
+    st = ix.stats(reset=True)
+    out = {"config": "configs[2]", "workload": f"{n}x{dim} l2sq top-{k}, {nq} queries/step, M=16 ef_add=128 ef_search={ef}",
+           "distribution": dist_kind + (str(rank) if dist_kind == "lowrank" else ""), "queries_per_s": nq / (kernel_ms * 1e-3),
+           "recall_at_10": round(r, 4), "ef_search": ef, "ef_sweep": sweep, "steps": steps, "build_vectors_per_s": n / build_s,
+           "roofline": hbm_roofline(ix, st, nq, dim, kernel_ms, "hnsw_search_kernel"), "seconds": round(time.perf_counter() - t0, 1)}
+    del ix, se, q
+    torch.cuda.empty_cache()
     return out
 
 
 def make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, total_rows, backend):
-    """The native path (libvs_ranks: ncclAllGather issued by the library) when RCCL is the backend; the torch.distributed
-    twin for gloo smoke tests, with VS_RANKS=torch, or when the native communicator cannot be created (every rank
-    agrees on the choice through an all-reduce, so no rank is left waiting in a collective the others never enter)."""
-    import torch
-    native = backend == "nccl" and os.environ.get("VS_RANKS", "native") != "torch"
+    """The native path (libvs_ranks: ncclAllGather issued by the library) when RCCL is the backend -- or, with
+    VS_RANKS_EXCHANGE=hostshm, the same library over its host-shared-memory exchange (several ranks on ONE device, where
+    RCCL refuses to pair them: test boxes); the torch.distributed twin for gloo smoke tests without it, with
+    VS_RANKS=torch, or when the native communicator cannot be created (every rank agrees on the choice through an
+    all-reduce, so no rank is left waiting in a collective the others never enter)."""
+    native = (backend == "nccl" or os.environ.get("VS_RANKS_EXCHANGE") == "hostshm") and os.environ.get("VS_RANKS", "native") != "torch"
     gs = None
     if dist is None:
         return ranks.RankedSearcher(ix, queries, k, None, total_rows)
@@ -230,7 +390,7 @@ def make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, total_rows, 
             gs = ranks.RankedSearcher(ix, queries, k, dist, total_rows)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] libvs_ranks unavailable on rank {dist.get_rank()}: {e!r}", file=sys.stderr)
-        ok = torch.tensor([1 if gs is not None else 0], device=queries.device)
+        ok = torch.tensor([1 if gs is not None else 0], device=queries.device if backend == "nccl" else "cpu")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             gs = None
@@ -241,7 +401,9 @@ def boundary_record(ix, queries_host, truth, k, seconds):
     """What a drop-in caller gets THROUGH the C ABI on this very index (reference call pattern): one query per
     vs_hnsw_search call from num_workers() + 1 blocking threads (usearch.rs:203-222, worker.rs:44-118), and the
     non-blocking entry point with 16 x 256 queries in flight; the reference's loop and histogram
-    (crates/benchmark/src/main.rs:435-604) as libvs_callers.so runs them."""
+    (crates/benchmark/src/main.rs:435-604) as libvs_callers.so runs them.  `filtered`: the reference dispatches every
+    filtered query through spawn_blocking (usearch.rs:937-948), i.e. the same blocking callers over
+    vs_hnsw_filtered_search, here with a predicate that admits 10 % / 1 % of the keys."""
     import ctypes as C
 
     class Res(C.Structure):
@@ -260,16 +422,71 @@ def boundary_record(ix, queries_host, truth, k, seconds):
     def ms(ns):
         return None if ns >= 2 ** 62 else round(ns / 1e6, 3)
 
+    def rec_of(r, rc, threads, inflight):
+        return {"threads": threads, "in_flight_per_thread": inflight, "queries_per_s": r.qps, "seconds": r.seconds,
+                "latency_min_ms": round(r.latency_min_ns / 1e6, 3), "p50_ms": ms(r.p50_ns), "p90_ms": ms(r.p90_ns),
+                "p99_ms": ms(r.p99_ns), "recall_at_10": round(r.recall_avg, 4), "errors": int(r.errors), "status": rc,
+                "kernel_launches": int(r.launches), "team_kernel_launches": int(r.team_launches)}
+
     for name, threads, inflight in (("blocking_callers", cores + 1, 1), ("async_in_flight", 16, 256)):
         r = Res()
         rc = L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, t.ctypes.data, threads, inflight, seconds, C.byref(r))
-        out[name] = {"threads": threads, "in_flight_per_thread": inflight, "queries_per_s": r.qps, "seconds": r.seconds,
-                     "latency_min_ms": round(r.latency_min_ns / 1e6, 3), "p50_ms": ms(r.p50_ns), "p90_ms": ms(r.p90_ns),
-                     "p99_ms": ms(r.p99_ns), "recall_at_10": round(r.recall_avg, 4), "errors": int(r.errors), "status": rc,
-                     "kernel_launches": int(r.launches), "team_kernel_launches": int(r.team_launches)}
+        out[name] = rec_of(r, rc, threads, inflight)
+    if hasattr(L, "vs_callers_run_filtered"):
+        L.vs_callers_run_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double,
+                                              C.POINTER(Res), C.POINTER(C.c_uint64)]
+        out["filtered"] = {}
+        for name, modulus in (("selectivity_10pct", 10), ("selectivity_1pct", 100)):
+            r = Res()
+            extra = (C.c_uint64 * 4)()
+            f0 = ix.filter_stats()
+            rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, cores + 1, max(seconds / 2, 1.0), C.byref(r), extra)
+            f1 = ix.filter_stats()
+            fr = rec_of(r, rc, cores + 1, 1)
+            fr.pop("recall_at_10", None)
+            nqd = max(int(r.queries), 1)
+            fr.update({"predicate": f"key % {modulus} == 0", "predicate_calls_per_query": extra[0] / nqd, "results_per_query": extra[1] / nqd,
+                       "walk_launches_per_query": (f1["lazy_rounds"] - f0["lazy_rounds"]) / nqd})
+            out["filtered"][name] = fr
     out["note"] = ("one query per C-ABI call; percentiles on the reference's histogram (10,000 buckets over 1..100 ms: anything "
                    "faster reads 1.0 ms); latency_min_ms is the raw minimum")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a) -> int:
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks (no GPU call has happened in this process;
+    torch.cuda.device_count() does not initialise the runtime on this image), relay their output, return their status."""
+    have = torch.cuda.device_count()
+    if not (a.same_device or a.dry_run) and have < a.gpus:
+        print(json.dumps({"error": f"bench.py --gpus {a.gpus}: this box shows {have} GPU(s); refusing to report a {a.gpus}-GPU number from fewer devices",
+                          "n_gpus_requested": a.gpus, "n_gpus_visible": have}), file=sys.stderr)
+        return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(a, world, rank, local):
+    """Brings the process group up on the chosen backend and has every rank report who it is: the launcher's CPU test."""
+    import torch.distributed as dist
+    me = {"rank": rank, "local_rank": local, "world_size": world, "pid": os.getpid(), "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}
+    everyone = [me]
+    if world > 1:
+        dist.init_process_group(a.backend if a.backend != "nccl" or torch.cuda.is_available() else "gloo")
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "backend": a.backend, "ranks": everyone}))
 
 
 def main():
@@ -281,6 +498,7 @@ def main():
                     help="vectors per GPU; default = the headline workload BASELINE.json's metric is quoted on (10M x 768 cosine); 1000000 = configs[1]")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--nq", type=int, default=10_000, help="queries per step per GPU")
+    ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps (recall / parity are measured on the first)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="cos", choices=["cos", "l2sq", "ip"])
     ap.add_argument("--dist", default="lowrank", choices=["lowrank", "gaussian", "clustered"])
@@ -292,15 +510,29 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall seconds of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-build-vectors", type=int, default=20_000, help="vectors the cpu_baseline leg inserts into the full-size index (0 = skip)")
     ap.add_argument("--boundary-seconds", type=float, default=3.0, help="seconds per leg of the through-the-C-ABI record (0 = skip)")
-    ap.add_argument("--no-side-records", action="store_true", help="skip the generator side records (gaussian / clustered / rank sweep at 1M)")
+    ap.add_argument("--no-side-records", action="store_true", help="skip the generator side records (gaussian / clustered / rank sweep at 1M) and the configs side records")
+    ap.add_argument("--configs", default="auto", help="BASELINE configs timed as side records at N=1: comma list of c2,c5,c3, 'none', or 'auto' (c2, c5, and c3 when >= 180 GiB of HBM is free)")
     ap.add_argument("--no-sharded-leg", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0")
+    ap.add_argument("--dry-run", action="store_true", help="bring the ranks up, report their environment, measure nothing")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print(json.dumps({"error": f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: the two must agree", "n_gpus_requested": a.gpus,
+                              "world_size": world}), file=sys.stderr)
+        sys.exit(2)
+    if a.dry_run:
+        dry_run(a, world, rank, local)
+        return
     if a.same_device:
         local = 0
     torch.cuda.set_device(local)
@@ -319,32 +551,53 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def reduce_scalar(v, op):
+        t = torch.tensor([v], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
     n, dim, nq, k = a.n, a.dim, a.nq, a.k
+    nb = max(1, a.query_batches)
     shard_mode = a.mode == "shard"  # (at N = 1: the same code path over a world of one -- no collective, same pack / merge / pipeline)
     # replica: same base on every rank, own queries; shard: own base (key range r*n..), same queries
     base = make_data(n, dim, a.dist, 1234 + (rank if shard_mode else 0), dev, a.rank)
-    queries = make_data(nq, dim, a.dist, 4321 + (0 if shard_mode else rank), dev, a.rank)
+    qseed = 4321 + (0 if shard_mode else rank)
+    batches = [make_data(nq, dim, a.dist, qseed + 1000 * b, dev, a.rank) for b in range(nb)]
+    queries = batches[0]
     keys = np.arange(n, dtype=np.uint64) + (np.uint64(rank * n) if shard_mode else np.uint64(0))
     ix, build_s = build_index(vs, base, keys, a.metric, quantization=a.quantization)
+    del base
+    torch.cuda.empty_cache()
     st = ix.stats(reset=True)
     build_info = {"vectors_per_s": n / build_s, "seconds": build_s, "vectors": n,
                   "evals_per_add": st["add_evals"] / max(st["added"], 1),
                   "insert_evals_per_add": (st["add_evals"] - st["link_evals"]) / max(st["added"], 1),  # hnsw_insert_kernel's share
                   "hops_per_add": st["add_hops"] / max(st["added"], 1)}
-    se = Searcher(ix, queries, k)
+    se = Searcher(ix, batches, k)
     finish = lambda: None  # pipelined steppers: completes the batch still in flight
+    rccl_ranks, gs = None, None
     if shard_mode:
         # native path (libvs_ranks: one ncclAllGather per batch on its own stream, overlapped with the next walk);
         # the torch.distributed twin only where RCCL is not the backend (gloo smoke tests)
         gs = make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, n * world, a.backend)
+        if hasattr(gs, "ranks"):
+            rccl_ranks = gs.ranks.comm_info()["rccl_ranks"]
         truth = gs.exact()
-        step = gs.step
+        turn = [0]
+
+        def step(batch=None):
+            gs.q = batches[turn[0] % nb] if batch is None else batches[batch]
+            if batch is None:
+                turn[0] += 1
+            gs.step()
         finish = getattr(gs, "flush", finish)
         result_keys = lambda: gs.keys.cpu().numpy()
+        result_dist = lambda: gs.dists.cpu().numpy()
     else:
         truth, _ = se.exact()
         step = se.step
         result_keys = lambda: se.keys.cpu().numpy()
+        result_dist = lambda: se.dist.cpu().numpy()
 
     # ---- beam width: smallest of {64,96,...,256,320,...,512} reaching the recall target
     sweep = []
@@ -352,14 +605,12 @@ def main():
 
     def probe(ef):
         ix.set_expansion_search(ef)
-        step()
+        step(0)
         finish()
         torch.cuda.synchronize()
         r = recall_at_k(truth, result_keys())
         if dist is not None:
-            t = torch.tensor([r], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            r = float(t.item())
+            r = reduce_scalar(r, dist.ReduceOp.MIN)
         sweep.append({"ef": ef, "recall": round(r, 4)})
         return r
 
@@ -390,29 +641,12 @@ def main():
     finish()
     torch.cuda.synchronize()
     ix.stats(reset=True)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        ev[i][0].record()
-        step()
-        ev[i][1].record()
-    finish()
-    torch.cuda.synchronize()
+    kernel_ms, elapsed = timed_steps(step, finish, a.steps)  # HIP events on the launch stream
     barrier()
-    elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = reduce_scalar(elapsed, dist.ReduceOp.MAX)
     st = ix.stats(reset=True)
-    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))  # HIP events on the launch stream
-    e_q = st["search_evals"] / max(st["queries"], 1)
-    h_q = st["search_hops"] / max(st["queries"], 1)
-    row_b = ix.bytes_per_vector()  # dim * s, s = stored scalar size
-    b_q = e_q * row_b + h_q * ADJ_BYTES + dim * 4  # algorithmic bytes per query
-    achieved = b_q * nq / (kernel_ms * 1e-3) / 1e9
     total_q = nq * a.steps * (1 if shard_mode else world)
     value = total_q / elapsed
 
@@ -426,12 +660,9 @@ def main():
         "vs_baseline": None, "dtype": a.quantization, "data": "synthetic",
         "config": {"workload": f"{n}x{dim} {a.metric} top-{k} per GPU, {nq} queries/step, M=16 ef_add=128 ef_search={ef}" + ("" if a.quantization == "f32" else f" {a.quantization}"),
                    "distribution": a.dist + (f"{a.rank}" if a.dist == "lowrank" else ""), "mode": a.mode if (world > 1 or shard_mode) else "single",
-                   "index_vectors_total": n * (world if shard_mode else 1)},
+                   "index_vectors_total": n * (world if shard_mode else 1), "query_batches_rotated": nb},
         "recall_at_10": round(recall, 4), "ef_search": ef, "ef_sweep": sweep,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": search_kernel_name,
-                     "kernel_ms": kernel_ms, "bytes_per_query": b_q, "evals_per_query": e_q, "hops_per_query": h_q,
-                     "visited_overflow": st["visited_overflow"]},
+        "roofline": hbm_roofline(ix, st, nq, dim, kernel_ms, search_kernel_name),
         "build": build_info,
     }
     # PMC-measured HBM bytes per launch for this exact workload (profiles/*traffic.json, see profiles/README.md).  A record
@@ -449,40 +680,53 @@ def main():
                 out["roofline"]["traffic_source"] = {"file": os.path.relpath(tr, ROOT), "kernel_sources_sha16": rec.get("kernel_sources_sha16"),
                                                      "current_kernel_sources_sha16": sha_now, "stale": not fresh}
                 out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"] if fresh else None
+                if fresh and "dram" in rec:
+                    out["roofline"]["dram"] = rec["dram"]  # how much of the traffic came from HBM itself (TCC EA counters), how much from the Infinity Cache
         except Exception:
             pass
 
-    # ---- sharded leg at N>1 (RCCL all-gather + merge), reported beside the replica number
+    # ---- sharded legs at N>1 (RCCL all-gather + merge), reported beside the replica number: weak (n per GPU) and fixed total (n / N per GPU)
     if world > 1 and not shard_mode and not a.no_sharded_leg:
-        try:
-            sbase = make_data(n, dim, a.dist, 777 + rank, dev, a.rank)
-            skeys = np.arange(n, dtype=np.uint64) + np.uint64(rank * n)
-            six, sbuild = build_index(vs, sbase, skeys, a.metric, quantization=a.quantization)
-            six.set_expansion_search(ef)
-            sq = make_data(nq, dim, a.dist, 4321, dev, a.rank)
-            gs = make_sharded_searcher(six, sq, k, dist, vs, ranks, sharded, n * world, a.backend)
-            sfinish = getattr(gs, "flush", lambda: None)
-            struth = gs.exact()
-            gs.step()
-            sfinish()
-            torch.cuda.synchronize()
-            srec = recall_at_k(struth, gs.keys.cpu().numpy())
-            barrier()
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(max(a.steps // 2, 1)):
+        out["sharded"] = {}
+        for leg, per in (("weak", n), ("fixed_total", max(n // world, 1))):
+            try:
+                sbase = make_data(per, dim, a.dist, 777 + rank, dev, a.rank)
+                skeys = np.arange(per, dtype=np.uint64) + np.uint64(rank * per)
+                six, sbuild = build_index(vs, sbase, skeys, a.metric, quantization=a.quantization)
+                del sbase
+                six.set_expansion_search(ef)
+                sq = [make_data(nq, dim, a.dist, 4321 + 1000 * b, dev, a.rank) for b in range(nb)]
+                gs = make_sharded_searcher(six, sq[0], k, dist, vs, ranks, sharded, per * world, a.backend)
+                if hasattr(gs, "ranks"):
+                    rccl_ranks = gs.ranks.comm_info()["rccl_ranks"]
+                sfinish = getattr(gs, "flush", lambda: None)
+                struth = gs.exact()
                 gs.step()
-            sfinish()
-            torch.cuda.synchronize()
-            barrier()
-            tel = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
-            dist.all_reduce(tel, op=dist.ReduceOp.MAX)
-            out["sharded"] = {"path": type(gs).__name__, "index_vectors_total": n * world, "queries_per_s": nq * max(a.steps // 2, 1) / float(tel.item()),
-                              "recall_at_10": round(srec, 4), "collective": "one ncclAllGather (RCCL, libvs_ranks) of packed per-shard top-k per batch + topk_merge_kernel, overlapped with the next walk",
-                              "build_vectors_per_s_per_gpu": n / sbuild}
-            del six, sbase
-        except Exception as e:  # the replica number stands on its own
-            out["sharded"] = {"error": repr(e)}
+                sfinish()
+                torch.cuda.synchronize()
+                srec = recall_at_k(struth, gs.keys.cpu().numpy())
+                srec = reduce_scalar(srec, dist.ReduceOp.MIN)
+                sturn = [0]
+
+                def sstep():
+                    gs.q = sq[sturn[0] % nb]
+                    sturn[0] += 1
+                    gs.step()
+                ssteps = max(a.steps // 2, 1)
+                barrier()
+                _, sel = timed_steps(sstep, sfinish, ssteps)
+                barrier()
+                sel = reduce_scalar(sel, dist.ReduceOp.MAX)
+                out["sharded"][leg] = {"path": type(gs).__name__, "vectors_per_gpu": per, "index_vectors_total": per * world, "queries_per_s": nq * ssteps / sel,
+                                       "recall_at_10": round(srec, 4), "ef_search": ef, "steps": ssteps, "build_vectors_per_s_per_gpu": per / sbuild,
+                                       "unanswered_queries": gs.ranks.unanswered() if hasattr(gs, "ranks") else None}
+                del six, gs, sq
+                torch.cuda.empty_cache()
+            except Exception as e:  # the replica number stands on its own
+                out["sharded"][leg] = {"error": repr(e)}
+        out["sharded"]["collective"] = "one ncclAllGather (RCCL, libvs_ranks) of packed per-shard top-k per batch + topk_merge_kernel, overlapped with the next walk"
+    if world > 1 or shard_mode:
+        out["rccl_ranks"] = rccl_ranks  # ncclCommCount of libvs_ranks' communicator (1 at N = 1; None: the torch twin served the sharded path)
 
     # ---- through the boundary: what a drop-in caller of the trait gets on this index (N=1 only)
     if world == 1 and a.boundary_seconds > 0:
@@ -491,28 +735,62 @@ def main():
         except Exception as e:
             out["boundary"] = {"error": repr(e)}
 
-    # ---- the same metric on the survey's own generators, and across the default generator's intrinsic dimension (N=1 only)
-    if world == 1 and not a.no_side_records and a.quantization == "f32":
-        try:
-            out["generators_at_1m"] = side_records(vs, dev, dim, a.metric, k)
-        except Exception as e:
-            out["generators_at_1m"] = {"error": repr(e)}
-
-    # ---- CPU baseline: rank 0, N=1 only, bounded
+    # ---- CPU baseline + id parity at full size: rank 0, N=1 only, bounded
+    violations = 0
     if world == 1 and a.cpu_seconds > 0:
         try:
+            step(0)
+            finish()
+            torch.cuda.synchronize()
+            gk, gd = result_keys().view(np.uint64).copy(), result_dist().copy()
             extra = make_data(a.cpu_build_vectors, dim, a.dist, 97531, dev, a.rank).cpu().numpy() if a.cpu_build_vectors else None
-            cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds, extra)
+            cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds, gk, gd, extra)
             cb["recall_at_10"] = round(recall_at_k(truth, ckeys), 4)
             out["cpu_baseline"] = cb
+            violations = cb["id_parity"]["violations"]
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
 
+    # ---- the other BASELINE configs and the survey's own generators as side records (N=1 only); the headline index is released first
+    if world == 1 and not a.no_side_records and a.quantization == "f32":
+        want = a.configs.split(",") if a.configs not in ("auto", "none") else []
+        import gc
+        se = ix = step = finish = probe = result_keys = result_dist = gs = None  # every reference to the headline index
+        gc.collect()
+        torch.cuda.empty_cache()
+        free_b, _ = torch.cuda.mem_get_info()
+        if a.configs == "auto":
+            want = ["c2", "c5"] + (["c3"] if free_b >= 180 * 2 ** 30 else [])
+        out["configs"] = []
+        try:
+            gens, c2 = side_records(vs, dev, dim, a.metric, k)
+            out["generators_at_1m"] = gens
+            if c2 is not None and "c2" in want:
+                out["configs"].append(c2)
+        except Exception as e:
+            out["generators_at_1m"] = {"error": repr(e)}
+        if "c5" in want:
+            try:
+                out["configs"].append(config_c5(vs, dev, 10_000_000, 768, k, a.dist, a.rank))
+            except Exception as e:
+                out["configs"].append({"config": "configs[4]", "error": repr(e)})
+        if "c3" in want:
+            try:
+                out["configs"].append(config_c3(vs, dev, 10_000_000, k, a.dist, a.rank, a.target_recall))
+            except Exception as e:
+                out["configs"].append({"config": "configs[2]", "error": repr(e)})
+        elif a.configs == "auto":
+            out["configs"].append({"config": "configs[2]", "skipped": f"{free_b / 2 ** 30:.0f} GiB of HBM free, 180 needed"})
+
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if violations:
+        print(f"[bench] id parity against the CPU restatement: {violations} violation(s)", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -70,7 +70,9 @@ typedef struct vs_hnsw_options {
                          of at most one team per CU),
                          bit 4 = usearch-order walk (two structures, exact tie order) for every search of this index (default:
                          i8 / b1 storage only), bit 5 = always the global-bitmap instance of that walk,
-                         bit 6 = wide visited tags (the instances for indexes above 2^25 / 2^26 slots) on a small index */
+                         bit 6 = wide visited tags (the instances for indexes above 2^25 / 2^26 slots) on a small index,
+                         bit 7 = 64-entry global heap for the global-bitmap walk (a flooding walk then reports "outgrew its
+                         workspace", which the host entry points answer by ranking exhaustively) */
 } vs_hnsw_options;
 
 /* -- lifecycle: usearch::Index::new (usearch.rs:172), drop ------------------------------- */
@@ -142,6 +144,10 @@ VS_API int vs_hnsw_memory_info(vs_hnsw* index, uint64_t out[4]);
 /* Single-query dispatcher (vs_hnsw_search / _async), process-wide: [0] kernel launches, [1] queries,
  * [2] launches and [3] queries that took the team kernel (8 wavefronts per query, lightly loaded device). */
 VS_API int vs_search_service_stats(uint64_t out[4]);
+
+/* The usearch-order walk: [0] the instance (kernels.hpp WALK_*) the index's last search launch took, ~0 if none yet;
+ * [1] queries (process-wide) the single-query dispatcher answered by exhaustive ranking because their walk outgrew its workspace. */
+VS_API int vs_hnsw_walk_info(vs_hnsw* index, uint64_t out[2]);
 
 /* Filtered search on indexes above 65,536 slots asks the predicate lazily (only for members a walk needs a verdict for, in
  * rounds): [0] walk launches and [1] predicate calls spent that way so far. */

@@ -32,11 +32,22 @@ typedef struct vs_ranks vs_ranks;
 /* Rank 0 creates the id (ncclGetUniqueId) and hands it to every other rank out of band. */
 VS_API int vs_ranks_unique_id(uint8_t id[VS_RANKS_ID_BYTES]);
 
-/* Joins the communicator (ncclCommInitRank; collective: every rank calls it) around this rank's shard.  `shard` stays
+/* Joins the communicator (ncclCommInitRank; collective: every rank calls it -- a rank that never arrives leaves the others
+ * waiting inside RCCL's bootstrap, as with any NCCL program: launch all ranks or none) around this rank's shard.
+ * A search call, by contrast, never leaves the others hanging: a rank whose local search fails still enters the all-gather
+ * with an empty block and reports its error afterwards.  `shard` stays
  * owned by the caller and must outlive the handle.  total_rows: size of the key space that is split into ranges. */
 VS_API int vs_ranks_create(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_RANKS_ID_BYTES], uint64_t total_rows,
                            vs_ranks** out);
 VS_API void vs_ranks_free(vs_ranks* r);
+
+/* What the handle is part of: this rank, the world it was created with, and the size of the RCCL communicator itself
+ * (ncclCommCount; 1 when world == 1 and no communicator exists).  bench.py prints comm_ranks as `rccl_ranks`. */
+VS_API int vs_ranks_world(const vs_ranks* r, int* rank, int* world, int* comm_ranks);
+/* Queries (cumulative) to which THIS rank's shard contributed no candidates: its walk outgrew its workspace (d_found =
+ * 0xFFFFFFFF from vs_hnsw_search_batch_device) or its local search failed to launch.  Such rows enter the all-gather as
+ * (free key, +inf), so the merge of every rank stays well defined; a non-zero count means recall was lost.  Synchronises. */
+VS_API int vs_ranks_unanswered(vs_ranks* r, uint64_t* queries);
 
 /* Key-range ownership. */
 VS_API int vs_ranks_owner(const vs_ranks* r, uint64_t key);

@@ -75,6 +75,8 @@ def lib():
         L.orc_search_batch.argtypes = [vp, vp, sz, sz, vp, vp, vp, sz]
         L.orc_stats.argtypes = [vp, u64p, C.c_int]
         L.orc_exact_search.argtypes = [vp, vp, sz, u64p, f32p, C.POINTER(sz)]
+        L.orc_distance_to_slot.restype = C.c_float
+        L.orc_distance_to_slot.argtypes = [vp, vp, C.c_uint32]
         L.orc_export_graph.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orc_import_graph.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_uint32]
         L.orc_vectors.restype = vp
@@ -241,6 +243,11 @@ class OracleIndex:
         self._check(self.L.orc_exact_search(self.h, _ptr(v), k, keys.ctypes.data_as(C.POINTER(C.c_uint64)),
                                             d.ctypes.data_as(C.POINTER(C.c_float)), C.byref(found)))
         return keys[:found.value], d[:found.value]
+
+    def distance_to_slot(self, query, slot: int) -> float:
+        """The index's own distance from an f32 query (cast as search casts it) to the stored row of `slot`."""
+        q = np.ascontiguousarray(query, dtype=np.float32)
+        return float(self.L.orc_distance_to_slot(self.h, _ptr(q), int(slot)))
 
     def stats(self, reset: bool = False):
         out = (C.c_uint64 * 2)()

@@ -934,6 +934,16 @@ int orc_exact_search(void* h, const void* q, size_t k, uint64_t* keys, float* d,
     return 0;
 }
 
+// The index's own distance from an f32 query (cast as a search casts it) to the stored row of `slot`: what the parity
+// checks use to decide whether two ids that swapped places are an f32 near-tie.
+float orc_distance_to_slot(void* h, const float* q, uint32_t slot) {
+    Index* ix = (Index*)h;
+    Context c;
+    std::vector<uint8_t> casted(ix->bytes_per_vector);
+    cast_from_f32(ix->scalar, q, ix->dim, casted.data());
+    return ix->measure(casted.data(), ix->vec(slot), c);
+}
+
 // Graph export / import in the flat layout shared with the HIP engine's
 // vs_hnsw_export_graph / vs_hnsw_import_graph (include/vs_hnsw.h):
 //   levels[n] (i32), keys[n] (u64, ~0 = removed), adj0[n*M0] (0xFFFFFFFF padded),

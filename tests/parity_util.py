@@ -41,6 +41,63 @@ def assert_same_results(got_keys, got_dist, want_keys, want_dist, oracle_distanc
     return ties
 
 
+def count_parity(got_keys, got_dist, want_keys, want_dist, want_found, oracle_distance_of=None, exact=False, got_found=None):
+    """The same bar as assert_same_results over a whole batch, counted instead of asserted (bench.py's cpu_baseline leg,
+    the full-size tests).  got_* / want_*: nq x k arrays (engine / oracle), want_found: oracle's result count per query;
+    oracle_distance_of(query_index, key) -> the oracle's distance from that query to that member.
+    A VIOLATION is a position where the two disagree and the parity bar does not allow it: a different result count,
+    a distance beyond TOL, or ids that differ although the oracle's own distances of the two are not within TOL
+    (exact=True: any difference in ids or distance bits).  Returns {rows, identical_rows, near_tie_positions,
+    near_tie_rows, violations, violation_rows, first_violations}."""
+    gk = np.asarray(got_keys).view(np.uint64) if np.asarray(got_keys).dtype == np.int64 else np.asarray(got_keys, dtype=np.uint64)
+    wk = np.asarray(want_keys, dtype=np.uint64)
+    gd, wd = np.asarray(got_dist, dtype=np.float32), np.asarray(want_dist, dtype=np.float32)
+    nq, k = wk.shape
+    found = np.asarray(want_found, dtype=np.int64)
+    pos = np.arange(k)[None, :] < found[:, None]          # positions the oracle filled
+    ids_differ = (gk != wk) & pos
+    if exact:
+        dist_bad = (gd.view(np.uint32) != wd.view(np.uint32)) & pos
+    else:
+        with np.errstate(invalid="ignore"):  # padding: inf - inf
+            dist_bad = (np.abs(gd.astype(np.float64) - wd.astype(np.float64)) > TOL * np.maximum(1.0, np.abs(wd.astype(np.float64)))) & pos
+    count_bad = np.zeros(nq, dtype=bool)
+    if got_found is not None:
+        count_bad = np.asarray(got_found, dtype=np.int64) != found
+    else:  # the engine pads with the free key
+        gfound = (gk != np.uint64(0xFFFFFFFFFFFFFFFF)).sum(axis=1)
+        count_bad = gfound != found
+    violations, ties, first = 0, 0, []
+    tie_rows, bad_rows = set(), set()
+    for qi in np.nonzero(count_bad)[0]:
+        violations += 1
+        bad_rows.add(int(qi))
+        if len(first) < 5:
+            first.append({"query": int(qi), "what": "result count", "oracle": int(found[qi])})
+    for qi, j in zip(*np.nonzero(dist_bad & ~ids_differ)):
+        violations += 1
+        bad_rows.add(int(qi))
+        if len(first) < 5:
+            first.append({"query": int(qi), "position": int(j), "what": "distance", "engine": float(gd[qi, j]), "oracle": float(wd[qi, j])})
+    for qi, j in zip(*np.nonzero(ids_differ)):
+        ok = False
+        if not exact and oracle_distance_of is not None and not dist_bad[qi, j]:
+            ok = close(oracle_distance_of(int(qi), int(gk[qi, j])), wd[qi, j])
+        if ok:
+            ties += 1
+            tie_rows.add(int(qi))
+        else:
+            violations += 1
+            bad_rows.add(int(qi))
+            if len(first) < 5:
+                first.append({"query": int(qi), "position": int(j), "what": "id", "engine": int(gk[qi, j]), "oracle": int(wk[qi, j]),
+                              "engine_distance": float(gd[qi, j]), "oracle_distance": float(wd[qi, j])})
+    differing = set(np.nonzero((ids_differ | dist_bad).any(axis=1) | count_bad)[0].tolist())
+    return {"rows": int(nq), "identical_rows": int(nq - len(differing)), "near_tie_positions": int(ties), "near_tie_rows": len(tie_rows - bad_rows),
+            "violations": int(violations), "violation_rows": len(bad_rows), "first_violations": first,
+            "bar": "exact: ids and distance bits" if exact else f"ids position by position; a differing id only where the oracle's own two distances are within {TOL} (f32 near-tie); distances within {TOL}*max(1,|d|)"}
+
+
 def lattice(n, dim, seed, span=64):
     """Vectors with small integer coordinates: every l2sq / inner product of two of them is an integer far below 2^24,
     hence exact in f32 whatever the summation order -- the engine and the oracle then compute bit-identical distances

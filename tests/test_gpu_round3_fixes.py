@@ -1,0 +1,124 @@
+"""Regression tests of the round-2 advisor findings: a walk that reports "outgrew its workspace" inside the
+single-query dispatcher is answered by exhaustive ranking (never by a memcpy of 2^32 entries); the walk instance is chosen
+by the slot domain of ITS OWN visited table; the inner-product certificate's norm bound follows rows that re-use a
+removed slot."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+USEARCH_ORDER, GLOBAL_WALK, TINY_HEAP = 16, 32, 128
+WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512, WALK_LDS_320 = 1, 2, 3, 8
+
+
+def vs():
+    import vector_store_amd as v
+    return v
+
+
+def _data(n, dim, seed):
+    rng = np.random.default_rng(seed)
+    r = min(16, dim)
+    w = rng.standard_normal((r, dim)).astype(np.float32) / np.sqrt(r)
+    return (rng.standard_normal((n, r)).astype(np.float32) @ w + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+
+
+@pytest.mark.timeout(600)
+def test_dispatcher_ranks_exhaustively_when_a_walk_outgrows_its_workspace():
+    """Mass removes leave fewer live members than the beam: `top` never fills, the walk floods the whole graph, and with
+    the 64-entry heap hook `next` overflows -> kWalkFailed.  vs_hnsw_search and vs_hnsw_search_async must then return the
+    exact answer (the header's promise), through the dispatcher thread."""
+    v = vs()
+    n, dim, k = 20000, 16, 10
+    base = _data(n, dim, 11)
+    ix = v.HipUsearchIndex(dim, v.L2SQ, expansion_search=64, _stress=USEARCH_ORDER | GLOBAL_WALK | TINY_HEAP)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    keep = [17, 4321, 9999, 15000, 19999]
+    for key in range(n):
+        if key not in keep:
+            assert ix.remove(key)
+    q = _data(8, dim, 12)
+    before = ix.walk_info()["ranked_fallbacks"]
+    for i in range(len(q)):
+        want = sorted(keep, key=lambda s: float(((q[i] - base[s]) ** 2).sum()))
+        # vs_hnsw_search sees the global-walk route itself (search_host + rank_all) ...
+        got_k, got_d = ix.search(q[i], k)
+        assert got_k.tolist() == want, (i, got_k, want)
+        # ... the non-blocking entry point goes through the dispatcher: that is where the sentinel used to be memcpy'd
+        done = threading.Event()
+        res = {}
+
+        def on_done(keys, dist, status, res=res, done=done):
+            res["keys"], res["dist"], res["status"] = keys.copy(), dist.copy(), status
+            done.set()
+        holder = ix.search_async(q[i], k, on_done)
+        assert done.wait(120)
+        del holder
+        assert res["status"] == 0 and res["keys"].tolist() == want, (i, res)
+        assert np.allclose(res["dist"], [float(((q[i] - base[s]) ** 2).sum()) for s in want], rtol=1e-5)
+    assert ix.walk_info()["ranked_fallbacks"] >= before + len(q)
+
+
+@pytest.mark.timeout(600)
+def test_walk_instance_is_chosen_by_its_own_visited_domain(monkeypatch):
+    """ef 288 takes the 320-entry instance, whose visited table is the 256 instance's (25 slot bits), not the 512
+    instance's (26): an index of 2^25 < slots <= 2^26 must move to the 512 instance, beyond 2^26 to the global bitmap.
+    VS_HNSW_WALK_DOMAIN_SLOTS makes a small index pretend; all three routes return the same ids."""
+    v = vs()
+    n, dim, k, ef = 30000, 64, 10, 288
+    base = _data(n, dim, 21)
+    q = _data(200, dim, 22)
+    results, instances = [], []
+    graph = None
+    for pretend in (0, (1 << 25) + 1, (1 << 26) + 1):
+        if pretend:
+            monkeypatch.setenv("VS_HNSW_WALK_DOMAIN_SLOTS", str(pretend))
+        else:
+            monkeypatch.delenv("VS_HNSW_WALK_DOMAIN_SLOTS", raising=False)
+        ix = v.HipUsearchIndex(dim, v.COS, expansion_search=ef, quantization=v.I8)
+        if graph is None:
+            ix.reserve(n)
+            ix.add_batch(np.arange(n, dtype=np.uint64), base)
+            graph = ix.export_graph()
+        else:
+            ix.import_graph(graph)
+        keys, dist, found = ix.search_batch(q, k)
+        results.append((keys, dist, found))
+        instances.append(ix.walk_info()["last_instance"])
+    assert instances == [WALK_LDS_320, WALK_LDS_512, WALK_GLOBAL_512], instances
+    for keys, dist, found in results[1:]:
+        assert np.array_equal(keys, results[0][0]) and np.array_equal(dist.view(np.uint32), results[0][1].view(np.uint32))
+
+
+@pytest.mark.timeout(600)
+def test_ip_certificate_follows_a_reused_slots_norm():
+    """Inner product, >= 65,536 rows: the split-bf16 nomination certifies with eps ~ |q| * max|row|.  A vector 100x longer
+    than anything before it is added into a REUSED slot (below the high-water mark the norm pass had covered): the exact
+    search must still equal a float64 brute force."""
+    v = vs()
+    n, dim, k = 70000, 96, 10
+    rng = np.random.default_rng(31)
+    base = _data(n, dim, 31)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    ix = v.HipUsearchIndex(dim, v.IP)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    q = _data(64, dim, 32)
+    ix.exact_search_batch(q, k)  # norm state now covers every slot
+    assert ix.remove(12345)
+    big = (100.0 * base[777] + 0.3 * rng.standard_normal(dim)).astype(np.float32)
+    ix.add(1 << 40, big)
+    keys, dist, found = ix.exact_search_batch(q, k)
+    rows = base.copy().astype(np.float64)
+    rows[12345] = big
+    ids = np.arange(n, dtype=np.uint64)
+    ids[12345] = 1 << 40
+    d = 1.0 - q.astype(np.float64) @ rows.T
+    for i in range(len(q)):
+        order = np.argsort(d[i], kind="stable")[:k]
+        assert keys[i].tolist() == ids[order].tolist(), (i, keys[i], ids[order])
+        assert np.allclose(dist[i], d[i][order], rtol=1e-4, atol=1e-4)

@@ -37,13 +37,17 @@ def _worker(rank, world, port, total, dim, nq, k, out):
             dd = torch.from_numpy(np.take_along_axis(d, order, axis=1).astype(np.float32))
             return keys, dd
 
-        def merge(gk, gd, out_k, out_d):
-            mk, md = sharded.merge_topk_reference(gk.numpy().view(np.uint64), gd.numpy(), k)
+        def merge(blocks, out_k, out_d):  # numpy statement of vs_topk_merge_packed_device over ranks.cpp's block layout
+            mk, md = sharded.merge_packed_reference(blocks.numpy(), world, nq, k)
             out_k.copy_(torch.from_numpy(mk.view(np.int64)))
             out_d.copy_(torch.from_numpy(md))
 
         s = sharded.ShardedSearcher(None, torch.from_numpy(q), k, dist, None, local_search, merge)
         s.step()
+        # the receive buffer holds every rank's packed block exactly as ranks.cpp lays it out
+        lk, ld = local_search(False)
+        assert np.array_equal(s.gathered[rank].numpy(), sharded.pack_block(lk.numpy().view(np.uint64), ld.numpy()))
+        assert s.gathered.shape == (world, sharded.block_bytes(nq, k)) and sharded.block_bytes(nq, k) % 16 == 0
         d_all = ((q[:, None, :] - base[None, :, :]) ** 2).sum(-1)
         truth = np.argsort(d_all, axis=1, kind="stable")[:, :k]
         ok = np.array_equal(s.keys.numpy(), truth.astype(np.int64))
@@ -75,6 +79,18 @@ def test_merge_reference_handles_padding():
     assert k[0].tolist() == [1, 7, 2] and np.allclose(d[0], [0.1, 0.3, 0.5])
     k, d = sharded.merge_topk_reference(pk[:, :, 2:], pd[:, :, 2:], 3)
     assert (k == free).all() and np.isinf(d).all()
+
+
+def test_packed_block_layout_round_trips():
+    rng = np.random.default_rng(1)
+    parts, nq, k = 3, 7, 5  # 7 * 5 * 12 = 420 bytes: padded to 432
+    keys = rng.integers(0, 1 << 60, size=(parts, nq, k), dtype=np.uint64)
+    d = np.sort(rng.random((parts, nq, k)).astype(np.float32), axis=2)
+    assert sharded.block_bytes(nq, k) == 432
+    blocks = np.stack([sharded.pack_block(keys[p], d[p]) for p in range(parts)])
+    a = sharded.merge_packed_reference(blocks, parts, nq, k)
+    b = sharded.merge_topk_reference(keys, d, k)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 @pytest.mark.timeout(300)

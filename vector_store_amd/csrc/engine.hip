@@ -303,6 +303,8 @@ struct WalkRes {
     DeviceBuf allow;      // filtered search: the allow-bitmap of the query
     std::mutex mu;        // held while a call sizes the buffers and enqueues its launches
     uint32_t* retry_seen = nullptr;  // pinned: [retried queries of the last LDS-instance launch, its batch size, its instance]
+    hipEvent_t retry_seen_ev = nullptr;  // recorded behind the copy of word 0: the record is read only once it has landed, so the
+                                         // count always belongs to the (batch size, instance) the host wrote with it
     bool retry_seen_valid = false;
     const void* retry_seen_owner = nullptr;  // the index that launch searched (streams are shared between indexes)
     size_t g_layout[3] = {0, 0, 0};  // (bitmap words, stride, bytes) the bitmaps of g_space are known to be zero for
@@ -355,6 +357,10 @@ struct Engine {
     std::atomic<bool> small_table_ok{true};  // usearch-order walk, beams <= 128: the half-size visited table is paying off
     bool force_wide_tags = false;     // reserved bit 6 (tests): wide visited tags although the index is small
     bool force_global_walk = false;   // reserved bit 5 (tests): every search takes the global-bitmap walk instance
+    uint64_t walk_domain_override = 0;  // VS_HNSW_WALK_DOMAIN_SLOTS (tests): the slot count the walk's instance choice assumes
+    std::atomic<uint32_t> last_walk_instance{0xFFFFFFFFu};  // walk instance of the last search_device call (vs_hnsw_walk_info)
+    bool tiny_walk_heap = false;      // reserved bit 7 (tests): the global-bitmap walk's `next` gets 64 entries of global memory, so a
+                                      // walk that floods the graph (fewer live members than the beam) reports kWalkFailed
     int team_mode = 0;                // 0 = by batch size; reserved bit 2 = always a team per query, bit 3 = never
     uint32_t team_max_nq = 256;       // batches up to one team per CU take the team kernel
     int scalar = VS_SCALAR_F32;
@@ -464,10 +470,12 @@ struct Engine {
         order_mode = (o.reserved & 16) ? 1 : 0;
         force_global_walk = (o.reserved & 32) != 0;
         force_wide_tags = (o.reserved & 64) != 0;
+        tiny_walk_heap = (o.reserved & 128) != 0;
         if (const char* ff = std::getenv("VS_HNSW_FILTER")) eager_filter = !std::strcmp(ff, "eager");
         if (const char* xf = std::getenv("VS_HNSW_EXACT")) exact_f32_only = !std::strcmp(xf, "f32");
         if (const char* tn = std::getenv("VS_HNSW_TIE")) tie_newest = std::strcmp(tn, "random") != 0;
         if (const char* fw = std::getenv("VS_HNSW_WALK")) force_global_walk = !std::strcmp(fw, "global");
+        if (const char* ds = std::getenv("VS_HNSW_WALK_DOMAIN_SLOTS")) walk_domain_override = std::strtoull(ds, nullptr, 10);
         if (const char* om = std::getenv("VS_HNSW_ORDER")) order_mode = !std::strcmp(om, "usearch") ? 1 : !std::strcmp(om, "fused") ? 2 : order_mode;
         if (const char* cr = std::getenv("VS_HNSW_CHUNK")) chunk_rows = (uint32_t)std::max(1024, std::atoi(cr));                      // build experiments
         if (const char* sb = std::getenv("VS_HNSW_MAX_SUBBATCH")) max_sub_batch = (uint32_t)std::max(1, std::atoi(sb));
@@ -725,6 +733,10 @@ struct Engine {
             HIP_OK(launch_scatter_u64(d_keys, d_slots, d_keyv, m, st));
             HIP_OK(launch_scatter_u32((uint32_t*)d_levels, d_slots, (const uint32_t*)d_lv, m, st));
             HIP_OK(launch_scatter_u32(d_upper_off, d_slots, d_uoff, m, st));
+            if (!reuse_rows.empty()) {  // a reused slot lies below max_norm_slots: the certificate's norm bound is recomputed over every row
+                std::lock_guard<std::mutex> ng(norm_mu);
+                max_norm_slots = 0;
+            }
             if (!reuse_rows.empty()) {  // usearch update(): the reused node's links are zeroed first
                 uint32_t* d_rr = (uint32_t*)w->d.ensure((reuse_rows.size() + reuse_upper.size()) * 4 + 64);
                 HIP_OK(hipMemcpyAsync(d_rr, reuse_rows.data(), reuse_rows.size() * 4, hipMemcpyHostToDevice, st));
@@ -1010,7 +1022,7 @@ struct Engine {
             auto global_space = [&](WalkArgs& w, uint32_t inst, uint32_t want_grid, bool deep_heap) {
                 w.bitmap_words = (uint32_t)((slots + 31) / 32);
                 w.vlog_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(slots, 1u << 16));
-                w.heap_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(slots, deep_heap ? (1u << 18) : (1u << 16)));
+                w.heap_cap = tiny_walk_heap ? 64u : (uint32_t)std::max<size_t>(64, std::min<size_t>(slots, deep_heap ? (1u << 18) : (1u << 16)));
                 w.space_stride = walk_space_stride(w.bitmap_words, w.vlog_cap, w.heap_cap);
                 const uint32_t budget_grid = (uint32_t)std::max<size_t>(16, (4ull << 30) / w.space_stride);
                 uint32_t grid = 0;
@@ -1031,15 +1043,22 @@ struct Engine {
             // How the previous launch on this stream fared: the half-size table goes back to the full one when > 5 % of a
             // batch outgrew it; an instance most of whose queries outgrow its LDS structures (structureless data: `next`
             // holds thousands of equal-distance entries) is skipped from then on -- the retry launch is exact but narrow.
-            if (wr.retry_seen_valid && wr.retry_seen_owner == this) {
+            if (wr.retry_seen_valid && wr.retry_seen_owner == this && hipEventQuery(wr.retry_seen_ev) == hipSuccess) {
                 const uint32_t seen = wr.retry_seen[0], of = wr.retry_seen[1], which = wr.retry_seen[2] & 15u;
                 if (of >= 64 && which == WALK_LDS_128_SMALL && seen * 20 > of) small_table_ok = false;
                 else if (of >= 64 && which != WALK_LDS_128_SMALL && which != WALK_LDS_128_TINY && seen * 4 > of) lds_walk_bad[which] = true;
             }
             wr.retry_seen_valid = false;
             const bool small = ef <= 128 && small_table_ok.load() && slots <= (1ull << walk_small_table_bits()) && !stress_small_table;
-            const uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : ef <= kWalk320MaxBeam ? WALK_LDS_320 : WALK_LDS_512;
-            if (global || lds_walk_bad[inst].load()) {
+            uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : ef <= kWalk320MaxBeam ? WALK_LDS_320 : WALK_LDS_512;
+            // The visited tags of the instance actually chosen must tell every slot apart (needs_global_walk asks by beam, and
+            // the 320-entry instance carries the 256 instance's 25-bit table, not the 512 instance's 26 bits): a wider
+            // instance first, the global bitmap beyond that.  walk_domain_override: test hook (pretends the index is larger).
+            const uint64_t domain_slots = std::max<uint64_t>(slots, walk_domain_override);
+            if (inst == WALK_LDS_320 && domain_slots > (1ull << walk_instance_domain_bits(inst))) inst = WALK_LDS_512;
+            const bool out_of_domain = inst != WALK_LDS_128_TINY && domain_slots > (1ull << walk_instance_domain_bits(inst));
+            last_walk_instance = (global || out_of_domain || lds_walk_bad[inst].load()) ? g_inst : inst;
+            if (global || out_of_domain || lds_walk_bad[inst].load()) {
                 const uint32_t grid = global_space(a, g_inst, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
                 a.work_counter = retry + 1;
                 HIP_OK(launch_walk(a, iters, g_inst, grid, st, nullptr));
@@ -1082,12 +1101,18 @@ struct Engine {
             HIP_OK(launch_walk(a, iters, launch_inst, grid, st, nullptr));
             HIP_OK(launch_walk(r, iters, WALK_GLOBAL_512, rgrid, st, nullptr));
             {  // how many queries of this launch had to be retried: looked at by the next launch on this stream
-                if (!wr.retry_seen) HIP_OK(hipHostMalloc((void**)&wr.retry_seen, 16, hipHostMallocDefault));
+                if (!wr.retry_seen) {
+                    HIP_OK(hipHostMalloc((void**)&wr.retry_seen, 16, hipHostMallocDefault));
+                    HIP_OK(hipEventCreateWithFlags(&wr.retry_seen_ev, hipEventDisableTiming));
+                }
+                // a copy of an earlier launch may still be in flight (pipelined callers): it lands before this one's (stream
+                // order), and the record is not read until this launch's event has fired
                 wr.retry_seen[1] = (uint32_t)nq;
                 wr.retry_seen[2] = inst;
                 wr.retry_seen_owner = this;
                 HIP_OK(hipMemcpyAsync(&wr.retry_seen[0], retry, 4, hipMemcpyDeviceToHost, st));
-                wr.retry_seen_valid = true;  // (read one launch later: by then the copy has long landed; a stale value only delays the switch)
+                HIP_OK(hipEventRecord(wr.retry_seen_ev, st));
+                wr.retry_seen_valid = true;
             }
             if (walk_debug) {
                 std::vector<uint32_t> h(nq * 12);
@@ -1552,17 +1577,32 @@ class SearchService {
         const size_t k = s.reqs.empty() ? 0 : s.reqs[0].k;
         for (size_t i = 0; i < s.reqs.size(); ++i) {
             SearchReq& r = s.reqs[i];
-            if (s.status == VS_OK) {
-                const size_t f = s.h_f[i];
+            int status = s.status;
+            if (status == VS_OK && s.h_f[i] == kWalkFailed) {
+                // The walk outgrew its workspace (e.g. fewer live members than the beam after mass removes: `top` never
+                // fills and the walk floods the graph): rank exhaustively, as the header promises for every host entry point.
+                try {
+                    *r.found = r.e->rank_all(r.q.data(), k, r.keys, r.dist);
+                    n_ranked_fallbacks += 1;
+                } catch (const Fail& f) {
+                    status = f.code;
+                    s.err = f.msg;
+                } catch (const std::exception& x) {
+                    status = VS_ERR_DEVICE;
+                    s.err = x.what();
+                }
+            } else if (status == VS_OK) {
+                const size_t f = std::min<size_t>(s.h_f[i], k);
                 std::memcpy(r.keys, s.h_k + i * k, f * 8);
                 std::memcpy(r.dist, s.h_d + i * k, f * 4);
                 *r.found = f;
-            } else {
+            }
+            if (status != VS_OK) {
                 *r.found = 0;
                 g_async_err = s.err;
                 g_err = s.err;  // vs_hnsw_last_error() inside the completion callback
             }
-            r.cb(r.ctx, s.status);
+            r.cb(r.ctx, status);
         }
         s.reqs.clear();
     }
@@ -1617,6 +1657,7 @@ class SearchService {
     static thread_local std::string g_async_err;
     // launches / queries, and how many of them went to the team kernel (process-wide; vs_search_service_stats)
     static inline std::atomic<unsigned long long> n_batches{0}, n_team_batches{0}, n_queries{0}, n_team_queries{0};
+    static inline std::atomic<unsigned long long> n_ranked_fallbacks{0};  // queries whose walk reported kWalkFailed and were ranked exhaustively
 };
 thread_local std::string SearchService::g_async_err;
 
@@ -1925,6 +1966,14 @@ int vs_hnsw_filter_stats(vs_hnsw* h, uint64_t out[2]) {
     return VS_OK;
 }
 
+int vs_hnsw_walk_info(vs_hnsw* h, uint64_t out[2]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    const uint32_t inst = h->e.last_walk_instance.load();
+    out[0] = inst == 0xFFFFFFFFu ? ~0ull : inst;
+    out[1] = vs::SearchService::n_ranked_fallbacks.load();
+    return VS_OK;
+}
+
 int vs_hnsw_exact_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.block_batches.load();
@@ -2016,6 +2065,10 @@ int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const void* vectors, const int32_
         }
         e.live = live;
         e.committed = live;
+        {
+            std::lock_guard<std::mutex> ng(e.norm_mu);
+            e.max_norm_slots = 0;  // the contents were replaced
+        }
         e.max_level = max_level;
         e.entry_slot = entry_slot;
     });

@@ -116,6 +116,7 @@ hipError_t launch_link(const LinkArgs& a, uint32_t iters, hipStream_t s);
 // bits of slot ids the visited table of the kernel chosen for `ef` can distinguish (wide: the 4-extra-tag-bit instance)
 uint32_t visited_domain_bits(uint32_t ef, bool wide = false);
 uint32_t walk_small_table_bits();  // slot bits WALK_LDS_128_SMALL can tell apart
+uint32_t walk_instance_domain_bits(uint32_t instance);  // slot bits the LDS visited table of walk instance `instance` can tell apart (32: global bitmap)
 
 // f32 rows (dim floats, src_stride apart) -> storage rows (cast as usearch does, zero padded) + aux;
 // rows given by slots[] or first + i

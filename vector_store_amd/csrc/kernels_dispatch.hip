@@ -24,6 +24,19 @@ bool search_supported(uint32_t iters, uint32_t ef) {
 
 uint32_t walk_small_table_bits() { return VisitedCfg<512, 2>::domain_bits; }
 
+// must name the same VisitedCfg as the instance table in kernels_walk.hip (walk_ef)
+uint32_t walk_instance_domain_bits(uint32_t instance) {
+    switch (instance & ~kWalkTeamFlag) {
+        case WALK_LDS_128: return VisitedCfg<1024, 1>::domain_bits;
+        case WALK_LDS_128_SMALL: return VisitedCfg<512, 2>::domain_bits;
+        case WALK_LDS_128_TINY: return VisitedCfg<256, 1>::domain_bits;
+        case WALK_LDS_256:
+        case WALK_LDS_320: return VisitedCfg<1024, 2>::domain_bits;
+        case WALK_LDS_512: return VisitedCfg<2048, 2>::domain_bits;
+        default: return 32;
+    }
+}
+
 uint32_t visited_domain_bits(uint32_t ef, bool wide) {
     if (wide) return ef <= 128 ? VisitedCfg<1024, 1, true>::domain_bits : ef <= 256 ? VisitedCfg<1024, 2, true>::domain_bits : VisitedCfg<2048, 2, true>::domain_bits;
     return ef <= 128 ? VisitedCfg<1024, 1>::domain_bits : ef <= 256 ? VisitedCfg<1024, 2>::domain_bits : VisitedCfg<2048, 2>::domain_bits;

@@ -13,6 +13,22 @@
 namespace {
 thread_local std::string g_err;
 constexpr uint64_t kIdxMask = (1ull << 48) - 1;
+constexpr uint32_t kWalkFailedFound = 0xFFFFFFFFu;  // vs_hnsw_search_batch_device: "the walk outgrew its workspace, no answer"
+
+// One thread per (query, position): rows of this rank's block that carry no answer -- the whole block when the local
+// search could not be launched (all = 1), else the queries flagged kWalkFailed -- are filled with (free key, +inf) before
+// they are gathered, so no rank ever merges what a previous batch left in the buffer; *failed counts such queries.
+__global__ void blank_unanswered_rows(uint64_t* keys, float* dist, const uint32_t* found, uint32_t nq, uint32_t k, int all,
+                                      unsigned long long* failed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * k) return;
+    const uint32_t q = i / k;
+    if (all || found[q] == kWalkFailedFound) {
+        keys[i] = ~0ull;
+        dist[i] = __builtin_inff();
+        if (i % k == 0) atomicAdd(failed, 1ull);
+    }
+}
 
 struct Fail {
     int code;
@@ -55,6 +71,7 @@ struct vs_ranks {
     uint64_t total_rows = 0, per = 1;
     ncclComm_t comm = nullptr;
     hipStream_t comm_stream = nullptr;
+    unsigned long long* d_failed = nullptr;  // queries this rank contributed no answer to (see blank_unanswered_rows)
     struct Slot {
         char* gathered = nullptr;  // world x block bytes; this rank's block is written by its walk, in place
         uint32_t* local_found = nullptr;
@@ -92,17 +109,24 @@ struct vs_ranks {
         if (s.merged) HIP_OK(hipStreamWaitEvent(st, s.merged, 0));  // this slot's previous merge has read the blocks the walk is about to rewrite
         ensure(s, block, nq);
         char* mine = s.gathered + (size_t)rank * block;
-        if (exact)
-            VS_OK_OR_THROW(vs_hnsw_exact_search_batch_device(shard, d_q, nq, dim, k, (uint64_t*)mine, (float*)(mine + nq * k * 8),
-                                                             s.local_found, st));
-        else
-            VS_OK_OR_THROW(vs_hnsw_search_batch_device(shard, d_q, nq, dim, k, (uint64_t*)mine, (float*)(mine + nq * k * 8),
-                                                       s.local_found, st));
+        // A rank whose local search fails must still enter the collective -- the others are already on their way into it
+        // and would wait for ever -- so the failure is kept, an empty block is gathered, and the error is reported after
+        // the all-gather and the merge are enqueued.
+        int local_rc = exact ? vs_hnsw_exact_search_batch_device(shard, d_q, nq, dim, k, (uint64_t*)mine, (float*)(mine + nq * k * 8),
+                                                                 s.local_found, st)
+                             : vs_hnsw_search_batch_device(shard, d_q, nq, dim, k, (uint64_t*)mine, (float*)(mine + nq * k * 8),
+                                                           s.local_found, st);
+        std::string local_err = local_rc == VS_OK ? std::string() : std::string(vs_hnsw_last_error());
+        const uint32_t cells = (uint32_t)(nq * k);
+        hipLaunchKernelGGL(blank_unanswered_rows, dim3((cells + 255) / 256), dim3(256), 0, st, (uint64_t*)mine, (float*)(mine + nq * k * 8),
+                           s.local_found, (uint32_t)nq, (uint32_t)k, local_rc == VS_OK ? 0 : 1, d_failed);
+        HIP_OK(hipGetLastError());
         HIP_OK(hipEventRecord(s.walked, st));
         HIP_OK(hipStreamWaitEvent(comm_stream, s.walked, 0));
         if (world > 1) NCCL_OK(ncclAllGather(mine, s.gathered, block, ncclChar, comm, comm_stream));  // in place: sendbuff = recvbuff + rank * count
         VS_OK_OR_THROW(vs_topk_merge_packed_device(s.gathered, (size_t)world, block, nq, k, d_keys, d_dist, d_found, comm_stream));
         HIP_OK(hipEventRecord(s.merged, comm_stream));
+        if (local_rc != VS_OK) throw Fail{local_rc, "local shard search failed (an empty block was gathered so that the other ranks go on): " + local_err};
     }
 };
 
@@ -131,6 +155,8 @@ int vs_ranks_create(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_RAN
         r->per = (r->total_rows + (uint64_t)world - 1) / (uint64_t)world;
         try {
             HIP_OK(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+            HIP_OK(hipMalloc((void**)&r->d_failed, 8));
+            HIP_OK(hipMemset(r->d_failed, 0, 8));
             if (world > 1) {
                 ncclUniqueId u;
                 std::memcpy(&u, id, sizeof u);
@@ -153,9 +179,33 @@ void vs_ranks_free(vs_ranks* r) {
         if (s.walked) (void)hipEventDestroy(s.walked);
         if (s.merged) (void)hipEventDestroy(s.merged);
     }
+    if (r->d_failed) (void)hipFree(r->d_failed);
     if (r->comm) (void)ncclCommDestroy(r->comm);
     if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
     delete r;
+}
+
+int vs_ranks_world(const vs_ranks* r, int* rank, int* world, int* comm_ranks) {
+    return guarded([&] {
+        if (!r) throw Fail{VS_ERR_INVALID_ARGUMENT, "null handle"};
+        if (rank) *rank = r->rank;
+        if (world) *world = r->world;
+        if (comm_ranks) {
+            int n = 1;
+            if (r->comm) NCCL_OK(ncclCommCount(r->comm, &n));
+            *comm_ranks = n;
+        }
+    });
+}
+
+int vs_ranks_unanswered(vs_ranks* r, uint64_t* queries) {
+    return guarded([&] {
+        if (!r || !queries) throw Fail{VS_ERR_INVALID_ARGUMENT, "null argument"};
+        HIP_OK(hipDeviceSynchronize());
+        unsigned long long v = 0;
+        HIP_OK(hipMemcpy(&v, r->d_failed, 8, hipMemcpyDeviceToHost));
+        *queries = v;
+    });
 }
 
 int vs_ranks_owner(const vs_ranks* r, uint64_t key) {

@@ -93,6 +93,7 @@ def lib():
     L.vs_hnsw_memory_info.argtypes = [vp, vp]
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
     L.vs_hnsw_exact_stats.argtypes = [vp, vp]
+    L.vs_hnsw_walk_info.argtypes = [vp, vp]
     L.vs_hnsw_graph_info_get.argtypes = [vp, C.POINTER(_GraphInfo)]
     L.vs_hnsw_export_graph.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.vs_hnsw_import_graph.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz, C.c_int32, C.c_uint32]
@@ -284,6 +285,11 @@ class HipUsearchIndex:
         out = np.zeros(2, dtype=np.uint64)
         _check(self.L.vs_hnsw_exact_stats(self.h, _p(out)))
         return {"block_batches": int(out[0]), "block_fallbacks": int(out[1])}
+
+    def walk_info(self) -> dict:
+        out = np.zeros(2, dtype=np.uint64)
+        _check(self.L.vs_hnsw_walk_info(self.h, _p(out)))
+        return {"last_instance": None if int(out[0]) == 0xFFFFFFFFFFFFFFFF else int(out[0]), "ranked_fallbacks": int(out[1])}
 
     def graph_info(self) -> dict:
         gi = _GraphInfo()

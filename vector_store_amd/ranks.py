@@ -29,6 +29,8 @@ def lib():
         L.vs_ranks_unique_id.argtypes = [vp]
         L.vs_ranks_create.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.POINTER(vp)]
         L.vs_ranks_free.argtypes = [vp]
+        L.vs_ranks_world.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vs_ranks_unanswered.argtypes = [vp, C.POINTER(u64)]
         L.vs_ranks_owner.argtypes = [vp, u64]
         L.vs_ranks_range.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.vs_ranks_add_batch.argtypes = [vp, vp, vp, sz, sz, C.POINTER(sz)]
@@ -71,6 +73,17 @@ class Ranks:
 
     def __del__(self):
         self.close()
+
+    def comm_info(self) -> dict:
+        """rank / world the handle was created with, and the RCCL communicator's own size (ncclCommCount)."""
+        r, w, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self.L.vs_ranks_world(self.h, C.byref(r), C.byref(w), C.byref(c)))
+        return {"rank": r.value, "world": w.value, "rccl_ranks": c.value}
+
+    def unanswered(self) -> int:
+        v = C.c_uint64(0)
+        self._check(self.L.vs_ranks_unanswered(self.h, C.byref(v)))
+        return v.value
 
     def owner(self, key: int) -> int:
         return self.L.vs_ranks_owner(self.h, key)

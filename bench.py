@@ -575,13 +575,14 @@ def main():
                   "hops_per_add": st["add_hops"] / max(st["added"], 1)}
     se = Searcher(ix, batches, k)
     finish = lambda: None  # pipelined steppers: completes the batch still in flight
-    rccl_ranks, gs = None, None
+    rccl_ranks, gs, exchange_kind = None, None, None
     if shard_mode:
         # native path (libvs_ranks: one ncclAllGather per batch on its own stream, overlapped with the next walk);
         # the torch.distributed twin only where RCCL is not the backend (gloo smoke tests)
         gs = make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, n * world, a.backend)
         if hasattr(gs, "ranks"):
-            rccl_ranks = gs.ranks.comm_info()["rccl_ranks"]
+            ci = gs.ranks.comm_info()
+            rccl_ranks, exchange_kind = ci["rccl_ranks"], ci["exchange"]
         truth = gs.exact()
         turn = [0]
 
@@ -698,7 +699,8 @@ def main():
                 sq = [make_data(nq, dim, a.dist, 4321 + 1000 * b, dev, a.rank) for b in range(nb)]
                 gs = make_sharded_searcher(six, sq[0], k, dist, vs, ranks, sharded, per * world, a.backend)
                 if hasattr(gs, "ranks"):
-                    rccl_ranks = gs.ranks.comm_info()["rccl_ranks"]
+                    ci = gs.ranks.comm_info()
+                    rccl_ranks, exchange_kind = ci["rccl_ranks"], ci["exchange"]
                 sfinish = getattr(gs, "flush", lambda: None)
                 struth = gs.exact()
                 gs.step()
@@ -727,6 +729,9 @@ def main():
         out["sharded"]["collective"] = "one ncclAllGather (RCCL, libvs_ranks) of packed per-shard top-k per batch + topk_merge_kernel, overlapped with the next walk"
     if world > 1 or shard_mode:
         out["rccl_ranks"] = rccl_ranks  # ncclCommCount of libvs_ranks' communicator (1 at N = 1; None: the torch twin served the sharded path)
+        out["exchange"] = exchange_kind
+    if a.same_device and world > 1:
+        out["same_device"] = True  # testing aid: every rank on GPU 0 -- exercises the N > 1 code, is NOT a scaling measurement
 
     # ---- through the boundary: what a drop-in caller of the trait gets on this index (N=1 only)
     if world == 1 and a.boundary_seconds > 0:

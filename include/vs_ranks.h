@@ -39,6 +39,15 @@ VS_API int vs_ranks_unique_id(uint8_t id[VS_RANKS_ID_BYTES]);
  * owned by the caller and must outlive the handle.  total_rows: size of the key space that is split into ranges. */
 VS_API int vs_ranks_create(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_RANKS_ID_BYTES], uint64_t total_rows,
                            vs_ranks** out);
+/* The same with the exchange named explicitly.  VS_RANKS_RCCL (what vs_ranks_create uses unless the environment says
+ * VS_RANKS_EXCHANGE=hostshm): ncclAllGather over xGMI, one rank per GPU -- the product path.  VS_RANKS_HOSTSHM: the
+ * all-gather goes through a POSIX shared-memory segment named after the id (D2H, flags, H2D on the communicator stream):
+ * for ranks that SHARE a device, which RCCL refuses to pair -- the one-GPU boxes of the test pool run the whole sharded
+ * path (in-place blocks, two-slot pipeline, packed merge) with world > 1 that way.  Not a data path for production. */
+typedef enum vs_ranks_exchange { VS_RANKS_RCCL = 0, VS_RANKS_HOSTSHM = 1 } vs_ranks_exchange;
+VS_API int vs_ranks_create_ex(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_RANKS_ID_BYTES], uint64_t total_rows,
+                              int exchange, vs_ranks** out);
+VS_API int vs_ranks_exchange_kind(const vs_ranks* r); /* vs_ranks_exchange of the handle */
 VS_API void vs_ranks_free(vs_ranks* r);
 
 /* What the handle is part of: this rank, the world it was created with, and the size of the RCCL communicator itself

@@ -77,6 +77,48 @@ def test_packed_merge_equals_the_two_array_merge():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.timeout(900)
+def test_two_ranks_share_one_device_over_the_host_exchange():
+    """world = 2 through the NATIVE library on a one-GPU box: RCCL refuses two ranks on one device, so the all-gather goes
+    through libvs_ranks' host-shared-memory exchange (VS_RANKS_EXCHANGE=hostshm); everything else -- in-place packed
+    blocks, the two-slot pipeline, vs_topk_merge_packed_device -- is the path configs[3] runs.  tests/ranks_world2_worker.py
+    holds the assertions."""
+    import json
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", VS_RANKS_EXCHANGE="hostshm")
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(var, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "tests", "ranks_world2_worker.py")], env=env, text=True, capture_output=True,
+                         timeout=800, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["ok"] and rec["world"] == 2 and rec["exchange"] == "hostshm" and rec["recall_at_10"] >= 0.9
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_on_one_device_runs_both_sharded_legs():
+    """bench.py --gpus 2 as the driver's launcher would start it, both ranks on GPU 0 (--same-device, gloo + host exchange):
+    the replica path, the weak and the fixed-total sharded legs, rccl_ranks / exchange in the line."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VS_RANKS_EXCHANGE="hostshm")
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(var, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--vectors", "100000",
+                          "--dim", "96", "--nq", "1000", "--steps", "4", "--warmup", "1", "--ef", "96"], env=env, text=True, capture_output=True,
+                         timeout=800, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["same_device"] is True and rec["rccl_ranks"] == 2 and rec["exchange"] == "hostshm"
+    assert rec["sharded"]["weak"]["index_vectors_total"] == 200000 and rec["sharded"]["fixed_total"]["index_vectors_total"] == 100000
+    for leg in ("weak", "fixed_total"):
+        assert rec["sharded"][leg]["path"] == "RankedSearcher" and rec["sharded"][leg]["recall_at_10"] >= 0.9
+        assert rec["sharded"][leg]["unanswered_queries"] == 0 and rec["sharded"][leg]["queries_per_s"] > 0
+
+
 def test_two_ranks_over_rccl():
     """bench.py --gpus 2 --mode shard: two processes, two GPUs, nccl backend, libvs_ranks on the data path."""
     import torch
@@ -90,4 +132,4 @@ def test_two_ranks_over_rccl():
     import json
     rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["config"]["mode"] == "shard" and rec["config"]["index_vectors_total"] == 400000
-    assert rec["recall_at_10"] >= 0.9 and rec["value"] > 0
+    assert rec["recall_at_10"] >= 0.9 and rec["value"] > 0 and rec["rccl_ranks"] == 2 and rec["exchange"] == "rccl"

@@ -5,9 +5,17 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -65,8 +73,108 @@ int guarded(F&& f) {
 }
 }  // namespace
 
+// VS_RANKS_HOSTSHM: the all-gather through a POSIX shared-memory segment instead of RCCL -- for ranks that share ONE
+// device (RCCL refuses to pair those: "duplicate GPU"), i.e. the one-GPU boxes the tests run on.  Everything around the
+// exchange is the product path unchanged: the walk writes this rank's packed block in place, the exchange fills the other
+// ranks' blocks of the same receive buffer on the communicator stream, the packed merge follows, two slots pipeline it.
+// Per slot and generation g: wait until every rank has consumed generation g - 1 of the slot, copy the block out (D2H),
+// publish "arrived", wait for every rank's arrival, copy the other blocks in (H2D), publish "consumed".  The waits run
+// as host functions on the communicator stream and give up after kWaitSeconds (the handle then reports the failure).
+struct HostExchange {
+    static constexpr size_t kCtlBytes = 8192, kBlockCap = 8u << 20, kMaxWorld = 64;
+    static constexpr int kWaitSeconds = 60;
+    struct Ctl {
+        std::atomic<uint64_t> arrived[2][kMaxWorld], consumed[2][kMaxWorld];
+        std::atomic<uint32_t> attached;
+    };
+    static_assert(sizeof(Ctl) <= kCtlBytes, "control block");
+    std::string name;
+    char* base = nullptr;
+    size_t bytes = 0;
+    int rank = 0, world = 1;
+    bool registered = false;
+    uint64_t gen[2] = {0, 0};
+    std::atomic<bool> failed{false};
+
+    Ctl* ctl() const { return reinterpret_cast<Ctl*>(base); }
+    char* block(int slot, int r) const { return base + kCtlBytes + ((size_t)slot * (size_t)world + (size_t)r) * kBlockCap; }
+
+    void open(const uint8_t* id, int rank_, int world_) {
+        rank = rank_;
+        world = world_;
+        if (world > (int)kMaxWorld) throw Fail{VS_ERR_UNSUPPORTED, "host exchange: at most 64 ranks"};
+        char hex[40];
+        for (int i = 0; i < 16; ++i) snprintf(hex + 2 * i, 3, "%02x", id[(i * 7 + 3) % VS_RANKS_ID_BYTES] ^ id[i]);
+        name = std::string("/vs_ranks_") + hex;
+        bytes = kCtlBytes + 2 * (size_t)world * kBlockCap;
+        int fd = shm_open(name.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd < 0) throw Fail{VS_ERR_DEVICE, "shm_open " + name + " failed"};
+        if (ftruncate(fd, (off_t)bytes) != 0) {
+            close(fd);
+            throw Fail{VS_ERR_OUT_OF_MEMORY, "ftruncate of the exchange segment failed"};
+        }
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) throw Fail{VS_ERR_OUT_OF_MEMORY, "mmap of the exchange segment failed"};
+        base = (char*)p;
+        registered = hipHostRegister(base, bytes, hipHostRegisterDefault) == hipSuccess;  // pageable copies work too, only slower
+        ctl()->attached.fetch_add(1);
+    }
+    void close_segment() {
+        if (!base) return;
+        if (registered) (void)hipHostUnregister(base);
+        const bool last = ctl()->attached.fetch_sub(1) == 1;
+        munmap(base, bytes);
+        base = nullptr;
+        if (last || rank == 0) shm_unlink(name.c_str());
+    }
+
+    struct Wait {
+        HostExchange* x;
+        int slot, what;  // 0: every rank consumed generation g - 1; 1: publish arrival, wait for everyone's; 2: publish consumption
+        uint64_t g;
+    };
+    static void host_step(void* p) {
+        Wait* w = (Wait*)p;
+        HostExchange& x = *w->x;
+        Ctl* c = x.ctl();
+        auto all_at_least = [&](std::atomic<uint64_t>* v, uint64_t want) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                bool ok = true;
+                for (int r = 0; r < x.world; ++r) ok = ok && v[r].load(std::memory_order_acquire) >= want;
+                if (ok) return;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kWaitSeconds)) {
+                    x.failed = true;
+                    return;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+        };
+        if (w->what == 0) all_at_least(c->consumed[w->slot], w->g);
+        else if (w->what == 1) {
+            c->arrived[w->slot][x.rank].store(w->g + 1, std::memory_order_release);
+            all_at_least(c->arrived[w->slot], w->g + 1);
+        } else c->consumed[w->slot][x.rank].store(w->g + 1, std::memory_order_release);
+        delete w;
+    }
+    void all_gather(int slot, char* gathered, size_t block_bytes, hipStream_t st) {
+        if (failed.load()) throw Fail{VS_ERR_DEVICE, "host exchange: a rank did not arrive within " + std::to_string(kWaitSeconds) + " s"};
+        if (block_bytes > kBlockCap) throw Fail{VS_ERR_UNSUPPORTED, "host exchange: batch above 8 MiB per rank"};
+        const uint64_t g = gen[slot]++;
+        HIP_OK(hipLaunchHostFunc(st, host_step, new Wait{this, slot, 0, g}));
+        HIP_OK(hipMemcpyAsync(block(slot, rank), gathered + (size_t)rank * block_bytes, block_bytes, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipLaunchHostFunc(st, host_step, new Wait{this, slot, 1, g}));
+        for (int r = 0; r < world; ++r)
+            if (r != rank) HIP_OK(hipMemcpyAsync(gathered + (size_t)r * block_bytes, block(slot, r), block_bytes, hipMemcpyHostToDevice, st));
+        HIP_OK(hipLaunchHostFunc(st, host_step, new Wait{this, slot, 2, g}));
+    }
+};
+
 struct vs_ranks {
     vs_hnsw* shard = nullptr;
+    int exchange = VS_RANKS_RCCL;
+    HostExchange host;
     int rank = 0, world = 1;
     uint64_t total_rows = 0, per = 1;
     ncclComm_t comm = nullptr;
@@ -123,7 +231,8 @@ struct vs_ranks {
         HIP_OK(hipGetLastError());
         HIP_OK(hipEventRecord(s.walked, st));
         HIP_OK(hipStreamWaitEvent(comm_stream, s.walked, 0));
-        if (world > 1) NCCL_OK(ncclAllGather(mine, s.gathered, block, ncclChar, comm, comm_stream));  // in place: sendbuff = recvbuff + rank * count
+        if (world > 1 && exchange == VS_RANKS_HOSTSHM) host.all_gather(si, s.gathered, block, comm_stream);
+        else if (world > 1) NCCL_OK(ncclAllGather(mine, s.gathered, block, ncclChar, comm, comm_stream));  // in place: sendbuff = recvbuff + rank * count
         VS_OK_OR_THROW(vs_topk_merge_packed_device(s.gathered, (size_t)world, block, nq, k, d_keys, d_dist, d_found, comm_stream));
         HIP_OK(hipEventRecord(s.merged, comm_stream));
         if (local_rc != VS_OK) throw Fail{local_rc, "local shard search failed (an empty block was gathered so that the other ranks go on): " + local_err};
@@ -144,20 +253,30 @@ int vs_ranks_unique_id(uint8_t id[VS_RANKS_ID_BYTES]) {
 }
 
 int vs_ranks_create(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_RANKS_ID_BYTES], uint64_t total_rows, vs_ranks** out) {
+    const char* x = std::getenv("VS_RANKS_EXCHANGE");
+    return vs_ranks_create_ex(shard, rank, world, id, total_rows, x && !std::strcmp(x, "hostshm") ? VS_RANKS_HOSTSHM : VS_RANKS_RCCL, out);
+}
+
+int vs_ranks_create_ex(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_RANKS_ID_BYTES], uint64_t total_rows, int exchange,
+                       vs_ranks** out) {
     return guarded([&] {
+        if (exchange != VS_RANKS_RCCL && exchange != VS_RANKS_HOSTSHM) throw Fail{VS_ERR_INVALID_ARGUMENT, "unknown exchange"};
         if (!shard || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id))
             throw Fail{VS_ERR_INVALID_ARGUMENT, "invalid argument"};
         vs_ranks* r = new vs_ranks();
         r->shard = shard;
         r->rank = rank;
         r->world = world;
+        r->exchange = exchange;
         r->total_rows = total_rows ? total_rows : 1;
         r->per = (r->total_rows + (uint64_t)world - 1) / (uint64_t)world;
         try {
             HIP_OK(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
             HIP_OK(hipMalloc((void**)&r->d_failed, 8));
             HIP_OK(hipMemset(r->d_failed, 0, 8));
-            if (world > 1) {
+            if (world > 1 && exchange == VS_RANKS_HOSTSHM) {
+                r->host.open(id, rank, world);
+            } else if (world > 1) {
                 ncclUniqueId u;
                 std::memcpy(&u, id, sizeof u);
                 NCCL_OK(ncclCommInitRank(&r->comm, world, u, rank));
@@ -179,6 +298,7 @@ void vs_ranks_free(vs_ranks* r) {
         if (s.walked) (void)hipEventDestroy(s.walked);
         if (s.merged) (void)hipEventDestroy(s.merged);
     }
+    r->host.close_segment();
     if (r->d_failed) (void)hipFree(r->d_failed);
     if (r->comm) (void)ncclCommDestroy(r->comm);
     if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
@@ -193,10 +313,13 @@ int vs_ranks_world(const vs_ranks* r, int* rank, int* world, int* comm_ranks) {
         if (comm_ranks) {
             int n = 1;
             if (r->comm) NCCL_OK(ncclCommCount(r->comm, &n));
+            else if (r->host.base) n = (int)r->host.ctl()->attached.load();
             *comm_ranks = n;
         }
     });
 }
+
+int vs_ranks_exchange_kind(const vs_ranks* r) { return r ? r->exchange : -1; }
 
 int vs_ranks_unanswered(vs_ranks* r, uint64_t* queries) {
     return guarded([&] {
@@ -255,6 +378,7 @@ int vs_ranks_wait(vs_ranks* r, int slot, void* stream) {
     return guarded([&] {
         if (!r || slot < 0 || slot > 1) throw Fail{VS_ERR_INVALID_ARGUMENT, "invalid argument"};
         if (r->slot[slot].merged) HIP_OK(hipStreamWaitEvent((hipStream_t)stream, r->slot[slot].merged, 0));
+        if (r->host.failed.load()) throw Fail{VS_ERR_DEVICE, "host exchange: a rank did not arrive in time"};
     });
 }
 

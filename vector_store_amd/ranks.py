@@ -28,6 +28,8 @@ def lib():
         vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
         L.vs_ranks_unique_id.argtypes = [vp]
         L.vs_ranks_create.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.POINTER(vp)]
+        L.vs_ranks_create_ex.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, C.POINTER(vp)]
+        L.vs_ranks_exchange_kind.argtypes = [vp]
         L.vs_ranks_free.argtypes = [vp]
         L.vs_ranks_world.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vs_ranks_unanswered.argtypes = [vp, C.POINTER(u64)]
@@ -78,7 +80,8 @@ class Ranks:
         """rank / world the handle was created with, and the RCCL communicator's own size (ncclCommCount)."""
         r, w, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._check(self.L.vs_ranks_world(self.h, C.byref(r), C.byref(w), C.byref(c)))
-        return {"rank": r.value, "world": w.value, "rccl_ranks": c.value}
+        return {"rank": r.value, "world": w.value, "rccl_ranks": c.value,
+                "exchange": {0: "rccl", 1: "hostshm"}.get(self.L.vs_ranks_exchange_kind(self.h), "?")}
 
     def unanswered(self) -> int:
         v = C.c_uint64(0)

@@ -58,26 +58,35 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 // branch-free: one compare per score against the query's similarity threshold, OR-ed over the tile; only a wave that saw a
 // score at or above a threshold walks its accumulators again and appends (rare).  The B plane is padded to whole tiles.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TN, int BK, int STAGES, int SHAPE, bool WRITE_D>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void tile_ring_kernel(
+// RA / RB: ring depths of the A (queries, from L2) and B (rows, from HBM) stages.  RA != RB: the waves specialise as loaders --
+// waves 0..NW/2-1 issue every A piece, the others every B piece -- because vmcnt is per wave and in order: a wave that loads
+// both would have to wait for its old (slow, HBM) B loads before it could see a young (fast, L2) A stage land.
+// WM: waves along the queries (2: 128 x TN/4 per wave, 8 waves; 4: 64 x TN/4 per wave, 16 waves).  EPI 0: no epilogue (timing aid).
+template <int TN, int BK, int RA, int RB, int SHAPE, int WM, int EPI, bool WRITE_D>
+__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM))) void tile_ring_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint32_t n_rows, const float* __restrict__ sthr,
     const float* __restrict__ row_scale, float* __restrict__ D, uint32_t d_rows, uint2* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
     uint32_t cand_cap) {
     constexpr int TM = 256, CH = BK / 8;             // CH: 16-byte chunks per row per step
-    constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2, ST_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_PW = A_BYTES / 1024 / 8, B_PW = B_BYTES / 1024 / 8;  // 1-KiB pieces (one wave-instruction each) per wave per step
-    constexpr int GL = A_PW + B_PW;                                      // LDS-DMA instructions per wave per step
+    constexpr int NW = 4 * WM;                       // waves per workgroup
+    constexpr bool SPLIT = RA != RB;
+    constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2, RING_BYTES = RA * A_BYTES + RB * B_BYTES;
+    constexpr int A_LW = SPLIT ? NW / 2 : NW, B_LW = SPLIT ? NW / 2 : NW;  // waves that load A / B
+    constexpr int A_PW = A_BYTES / 1024 / A_LW, B_PW = B_BYTES / 1024 / B_LW;  // 1-KiB pieces (one wave-instruction each) per loading wave per step
     constexpr int ROWS_PP = 1024 / (BK * 2);                             // rows per piece
     constexpr int KSTEPS = kK / BK;
     constexpr int WN = TN / 4;                                           // columns (rows of B) per wave
     constexpr int FR = SHAPE == 32 ? 32 : 16;                            // fragment rows
-    constexpr int MT = 128 / FR, NT = WN / FR;
+    constexpr int WROWS = TM / WM;                                       // query rows per wave
+    constexpr int MT = WROWS / FR, NT = WN / FR;
     constexpr int KSUB = SHAPE == 32 ? 16 : 32;                          // k per MFMA
     constexpr int ACC = SHAPE == 32 ? 16 : 4;
     using acc_t = typename std::conditional<SHAPE == 32, f32x16, f32x4>::type;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    float* thr_s = reinterpret_cast<float*>(lds + STAGES * ST_BYTES);
+    float* thr_s = reinterpret_cast<float*>(lds + RING_BYTES);
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+    const bool loads_a = !SPLIT || w < (uint32_t)(NW / 2), loads_b = !SPLIT || w >= (uint32_t)(NW / 2);
+    const uint32_t la = SPLIT ? w : w, lb = SPLIT ? w - NW / 2 : w;  // index among the waves that load A / B
     const uint32_t n_tiles = (n_rows + TN - 1) / TN;
     if (t < TM) thr_s[t] = sthr[t];
 
@@ -85,33 +94,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint32_t a_off[A_PW], b_off[B_PW];
 #pragma unroll
     for (int i = 0; i < A_PW; ++i) {
-        const uint32_t p = w * A_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
+        const uint32_t p = la * A_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
         a_off[i] = row * (kK * 2) + ((slot ^ swz<BK, SHAPE>(row)) % CH) * 16;
     }
 #pragma unroll
     for (int i = 0; i < B_PW; ++i) {
-        const uint32_t p = w * B_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
+        const uint32_t p = lb * B_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
         b_off[i] = row * (kK * 2) + ((slot ^ swz<BK, SHAPE>(row)) % CH) * 16;
     }
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* Bb = reinterpret_cast<const char*>(B);
-    auto stage = [&](uint32_t sg, uint32_t tile, uint32_t ks) {
-        char* base = lds + (sg % STAGES) * ST_BYTES;
-        const char* bt = Bb + (size_t)tile * TN * (kK * 2) + ks * (BK * 2);  // wave-uniform
-        const char* at = Ab + ks * (BK * 2);
+    auto stage_a = [&](uint32_t sg) {
+        char* base = lds + (sg % RA) * A_BYTES;
+        const char* at = Ab + (sg % KSTEPS) * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < A_PW; ++i) glds16(at + a_off[i], base + (w * A_PW + i) * 1024);
+        for (int i = 0; i < A_PW; ++i) glds16(at + a_off[i], base + (la * A_PW + i) * 1024);
+    };
+    auto stage_b = [&](uint32_t sg, uint32_t tile) {
+        char* base = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
+        const char* bt = Bb + (size_t)tile * TN * (kK * 2) + (sg % KSTEPS) * (BK * 2);  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < B_PW; ++i) glds16(bt + b_off[i], base + A_BYTES + (w * B_PW + i) * 1024);
+        for (int i = 0; i < B_PW; ++i) glds16(bt + b_off[i], base + (lb * B_PW + i) * 1024);
     };
 
     uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
     const uint32_t total = my_tiles * KSTEPS;
     if (!total) return;
     auto tile_of = [&](uint32_t sg) { return blockIdx.x + (sg / KSTEPS) * gridDim.x; };
+    if (loads_a) {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if ((uint32_t)s < total) stage(s, tile_of(s), s % KSTEPS);
+        for (int s = 0; s < RA - 1; ++s)
+            if ((uint32_t)s < total) stage_a(s);
+    }
+    if (loads_b) {
+#pragma unroll
+        for (int s = 0; s < RB - 1; ++s)
+            if ((uint32_t)s < total) stage_b(s, tile_of(s));
+    }
 
     // LDS byte offsets of this lane's fragment rows (chunk 0 position; the k sub-step XORs the chunk index in)
     const uint32_t frow = lane & (FR - 1), fk = lane / FR;  // fragment row, 8-element k chunk within the MFMA's k
@@ -125,27 +144,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < ACC; ++r) acc[i][j][r] = 0.f;
         for (uint32_t ks = 0; ks < (uint32_t)KSTEPS; ++ks, ++sg) {
-            // stage sg has landed once at most STAGES - 2 younger stages are in flight (the very last steps drain everything)
-            if (sg + STAGES - 2 < total) wait_vm<(STAGES - 2) * GL>();
-            else wait_vm<0>();
+            // stage sg has landed once at most (ring - 2) younger stages of this wave are in flight (the very last steps drain everything)
+            if constexpr (!SPLIT) {
+                if (sg + RA - 2 < total) wait_vm<(RA - 2) * (A_PW + B_PW)>();
+                else wait_vm<0>();
+            } else if (loads_a) {
+                if (sg + RA - 2 < total) wait_vm<(RA - 2) * A_PW>();
+                else wait_vm<0>();
+            } else {
+                if (sg + RB - 2 < total) wait_vm<(RB - 2) * B_PW>();
+                else wait_vm<0>();
+            }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();  // everyone's pieces of stage sg are in LDS; everyone has finished reading stage sg - 1
             asm volatile("" ::: "memory");
-            if (sg + STAGES - 1 < total) stage(sg + STAGES - 1, tile_of(sg + STAGES - 1), (sg + STAGES - 1) % KSTEPS);
-            const char* base = lds + (sg % STAGES) * ST_BYTES;
+            if (loads_a && sg + RA - 1 < total) stage_a(sg + RA - 1);
+            if (loads_b && sg + RB - 1 < total) stage_b(sg + RB - 1, tile_of(sg + RB - 1));
+            const char* base = lds + (sg % RA) * A_BYTES;
+            const char* bbase = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
 #pragma unroll
             for (int kk = 0; kk < BK / KSUB; ++kk) {
                 bf16x8 fa[MT], fb[NT];
                 const uint32_t kc = kk * (KSUB / 8) + fk;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const uint32_t row = wm * 128 + i * FR + frow;
+                    const uint32_t row = wm * WROWS + i * FR + frow;
                     fa[i] = *reinterpret_cast<const bf16x8*>(base + row * (BK * 2) + ((kc ^ swz<BK, SHAPE>(row)) % CH) * 16);
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const uint32_t row = wn * WN + j * FR + frow;
-                    fb[j] = *reinterpret_cast<const bf16x8*>(base + A_BYTES + row * (BK * 2) + ((kc ^ swz<BK, SHAPE>(row)) % CH) * 16);
+                    fb[j] = *reinterpret_cast<const bf16x8*>(bbase + row * (BK * 2) + ((kc ^ swz<BK, SHAPE>(row)) % CH) * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -156,6 +185,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 if constexpr (BK / KSUB > 2) __builtin_amdgcn_sched_barrier(0);  // keeps the fragment registers of one sub-step live at a time
             }
+        }
+        if constexpr (EPI == 0) {  // timing aid: the K loop alone (the accumulators stay live)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+            continue;
         }
         // ---- epilogue: C/D layout -- column (row of B) on the lane, query rows in the registers
         float rs[NT];
@@ -168,7 +204,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float4 th[ACC / 4];
 #pragma unroll
             for (int r4 = 0; r4 < ACC / 4; ++r4)  // 32x32: q = 8 * r4 + 4 * (lane >> 5) + (r & 3); 16x16: q = 4 * (lane >> 4) + r
-                th[r4] = *reinterpret_cast<const float4*>(&thr_s[wm * 128 + i * FR + (SHAPE == 32 ? 8 * r4 + 4 * fk : 4 * fk)]);
+                th[r4] = *reinterpret_cast<const float4*>(&thr_s[wm * WROWS + i * FR + (SHAPE == 32 ? 8 * r4 + 4 * fk : 4 * fk)]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 float m = -__builtin_inff();
@@ -190,7 +226,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     // the tile's accumulators go through this wave's LDS scratch, so that the walk over them needs no runtime
                     // register index (which would put ALL accumulators in scratch memory on every tile)
                     constexpr int HALF = ACC > 8 ? 8 : ACC;  // registers per pass through the scratch (2 KiB per wave at most)
-                    float* sc = reinterpret_cast<float*>(lds + STAGES * ST_BYTES + 1024) + w * (HALF * 64);
+                    float* sc = reinterpret_cast<float*>(lds + RING_BYTES + 1024) + w * (HALF * 64);
                     const uint32_t n = tile * TN + wn * WN + j * FR + frow;
 #pragma unroll
                     for (int h = 0; h < ACC / HALF; ++h) {
@@ -199,7 +235,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
                         for (int rr = 0; rr < HALF; ++rr) {
                             const int r = h * HALF + rr;
-                            const uint32_t q = wm * 128 + i * FR + (SHAPE == 32 ? (r & 3) + 8 * (r >> 2) + 4 * fk : 4 * fk + r);
+                            const uint32_t q = wm * WROWS + i * FR + (SHAPE == 32 ? (r & 3) + 8 * (r >> 2) + 4 * fk : 4 * fk + r);
                             const float v = sc[rr * 64 + lane];
                             if (v >= thr_s[q] && n < n_rows) {
                                 const uint32_t at = atomicAdd(&cand_cnt[q], 1u);
@@ -217,7 +253,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const uint32_t n = tile * TN + wn * WN + j * FR + frow;
 #pragma unroll
                     for (int r = 0; r < ACC; ++r) {
-                        const uint32_t q = wm * 128 + i * FR + (SHAPE == 32 ? (r & 3) + 8 * (r >> 2) + 4 * fk : 4 * fk + r);
+                        const uint32_t q = wm * WROWS + i * FR + (SHAPE == 32 ? (r & 3) + 8 * (r >> 2) + 4 * fk : 4 * fk + r);
                         if (n < d_rows) D[(size_t)q * d_rows + n] = 1.0f - acc[i][j][r] * rs[j];
                     }
                 }
@@ -248,24 +284,28 @@ struct Ctx {
     int cus;
 };
 
-template <int TN, int BK, int STAGES, int SHAPE>
+template <int TN, int BK, int RA, int RB, int SHAPE, int WM = 2, int EPI = 1>
 static void run_variant(Ctx& c, const char* name) {
-    auto kernel = tile_ring_kernel<TN, BK, STAGES, SHAPE, false>;
-    auto kernel_d = tile_ring_kernel<TN, BK, STAGES, SHAPE, true>;
-    const size_t lds = (size_t)STAGES * (256 + TN) * BK * 2 + 1024 + 8 * (SHAPE == 32 ? 8 : 4) * 64 * 4;
+    auto kernel = tile_ring_kernel<TN, BK, RA, RB, SHAPE, WM, EPI, false>;
+    auto kernel_d = tile_ring_kernel<TN, BK, RA, RB, SHAPE, WM, 1, true>;
+    const size_t lds = (size_t)(RA * 256 + RB * TN) * BK * 2 + 1024 + 4 * WM * (SHAPE == 32 ? 8 : 4) * 64 * 4;
+    if (lds > 163840) {
+        printf("%-34s needs %zu B of LDS: skipped\n", name, lds);
+        return;
+    }
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipFuncAttributes fa{};
     HIP_OK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)));
     int per_cu = 0;
-    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, lds));
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256 * WM, lds));
     // validation: D for the first d_rows rows, thr = +inf for query 0..255 -> every score also appended (count check)
     std::vector<float> thr(256, INFINITY);  // similarity thresholds: +inf = nothing is appended
     thr[5] = 0.12f;                         // one query with a reachable threshold: its appended count is checked below
     HIP_OK(hipMemcpy(c.dThr, thr.data(), 1024, hipMemcpyHostToDevice));
     HIP_OK(hipMemset(c.dCnt, 0, 1024));
     HIP_OK(hipMemset(c.dD, 0xFF, (size_t)256 * c.d_rows * 4));
-    hipLaunchKernelGGL(kernel_d, dim3(3), dim3(512), lds, 0, c.dA, c.dB, c.d_rows, c.dThr, (const float*)nullptr, c.dD, c.d_rows, c.dCand, c.dCnt, 4096u);
+    hipLaunchKernelGGL(kernel_d, dim3(3), dim3(256 * WM), lds, 0, c.dA, c.dB, c.d_rows, c.dThr, (const float*)nullptr, c.dD, c.d_rows, c.dCand, c.dCnt, 4096u);
     HIP_OK(hipDeviceSynchronize());
     uint32_t cnt5 = 0;
     HIP_OK(hipMemcpy(&cnt5, c.dCnt + 5, 4, hipMemcpyDeviceToHost));
@@ -292,10 +332,10 @@ static void run_variant(Ctx& c, const char* name) {
     HIP_OK(hipEventCreate(&e0));
     HIP_OK(hipEventCreate(&e1));
     float best = 1e30f, sum = 0;
-    const int reps = 6;
+    const int reps = 10;
     for (int r = 0; r < reps + 1; ++r) {
         HIP_OK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, 0, c.dA, c.dB, c.rows, c.dThr, (const float*)nullptr, (float*)nullptr, 0u, c.dCand, c.dCnt, 4096u);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256 * WM), lds, 0, c.dA, c.dB, c.rows, c.dThr, (const float*)nullptr, (float*)nullptr, 0u, c.dCand, c.dCnt, 4096u);
         HIP_OK(hipEventRecord(e1, 0));
         HIP_OK(hipEventSynchronize(e1));
         float ms;
@@ -306,7 +346,7 @@ static void run_variant(Ctx& c, const char* name) {
         }
     }
     const double flops = 2.0 * 256 * (double)c.rows * kK, bytes = (double)c.rows * kK * 2;
-    printf("%-28s regs %3d scratch %3zu lds %6zu wg/cu %d | check worst %.2e bad %zu | %.3f ms (best %.3f) = %.0f TFLOP/s, %.2f TB/s of B | 10M rows: %.2f ms\n", name,
+    printf("%-34s regs %3d scratch %3zu lds %6zu wg/cu %d | check worst %.2e bad %zu | %.3f ms (best %.3f) = %.0f TFLOP/s, %.2f TB/s of B | 10M rows: %.2f ms\n", name,
            fa.numRegs, fa.localSizeBytes, lds, per_cu, worst, bad, sum / reps, best, flops / (sum / reps * 1e-3) / 1e12,
            bytes / (sum / reps * 1e-3) / 1e12, sum / reps * 1e7 / c.rows);
     fflush(stdout);
@@ -345,14 +385,15 @@ int main(int argc, char** argv) {
         }
         HIP_OK(hipMemcpy(c.dB, c.hB.data(), small * 2, hipMemcpyHostToDevice));
     }
-    run_variant<256, 32, 4, 32>(c, "TN256 BK32 ring4 32x32x16");
-    run_variant<256, 32, 4, 16>(c, "TN256 BK32 ring4 16x16x32");
-    run_variant<256, 64, 2, 32>(c, "TN256 BK64 ring2 32x32x16");
-    run_variant<256, 64, 2, 16>(c, "TN256 BK64 ring2 16x16x32");
-    run_variant<256, 32, 3, 32>(c, "TN256 BK32 ring3 32x32x16");
-    run_variant<128, 32, 3, 32>(c, "TN128 BK32 ring3 32x32x16");
-    run_variant<128, 32, 3, 16>(c, "TN128 BK32 ring3 16x16x32");
-    run_variant<128, 64, 2, 32>(c, "TN128 BK64 ring2 32x32x16");
-    run_variant<128, 64, 3, 32>(c, "TN128 BK64 ring3 32x32x16");
+    run_variant<256, 64, 2, 2, 16>(c, "TN256 BK64 A2 B2 16x16 (ref)");
+    run_variant<256, 64, 2, 2, 16, 2, 0>(c, "TN256 BK64 A2 B2 16x16 no-epilogue");
+    run_variant<256, 32, 3, 5, 16>(c, "TN256 BK32 A3 B5 16x16 split");
+    run_variant<256, 32, 3, 6, 16>(c, "TN256 BK32 A3 B6 16x16 split");
+    run_variant<256, 32, 2, 6, 16>(c, "TN256 BK32 A2 B6 16x16 split");
+    run_variant<256, 32, 4, 4, 16>(c, "TN256 BK32 A4 B4 16x16");
+    run_variant<256, 64, 2, 3, 16>(c, "TN256 BK64 A2 B3 16x16 split");
+    run_variant<256, 64, 2, 2, 16, 4>(c, "TN256 BK64 A2 B2 16x16 16 waves");
+    run_variant<256, 32, 3, 5, 16, 4>(c, "TN256 BK32 A3 B5 16x16 split 16w");
+    run_variant<256, 32, 3, 6, 32>(c, "TN256 BK32 A3 B6 32x32 split");
     return 0;
 }

@@ -486,7 +486,7 @@ struct Engine {
         M0 = 2 * M;
         ef_add = o.expansion_add ? (uint32_t)o.expansion_add : 128;
         ef_search = o.expansion_search ? (uint32_t)o.expansion_search : 64;
-        if (ef_add > 256) fail(VS_ERR_UNSUPPORTED, "expansion_add > 256 is not supported");
+        if (ef_add > 512) fail(VS_ERR_UNSUPPORTED, "expansion_add > 512 is not supported");
         inv_log_m = 1.0 / std::log((double)M);
         // Row layout: 16-byte chunks, lanes x iters of them.  Least padding first.  Among equals: the FEWEST lanes
         // that still read >= 128 contiguous bytes of a row per load instruction (lanes >= 8) with iters <= 6 --
@@ -497,7 +497,7 @@ struct Engine {
         static const uint32_t bits[] = {32, 16, 16, 8, 1};
         row_bytes = (uint32_t)(((uint64_t)dim * bits[scalar] + 7) / 8);
         const uint32_t chunks = (row_bytes + 15) / 16;
-        static const uint32_t ok_iters[] = {1, 2, 3, 4, 6, 8};
+        static const uint32_t ok_iters[] = {1, 2, 3, 4, 6, 8, 12, 16};
         uint32_t best = 0;
         bool best_pref = false;
         iters = 0;
@@ -526,7 +526,7 @@ struct Engine {
                     iters = it;
                 }
             }
-        if (!iters) fail(VS_ERR_UNSUPPORTED, "vectors above 8 KiB per row are not supported");
+        if (!iters) fail(VS_ERR_UNSUPPORTED, "vectors above 16 KiB per row are not supported");
         stride4 = iters * lanes;
         // link kernel: ~18 KiB of accepted rows per wave in LDS (7 waves per CU; measured at 2M x 768: 3 / 4 / 6 / 8 / 11 rows ->
         // link kernel 0.79 / 0.73 / 0.62 / 0.64 / 0.79 s, 0.98 s without), at most the M0 a list can hold

@@ -392,7 +392,8 @@ __device__ __forceinline__ void group_reduce(const IndexView& ix, const RowGroup
 template <int AR, int I, int TEAM = 1, bool NT = false>
 __device__ __forceinline__ void eval_batch(const IndexView& ix, const Query<AR, I>& q, const uint32_t* u_slot,
                                            float* u_dist, uint32_t m, int lane, uint32_t w = 0) {
-    constexpr int U = (I >= 6 || (AR == AR_I8 && I >= 3)) ? 2 : 4;  // more loads per group at I <= 2 measured no gain
+    constexpr int U = I >= 12 ? 1 : (I >= 6 || (AR == AR_I8 && I >= 3)) ? 2 : 4;  // more loads per group at I <= 2 measured no gain; rows of
+                                                                                  // 12 / 16 KiB (I = 12 / 16): one wave-load group of 12-16 KiB in flight per buffer
     const uint32_t lg = ix.lanes_log2;
     const uint32_t vshift = 6u - lg;  // V = 64 >> lg vectors per wave-load
     const uint32_t grp = (uint32_t)lane >> lg, li = (uint32_t)lane & (ix.lanes - 1);

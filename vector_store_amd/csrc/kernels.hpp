@@ -108,7 +108,7 @@ template <int AR> hipError_t launch_insert_ar(const InsertArgs& a, uint32_t iter
 template <int AR> hipError_t launch_link_ar(const LinkArgs& a, uint32_t iters, hipStream_t s);
 int arith_of(int scalar, int metric);
 
-// iters = stride4 / lanes must be one of {1,2,3,4,6,8}; search ef <= 512, insert ef_add <= 256.
+// iters = stride4 / lanes must be one of {1,2,3,4,6,8,12,16}; search ef <= 512, insert ef_add <= 512.
 bool search_supported(uint32_t iters, uint32_t ef);
 hipError_t launch_search(const SearchArgs& a, uint32_t iters, hipStream_t s);
 hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s);

@@ -347,9 +347,25 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
 }
 
 
+// Rows of 12 / 16 KiB (I = 12 / 16: 3072-d / 4096-d f32) get a reduced set of instances -- one wave per query, rows always
+// loaded non-temporally (a table of such rows is far beyond the caches long before it matters), no team forms --, which
+// keeps the build time of the eight arithmetics in check; same code, same results.
 template <int AR, int I>
 static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
     dim3 grid(a.nq), block(64);
+    if constexpr (I >= 12) {
+        if (a.wide_tags) {
+            if (a.ef <= 256) hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, 1, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 512, 2048, 2, 1, true, true>), grid, block, 0, s, a);
+        } else if (a.ef <= 128) {
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, 1, true>), grid, block, 0, s, a);
+        } else if (a.ef <= 256) {
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, 1, true>), grid, block, 0, s, a);
+        } else {
+            hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 512, 2048, 2, 1, true>), grid, block, 0, s, a);
+        }
+        return hipGetLastError();
+    }
     if (a.wide_tags) {  // huge index: always far beyond the caches (non-temporal rows), one wave per query
         if (a.ef <= 128)
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, 1, true, true>), grid, block, 0, s, a);
@@ -398,6 +414,15 @@ static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
 template <int AR, int I>
 static hipError_t insert_ef(const InsertArgs& a, hipStream_t s) {
     dim3 grid(a.n), block(64);
+    if (a.ef_add > 256) {  // construction beams of 257..512: ONE instance (512-entry list, wide two-choice tags, non-temporal rows)
+        hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 512, 2048, 2, 1, true, true>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    if constexpr (I >= 12) {
+        if (a.wide_tags || a.ef_add > 128) hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 256, 1024, 2, 1, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 128, 1024, 1, 1, true>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if (a.wide_tags) {
         if (a.ef_add <= 128)
             hipLaunchKernelGGL((hnsw_insert_kernel<AR, I, 128, 1024, 1, 1, true, true>), grid, block, 0, s, a);
@@ -434,6 +459,8 @@ hipError_t launch_search_ar<VS_AR>(const SearchArgs& a, uint32_t iters, hipStrea
         case 4: return search_ef<VS_AR, 4>(a, s);
         case 6: return search_ef<VS_AR, 6>(a, s);
         case 8: return search_ef<VS_AR, 8>(a, s);
+        case 12: return search_ef<VS_AR, 12>(a, s);
+        case 16: return search_ef<VS_AR, 16>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -447,6 +474,8 @@ hipError_t launch_insert_ar<VS_AR>(const InsertArgs& a, uint32_t iters, hipStrea
         case 4: return insert_ef<VS_AR, 4>(a, s);
         case 6: return insert_ef<VS_AR, 6>(a, s);
         case 8: return insert_ef<VS_AR, 8>(a, s);
+        case 12: return insert_ef<VS_AR, 12>(a, s);
+        case 16: return insert_ef<VS_AR, 16>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -462,6 +491,8 @@ hipError_t launch_link_ar<VS_AR>(const LinkArgs& a, uint32_t iters, hipStream_t 
         case 4: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 4>), grid, block, dyn, s, a); break;
         case 6: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 6>), grid, block, dyn, s, a); break;
         case 8: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 8>), grid, block, dyn, s, a); break;
+        case 12: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 12>), grid, block, dyn, s, a); break;
+        case 16: hipLaunchKernelGGL((hnsw_link_kernel<VS_AR, 16>), grid, block, dyn, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -19,7 +19,7 @@ int arith_of(int scalar, int metric) {
 }
 
 bool search_supported(uint32_t iters, uint32_t ef) {
-    return (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8) && ef >= 1 && ef <= 512;
+    return (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8 || iters == 12 || iters == 16) && ef >= 1 && ef <= 512;
 }
 
 uint32_t walk_small_table_bits() { return VisitedCfg<512, 2>::domain_bits; }
@@ -38,6 +38,7 @@ uint32_t walk_instance_domain_bits(uint32_t instance) {
 }
 
 uint32_t visited_domain_bits(uint32_t ef, bool wide) {
+    // (the insert kernel's instance for expansion_add of 257..512 always carries the wide tags: engine.hip passes wide = true there)
     if (wide) return ef <= 128 ? VisitedCfg<1024, 1, true>::domain_bits : ef <= 256 ? VisitedCfg<1024, 2, true>::domain_bits : VisitedCfg<2048, 2, true>::domain_bits;
     return ef <= 128 ? VisitedCfg<1024, 1>::domain_bits : ef <= 256 ? VisitedCfg<1024, 2>::domain_bits : VisitedCfg<2048, 2>::domain_bits;
 }
@@ -68,7 +69,7 @@ hipError_t launch_walk(const WalkArgs& a, uint32_t iters, uint32_t instance, uin
 
 hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    if (!search_supported(iters, a.ef_add) || a.ef_add > 256) return hipErrorInvalidValue;
+    if (!search_supported(iters, a.ef_add)) return hipErrorInvalidValue;
     VS_DISPATCH(launch_insert_ar, (a, iters, s))
 }
 

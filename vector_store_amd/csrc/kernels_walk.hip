@@ -214,6 +214,20 @@ constexpr int kWalkHeapLds = VS_WALK_LCAP;  // entries of `next` in LDS (LDS ins
 
 template <int AR, int I>
 static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out) {
+    if constexpr (I >= 12) {  // rows of 12 / 16 KiB: a reduced set of instances (build time), each request served by the next larger one
+        switch (instance & ~kWalkTeamFlag) {
+            case WALK_LDS_128:
+            case WALK_LDS_128_SMALL:
+            case WALK_LDS_128_TINY: return walk_launch<AR, I, 128, kWalkHeapLds, 1024, 1, false>(a, grid_cap, s, grid_out);
+            case WALK_LDS_256:
+            case WALK_LDS_320:
+            case WALK_LDS_512: return walk_launch<AR, I, 512, 1690, 2048, 2, false>(a, grid_cap, s, grid_out);
+            case WALK_GLOBAL_512: return walk_launch<AR, I, 512, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
+            case WALK_GLOBAL_2048: return walk_launch<AR, I, 2048, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
+            case WALK_GLOBAL_10240: return walk_launch<AR, I, 10240, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (instance) {
         // `next` in LDS: 4 x the beam (largest heap seen at 1M x 768: 469 / 792 at beams of 128 / 256); beyond -> retry instance
         case WALK_LDS_128: return walk_launch<AR, I, 128, kWalkHeapLds, 1024, 1, false>(a, grid_cap, s, grid_out);
@@ -250,6 +264,8 @@ hipError_t launch_walk_ar<VS_AR>(const WalkArgs& a, uint32_t iters, uint32_t ins
         case 4: return walk_ef<VS_AR, 4>(a, instance, grid_cap, s, grid_out);
         case 6: return walk_ef<VS_AR, 6>(a, instance, grid_cap, s, grid_out);
         case 8: return walk_ef<VS_AR, 8>(a, instance, grid_cap, s, grid_out);
+        case 12: return walk_ef<VS_AR, 12>(a, instance, grid_cap, s, grid_out);
+        case 16: return walk_ef<VS_AR, 16>(a, instance, grid_cap, s, grid_out);
         default: return hipErrorInvalidValue;
     }
 }

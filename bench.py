@@ -325,14 +325,20 @@ def config_c5(vs, dev, n, dim, k, dist_kind, rank):
     walk_ms, _ = timed_steps(walk, lambda: None, batches)
     rec = recall_at_k(tk.cpu().numpy(), wk.cpu().numpy())
     flops = 2.0 * nq * n * dim
-    issued = 3.0 * flops / (exact_ms * 1e-3) / 1e12
+    # which nomination pass served: the one-product pass over the bf16 plane (1 MFMA product per score, 2 bytes per element
+    # streamed) or, when it handed batches on, the split-bf16 pass (3 products, the f32 rows)
+    plane = x1.get("plane_batches", 0) - x0.get("plane_batches", 0) > 0 and x1.get("plane_fallbacks", 0) == x0.get("plane_fallbacks", 0)
+    products, row_bytes = (1.0, 2.0 * ((dim + 63) // 64 * 64)) if plane else (3.0, 4.0 * dim)
+    issued = products * flops / (exact_ms * 1e-3) / 1e12
     out = {"config": "configs[4]", "workload": f"{n}x{dim} ip (unit vectors), batches of {nq} queries, top-{k}", "distribution": dist_kind + (str(rank) if dist_kind == "lowrank" else ""),
            "ms_per_batch": exact_ms, "queries_per_s": nq / exact_ms * 1e3, "batches_timed": batches,
+           "plane_batches": x1.get("plane_batches", 0) - x0.get("plane_batches", 0), "plane_fallback_batches": x1.get("plane_fallbacks", 0) - x0.get("plane_fallbacks", 0),
            "block_search_batches": x1["block_batches"] - x0["block_batches"], "f32_fallback_batches": x1["block_fallbacks"] - x0["block_fallbacks"],
            "roofline": {"bound": "mfma", "achieved": issued, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / BF16_PEAK_TFLOPS, "traffic": None,
-                        "kernel": "block_dist_bf16x3_kernel (+ selection, f32 re-score, certificate: the whole batch is timed)",
-                        "f32_equivalent_tflops": flops / (exact_ms * 1e-3) / 1e12,
-                        "hbm_floor": {"bytes_per_batch": float(n) * dim * 4, "achieved_gbs": float(n) * dim * 4 / (exact_ms * 1e-3) / 1e9, "frac_of_8tbs": float(n) * dim * 4 / (exact_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                        "kernel": ("p1_tile_kernel (one bf16 product per score over the bf16 plane)" if plane else "block_dist_bf16x3_kernel (three split-bf16 products)") +
+                                  " + selection, f32 re-score, certificate: the whole batch is timed",
+                        "mfma_products_per_score": products, "f32_equivalent_tflops": flops / (exact_ms * 1e-3) / 1e12,
+                        "hbm_floor": {"bytes_per_batch": float(n) * row_bytes, "achieved_gbs": float(n) * row_bytes / (exact_ms * 1e-3) / 1e9, "frac_of_8tbs": float(n) * row_bytes / (exact_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
            "hnsw_walk_ef200": {"ms_per_batch": walk_ms, "queries_per_s": nq / walk_ms * 1e3, "recall_at_10_vs_exact": round(rec, 4)},
            "build_vectors_per_s": n / build_s, "seconds": round(time.perf_counter() - t0, 1)}
     del ix, q

@@ -35,6 +35,13 @@ typedef struct vs_callers_result {
 VS_API int vs_callers_run(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, const uint64_t* truth,
                           unsigned threads, unsigned inflight, double seconds, vs_callers_result* out);
 
+/* The same loop over vs_hnsw_filtered_search: the reference runs every filtered query on a blocking thread (spawn_blocking,
+ * usearch.rs:937-948) with a predicate that takes a table read-lock per call (usearch.rs:1118-1124).  Predicate here:
+ * key % modulus == 0 (selectivity 1 / modulus), counted.  extra: [0] predicate calls, [1] results returned, [2..3] 0.
+ * `errors` also counts results the predicate rejects (must stay 0). */
+VS_API int vs_callers_run_filtered(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus,
+                                   unsigned threads, double seconds, vs_callers_result* out, uint64_t extra[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,9 @@ VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
  * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's
  * certificate failed. */
 VS_API int vs_hnsw_exact_stats(vs_hnsw* index, uint64_t out[2]);
+/* Round 3: the first stage of the exact search is a ONE-product bf16 pass over a bf16 plane of the rows (built lazily, +2 bytes per
+ * element of HBM): [0] batches that took it, [1] of them handed on to the split-bf16 pass (uncertified), [2] / [3] as exact_stats. */
+VS_API int vs_hnsw_exact_stats2(vs_hnsw* index, uint64_t out[4]);
 
 /* -- graph export / import (flat layout; see oracle/cpu_hnsw.cpp orc_export_graph) ------- */
 typedef struct vs_hnsw_graph_info {

@@ -39,8 +39,9 @@ __device__ __forceinline__ uint32_t swz(uint32_t row) {
 }
 
 // 16 bytes global -> LDS, asynchronously (LDS-DMA): destination = wave-uniform base + lane * 16
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* g, void* lds_base_uniform) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_void*)lds_base_uniform, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_void*)lds_base_uniform, 16, 0, AUX);
 }
 
 template <int N>
@@ -61,7 +62,10 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 // RA / RB: ring depths of the A (queries, from L2) and B (rows, from HBM) stages.  RA != RB: the waves specialise as loaders --
 // waves 0..NW/2-1 issue every A piece, the others every B piece -- because vmcnt is per wave and in order: a wave that loads
 // both would have to wait for its old (slow, HBM) B loads before it could see a young (fast, L2) A stage land.
-// WM: waves along the queries (2: 128 x TN/4 per wave, 8 waves; 4: 64 x TN/4 per wave, 16 waves).  EPI 0: no epilogue (timing aid).
+// WM: waves along the queries (2: 128 x TN/4 per wave, 8 waves; 4: 64 x TN/4 per wave, 16 waves).
+// EPI: bit 0 epilogue on (off: timing aid), bit 1 B loads non-temporal, bit 2 no B loads (A path alone), bit 3 no A loads (B path alone),
+// bit 4: B (and A) stored TILE-MAJOR in LDS image order -- a stage is ONE contiguous block of memory (timing only: the probe's
+// data is random, so the values are not re-laid out and the check is skipped).
 template <int TN, int BK, int RA, int RB, int SHAPE, int WM, int EPI, bool WRITE_D>
 __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM))) void tile_ring_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint32_t n_rows, const float* __restrict__ sthr,
@@ -95,26 +99,29 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
 #pragma unroll
     for (int i = 0; i < A_PW; ++i) {
         const uint32_t p = la * A_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
-        a_off[i] = row * (kK * 2) + ((slot ^ swz<BK, SHAPE>(row)) % CH) * 16;
+        a_off[i] = (EPI & 16) ? p * 1024 + lane * 16 : row * (kK * 2) + ((slot ^ swz<BK, SHAPE>(row)) % CH) * 16;
     }
 #pragma unroll
     for (int i = 0; i < B_PW; ++i) {
         const uint32_t p = lb * B_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
-        b_off[i] = row * (kK * 2) + ((slot ^ swz<BK, SHAPE>(row)) % CH) * 16;
+        b_off[i] = (EPI & 16) ? p * 1024 + lane * 16 : row * (kK * 2) + ((slot ^ swz<BK, SHAPE>(row)) % CH) * 16;
     }
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* Bb = reinterpret_cast<const char*>(B);
     auto stage_a = [&](uint32_t sg) {
         char* base = lds + (sg % RA) * A_BYTES;
-        const char* at = Ab + (sg % KSTEPS) * (BK * 2);
+        const char* at = Ab + ((EPI & 16) ? (size_t)(sg % KSTEPS) * A_BYTES : (size_t)(sg % KSTEPS) * (BK * 2));
 #pragma unroll
-        for (int i = 0; i < A_PW; ++i) glds16(at + a_off[i], base + (la * A_PW + i) * 1024);
+        for (int i = 0; i < A_PW; ++i)
+            if constexpr (!(EPI & 8)) glds16(at + a_off[i], base + (la * A_PW + i) * 1024);
     };
     auto stage_b = [&](uint32_t sg, uint32_t tile) {
         char* base = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
-        const char* bt = Bb + (size_t)tile * TN * (kK * 2) + (sg % KSTEPS) * (BK * 2);  // wave-uniform
+        const char* bt = (EPI & 16) ? Bb + ((size_t)tile * KSTEPS + (sg % KSTEPS)) * B_BYTES
+                                    : Bb + (size_t)tile * TN * (kK * 2) + (sg % KSTEPS) * (BK * 2);  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < B_PW; ++i) glds16(bt + b_off[i], base + (lb * B_PW + i) * 1024);
+        for (int i = 0; i < B_PW; ++i)
+            if constexpr (!(EPI & 4)) glds16<(EPI & 2) ? 2 : 0>(bt + b_off[i], base + (lb * B_PW + i) * 1024);
     };
 
     uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
                 if constexpr (BK / KSUB > 2) __builtin_amdgcn_sched_barrier(0);  // keeps the fragment registers of one sub-step live at a time
             }
         }
-        if constexpr (EPI == 0) {  // timing aid: the K loop alone (the accumulators stay live)
+        if constexpr ((EPI & 1) == 0) {  // timing aid: the K loop alone (the accumulators stay live)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -386,14 +393,16 @@ int main(int argc, char** argv) {
         HIP_OK(hipMemcpy(c.dB, c.hB.data(), small * 2, hipMemcpyHostToDevice));
     }
     run_variant<256, 64, 2, 2, 16>(c, "TN256 BK64 A2 B2 16x16 (ref)");
-    run_variant<256, 64, 2, 2, 16, 2, 0>(c, "TN256 BK64 A2 B2 16x16 no-epilogue");
-    run_variant<256, 32, 3, 5, 16>(c, "TN256 BK32 A3 B5 16x16 split");
-    run_variant<256, 32, 3, 6, 16>(c, "TN256 BK32 A3 B6 16x16 split");
-    run_variant<256, 32, 2, 6, 16>(c, "TN256 BK32 A2 B6 16x16 split");
-    run_variant<256, 32, 4, 4, 16>(c, "TN256 BK32 A4 B4 16x16");
-    run_variant<256, 64, 2, 3, 16>(c, "TN256 BK64 A2 B3 16x16 split");
-    run_variant<256, 64, 2, 2, 16, 4>(c, "TN256 BK64 A2 B2 16x16 16 waves");
-    run_variant<256, 32, 3, 5, 16, 4>(c, "TN256 BK32 A3 B5 16x16 split 16w");
-    run_variant<256, 32, 3, 6, 32>(c, "TN256 BK32 A3 B6 32x32 split");
+    run_variant<256, 64, 2, 2, 16, 2, 3>(c, "ref + B nt");
+    run_variant<256, 64, 2, 2, 16, 2, 17>(c, "tile-major");
+    run_variant<256, 64, 2, 2, 16, 2, 19>(c, "tile-major + B nt");
+    run_variant<256, 64, 2, 2, 16, 2, 25>(c, "tile-major, B loads only");
+    run_variant<256, 64, 2, 2, 16, 2, 27>(c, "tile-major, B loads only, nt");
+    run_variant<256, 32, 4, 4, 16, 2, 19>(c, "tile-major BK32 A4 B4 + B nt");
+    run_variant<256, 32, 3, 6, 16, 2, 19>(c, "tile-major BK32 A3 B6 split + B nt");
+    run_variant<256, 64, 2, 2, 16, 4, 19>(c, "tile-major 16 waves + B nt");
+    run_variant<256, 64, 2, 2, 16, 2, 18>(c, "tile-major + B nt, no epilogue");
+    run_variant<256, 64, 2, 2, 16, 2, 13>(c, "no loads at all");
+    run_variant<256, 64, 2, 2, 16, 2, 12>(c, "no loads at all, no epilogue");
     return 0;
 }

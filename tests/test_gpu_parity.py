@@ -828,13 +828,17 @@ def test_heavily_duplicated_data_builds_as_well_as_the_cpu_algorithm():
     assert gpu >= cpu - 0.03 and gpu >= 0.6, (gpu, cpu)
 
 
+@pytest.mark.parametrize("path", ["plane", "bf16x3"])
 @pytest.mark.parametrize("metric,quant", [("cos", "f32"), ("ip", "f32"), ("cos", "f16")])
-def test_exact_search_split_bf16_nomination_is_certified_or_falls_back(metric, quant):
-    """Exact search on large float indexes nominates with split-bf16 MFMA tiles (three bf16 products per f32 product), re-scores
-    the nominees in f32 and certifies the answer; a query whose certificate fails (a crowd of equal scores at the cut) sends
-    the batch to the f32-input MFMA path.  Same ids as that path either way; both cases are provoked."""
+def test_exact_search_split_bf16_nomination_is_certified_or_falls_back(metric, quant, path):
+    """Exact search on large float indexes nominates with bf16 MFMA tiles -- round 3: ONE product per score over a bf16 plane of
+    the rows ("plane", the default); round 2: three products of split-bf16 pairs (VS_HNSW_EXACT=bf16x3) --, re-scores the
+    nominees in f32 and certifies the answer; a query whose certificate fails (a crowd of equal scores at the cut) sends the
+    batch on: plane -> split bf16 -> f32-input MFMA path.  Same ids as the f32 path either way; every case is provoked."""
     import os
     v = vs()
+    fast_env = None if path == "plane" else "bf16x3"
+    batches, fallbacks = ("plane_batches", "plane_fallbacks") if path == "plane" else ("block_batches", "block_fallbacks")
     n, dim, k = 80000, 96, 10
     data = _dataset(n + 64, dim, 13)
     base, q = data[:n].copy(), data[n:]
@@ -853,20 +857,22 @@ def test_exact_search_split_bf16_nomination_is_certified_or_falls_back(metric, q
         ix.reserve(n)
         ix.add_batch(np.arange(n, dtype=np.uint64), base)
         return ix
-    fast, ref = build(None), build("f32")
+    fast, ref = build(fast_env), build("f32")
     fk, fd, ff = fast.exact_search_batch(q, k)
     rk, rd, rf = ref.exact_search_batch(q, k)
-    st = fast.exact_stats()
-    assert st["block_batches"] >= 1 and st["block_fallbacks"] == 0 and ref.exact_stats()["block_batches"] == 0
+    st, rst = fast.exact_stats(), ref.exact_stats()
+    assert st[batches] >= 1 and st[fallbacks] == 0 and rst["block_batches"] == 0 and rst["plane_batches"] == 0
+    if path == "plane":
+        assert st["block_batches"] == 0  # nothing was handed on
     assert (ff == k).all() and np.allclose(fd, rd, rtol=1e-5, atol=2e-5)
     assert np.mean([fk[i].tolist() == rk[i].tolist() for i in range(len(q))]) >= 0.97      # f32 near-ties may swap
     assert all(set(fk[i].tolist()) == set(rk[i].tolist()) or np.isclose(fd[i, -1], rd[i, -1], rtol=1e-5, atol=2e-5) for i in range(len(q)))
     # 300 copies of one vector right at the query: the 64 nominees all tie with 236 rows outside -> no certificate -> f32 path
     base[1000:1300] = q[0] / (np.linalg.norm(q[0]) if metric == "ip" else 1.0)
-    fast2, ref2 = build(None), build("f32")
+    fast2, ref2 = build(fast_env), build("f32")
     fk, fd, ff = fast2.exact_search_batch(q[:4], k)
     rk, rd, rf = ref2.exact_search_batch(q[:4], k)
-    assert fast2.exact_stats()["block_fallbacks"] == 1
+    assert fast2.exact_stats()[fallbacks] == 1 and fast2.exact_stats()["block_fallbacks"] == 1  # (the plane's 256 nominees tie with 44 rows outside, too)
     assert np.array_equal(fk, rk) and np.array_equal(fd, rd)          # the very same kernels answered
     assert set(fk[0].tolist()) <= set(range(1000, 1300))
     # Row blocks after the first pass on only the scores at or below each query's threshold.  (a) members of the second block
@@ -875,21 +881,79 @@ def test_exact_search_split_bf16_nomination_is_certified_or_falls_back(metric, q
     base = data[:n].copy()
     if metric == "ip":
         base /= np.linalg.norm(base, axis=1, keepdims=True)
-    fast3, ref3 = build(None), build("f32")
+    fast3, ref3 = build(fast_env), build("f32")
     gone = list(range(65536, n, 3))
     for key in gone:
         assert fast3.remove(key) and ref3.remove(key)
     fk, fd, ff = fast3.exact_search_batch(q, k)
     rk, rd, rf = ref3.exact_search_batch(q, k)
-    assert fast3.exact_stats()["block_fallbacks"] == 0 and not (set(fk.ravel().tolist()) & set(gone))
+    assert fast3.exact_stats()[fallbacks] == 0 and not (set(fk.ravel().tolist()) & set(gone))
     assert np.allclose(fd, rd, rtol=1e-5, atol=2e-5)
     assert all(set(fk[i].tolist()) == set(rk[i].tolist()) or np.isclose(fd[i, -1], rd[i, -1], rtol=1e-5, atol=2e-5) for i in range(len(q)))
     qn = q[0] / np.linalg.norm(q[0])
     order = np.argsort(-(1.0 - (base @ qn) / (np.linalg.norm(base, axis=1) if metric == "cos" else 1.0)), kind="stable")
     base = base[order]
-    fast4, ref4 = build(None), build("f32")
+    fast4, ref4 = build(fast_env), build("f32")
     fk, fd, ff = fast4.exact_search_batch(q[:8], k)
     rk, rd, rf = ref4.exact_search_batch(q[:8], k)
-    assert fast4.exact_stats()["block_fallbacks"] == 1
+    assert fast4.exact_stats()[fallbacks] == 1
     assert np.array_equal(fk, rk) and np.array_equal(fd, rd)
     assert fk[0].min() >= n - 64                                       # the nearest rows are the last ones stored
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("metric,quant,dim,k", [("cos", "f32", 128, 10), ("ip", "f32", 200, 64), ("cos", "bf16", 96, 10), ("ip", "f16", 768, 10)])
+def test_one_product_plane_search_equals_the_f32_path(metric, quant, dim, k):
+    """The bf16-plane pass at a size where its persistent tile kernel runs several chunks (300k rows: 64k through the score
+    block, then 64k..300k thresholded), more than 256 queries (two query blocks), adds after the first search (the plane is
+    extended), a removed member and a re-used slot (the plane is rebuilt): every batch certified, ids == the f32 path's."""
+    import os
+    v = vs()
+    n, nq = 300_000, 300
+    data = _dataset(n + nq + 2000, dim, 29)
+    base, q, extra = data[:n].copy(), data[n:n + nq], data[n + nq:]
+    if metric == "ip":
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+        extra = extra / np.linalg.norm(extra, axis=1, keepdims=True)
+
+    def build(env):
+        old = os.environ.pop("VS_HNSW_EXACT", None)
+        if env:
+            os.environ["VS_HNSW_EXACT"] = env
+        try:
+            ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS[quant])
+        finally:
+            os.environ.pop("VS_HNSW_EXACT", None)
+            if old:
+                os.environ["VS_HNSW_EXACT"] = old
+        ix.reserve(n + len(extra))
+        ix.add_batch(np.arange(n, dtype=np.uint64), base)
+        return ix
+
+    fast, ref = build(None), build("f32")
+
+    def same(queries):
+        fk, fd, ff = fast.exact_search_batch(queries, k)
+        rk, rd, rf = ref.exact_search_batch(queries, k)
+        assert (ff == rf).all() and np.allclose(fd, rd, rtol=1e-5, atol=2e-5)
+        assert np.mean([fk[i].tolist() == rk[i].tolist() for i in range(len(queries))]) >= 0.97  # f32 near-ties may swap
+        assert all(set(fk[i].tolist()) == set(rk[i].tolist()) or np.isclose(fd[i, -1], rd[i, -1], rtol=1e-5, atol=2e-5) for i in range(len(queries)))
+        return fk
+
+    same(q)
+    st = fast.exact_stats()
+    assert st["plane_batches"] == 1 and st["plane_fallbacks"] == 0 and st["block_batches"] == 0
+    assert fast.memory_info()["bytes"] > ref.memory_info()["bytes"]  # the plane is accounted for
+    for ix in (fast, ref):   # rows added after the plane was built, one of them the nearest neighbour of query 0
+        e = extra.copy()
+        e[0] = q[0] / (np.linalg.norm(q[0]) if metric == "ip" else 1.0)
+        ix.add_batch(np.arange(n, n + len(e), dtype=np.uint64), e)
+    fk = same(q)
+    assert fk[0][0] == n
+    for ix in (fast, ref):   # a removed member is never a result; its slot is re-used by a row that must be found
+        assert ix.remove(n)
+        ix.add(1 << 40, q[1] / (np.linalg.norm(q[1]) if metric == "ip" else 1.0))
+    fk = same(q)
+    assert n not in fk and fk[1][0] == 1 << 40
+    st = fast.exact_stats()
+    assert st["plane_batches"] == 3 and st["plane_fallbacks"] == 0

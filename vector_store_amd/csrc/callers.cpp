@@ -153,3 +153,80 @@ extern "C" int vs_callers_run(vs_hnsw* h, const float* queries, size_t nq, size_
     out->team_launches = sv1[2] - sv0[2];
     return VS_OK;
 }
+
+// The reference dispatches every filtered query through spawn_blocking (usearch.rs:937-948): `threads` blocking callers of
+// vs_hnsw_filtered_search, each with its own predicate context (the reference's closure takes a table read-lock and evaluates
+// the restriction per candidate, usearch.rs:1118-1124; here: key % modulus == 0, counted).  extra[0] = predicate calls,
+// extra[1] = results returned, over the whole run.
+extern "C" int vs_callers_run_filtered(vs_hnsw* h, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus, unsigned threads,
+                                       double seconds, vs_callers_result* out, uint64_t extra[4]) {
+    if (!h || !queries || !nq || !k || !threads || !out || !modulus || !extra) return VS_ERR_INVALID_ARGUMENT;
+    struct Ctx {
+        uint64_t modulus;
+        std::atomic<uint64_t>* calls;
+    };
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> calls{0}, results{0};
+    std::vector<SearchMeasure> per(threads);
+    std::vector<uint64_t> errors(threads, 0);
+    auto t0 = Clock::now();
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; ++t)
+        th.emplace_back([&, t] {
+            std::mt19937_64 g(t * 104729 + 7);
+            std::vector<uint64_t> keys(k);
+            std::vector<float> dist(k);
+            uint64_t local_calls = 0;
+            struct Local {
+                uint64_t modulus;
+                uint64_t* calls;
+            } ctx{modulus, &local_calls};
+            auto pred = [](uint64_t key, void* c) -> int {
+                Local* l = (Local*)c;
+                ++*l->calls;
+                return key % l->modulus == 0 ? 1 : 0;
+            };
+            while (!stop.load(std::memory_order_relaxed)) {
+                const size_t qi = g() % nq;
+                size_t found = 0;
+                auto s = Clock::now();
+                int rc = vs_hnsw_filtered_search(h, queries + qi * dim, dim, k, pred, &ctx, keys.data(), dist.data(), &found);
+                int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
+                if (rc != VS_OK) {
+                    ++errors[t];
+                    break;
+                }
+                for (size_t i = 0; i < found; ++i)
+                    if (keys[i] % modulus != 0) ++errors[t];  // a result the predicate rejects
+                results += found;
+                per[t].record(ns, 0.0);
+            }
+            calls += local_calls;
+        });
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    stop = true;
+    for (auto& x : th) x.join();
+    const double wall = std::chrono::duration<double>(Clock::now() - t0).count();
+    SearchMeasure all;
+    for (auto& m : per) all.append(m);
+    out->seconds = wall;
+    out->queries = all.count;
+    out->qps = all.count / wall;
+    out->latency_min_ns = all.count ? all.latency_min : 0;
+    out->latency_max_ns = all.latency_max;
+    out->p01_ns = all.histogram.percentile(1);
+    out->p10_ns = all.histogram.percentile(10);
+    out->p25_ns = all.histogram.percentile(25);
+    out->p50_ns = all.histogram.percentile(50);
+    out->p75_ns = all.histogram.percentile(75);
+    out->p90_ns = all.histogram.percentile(90);
+    out->p99_ns = all.histogram.percentile(99);
+    out->recall_avg = -1.0;
+    out->errors = 0;
+    for (uint64_t e : errors) out->errors += e;
+    out->launches = out->team_launches = 0;
+    extra[0] = calls.load();
+    extra[1] = results.load();
+    extra[2] = extra[3] = 0;
+    return VS_OK;
+}

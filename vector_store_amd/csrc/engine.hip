@@ -351,6 +351,16 @@ struct Engine {
     float max_norm_value = 0.f;              // max |row| over rows [0, max_norm_slots) (inner product: scales the certificate)
     size_t max_norm_slots = 0;
     uint32_t* d_max_norm = nullptr;
+    // One-product block search (kernels_misc.hip "block search, ONE bf16 product"): a bf16 plane of the rows, built lazily by the
+    // first exact search that can use it and extended incrementally; rows [0, plane_done) are converted.
+    std::mutex plane_mu;                     // held across a search that uses the plane (it may be resized by the next one)
+    Arena ar_plane;
+    size_t plane_done = 0, plane_rows_cap = 0;
+    uint32_t* d_rho = nullptr;
+    float plane_rho = 0.f;                   // max |c - bf16(c)| / |c| over the plane's rows
+    bool plane_failed = false;               // no HBM left for the plane: the split-bf16 path serves from then on
+    int exact_mode = 0;                      // VS_HNSW_EXACT: 0 = bf16 plane -> split bf16 -> f32; 1 = "bf16x3": split bf16 -> f32; 2 = "f32"
+    std::atomic<uint64_t> plane_batches{0}, plane_fallbacks{0};
     bool eager_filter = false;               // VS_HNSW_FILTER=eager: always one predicate call per live member (the full bitmap)
     std::atomic<uint64_t> lazy_rounds{0}, lazy_predicate_calls{0};  // filtered_lazy: rounds / predicate calls so far (tests)
     std::atomic<bool> lds_walk_bad[16] = {};  // per walk instance: more than a quarter of a batch outgrew its LDS structures -> global-bitmap instance at once
@@ -448,7 +458,8 @@ struct Engine {
     ~Engine() {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
-        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels}) a->release();
+        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) a->release();
+        if (d_rho) (void)hipFree(d_rho);
         if (d_stats) (void)hipFree(d_stats);
         if (d_max_norm) (void)hipFree(d_max_norm);
     }
@@ -472,7 +483,10 @@ struct Engine {
         force_wide_tags = (o.reserved & 64) != 0;
         tiny_walk_heap = (o.reserved & 128) != 0;
         if (const char* ff = std::getenv("VS_HNSW_FILTER")) eager_filter = !std::strcmp(ff, "eager");
-        if (const char* xf = std::getenv("VS_HNSW_EXACT")) exact_f32_only = !std::strcmp(xf, "f32");
+        if (const char* xf = std::getenv("VS_HNSW_EXACT")) {
+            exact_f32_only = !std::strcmp(xf, "f32");
+            exact_mode = exact_f32_only ? 2 : !std::strcmp(xf, "bf16x3") ? 1 : 0;
+        }
         if (const char* tn = std::getenv("VS_HNSW_TIE")) tie_newest = std::strcmp(tn, "random") != 0;
         if (const char* fw = std::getenv("VS_HNSW_WALK")) force_global_walk = !std::strcmp(fw, "global");
         if (const char* ds = std::getenv("VS_HNSW_WALK_DOMAIN_SLOTS")) walk_domain_override = std::strtoull(ds, nullptr, 10);
@@ -734,8 +748,12 @@ struct Engine {
             HIP_OK(launch_scatter_u32((uint32_t*)d_levels, d_slots, (const uint32_t*)d_lv, m, st));
             HIP_OK(launch_scatter_u32(d_upper_off, d_slots, d_uoff, m, st));
             if (!reuse_rows.empty()) {  // a reused slot lies below max_norm_slots: the certificate's norm bound is recomputed over every row
-                std::lock_guard<std::mutex> ng(norm_mu);
-                max_norm_slots = 0;
+                {
+                    std::lock_guard<std::mutex> ng(norm_mu);
+                    max_norm_slots = 0;
+                }
+                std::lock_guard<std::mutex> pg(plane_mu);  // ... and below plane_done: the bf16 plane is converted again
+                plane_done = 0;
             }
             if (!reuse_rows.empty()) {  // usearch update(): the reused node's links are zeroed first
                 uint32_t* d_rr = (uint32_t*)w->d.ensure((reuse_rows.size() + reuse_upper.size()) * 4 + 64);
@@ -1175,6 +1193,45 @@ struct Engine {
         return max_norm_value;
     }
 
+    // The bf16 plane covers rows [0, slots) (+ zero rows up to a whole tile).  plane_mu and view_mu (shared) are held.
+    bool ensure_plane(const IndexView& ix, hipStream_t st) {
+        const size_t kp = block1_plane_k(ix);
+        const size_t rows_cap = block1_plane_rows((uint32_t)std::max(capacity, slots));
+        try {
+            if (rows_cap != plane_rows_cap) {
+                HIP_OK(hipStreamSynchronize(st));
+                size_t free_b = 0, total_b = 0;
+                HIP_OK(hipMemGetInfo(&free_b, &total_b));
+                const size_t want = rows_cap * kp * 2;
+                if (ar_plane.extra_needed(want, device) + (1ull << 30) > free_b) fail(VS_ERR_OUT_OF_MEMORY, "no HBM for the bf16 plane");
+                const size_t keep = std::min(plane_done, rows_cap) * kp * 2;
+                ar_plane.resize(want, keep, device);
+                plane_rows_cap = rows_cap;
+                plane_done = std::min(plane_done, rows_cap);
+            }
+            if (!d_rho) {
+                HIP_OK(hipMalloc((void**)&d_rho, 4));
+                HIP_OK(hipMemset(d_rho, 0, 4));
+            }
+            const size_t n = slots, end = block1_plane_rows((uint32_t)n);
+            if (plane_done < n || plane_done == 0) {
+                // rows added since the last search, and the zero rows that pad the last tile (they may since have become real rows)
+                const size_t first = plane_done / 256 * 256;
+                HIP_OK(launch_block1_plane_rows(ix, (uint16_t*)ar_plane.base, (uint32_t)first, (uint32_t)end, (uint32_t)n, d_rho, st));
+                uint32_t bits = 0;
+                HIP_OK(hipMemcpyAsync(&bits, d_rho, 4, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                std::memcpy(&plane_rho, &bits, 4);
+                plane_done = n;
+            }
+            return true;
+        } catch (const Fail& f) {
+            if (f.code != VS_ERR_OUT_OF_MEMORY) throw;
+            plane_failed = true;  // the other exact paths serve
+            return false;
+        }
+    }
+
     void exact_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
                       hipStream_t st, WorkCtx& w) {
         if (k == 0 || k > 256) fail(VS_ERR_UNSUPPORTED, "exact search supports 1 <= k <= 256");
@@ -1190,8 +1247,24 @@ struct Engine {
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;
-        // Large float indexes, cos / ip, k <= 64: nominate with the split-bf16 MFMA pass, re-score the nominees exactly,
-        // certify; only a batch with an uncertified query (dense ties at the cut) pays the f32 path as well.
+        // Large float indexes, cos / ip, k <= 64: nominate with ONE bf16 product per score over the bf16 plane of the rows, re-score
+        // the nominees exactly, certify; an uncertified batch goes on to the split-bf16 pass, and from there to the f32 path.
+        if (block1_supported(a.ix, a.k) && slots >= (1u << 16) && !a.use_valu && exact_mode == 0 && !plane_failed) {
+            std::lock_guard<std::mutex> pg(plane_mu);
+            if (ensure_plane(a.ix, st)) {
+                const float mx = metric == VS_METRIC_IP ? max_row_norm(a.ix, st) : 1.f;
+                char* scratch = (char*)w.f.ensure(block1_scratch_bytes((uint32_t)nq, dim) + 256);
+                uint32_t* d_unc = (uint32_t*)scratch;
+                HIP_OK(hipMemsetAsync(d_unc, 0, 4, st));
+                HIP_OK(launch_block1_search(a, scratch + 256, (const uint16_t*)ar_plane.base, plane_rho, mx, d_unc, st));
+                uint32_t unc = 0;
+                HIP_OK(hipMemcpyAsync(&unc, d_unc, 4, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                plane_batches += 1;
+                if (unc == 0) return;
+                plane_fallbacks += 1;
+            }
+        }
         if (block_search_supported(a.ix, a.k) && slots >= (1u << 16) && !a.use_valu && !exact_f32_only) {
             const float mx = metric == VS_METRIC_IP ? max_row_norm(a.ix, st) : 1.f;
             char* scratch = (char*)w.f.ensure(block_scratch_bytes((uint32_t)nq, dim) + 256);
@@ -1948,7 +2021,7 @@ int vs_hnsw_memory_info(vs_hnsw* h, uint64_t out[4]) {
         std::lock_guard<std::mutex> g(h->e.mod_mu);
         Engine& e = h->e;
         out[0] = out[1] = out[2] = 0;
-        for (const vs::Arena* a : {&e.ar_vectors, &e.ar_aux, &e.ar_adj0, &e.ar_upper, &e.ar_upper_off, &e.ar_keys, &e.ar_levels}) {
+        for (const vs::Arena* a : {&e.ar_vectors, &e.ar_aux, &e.ar_adj0, &e.ar_upper, &e.ar_upper_off, &e.ar_keys, &e.ar_levels, &e.ar_plane}) {
             out[0] += a->bytes;
             if (a->vmm) {
                 out[1] += a->bytes;
@@ -1978,6 +2051,15 @@ int vs_hnsw_exact_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.block_batches.load();
     out[1] = h->e.block_fallbacks.load();
+    return VS_OK;
+}
+
+int vs_hnsw_exact_stats2(vs_hnsw* h, uint64_t out[4]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.plane_batches.load();
+    out[1] = h->e.plane_fallbacks.load();
+    out[2] = h->e.block_batches.load();
+    out[3] = h->e.block_fallbacks.load();
     return VS_OK;
 }
 
@@ -2068,6 +2150,10 @@ int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const void* vectors, const int32_
         {
             std::lock_guard<std::mutex> ng(e.norm_mu);
             e.max_norm_slots = 0;  // the contents were replaced
+        }
+        {
+            std::lock_guard<std::mutex> pg(e.plane_mu);
+            e.plane_done = 0;
         }
         e.max_level = max_level;
         e.entry_slot = entry_slot;

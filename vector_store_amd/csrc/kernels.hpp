@@ -152,6 +152,16 @@ hipError_t launch_exact(const ExactArgs& a, void* scratch, hipStream_t s);
 bool block_search_supported(const IndexView& ix, uint32_t k);
 size_t block_scratch_bytes(uint32_t nq, uint32_t dim);
 hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_norm, uint32_t* d_uncertified, hipStream_t s);
+// The one-product form (round 3): a bf16 plane of the rows (block1_plane_rows(slots) x block1_plane_k(ix), kept by the engine),
+// ONE v_mfma_f32_16x16x32_bf16 product per score, the same re-score + certificate; rho = max |c - bf16(c)| / |c| over the plane's
+// rows (launch_block1_plane_rows accumulates its f32 bits with atomicMax).  Needs >= 65,536 slots, k <= 64, float storage, cos / ip.
+bool block1_supported(const IndexView& ix, uint32_t k);
+uint32_t block1_plane_k(const IndexView& ix);
+uint32_t block1_plane_rows(uint32_t slots);
+size_t block1_scratch_bytes(uint32_t nq, uint32_t dim);
+hipError_t launch_block1_plane_rows(const IndexView& ix, uint16_t* plane, uint32_t first, uint32_t end, uint32_t slots, uint32_t* d_rho_bits, hipStream_t s);
+hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_t* plane, float rho, float max_row_norm, uint32_t* d_uncertified,
+                                hipStream_t s);
 hipError_t launch_row_norm_max(const IndexView& ix, uint32_t first, uint32_t n, uint32_t* d_max_bits, hipStream_t s);
 
 // out[s] = distance(query, row s) for s in [0, n): one wave per row; result copied to host_out.

@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void block_rescore_kernel(IndexView ix, const 
 __global__ __launch_bounds__(64) void block_final_kernel(IndexView ix, uint32_t k, uint32_t C, const uint64_t* cand_slot, const float* cand_approx,
                                                          const uint32_t* cand_found, const float* exact_d, const float* qnorm,
                                                          float max_row_norm, uint64_t* out_keys, float* out_dist, uint32_t* out_found,
-                                                         uint32_t* uncertified) {
+                                                         uint32_t* uncertified, const float* eps_q = nullptr) {
     __shared__ float sd[kBlockC];
     __shared__ uint32_t ss[kBlockC];
     const uint32_t q = blockIdx.x;
@@ -967,7 +967,9 @@ __global__ __launch_bounds__(64) void block_final_kernel(IndexView ix, uint32_t 
         if (n == C) {  // rows outside the nominees exist: they score at least (worst nominated approximate score - eps)
             // split residuals (3 x 2^-18) + worst-case f32 accumulation of both scores (2 x K x 2^-24), times |q| |c|
             const float scale = ix.metric == COS ? 1.f : qnorm[q] * max_row_norm;
-            const float eps = (1.15e-5f + 1.2e-7f * (float)((ix.dim + 31u) & ~31u)) * 1.05f * scale + 1e-6f;
+            // eps_q != nullptr: the one-product nomination pass's own bound (p1_eps_kernel) + the exact score's f32 accumulation
+            const float eps = eps_q ? eps_q[q] + 1.2e-7f * (float)((ix.dim + 31u) & ~31u) * scale
+                                    : (1.15e-5f + 1.2e-7f * (float)((ix.dim + 31u) & ~31u)) * 1.05f * scale + 1e-6f;
             const float t = cand_approx[(size_t)q * C + C - 1];
             if (!(kth < t - eps)) atomicAdd(uncertified, 1u);
         }
@@ -1079,6 +1081,390 @@ hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_
     hipLaunchKernelGGL(block_rescore_kernel, dim3(a.nq, C / 4), dim3(256), 0, s, a.ix, qd, kpad, q_aux, C, cand_slot, cand_found, exact_d);
     hipLaunchKernelGGL(block_final_kernel, dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, qnorm,
                        max_row_norm, a.out_keys, a.out_dist, a.out_found, d_uncertified);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- block search, ONE bf16 product per score (round 3)
+// The same exact answer with a third of the matrix work and half of the HBM bytes of the split-bf16 pass above.  The index
+// keeps a bf16 PLANE of its rows (round to nearest, built lazily and incrementally next to the f32 / f16 rows: 288 GB of
+// HBM are there to be used), the queries are rounded to bf16 once per batch (cosine: after scaling by 1 / |q|), and
+//     s~(q, c) = sum_k qh[k] ch[k]            (v_mfma_f32_16x16x32_bf16, f32 accumulate)
+// nominates.  Error of a score, rigorous: |q.c - qh.ch| <= |q - qh| |c| + |qh| |c - ch| + K 2^-24 |qh| |c| with
+// |q - qh| measured per query (r_q) and |c - ch| <= rho |c|, rho = the largest relative rounding residual over the rows of
+// the plane (measured when the plane is built, <= 2^-9).  The C = 256 best approximate scores per query are re-scored with
+// exact f32 arithmetic and certified exactly as above (k-th exact score below the C-th approximate score - eps); a batch
+// with an uncertified query falls back to the split-bf16 path, and from there to the f32 path.
+//
+// Tile kernel: 256 queries (all of a batch) x 256 rows per workgroup of 8 waves (2 x 4: 128 x 64 per wave, 128 accumulator
+// registers), K in steps of 64 through LDS rings filled by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
+// ds_write), XOR-swizzled on the SOURCE side so that the fragment reads (ds_read_b128) are bank-conflict free
+// (scripts/probe/lds_swizzle_check.py), one raw s_barrier per step with counted vmcnt waits, persistent over the row tiles
+// of a launch (the ring runs on into the next tile during the epilogue).  Epilogue: common path branch-free (largest
+// score - threshold per 16 x 16 tile); a tile that holds a nominee goes through a per-wave LDS scratch and appends.
+// Measured structure and variants: scripts/probe/tile1_probe.hip.
+constexpr int kP1TN = 256, kP1BK = 64, kP1RA = 2, kP1RB = 2;
+constexpr uint32_t kP1C = 256;            // nominees per query
+constexpr uint32_t kP1FirstRows = 65536;  // rows of the first launch (through the score block D and the select pass)
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ uint32_t p1_swz(uint32_t row) { return (row >> 1) & 7u; }
+__device__ __forceinline__ void p1_glds16(const void* g, void* lds_base_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void p1_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// plane[r][0..kp) = bf16(row r) (zero beyond dim and for rows >= slots); *rho_bits = max over rows of |c - ch| / |c|
+__global__ __launch_bounds__(256) void p1_plane_rows_kernel(IndexView ix, uint32_t first, uint32_t end, uint32_t slots, uint32_t kp,
+                                                            uint16_t* plane, uint32_t* rho_bits) {
+    const uint32_t r = first + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    if (r >= end) return;
+    float sq = 0.f, res = 0.f;
+    for (uint32_t k = (uint32_t)lane * 4u; k < kp; k += kWave * 4u) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < slots) load4_dequant(ix, (size_t)r, k, v);
+        uint32_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = float_to_bf16_bits(v[j]);
+            const float e = v[j] - bf16_bits_to_float(h[j]);
+            sq = fmaf(v[j], v[j], sq);
+            res = fmaf(e, e, res);
+        }
+        *reinterpret_cast<uint2*>(plane + (size_t)r * kp + k) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    }
+    for (int o = 32; o; o >>= 1) {
+        sq += __shfl_xor(sq, o);
+        res += __shfl_xor(res, o);
+    }
+    if (lane == 0 && sq > 0.f && res == res) atomicMax(rho_bits, __float_as_uint(sqrtf(res / sq) * 1.0001f));
+}
+
+// qd (nq x kpad f32: the form the metric sees) -> A (rows_pad x kp bf16; cosine: scaled by q_aux = 1 / |q| first), |A_q|, r_q
+__global__ __launch_bounds__(256) void p1_round_queries_kernel(const float* qd, const float* q_aux, int cosine, uint32_t nq, uint32_t rows_pad,
+                                                               uint32_t kpad, uint32_t kp, uint16_t* A, float* a_norm, float* r_q) {
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    if (w >= rows_pad) return;
+    const float sc = w < nq ? (cosine ? q_aux[w] : 1.f) : 0.f;
+    float an = 0.f, rs = 0.f;
+    for (uint32_t e = lane; e < kp; e += kWave) {
+        const float x = (w < nq && e < kpad) ? qd[(size_t)w * kpad + e] * sc : 0.f;
+        const uint32_t h = float_to_bf16_bits(x);
+        const float hv = bf16_bits_to_float(h), d = x - hv;
+        A[(size_t)w * kp + e] = (uint16_t)h;
+        an = fmaf(hv, hv, an);
+        rs = fmaf(d, d, rs);
+    }
+    for (int o = 32; o; o >>= 1) {
+        an += __shfl_xor(an, o);
+        rs += __shfl_xor(rs, o);
+    }
+    if (lane == 0 && w < nq) {
+        a_norm[w] = sqrtf(an) * 1.0001f;
+        r_q[w] = sqrtf(rs) * 1.0001f;
+    }
+}
+
+// eps_q = bound of |approximate score - exact score| for query q (see the header of this section); a zero-norm cosine query
+// has no meaningful approximate scores (every row ties at 1 while SimSIMD's zero rules order them): the batch is left to the
+// other paths.
+__global__ void p1_eps_kernel(uint32_t nq, const float* q_aux, const float* a_norm, const float* r_q, float rho, float row_norm_max, float kdim, int cosine,
+                              float* eps_q, uint32_t* uncertified) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    if (cosine && !(q_aux[q] > 0.f)) atomicAdd(uncertified, 1u);
+    const float e = (r_q[q] + a_norm[q] * (rho + 1.2e-7f * kdim)) * row_norm_max;
+    eps_q[q] = e * 1.05f + 2e-6f;
+}
+
+// Scores of queries [0, 256) of A against plane rows [n_begin, n_end) (n_begin a multiple of 256; the plane is padded to
+// whole tiles).  WRITE_D: every score (as a distance 1 - s) into D[q][n - n_begin] (the first launch: kExactCH columns);
+// else: scores at or above 1 - thr[q] are appended to cand[q] as (distance bits, slot).  row_scale: cosine: 1 / |row| (aux).
+template <bool WRITE_D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void p1_tile_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint32_t kp, uint32_t nq_blk, uint32_t n_begin, uint32_t n_end,
+    const float* __restrict__ thr, const float* __restrict__ row_scale, float* __restrict__ D, uint2* __restrict__ cand,
+    uint32_t* __restrict__ cand_cnt, uint32_t cand_cap) {
+    constexpr int TM = 256, TN = kP1TN, BK = kP1BK, RA = kP1RA, RB = kP1RB, CH = BK / 8;
+    constexpr int NW = 8;
+    constexpr bool SPLIT = RA != RB;
+    constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2, RING_BYTES = RA * A_BYTES + RB * B_BYTES;
+    constexpr int A_LW = SPLIT ? NW / 2 : NW, B_LW = SPLIT ? NW / 2 : NW;
+    constexpr int A_PW = A_BYTES / 1024 / A_LW, B_PW = B_BYTES / 1024 / B_LW;  // 1-KiB pieces (one wave-instruction each) per loading wave per step
+    constexpr int ROWS_PP = 1024 / (BK * 2);
+    constexpr int WN = TN / 4, FR = 16, WROWS = TM / 2, MT = WROWS / FR, NT = WN / FR, ACC = 4;
+    extern __shared__ __attribute__((aligned(1024))) char p1_lds[];
+    char* lds = p1_lds;
+    float* thr_s = reinterpret_cast<float*>(lds + RING_BYTES);
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+    const bool loads_a = !SPLIT || w < (uint32_t)(NW / 2), loads_b = !SPLIT || w >= (uint32_t)(NW / 2);
+    const uint32_t la = w, lb = SPLIT ? w - NW / 2 : w;
+    const uint32_t ksteps = kp / BK, row_bytes = kp * 2;
+    const uint32_t tile0 = n_begin / TN, n_tiles = (n_end - n_begin + TN - 1) / TN;
+    // similarity thresholds: a score s is a nominee iff s >= 1 - thr; queries beyond the batch never nominate
+    if (t < TM) thr_s[t] = (!WRITE_D && t < nq_blk) ? 1.0f - thr[t] : __builtin_inff();
+
+    uint32_t a_off[A_PW], b_off[B_PW];
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const uint32_t p = la * A_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
+        a_off[i] = row * row_bytes + ((slot ^ p1_swz(row)) % CH) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) {
+        const uint32_t p = lb * B_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
+        b_off[i] = row * row_bytes + ((slot ^ p1_swz(row)) % CH) * 16;
+    }
+    const char* Ab = reinterpret_cast<const char*>(A);
+    const char* Bb = reinterpret_cast<const char*>(B);
+    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const uint32_t total = my_tiles * ksteps;
+    if (!total) return;
+    // prefetch cursors (flattened step -> (tile, k step)) of the A and B loaders
+    uint32_t pa = 0, pa_ks = 0, pb = 0, pb_ks = 0, pb_tile = blockIdx.x;
+    auto stage_a = [&]() {
+        char* base = lds + (pa % RA) * A_BYTES;
+        const char* at = Ab + pa_ks * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) p1_glds16(at + a_off[i], base + (la * A_PW + i) * 1024);
+        ++pa;
+        if (++pa_ks == ksteps) pa_ks = 0;
+    };
+    auto stage_b = [&]() {
+        char* base = lds + RA * A_BYTES + (pb % RB) * B_BYTES;
+        const char* bt = Bb + (size_t)(tile0 + pb_tile) * TN * row_bytes + pb_ks * (BK * 2);  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) p1_glds16(bt + b_off[i], base + (lb * B_PW + i) * 1024);
+        ++pb;
+        if (++pb_ks == ksteps) {
+            pb_ks = 0;
+            pb_tile += gridDim.x;
+        }
+    };
+    if (loads_a)
+        for (int s = 0; s < RA - 1; ++s)
+            if (pa < total) stage_a();
+    if (loads_b)
+        for (int s = 0; s < RB - 1; ++s)
+            if (pb < total) stage_b();
+
+    const uint32_t frow = lane & (FR - 1), fk = lane / FR;
+    uint32_t sg = 0;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        f32x4v acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < ACC; ++r) acc[i][j][r] = 0.f;
+        for (uint32_t ks = 0; ks < ksteps; ++ks, ++sg) {
+            // stage sg has landed once at most (ring - 2) younger stages of this wave are in flight (the last steps drain)
+            if constexpr (!SPLIT) {
+                if (sg + RA - 2 < total) p1_wait_vm<(RA - 2) * (A_PW + B_PW)>();
+                else p1_wait_vm<0>();
+            } else if (loads_a) {
+                if (sg + RA - 2 < total) p1_wait_vm<(RA - 2) * A_PW>();
+                else p1_wait_vm<0>();
+            } else {
+                if (sg + RB - 2 < total) p1_wait_vm<(RB - 2) * B_PW>();
+                else p1_wait_vm<0>();
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // everyone's pieces of stage sg are in LDS; everyone has finished reading stage sg - 1
+            asm volatile("" ::: "memory");
+            if (loads_a && pa < total) stage_a();
+            if (loads_b && pb < total) stage_b();
+            const char* abase = lds + (sg % RA) * A_BYTES;
+            const char* bbase = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8 fa[MT], fb[NT];
+                const uint32_t kc = kk * 4 + fk;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const uint32_t row = wm * WROWS + i * FR + frow;
+                    fa[i] = *reinterpret_cast<const bf16x8*>(abase + row * (BK * 2) + ((kc ^ p1_swz(row)) % CH) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint32_t row = wn * WN + j * FR + frow;
+                    fb[j] = *reinterpret_cast<const bf16x8*>(bbase + row * (BK * 2) + ((kc ^ p1_swz(row)) % CH) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: C/D layout -- column (row of the plane) on the lane, query rows in the registers
+        const uint32_t nbase = n_begin + tile * TN + wn * WN + frow;
+        float rs[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rs[j] = !row_scale ? 1.f : (nbase + j * FR < n_end ? row_scale[nbase + j * FR] : 0.f);  // (the plane's padding rows have no aux)
+        if constexpr (WRITE_D) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint32_t n = nbase + j * FR;
+#pragma unroll
+                    for (int r = 0; r < ACC; ++r) {
+                        const uint32_t q = wm * WROWS + i * FR + 4 * fk + r;
+                        if (n < n_end && q < nq_blk) D[(size_t)q * kExactCH + (n - n_begin)] = 1.0f - acc[i][j][r] * rs[j];
+                    }
+                }
+        } else {
+            float tmax[MT][NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float4 th = *reinterpret_cast<const float4*>(&thr_s[wm * WROWS + i * FR + 4 * fk]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float e0 = fmaf(acc[i][j][0], rs[j], -th.x), e1 = fmaf(acc[i][j][1], rs[j], -th.y);
+                    const float e2 = fmaf(acc[i][j][2], rs[j], -th.z), e3 = fmaf(acc[i][j][3], rs[j], -th.w);
+                    tmax[i][j] = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (__builtin_expect(__ballot(tmax[i][j] >= 0.f) != 0ull, 0)) {  // this 16 x 16 tile holds at least one nominee
+                        // the tile's scores go through this wave's LDS scratch: a runtime index into acc[][] would put ALL the
+                        // accumulators in scratch memory on every tile
+                        float* sc = reinterpret_cast<float*>(lds + RING_BYTES + 1024) + w * (ACC * 64);
+                        const uint32_t n = nbase + j * FR;
+#pragma unroll
+                        for (int r = 0; r < ACC; ++r) sc[r * 64 + lane] = acc[i][j][r] * rs[j];
+#pragma unroll 1
+                        for (int r = 0; r < ACC; ++r) {
+                            const uint32_t q = wm * WROWS + i * FR + 4 * fk + r;
+                            const float v = sc[r * 64 + lane];
+                            if (v >= thr_s[q] && n < n_end) {
+                                const uint32_t at = atomicAdd(&cand_cnt[q], 1u);
+                                if (at < cand_cap) cand[(size_t)q * cand_cap + at] = make_uint2(__float_as_uint(1.0f - v), n);
+                            }
+                        }
+                    }
+                }
+        }
+    }
+}
+constexpr size_t kP1LdsBytes = (size_t)(kP1RA * 256 + kP1RB * kP1TN) * kP1BK * 2 + 1024 + 8 * 4 * 64 * 4;
+
+bool block1_supported(const IndexView& ix, uint32_t k) {
+    return (ix.scalar == SC_F32 || ix.scalar == SC_F16 || ix.scalar == SC_BF16) && (ix.metric == COS || ix.metric == IP) && k >= 1 && k <= 64;
+}
+uint32_t block1_plane_k(const IndexView& ix) { return (ix.dim + 63u) & ~63u; }
+uint32_t block1_plane_rows(uint32_t slots) { return (slots + (uint32_t)kP1TN - 1u) / (uint32_t)kP1TN * (uint32_t)kP1TN; }
+
+hipError_t launch_block1_plane_rows(const IndexView& ix, uint16_t* plane, uint32_t first, uint32_t end, uint32_t slots, uint32_t* d_rho_bits,
+                                    hipStream_t s) {
+    if (end <= first) return hipSuccess;
+    hipLaunchKernelGGL(p1_plane_rows_kernel, dim3((end - first + 3) / 4), dim3(256), 0, s, ix, first, end, slots, block1_plane_k(ix), plane, d_rho_bits);
+    return hipGetLastError();
+}
+
+size_t block1_scratch_bytes(uint32_t nq, uint32_t dim) {
+    const size_t S = exact_segments(nq < 256 ? nq : 256), kpad = (dim + 31u) & ~31u, kp = (dim + 63u) & ~63u, rows = ((size_t)nq + 255) / 256 * 256;
+    return (size_t)kExactQB * kExactCH * 4 + (size_t)256 * S * kP1C * 8 + (size_t)256 * S * 4 + (size_t)nq * (4 * 5) + (size_t)nq * kpad * 4 +
+           rows * kp * 2 + (size_t)nq * kP1C * 16 + 8192;
+}
+
+// d_uncertified: one zeroed word; non-zero after the stream has drained => run the split-bf16 / f32 path instead.
+// plane: block1_plane_rows(slots) x block1_plane_k(ix) bf16.  rho: see p1_plane_rows_kernel.  max_row_norm: inner product only.
+hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_t* plane, float rho, float max_row_norm,
+                                uint32_t* d_uncertified, hipStream_t s) {
+    if (a.nq == 0) return hipSuccess;
+    if (!block1_supported(a.ix, a.k) || a.slots < kP1FirstRows) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
+        attr_set = true;
+    }
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t kpad = (a.ix.dim + 31u) & ~31u, kp = block1_plane_k(a.ix), C = kP1C;
+    const uint32_t S = exact_segments(a.nq < 256 ? a.nq : 256);
+    const uint32_t rows_pad = (a.nq + 255u) / 256u * 256u;
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    float* D = (float*)take((size_t)kExactQB * kExactCH * 4);
+    float* st_d = (float*)take((size_t)256 * S * C * 4);
+    uint32_t* st_s = (uint32_t*)take((size_t)256 * S * C * 4);
+    uint32_t* st_n = (uint32_t*)take((size_t)256 * S * 4);
+    float* q_aux = (float*)take((size_t)a.nq * 4);
+    float* a_norm = (float*)take((size_t)a.nq * 4);
+    float* r_q = (float*)take((size_t)a.nq * 4);
+    float* eps_q = (float*)take((size_t)a.nq * 4);
+    uint32_t* cand_found = (uint32_t*)take((size_t)a.nq * 4);
+    float* qd = (float*)take((size_t)a.nq * kpad * 4);
+    uint16_t* A = (uint16_t*)take((size_t)rows_pad * kp * 2);
+    uint64_t* cand_slot = (uint64_t*)take((size_t)a.nq * C * 8);
+    float* cand_approx = (float*)take((size_t)a.nq * C * 4);
+    float* exact_d = (float*)take((size_t)a.nq * C * 4);
+    hipError_t e = prepare_queries(a.ix, a.queries, a.q_stride, a.nq, kpad, qd, q_aux, s);
+    if (e != hipSuccess) return e;
+    const int cosine = a.ix.metric == COS ? 1 : 0;
+    hipLaunchKernelGGL(p1_round_queries_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, s, qd, q_aux, cosine, a.nq, rows_pad, kpad, kp, A, a_norm, r_q);
+    const float* row_scale = cosine ? a.ix.aux : nullptr;
+    // the select / merge kernels index their per-query state by (q0 + local query) with q0 = 0 per 256-query block here
+    uint2* cand = reinterpret_cast<uint2*>(D);
+    uint32_t* cand_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(D) + (size_t)256 * kBlockCandCap * 8);
+    float* thr = reinterpret_cast<float*>(cand_cnt + 256);
+    for (uint32_t q0 = 0; q0 < a.nq; q0 += 256) {
+        const uint32_t nqb = a.nq - q0 < 256u ? a.nq - q0 : 256u;
+        const uint16_t* Aq = A + (size_t)q0 * kp;
+        // first launch: every score of the first rows through D and the segmented select pass -> nominee lists (cand_*), thresholds
+        const uint32_t n1 = a.slots < kP1FirstRows ? a.slots : kP1FirstRows;
+        hipLaunchKernelGGL((p1_tile_kernel<true>), dim3((n1 + kP1TN - 1) / kP1TN), dim3(512), kP1LdsBytes, s, Aq, plane, kp, nqb, 0u, n1, (const float*)nullptr,
+                           row_scale, D, cand, cand_cnt, (uint32_t)kBlockCandCap);
+        hipLaunchKernelGGL(exact_select_kernel, dim3(nqb, S), dim3(64), 0, s, a.ix, D, 0u, 0u, n1, C, 1, 1, st_d, st_s, st_n, cand_slot + (size_t)q0 * C,
+                           cand_approx + (size_t)q0 * C, cand_found + q0, 1);
+        if (S > 1)
+            hipLaunchKernelGGL(exact_finish_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, S, C, st_d, st_s, st_n, cand_slot + (size_t)q0 * C,
+                               cand_approx + (size_t)q0 * C, cand_found + q0, 1);
+        if (n1 < a.slots) {
+            e = hipMemsetAsync(cand_cnt, 0, (size_t)256 * 4, s);  // D is free from here on: the candidate buffers live there
+            if (e != hipSuccess) return e;
+            // an empty merge publishes each query's first threshold (the worst score on its list, +inf while the list is short)
+            hipLaunchKernelGGL(block_merge_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
+                               cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified);
+        }
+        // the rest in chunks that grow 8 x: the thresholds are refreshed between them (C ln 8 ~ 530 candidates per query and chunk
+        // when the rows come in no particular order; a buffer that overflows raises `uncertified`)
+        for (uint32_t n0 = n1; n0 < a.slots;) {
+            const uint64_t want = (uint64_t)n0 * 8u;
+            const uint32_t nend = want >= a.slots ? a.slots : (uint32_t)want;
+            const uint32_t tiles = (nend - n0 + kP1TN - 1) / kP1TN;
+            const uint32_t grid = tiles < (uint32_t)cus ? tiles : (uint32_t)cus;
+            hipLaunchKernelGGL((p1_tile_kernel<false>), dim3(grid), dim3(512), kP1LdsBytes, s, Aq, plane, kp, nqb, n0, nend, thr, row_scale, (float*)nullptr, cand,
+                               cand_cnt, (uint32_t)kBlockCandCap);
+            hipLaunchKernelGGL(block_merge_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
+                               cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified);
+            n0 = nend;
+        }
+    }
+    // eps_q: bound of |approximate - exact| score; the certificate of block_final_kernel uses it instead of the split-bf16 bound
+    hipLaunchKernelGGL(p1_eps_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a.nq, q_aux, a_norm, r_q, rho, cosine ? 1.f : max_row_norm,
+                       (float)((a.ix.dim + 63u) & ~63u), cosine, eps_q, d_uncertified);
+    hipLaunchKernelGGL(block_rescore_kernel, dim3(a.nq, C / 4), dim3(256), 0, s, a.ix, qd, kpad, q_aux, C, cand_slot, cand_found, exact_d);
+    hipLaunchKernelGGL(block_final_kernel, dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, a_norm, max_row_norm,
+                       a.out_keys, a.out_dist, a.out_found, d_uncertified, (const float*)eps_q);
     return hipGetLastError();
 }
 

@@ -94,6 +94,7 @@ def lib():
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
     L.vs_hnsw_exact_stats.argtypes = [vp, vp]
     L.vs_hnsw_walk_info.argtypes = [vp, vp]
+    L.vs_hnsw_exact_stats2.argtypes = [vp, vp]
     L.vs_hnsw_graph_info_get.argtypes = [vp, C.POINTER(_GraphInfo)]
     L.vs_hnsw_export_graph.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.vs_hnsw_import_graph.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz, C.c_int32, C.c_uint32]
@@ -284,7 +285,9 @@ class HipUsearchIndex:
     def exact_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)
         _check(self.L.vs_hnsw_exact_stats(self.h, _p(out)))
-        return {"block_batches": int(out[0]), "block_fallbacks": int(out[1])}
+        out4 = np.zeros(4, dtype=np.uint64)
+        _check(self.L.vs_hnsw_exact_stats2(self.h, _p(out4)))
+        return {"block_batches": int(out[0]), "block_fallbacks": int(out[1]), "plane_batches": int(out4[0]), "plane_fallbacks": int(out4[1])}
 
     def walk_info(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)

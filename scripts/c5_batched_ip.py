@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4]: batched search, q = 256, 10M x 768 inner product (base L2-normalised).
-Times (a) the exact block-distance path (split-bf16 MFMA nomination + f32 re-score + certificate; VS_HNSW_EXACT=f32: the f32-input MFMA
-path of round 1) and (b) the HNSW walk on
-the same 256-query batches, with recall of (b) against (a).  Prints one JSON line."""
+Times (a) the exact block-distance path (round 3: ONE bf16 MFMA product per score over the index's bf16 plane + f32 re-score +
+certificate; VS_HNSW_EXACT=bf16x3: round 2's three split-bf16 products over the f32 rows; VS_HNSW_EXACT=f32: round 1's f32-input
+MFMA path) and (b) the HNSW walk on the same 256-query batches, with recall of (b) against (a).  Prints one JSON line.
+Fractions are against the dense bf16 MFMA peak (2,500 TFLOP/s) for the products actually issued and against the 8 TB/s HBM peak
+for the bytes the nomination pass has to stream (the bench.py `configs` record of configs[4] reports the same)."""
 import json
 import os
 import sys
@@ -56,12 +58,22 @@ def walk(b):
     ix.search_batch_device(q[o:].data_ptr(), nq, k, ok[o:].data_ptr(), od[o:].data_ptr(), of[o:].data_ptr(), s)
 
 
+x0 = ix.exact_stats()
 exact_ms = timed(exact)
+x1 = ix.exact_stats()
 walk_ms = timed(walk)
+mode = os.environ.get("VS_HNSW_EXACT", "")
+plane = x1["plane_batches"] > x0["plane_batches"] and x1["plane_fallbacks"] == x0["plane_fallbacks"]
+split = not plane and x1["block_batches"] > x0["block_batches"] and x1["block_fallbacks"] == x0["block_fallbacks"]
+products, row_bytes, peak = (1, 2 * ((dim + 63) // 64 * 64), 2500.0) if plane else (3, 4 * dim, 2500.0) if split else (1, 4 * dim, 157.3)
 rec = recall_at_k(tk.cpu().numpy(), ok.cpu().numpy())
 flops = 2.0 * nq * n * dim
 print(json.dumps({"workload": f"{n}x{dim} ip (unit vectors), batches of {nq} queries, top-{k}",
-                  "exact_mfma": {"ms_per_batch": exact_ms, "queries_per_s": nq / exact_ms * 1e3, "tflops": flops / exact_ms / 1e9,
-                                 "frac_of_157_tflops": flops / exact_ms / 1e9 / 157.0},
+                  "exact_mfma": {"path": "bf16 plane, 1 product" if plane else "split bf16, 3 products" if split else "f32-input MFMA",
+                                 "ms_per_batch": exact_ms, "queries_per_s": nq / exact_ms * 1e3, "f32_equivalent_tflops": flops / exact_ms / 1e9,
+                                 "issued_tflops": products * flops / exact_ms / 1e9, "mfma_peak_tflops": peak,
+                                 "frac_of_mfma_peak": products * flops / exact_ms / 1e9 / peak,
+                                 "streamed_gb_per_batch": n * row_bytes / 1e9, "frac_of_8tbs": n * row_bytes / (exact_ms * 1e-3) / 8e12,
+                                 "stats": {k_: x1[k_] - x0[k_] for k_ in x1}},
                   "hnsw_walk_ef200": {"ms_per_batch": walk_ms, "queries_per_s": nq / walk_ms * 1e3, "recall_at_10_vs_exact": rec},
                   "build_vectors_per_s": n / build_s}))

@@ -66,6 +66,7 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 // EPI: bit 0 epilogue on (off: timing aid), bit 1 B loads non-temporal, bit 2 no B loads (A path alone), bit 3 no A loads (B path alone),
 // bit 4: B (and A) stored TILE-MAJOR in LDS image order -- a stage is ONE contiguous block of memory (timing only: the probe's
 // data is random, so the values are not re-laid out and the check is skipped).
+// bit 5: B through REGISTERS (global_load_dwordx4 nt -> ds_write_b128 after the step's MFMAs) instead of LDS-DMA; needs bit 4, RA == RB == 2.
 template <int TN, int BK, int RA, int RB, int SHAPE, int WM, int EPI, bool WRITE_D>
 __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM))) void tile_ring_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint32_t n_rows, const float* __restrict__ sthr,
@@ -115,6 +116,18 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
         for (int i = 0; i < A_PW; ++i)
             if constexpr (!(EPI & 8)) glds16(at + a_off[i], base + (la * A_PW + i) * 1024);
     };
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 breg[B_PW];
+    auto load_b_regs = [&](uint32_t sg, uint32_t tile) {
+        const char* bt = Bb + ((size_t)tile * KSTEPS + (sg % KSTEPS)) * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) breg[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bt + b_off[i]));
+    };
+    auto store_b_regs = [&](uint32_t sg) {
+        char* base = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) *reinterpret_cast<u32x4*>(base + b_off[i]) = breg[i];
+    };
     auto stage_b = [&](uint32_t sg, uint32_t tile) {
         char* base = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
         const char* bt = (EPI & 16) ? Bb + ((size_t)tile * KSTEPS + (sg % KSTEPS)) * B_BYTES
@@ -133,7 +146,11 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
         for (int s = 0; s < RA - 1; ++s)
             if ((uint32_t)s < total) stage_a(s);
     }
-    if (loads_b) {
+    if constexpr (EPI & 32) {
+        load_b_regs(0, tile_of(0));
+        wait_vm<0>();
+        store_b_regs(0);
+    } else if (loads_b) {
 #pragma unroll
         for (int s = 0; s < RB - 1; ++s)
             if ((uint32_t)s < total) stage_b(s, tile_of(s));
@@ -166,7 +183,9 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
             __builtin_amdgcn_s_barrier();  // everyone's pieces of stage sg are in LDS; everyone has finished reading stage sg - 1
             asm volatile("" ::: "memory");
             if (loads_a && sg + RA - 1 < total) stage_a(sg + RA - 1);
-            if (loads_b && sg + RB - 1 < total) stage_b(sg + RB - 1, tile_of(sg + RB - 1));
+            if constexpr (EPI & 32) {
+                if (sg + 1 < total) load_b_regs(sg + 1, tile_of(sg + 1));
+            } else if (loads_b && sg + RB - 1 < total) stage_b(sg + RB - 1, tile_of(sg + RB - 1));
             const char* base = lds + (sg % RA) * A_BYTES;
             const char* bbase = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
 #pragma unroll
@@ -191,6 +210,12 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
                     }
                 if constexpr (BK / KSUB > 2) __builtin_amdgcn_sched_barrier(0);  // keeps the fragment registers of one sub-step live at a time
+            }
+            if constexpr (EPI & 32) {
+                if (sg + 1 < total) {
+                    __builtin_amdgcn_sched_barrier(0);  // the stores stay behind the step's MFMAs
+                    store_b_regs(sg + 1);                // (the compiler waits for the loads here: vmcnt)
+                }
             }
         }
         if constexpr ((EPI & 1) == 0) {  // timing aid: the K loop alone (the accumulators stay live)
@@ -392,17 +417,12 @@ int main(int argc, char** argv) {
         }
         HIP_OK(hipMemcpy(c.dB, c.hB.data(), small * 2, hipMemcpyHostToDevice));
     }
-    run_variant<256, 64, 2, 2, 16>(c, "TN256 BK64 A2 B2 16x16 (ref)");
-    run_variant<256, 64, 2, 2, 16, 2, 3>(c, "ref + B nt");
-    run_variant<256, 64, 2, 2, 16, 2, 17>(c, "tile-major");
-    run_variant<256, 64, 2, 2, 16, 2, 19>(c, "tile-major + B nt");
-    run_variant<256, 64, 2, 2, 16, 2, 25>(c, "tile-major, B loads only");
-    run_variant<256, 64, 2, 2, 16, 2, 27>(c, "tile-major, B loads only, nt");
-    run_variant<256, 32, 4, 4, 16, 2, 19>(c, "tile-major BK32 A4 B4 + B nt");
-    run_variant<256, 32, 3, 6, 16, 2, 19>(c, "tile-major BK32 A3 B6 split + B nt");
-    run_variant<256, 64, 2, 2, 16, 4, 19>(c, "tile-major 16 waves + B nt");
-    run_variant<256, 64, 2, 2, 16, 2, 18>(c, "tile-major + B nt, no epilogue");
-    run_variant<256, 64, 2, 2, 16, 2, 13>(c, "no loads at all");
-    run_variant<256, 64, 2, 2, 16, 2, 12>(c, "no loads at all, no epilogue");
+    run_variant<256, 64, 2, 2, 16, 2, 19>(c, "tile-major + B nt (ref)");
+    run_variant<256, 64, 2, 2, 16, 2, 49>(c, "tile-major, B via registers");
+    run_variant<256, 64, 2, 2, 16, 2, 57>(c, "tile-major, B via registers, no A loads");
+    run_variant<256, 64, 2, 2, 16, 4, 49>(c, "tile-major, B via registers, 16 waves");
+    run_variant<256, 64, 2, 2, 32, 2, 49>(c, "tile-major, B via registers, 32x32");
+    run_variant<256, 64, 2, 2, 16, 2, 48>(c, "tile-major, B via registers, no epilogue");
+    run_variant<256, 64, 2, 2, 16, 2, 19>(c, "tile-major + B nt (ref again)");
     return 0;
 }

@@ -38,7 +38,7 @@ def test_rows_of_up_to_16_kib(metric, kind, dim):
     ix = v.HipUsearchIndex(dim, v.METRICS[metric], expansion_search=96, quantization=v.SCALARS[kind])
     assert ix.bytes_per_vector() > 8192 or dim == 2500
     ix.reserve(n)
-    ix.add_batch(np.arange(n, dtype=np.uint64), base[: n - 100])
+    ix.add_batch(np.arange(n - 100, dtype=np.uint64), base[: n - 100])
     for i in range(n - 100, n):  # the last hundred one per FFI call
         ix.add(i, base[i])
     assert ix.size() == n
@@ -95,7 +95,7 @@ def test_construction_beams_up_to_512(ef_add):
     ix.reserve(n)
     ix.add_batch(np.arange(n, dtype=np.uint64), base)
     st = ix.stats()
-    assert st["visited_overflow"] == 0 and st["added"] == n
+    assert st["visited_overflow"] == 0 and st["added"] == n - 1 and ix.size() == n  # (the first member becomes the entry point without a walk)
     tk, _, _ = ix.exact_search_batch(q, k)
     gk, gd, gf = ix.search_batch(q, k)
     recall_gpu = np.mean([len(set(tk[i].tolist()) & set(gk[i].tolist())) / k for i in range(len(q))])

@@ -1101,6 +1101,11 @@ hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_
 // (scripts/probe/lds_swizzle_check.py), one raw s_barrier per step with counted vmcnt waits, persistent over the row tiles
 // of a launch (the ring runs on into the next tile during the epilogue).  Epilogue: common path branch-free (largest
 // score - threshold per 16 x 16 tile); a tile that holds a nominee goes through a per-wave LDS scratch and appends.
+// Both operands are stored TILE-MAJOR in LDS-image order: the 32 KiB a (256-row tile, 64-deep K step) stage occupies in LDS is
+// one contiguous block of the plane (and of the rounded query block), already XOR-swizzled, so a stage is filled by 32
+// wave-instructions that each copy 1 KiB of consecutive memory -- whole DRAM pages instead of 128 bytes out of every 1,536
+// (row-major: 3.9 TB/s of plane reads at best, scripts/probe/tile1_probe.hip).  The plane is a derived structure, read by
+// nothing else (the re-score reads the f32 rows), so its layout is free.
 // Measured structure and variants: scripts/probe/tile1_probe.hip.
 constexpr int kP1TN = 256, kP1BK = 64, kP1RA = 2, kP1RB = 2;
 constexpr uint32_t kP1C = 256;            // nominees per query
@@ -1108,16 +1113,22 @@ constexpr uint32_t kP1FirstRows = 65536;  // rows of the first launch (through t
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ uint32_t p1_swz(uint32_t row) { return (row >> 1) & 7u; }
+// byte offset of element k of row r in a tile-major operand of `ksteps` K steps per tile (k a multiple of 4: 8 bytes stay together)
+__device__ __forceinline__ size_t p1_offset(uint32_t r, uint32_t k, uint32_t ksteps) {
+    const uint32_t t = r >> 8, rt = r & 255u, ks = k >> 6, kw = k & 63u, chunk = kw >> 3;
+    return ((size_t)(t * ksteps + ks) * 256u + rt) * 128u + ((chunk ^ p1_swz(rt)) << 4) + ((kw & 7u) << 1);
+}
+template <int AUX>  // AUX 2: non-temporal (the plane streams through once per query block and must not displace the query block from L2)
 __device__ __forceinline__ void p1_glds16(const void* g, void* lds_base_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, AUX);
 }
 template <int N>
 __device__ __forceinline__ void p1_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// plane[r][0..kp) = bf16(row r) (zero beyond dim and for rows >= slots); *rho_bits = max over rows of |c - ch| / |c|
+// plane (tile-major, p1_offset) := bf16(row r) (zero beyond dim and for rows >= slots); *rho_bits = max over rows of |c - ch| / |c|
 __global__ __launch_bounds__(256) void p1_plane_rows_kernel(IndexView ix, uint32_t first, uint32_t end, uint32_t slots, uint32_t kp,
                                                             uint16_t* plane, uint32_t* rho_bits) {
     const uint32_t r = first + blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1135,7 +1146,7 @@ __global__ __launch_bounds__(256) void p1_plane_rows_kernel(IndexView ix, uint32
             sq = fmaf(v[j], v[j], sq);
             res = fmaf(e, e, res);
         }
-        *reinterpret_cast<uint2*>(plane + (size_t)r * kp + k) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(plane) + p1_offset(r, k, kp >> 6)) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     }
     for (int o = 32; o; o >>= 1) {
         sq += __shfl_xor(sq, o);
@@ -1144,7 +1155,7 @@ __global__ __launch_bounds__(256) void p1_plane_rows_kernel(IndexView ix, uint32
     if (lane == 0 && sq > 0.f && res == res) atomicMax(rho_bits, __float_as_uint(sqrtf(res / sq) * 1.0001f));
 }
 
-// qd (nq x kpad f32: the form the metric sees) -> A (rows_pad x kp bf16; cosine: scaled by q_aux = 1 / |q| first), |A_q|, r_q
+// qd (nq x kpad f32: the form the metric sees) -> A (rows_pad x kp bf16, tile-major; cosine: scaled by q_aux = 1 / |q| first), |A_q|, r_q
 __global__ __launch_bounds__(256) void p1_round_queries_kernel(const float* qd, const float* q_aux, int cosine, uint32_t nq, uint32_t rows_pad,
                                                                uint32_t kpad, uint32_t kp, uint16_t* A, float* a_norm, float* r_q) {
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1152,13 +1163,17 @@ __global__ __launch_bounds__(256) void p1_round_queries_kernel(const float* qd, 
     if (w >= rows_pad) return;
     const float sc = w < nq ? (cosine ? q_aux[w] : 1.f) : 0.f;
     float an = 0.f, rs = 0.f;
-    for (uint32_t e = lane; e < kp; e += kWave) {
-        const float x = (w < nq && e < kpad) ? qd[(size_t)w * kpad + e] * sc : 0.f;
-        const uint32_t h = float_to_bf16_bits(x);
-        const float hv = bf16_bits_to_float(h), d = x - hv;
-        A[(size_t)w * kp + e] = (uint16_t)h;
-        an = fmaf(hv, hv, an);
-        rs = fmaf(d, d, rs);
+    for (uint32_t e = (uint32_t)lane * 4u; e < kp; e += kWave * 4u) {
+        uint32_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = (w < nq && e + j < kpad) ? qd[(size_t)w * kpad + e + j] * sc : 0.f;
+            h[j] = float_to_bf16_bits(x);
+            const float hv = bf16_bits_to_float(h[j]), d = x - hv;
+            an = fmaf(hv, hv, an);
+            rs = fmaf(d, d, rs);
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(A) + p1_offset(w, e, kp >> 6)) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     }
     for (int o = 32; o; o >>= 1) {
         an += __shfl_xor(an, o);
@@ -1196,7 +1211,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2, RING_BYTES = RA * A_BYTES + RB * B_BYTES;
     constexpr int A_LW = SPLIT ? NW / 2 : NW, B_LW = SPLIT ? NW / 2 : NW;
     constexpr int A_PW = A_BYTES / 1024 / A_LW, B_PW = B_BYTES / 1024 / B_LW;  // 1-KiB pieces (one wave-instruction each) per loading wave per step
-    constexpr int ROWS_PP = 1024 / (BK * 2);
     constexpr int WN = TN / 4, FR = 16, WROWS = TM / 2, MT = WROWS / FR, NT = WN / FR, ACC = 4;
     extern __shared__ __attribute__((aligned(1024))) char p1_lds[];
     char* lds = p1_lds;
@@ -1204,7 +1218,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
     const bool loads_a = !SPLIT || w < (uint32_t)(NW / 2), loads_b = !SPLIT || w >= (uint32_t)(NW / 2);
     const uint32_t la = w, lb = SPLIT ? w - NW / 2 : w;
-    const uint32_t ksteps = kp / BK, row_bytes = kp * 2;
+    const uint32_t ksteps = kp / BK;
     const uint32_t tile0 = n_begin / TN, n_tiles = (n_end - n_begin + TN - 1) / TN;
     // similarity thresholds: a score s is a nominee iff s >= 1 - thr; queries beyond the batch never nominate
     if (t < TM) thr_s[t] = (!WRITE_D && t < nq_blk) ? 1.0f - thr[t] : __builtin_inff();
@@ -1212,13 +1226,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint32_t a_off[A_PW], b_off[B_PW];
 #pragma unroll
     for (int i = 0; i < A_PW; ++i) {
-        const uint32_t p = la * A_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
-        a_off[i] = row * row_bytes + ((slot ^ p1_swz(row)) % CH) * 16;
+        a_off[i] = (la * A_PW + i) * 1024 + lane * 16;  // tile-major operands: a stage is one contiguous block in LDS-image order
     }
 #pragma unroll
     for (int i = 0; i < B_PW; ++i) {
-        const uint32_t p = lb * B_PW + i, row = p * ROWS_PP + lane / CH, slot = lane % CH;
-        b_off[i] = row * row_bytes + ((slot ^ p1_swz(row)) % CH) * 16;
+        b_off[i] = (lb * B_PW + i) * 1024 + lane * 16;
     }
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* Bb = reinterpret_cast<const char*>(B);
@@ -1229,17 +1241,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint32_t pa = 0, pa_ks = 0, pb = 0, pb_ks = 0, pb_tile = blockIdx.x;
     auto stage_a = [&]() {
         char* base = lds + (pa % RA) * A_BYTES;
-        const char* at = Ab + pa_ks * (BK * 2);
+        const char* at = Ab + (size_t)pa_ks * A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_PW; ++i) p1_glds16(at + a_off[i], base + (la * A_PW + i) * 1024);
+        for (int i = 0; i < A_PW; ++i) p1_glds16<0>(at + a_off[i], base + (la * A_PW + i) * 1024);
         ++pa;
         if (++pa_ks == ksteps) pa_ks = 0;
     };
     auto stage_b = [&]() {
         char* base = lds + RA * A_BYTES + (pb % RB) * B_BYTES;
-        const char* bt = Bb + (size_t)(tile0 + pb_tile) * TN * row_bytes + pb_ks * (BK * 2);  // wave-uniform
+        const char* bt = Bb + ((size_t)(tile0 + pb_tile) * ksteps + pb_ks) * B_BYTES;  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < B_PW; ++i) p1_glds16(bt + b_off[i], base + (lb * B_PW + i) * 1024);
+        for (int i = 0; i < B_PW; ++i) p1_glds16<2>(bt + b_off[i], base + (lb * B_PW + i) * 1024);
         ++pb;
         if (++pb_ks == ksteps) {
             pb_ks = 0;
@@ -1428,7 +1440,7 @@ hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_
     float* thr = reinterpret_cast<float*>(cand_cnt + 256);
     for (uint32_t q0 = 0; q0 < a.nq; q0 += 256) {
         const uint32_t nqb = a.nq - q0 < 256u ? a.nq - q0 : 256u;
-        const uint16_t* Aq = A + (size_t)q0 * kp;
+        const uint16_t* Aq = A + (size_t)q0 * kp;  // (tile-major: query block q0 / 256 starts at row q0)
         // first launch: every score of the first rows through D and the segmented select pass -> nominee lists (cand_*), thresholds
         const uint32_t n1 = a.slots < kP1FirstRows ? a.slots : kP1FirstRows;
         hipLaunchKernelGGL((p1_tile_kernel<true>), dim3((n1 + kP1TN - 1) / kP1TN), dim3(512), kP1LdsBytes, s, Aq, plane, kp, nqb, 0u, n1, (const float*)nullptr,

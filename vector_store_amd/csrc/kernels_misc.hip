@@ -856,7 +856,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // in an order that keeps improving on everything seen before) raises `uncertified`: the host re-runs the batch on the f32 path.
 __global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt,
                                                          const uint2* cand, uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr,
-                                                         uint32_t* uncertified) {
+                                                         uint32_t* uncertified, const float* band_eps = nullptr, uint32_t band_k = 0) {
     __shared__ SelectShared sh;
     const int lane = lane_id();
     const uint32_t ql = blockIdx.x, qg = q0 + ql;
@@ -901,7 +901,12 @@ __global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t 
     }
     if (lane == 0) {
         list_n[qg] = sz;
-        thr[ql] = sz == C ? sh.lst_d[0][C - 1] : __builtin_inff();
+        float t = sz == C ? sh.lst_d[0][C - 1] : __builtin_inff();
+        // One-product pass: a row whose approximate score is more than 2 eps behind the k-th best so far cannot be among the true
+        // k best (the k rows in front of it are exactly within eps of their scores, it is exactly within eps of its own), so the
+        // tiles need not pass it on, whatever the nominee list still has room for.
+        if (band_eps && band_k && sz >= band_k) t = fminf(t, sh.lst_d[0][band_k - 1] + 2.0f * band_eps[ql]);
+        thr[ql] = t;
     }
 }
 
@@ -1109,7 +1114,6 @@ hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_
 // Measured structure and variants: scripts/probe/tile1_probe.hip.
 constexpr int kP1TN = 256, kP1BK = 64, kP1RA = 2, kP1RB = 2;
 constexpr uint32_t kP1C = 256;            // nominees per query
-constexpr uint32_t kP1FirstRows = 65536;  // rows of the first launch (through the score block D and the select pass)
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ uint32_t p1_swz(uint32_t row) { return (row >> 1) & 7u; }
@@ -1384,22 +1388,19 @@ hipError_t launch_block1_plane_rows(const IndexView& ix, uint16_t* plane, uint32
 }
 
 size_t block1_scratch_bytes(uint32_t nq, uint32_t dim) {
-    const size_t S = exact_segments(nq < 256 ? nq : 256), kpad = (dim + 31u) & ~31u, kp = (dim + 63u) & ~63u, rows = ((size_t)nq + 255) / 256 * 256;
-    return (size_t)kExactQB * kExactCH * 4 + (size_t)256 * S * kP1C * 8 + (size_t)256 * S * 4 + (size_t)nq * (4 * 5) + (size_t)nq * kpad * 4 +
-           rows * kp * 2 + (size_t)nq * kP1C * 16 + 8192;
+    const size_t kpad = (dim + 31u) & ~31u, kp = (dim + 63u) & ~63u, rows = ((size_t)nq + 255) / 256 * 256;
+    return (size_t)256 * kBlockCandCap * 8 + 256 * 8 + (size_t)nq * (4 * 5) + (size_t)nq * kpad * 4 + rows * kp * 2 + (size_t)nq * kP1C * 16 + 8192;
 }
 
 // d_uncertified: one zeroed word; non-zero after the stream has drained => run the split-bf16 / f32 path instead.
-// plane: block1_plane_rows(slots) x block1_plane_k(ix) bf16.  rho: see p1_plane_rows_kernel.  max_row_norm: inner product only.
+// plane: block1_plane_rows(slots) x block1_plane_k(ix) bf16, tile-major.  rho: see p1_plane_rows_kernel.  max_row_norm: inner product only.
 hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_t* plane, float rho, float max_row_norm,
                                 uint32_t* d_uncertified, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
-    if (!block1_supported(a.ix, a.k) || a.slots < kP1FirstRows) return hipErrorInvalidValue;
+    if (!block1_supported(a.ix, a.k) || a.slots < (1u << 16)) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
-        if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         attr_set = true;
     }
@@ -1407,7 +1408,6 @@ hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t kpad = (a.ix.dim + 31u) & ~31u, kp = block1_plane_k(a.ix), C = kP1C;
-    const uint32_t S = exact_segments(a.nq < 256 ? a.nq : 256);
     const uint32_t rows_pad = (a.nq + 255u) / 256u * 256u;
     char* p = (char*)scratch;
     auto take = [&](size_t bytes) {
@@ -1415,10 +1415,9 @@ hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_
         p += (bytes + 255) & ~(size_t)255;
         return r;
     };
-    float* D = (float*)take((size_t)kExactQB * kExactCH * 4);
-    float* st_d = (float*)take((size_t)256 * S * C * 4);
-    uint32_t* st_s = (uint32_t*)take((size_t)256 * S * C * 4);
-    uint32_t* st_n = (uint32_t*)take((size_t)256 * S * 4);
+    uint2* cand = (uint2*)take((size_t)256 * kBlockCandCap * 8);
+    uint32_t* cand_cnt = (uint32_t*)take((size_t)256 * 4);
+    float* thr = (float*)take((size_t)256 * 4);
     float* q_aux = (float*)take((size_t)a.nq * 4);
     float* a_norm = (float*)take((size_t)a.nq * 4);
     float* r_q = (float*)take((size_t)a.nq * 4);
@@ -1433,47 +1432,37 @@ hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_
     if (e != hipSuccess) return e;
     const int cosine = a.ix.metric == COS ? 1 : 0;
     hipLaunchKernelGGL(p1_round_queries_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, s, qd, q_aux, cosine, a.nq, rows_pad, kpad, kp, A, a_norm, r_q);
+    // eps_q: bound of |approximate - exact| score: the band of the thresholds (block_merge_kernel) and the certificate of
+    // block_final_kernel (instead of the split-bf16 bound)
+    hipLaunchKernelGGL(p1_eps_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a.nq, q_aux, a_norm, r_q, rho, cosine ? 1.f : max_row_norm,
+                       (float)((a.ix.dim + 63u) & ~63u), cosine, eps_q, d_uncertified);
+    e = hipMemsetAsync(cand_found, 0, (size_t)a.nq * 4, s);  // the nominee lists start empty
+    if (e != hipSuccess) return e;
     const float* row_scale = cosine ? a.ix.aux : nullptr;
-    // the select / merge kernels index their per-query state by (q0 + local query) with q0 = 0 per 256-query block here
-    uint2* cand = reinterpret_cast<uint2*>(D);
-    uint32_t* cand_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(D) + (size_t)256 * kBlockCandCap * 8);
-    float* thr = reinterpret_cast<float*>(cand_cnt + 256);
     for (uint32_t q0 = 0; q0 < a.nq; q0 += 256) {
         const uint32_t nqb = a.nq - q0 < 256u ? a.nq - q0 : 256u;
         const uint16_t* Aq = A + (size_t)q0 * kp;  // (tile-major: query block q0 / 256 starts at row q0)
-        // first launch: every score of the first rows through D and the segmented select pass -> nominee lists (cand_*), thresholds
-        const uint32_t n1 = a.slots < kP1FirstRows ? a.slots : kP1FirstRows;
-        hipLaunchKernelGGL((p1_tile_kernel<true>), dim3((n1 + kP1TN - 1) / kP1TN), dim3(512), kP1LdsBytes, s, Aq, plane, kp, nqb, 0u, n1, (const float*)nullptr,
-                           row_scale, D, cand, cand_cnt, (uint32_t)kBlockCandCap);
-        hipLaunchKernelGGL(exact_select_kernel, dim3(nqb, S), dim3(64), 0, s, a.ix, D, 0u, 0u, n1, C, 1, 1, st_d, st_s, st_n, cand_slot + (size_t)q0 * C,
-                           cand_approx + (size_t)q0 * C, cand_found + q0, 1);
-        if (S > 1)
-            hipLaunchKernelGGL(exact_finish_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, S, C, st_d, st_s, st_n, cand_slot + (size_t)q0 * C,
-                               cand_approx + (size_t)q0 * C, cand_found + q0, 1);
-        if (n1 < a.slots) {
-            e = hipMemsetAsync(cand_cnt, 0, (size_t)256 * 4, s);  // D is free from here on: the candidate buffers live there
-            if (e != hipSuccess) return e;
-            // an empty merge publishes each query's first threshold (the worst score on its list, +inf while the list is short)
-            hipLaunchKernelGGL(block_merge_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
-                               cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified);
-        }
-        // the rest in chunks that grow 8 x: the thresholds are refreshed between them (C ln 8 ~ 530 candidates per query and chunk
-        // when the rows come in no particular order; a buffer that overflows raises `uncertified`)
-        for (uint32_t n0 = n1; n0 < a.slots;) {
-            const uint64_t want = (uint64_t)n0 * 8u;
+        e = hipMemsetAsync(cand_cnt, 0, (size_t)256 * 4, s);
+        if (e != hipSuccess) return e;
+        // Every chunk of rows goes through the same thresholded tile kernel; a merge after each refreshes the thresholds (the
+        // worst score on a full nominee list, or -- far tighter -- the k-th best so far + 2 eps).  The first chunk is ONE tile:
+        // no thresholds yet, all of its 256 scores per query are passed on.  Chunks grow 16 x: k ln 16 ~ 28 rows per query
+        // and chunk beat the k-th best so far when the rows come in no particular order; a buffer that overflows (rows stored
+        // best-last) raises `uncertified` and the batch goes to the split-bf16 / f32 paths.
+        hipLaunchKernelGGL(block_merge_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
+                           cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);  // empty lists: thr = +inf
+        for (uint32_t n0 = 0; n0 < a.slots;) {
+            const uint64_t want = n0 ? (uint64_t)n0 * 16u : (uint64_t)kP1TN;
             const uint32_t nend = want >= a.slots ? a.slots : (uint32_t)want;
             const uint32_t tiles = (nend - n0 + kP1TN - 1) / kP1TN;
             const uint32_t grid = tiles < (uint32_t)cus ? tiles : (uint32_t)cus;
             hipLaunchKernelGGL((p1_tile_kernel<false>), dim3(grid), dim3(512), kP1LdsBytes, s, Aq, plane, kp, nqb, n0, nend, thr, row_scale, (float*)nullptr, cand,
                                cand_cnt, (uint32_t)kBlockCandCap);
             hipLaunchKernelGGL(block_merge_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
-                               cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified);
+                               cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);
             n0 = nend;
         }
     }
-    // eps_q: bound of |approximate - exact| score; the certificate of block_final_kernel uses it instead of the split-bf16 bound
-    hipLaunchKernelGGL(p1_eps_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a.nq, q_aux, a_norm, r_q, rho, cosine ? 1.f : max_row_norm,
-                       (float)((a.ix.dim + 63u) & ~63u), cosine, eps_q, d_uncertified);
     hipLaunchKernelGGL(block_rescore_kernel, dim3(a.nq, C / 4), dim3(256), 0, s, a.ix, qd, kpad, q_aux, C, cand_slot, cand_found, exact_d);
     hipLaunchKernelGGL(block_final_kernel, dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, a_norm, max_row_norm,
                        a.out_keys, a.out_dist, a.out_found, d_uncertified, (const float*)eps_q);

@@ -66,6 +66,13 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 // EPI: bit 0 epilogue on (off: timing aid), bit 1 B loads non-temporal, bit 2 no B loads (A path alone), bit 3 no A loads (B path alone),
 // bit 4: B (and A) stored TILE-MAJOR in LDS image order -- a stage is ONE contiguous block of memory (timing only: the probe's
 // data is random, so the values are not re-laid out and the check is skipped).
+// bit 6 (64): no MFMAs / fragment reads at all (pure streaming through the ring: what the load structure alone sustains);
+// bit 7 (128): every workgroup starts its K loop at a different step (ks0 = blockIdx mod KSTEPS) -- breaks the lockstep in which all
+// CUs read the same offset of their tiles; bits 12.. : (EPI >> 12) * 256 bytes of padding between the tiles of B;
+// bit 9 (512): STAGGERED loaders (RA == RB >= 3): waves 0..NW/2-1 issue their LDS-DMA at the top of a step, waves NW/2.. (the
+// other wave of each SIMD) after the step's MFMAs, so that on every SIMD one wave's VMEM issue runs under the other's MFMAs;
+// bit 8 (256): software-pipelined fragment reads (16x16x32 only): the A fragment of MFMA group i + 1 is read while group i multiplies,
+// pinned with sched_barrier, instead of the compiler's read -> wait -> multiply groups.
 // bit 5: B through REGISTERS (global_load_dwordx4 nt -> ds_write_b128 after the step's MFMAs) instead of LDS-DMA; needs bit 4, RA == RB == 2.
 template <int TN, int BK, int RA, int RB, int SHAPE, int WM, int EPI, bool WRITE_D>
 __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM))) void tile_ring_kernel(
@@ -111,7 +118,8 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
     const char* Bb = reinterpret_cast<const char*>(B);
     auto stage_a = [&](uint32_t sg) {
         char* base = lds + (sg % RA) * A_BYTES;
-        const char* at = Ab + ((EPI & 16) ? (size_t)(sg % KSTEPS) * A_BYTES : (size_t)(sg % KSTEPS) * (BK * 2));
+        const uint32_t ksa = (EPI & 128) ? (sg + blockIdx.x) % KSTEPS : sg % KSTEPS;
+        const char* at = Ab + ((EPI & 16) ? (size_t)ksa * A_BYTES : (size_t)ksa * (BK * 2));
 #pragma unroll
         for (int i = 0; i < A_PW; ++i)
             if constexpr (!(EPI & 8)) glds16(at + a_off[i], base + (la * A_PW + i) * 1024);
@@ -130,8 +138,10 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
     };
     auto stage_b = [&](uint32_t sg, uint32_t tile) {
         char* base = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
-        const char* bt = (EPI & 16) ? Bb + ((size_t)tile * KSTEPS + (sg % KSTEPS)) * B_BYTES
-                                    : Bb + (size_t)tile * TN * (kK * 2) + (sg % KSTEPS) * (BK * 2);  // wave-uniform
+        constexpr size_t PAD = (size_t)(EPI >> 12) * 256;
+        const uint32_t ksr = (EPI & 128) ? (sg + blockIdx.x) % KSTEPS : sg % KSTEPS;
+        const char* bt = (EPI & 16) ? Bb + (size_t)tile * (KSTEPS * B_BYTES + PAD) + (size_t)ksr * B_BYTES
+                                    : Bb + (size_t)tile * TN * (kK * 2) + ksr * (BK * 2);  // wave-uniform
 #pragma unroll
         for (int i = 0; i < B_PW; ++i)
             if constexpr (!(EPI & 4)) glds16<(EPI & 2) ? 2 : 0>(bt + b_off[i], base + (lb * B_PW + i) * 1024);
@@ -182,14 +192,43 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();  // everyone's pieces of stage sg are in LDS; everyone has finished reading stage sg - 1
             asm volatile("" ::: "memory");
-            if (loads_a && sg + RA - 1 < total) stage_a(sg + RA - 1);
+            const bool late = (EPI & 512) && w >= (uint32_t)(NW / 2);
+            if (!late && loads_a && sg + RA - 1 < total) stage_a(sg + RA - 1);
             if constexpr (EPI & 32) {
                 if (sg + 1 < total) load_b_regs(sg + 1, tile_of(sg + 1));
-            } else if (loads_b && sg + RB - 1 < total) stage_b(sg + RB - 1, tile_of(sg + RB - 1));
+            } else if (!late && loads_b && sg + RB - 1 < total) stage_b(sg + RB - 1, tile_of(sg + RB - 1));
             const char* base = lds + (sg % RA) * A_BYTES;
             const char* bbase = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
+            if constexpr ((EPI & 256) && SHAPE == 16) {
+                // all B fragments of the step up front (NT per k sub-step), then A fragment i + 1 under the MFMAs of fragment i
+                constexpr int KS = BK / KSUB;
+                bf16x8 fb[KS][NT];
+                auto a_frag = [&](int kk, int i) {
+                    const uint32_t row = wm * WROWS + i * FR + frow, kc = kk * (KSUB / 8) + fk;
+                    return *reinterpret_cast<const bf16x8*>(base + row * (BK * 2) + ((kc ^ swz<BK, SHAPE>(row)) % CH) * 16);
+                };
 #pragma unroll
-            for (int kk = 0; kk < BK / KSUB; ++kk) {
+                for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const uint32_t row = wn * WN + j * FR + frow, kc = kk * (KSUB / 8) + fk;
+                        fb[kk][j] = *reinterpret_cast<const bf16x8*>(bbase + row * (BK * 2) + ((kc ^ swz<BK, SHAPE>(row)) % CH) * 16);
+                    }
+                bf16x8 fa_cur = a_frag(0, 0);
+#pragma unroll
+                for (int g = 0; g < KS * MT; ++g) {
+                    const int kk = g / MT, i = g % MT;
+                    bf16x8 fa_next = fa_cur;
+                    if (g + 1 < KS * MT) fa_next = a_frag((g + 1) / MT, (g + 1) % MT);
+                    __builtin_amdgcn_sched_barrier(0);  // the read of the NEXT fragment stays in front of this group's MFMAs
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_cur, fb[kk][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fa_cur = fa_next;
+                }
+            } else
+#pragma unroll
+            for (int kk = 0; kk < ((EPI & 64) ? 0 : BK / KSUB); ++kk) {
                 bf16x8 fa[MT], fb[NT];
                 const uint32_t kc = kk * (KSUB / 8) + fk;
 #pragma unroll
@@ -210,6 +249,13 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM, WM
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
                     }
                 if constexpr (BK / KSUB > 2) __builtin_amdgcn_sched_barrier(0);  // keeps the fragment registers of one sub-step live at a time
+            }
+            if constexpr ((EPI & 512) != 0) {
+                if (late) {
+                    __builtin_amdgcn_sched_barrier(0);  // behind the step's MFMAs
+                    if (loads_a && sg + RA - 1 < total) stage_a(sg + RA - 1);
+                    if (loads_b && sg + RB - 1 < total) stage_b(sg + RB - 1, tile_of(sg + RB - 1));
+                }
             }
             if constexpr (EPI & 32) {
                 if (sg + 1 < total) {
@@ -401,7 +447,7 @@ int main(int argc, char** argv) {
     for (auto& v : c.hA) v = bf16_rn(nd(g) / sqrtf((float)kK));
     for (auto& v : c.hB) v = bf16_rn(nd(g) / sqrtf((float)kK));
     HIP_OK(hipMalloc(&c.dA, c.hA.size() * 2));
-    HIP_OK(hipMalloc(&c.dB, (size_t)c.rows * kK * 2));
+    HIP_OK(hipMalloc(&c.dB, (size_t)c.rows * kK * 2 + ((size_t)c.rows / 256 + 1) * 65536));
     HIP_OK(hipMalloc(&c.dThr, 1024));
     HIP_OK(hipMalloc(&c.dD, (size_t)256 * c.d_rows * 4));
     HIP_OK(hipMalloc(&c.dCand, (size_t)256 * 4096 * 8));
@@ -418,11 +464,14 @@ int main(int argc, char** argv) {
         HIP_OK(hipMemcpy(c.dB, c.hB.data(), small * 2, hipMemcpyHostToDevice));
     }
     run_variant<256, 64, 2, 2, 16, 2, 19>(c, "tile-major + B nt (ref)");
-    run_variant<256, 64, 2, 2, 16, 2, 49>(c, "tile-major, B via registers");
-    run_variant<256, 64, 2, 2, 16, 2, 57>(c, "tile-major, B via registers, no A loads");
-    run_variant<256, 64, 2, 2, 16, 4, 49>(c, "tile-major, B via registers, 16 waves");
-    run_variant<256, 64, 2, 2, 32, 2, 49>(c, "tile-major, B via registers, 32x32");
-    run_variant<256, 64, 2, 2, 16, 2, 48>(c, "tile-major, B via registers, no epilogue");
+    run_variant<256, 32, 3, 3, 16, 2, 19>(c, "BK32 ring3");
+    run_variant<256, 32, 3, 3, 16, 2, 19 + 512>(c, "BK32 ring3 staggered");
+    run_variant<256, 32, 4, 4, 16, 2, 19 + 512>(c, "BK32 ring4 staggered");
+    run_variant<256, 32, 4, 4, 16, 2, 19 + 512 + 256>(c, "BK32 ring4 staggered + pipelined reads");
+    run_variant<256, 32, 3, 3, 16, 2, 19 + 512 + 256>(c, "BK32 ring3 staggered + pipelined reads");
+    run_variant<256, 32, 4, 4, 16, 2, 18 + 512 + 256>(c, "BK32 ring4 stag + pipe, no epilogue");
+    run_variant<256, 32, 4, 4, 32, 2, 19 + 512>(c, "BK32 ring4 staggered 32x32");
+    run_variant<256, 32, 4, 4, 16, 2, 13 + 256>(c, "BK32 no loads + pipelined reads");
     run_variant<256, 64, 2, 2, 16, 2, 19>(c, "tile-major + B nt (ref again)");
     return 0;
 }

@@ -1114,6 +1114,7 @@ hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_
 // Measured structure and variants: scripts/probe/tile1_probe.hip.
 constexpr int kP1TN = 256, kP1BK = 64, kP1RA = 2, kP1RB = 2;
 constexpr uint32_t kP1C = 256;            // nominees per query
+constexpr uint32_t kP1FirstRows = 1024;   // rows whose scores are all kept (4 tiles), <= kBlockCandCap
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ uint32_t p1_swz(uint32_t row) { return (row >> 1) & 7u; }
@@ -1202,8 +1203,9 @@ __global__ void p1_eps_kernel(uint32_t nq, const float* q_aux, const float* a_no
 }
 
 // Scores of queries [0, 256) of A against plane rows [n_begin, n_end) (n_begin a multiple of 256; the plane is padded to
-// whole tiles).  WRITE_D: every score (as a distance 1 - s) into D[q][n - n_begin] (the first launch: kExactCH columns);
-// else: scores at or above 1 - thr[q] are appended to cand[q] as (distance bits, slot).  row_scale: cosine: 1 / |row| (aux).
+// whole tiles).  FIRST (the first rows of a search, no thresholds yet): EVERY score goes to cand[q][n - n_begin] as (distance
+// bits, slot) by plain stores -- the host sets cand_cnt[q] = n_end - n_begin; else: scores at or above 1 - thr[q] are appended
+// to cand[q] (atomic counter).  row_scale: cosine: 1 / |row| (aux).
 template <bool WRITE_D>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void p1_tile_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint32_t kp, uint32_t nq_blk, uint32_t n_begin, uint32_t n_end,
@@ -1332,7 +1334,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int r = 0; r < ACC; ++r) {
                         const uint32_t q = wm * WROWS + i * FR + 4 * fk + r;
-                        if (n < n_end && q < nq_blk) D[(size_t)q * kExactCH + (n - n_begin)] = 1.0f - acc[i][j][r] * rs[j];
+                        if (n < n_end && q < nq_blk) cand[(size_t)q * cand_cap + (n - n_begin)] = make_uint2(__float_as_uint(1.0f - acc[i][j][r] * rs[j]), n);
                     }
                 }
         } else {
@@ -1400,7 +1402,9 @@ hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_
     if (!block1_supported(a.ix, a.k) || a.slots < (1u << 16)) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
+        if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         attr_set = true;
     }
@@ -1442,17 +1446,20 @@ hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_
     for (uint32_t q0 = 0; q0 < a.nq; q0 += 256) {
         const uint32_t nqb = a.nq - q0 < 256u ? a.nq - q0 : 256u;
         const uint16_t* Aq = A + (size_t)q0 * kp;  // (tile-major: query block q0 / 256 starts at row q0)
-        e = hipMemsetAsync(cand_cnt, 0, (size_t)256 * 4, s);
+        // The first kP1FirstRows rows: no thresholds yet, every score is stored (plain stores, no atomics) and one merge per query
+        // builds the first nominee list.  Then chunks that grow 32 x, each followed by a merge that refreshes the thresholds (the
+        // worst score on a full nominee list, or -- far tighter -- the k-th best so far + 2 eps): about k (32 - 1) rows per query
+        // and chunk beat the threshold when the rows come in no particular order; a buffer that overflows (rows stored best-last)
+        // raises `uncertified` and the batch goes to the split-bf16 / f32 paths.
+        const uint32_t n1 = a.slots < kP1FirstRows ? a.slots : kP1FirstRows;
+        hipLaunchKernelGGL((p1_tile_kernel<true>), dim3((n1 + kP1TN - 1) / kP1TN), dim3(512), kP1LdsBytes, s, Aq, plane, kp, nqb, 0u, n1, (const float*)nullptr, row_scale,
+                           (float*)nullptr, cand, cand_cnt, (uint32_t)kBlockCandCap);
+        e = hipMemsetD32Async((hipDeviceptr_t)cand_cnt, (int)n1, 256, s);
         if (e != hipSuccess) return e;
-        // Every chunk of rows goes through the same thresholded tile kernel; a merge after each refreshes the thresholds (the
-        // worst score on a full nominee list, or -- far tighter -- the k-th best so far + 2 eps).  The first chunk is ONE tile:
-        // no thresholds yet, all of its 256 scores per query are passed on.  Chunks grow 16 x: k ln 16 ~ 28 rows per query
-        // and chunk beat the k-th best so far when the rows come in no particular order; a buffer that overflows (rows stored
-        // best-last) raises `uncertified` and the batch goes to the split-bf16 / f32 paths.
         hipLaunchKernelGGL(block_merge_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
-                           cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);  // empty lists: thr = +inf
-        for (uint32_t n0 = 0; n0 < a.slots;) {
-            const uint64_t want = n0 ? (uint64_t)n0 * 16u : (uint64_t)kP1TN;
+                           cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);
+        for (uint32_t n0 = n1; n0 < a.slots;) {
+            const uint64_t want = (uint64_t)n0 * 32u;
             const uint32_t nend = want >= a.slots ? a.slots : (uint32_t)want;
             const uint32_t tiles = (nend - n0 + kP1TN - 1) / kP1TN;
             const uint32_t grid = tiles < (uint32_t)cus ? tiles : (uint32_t)cus;

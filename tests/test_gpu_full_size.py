@@ -26,12 +26,37 @@ def _setup(n, ef, dim=768, metric="cos"):
     return vs, torch, ix, base, q
 
 
+def _oracle_parity(ix, qh, keys, dist, k, ef, exact=False, rows=1000):
+    """Round 3: ids against the CPU restatement AT FULL SIZE (not only properties): the oracle imports the GPU-built graph
+    (vectors exported straight into its arena) and searches the same queries; every position is compared with the bar of
+    tests/parity_util.py (a differing id only where the oracle's own two distances are an f32 near-tie).  Skipped when the
+    host cannot hold the vectors."""
+    import psutil
+
+    import oracle
+    from tests.parity_util import count_parity
+    slots = ix.graph_info()["slots"]
+    need = slots * ix.bytes_per_vector()
+    if psutil.virtual_memory().available < need * 1.3 + (8 << 30):
+        return None
+    o = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef, quantization=ix.scalar)
+    o.reserve(slots)
+    o.import_graph(ix.export_graph(vectors_out=o.vector_arena(slots)))
+    o.set_expansion_search(ef)
+    ok_, od_, of_ = o.search_batch(qh[:rows], k, threads=16)
+    rep = count_parity(keys[:rows], dist[:rows], ok_, od_, of_, lambda qi, key: o.distance_to_slot(qh[qi], int(key)), exact=exact)
+    assert rep["violations"] == 0, rep
+    assert rep["identical_rows"] >= rows * 0.98, rep  # near-ties are rare events
+    return rep
+
+
 def _check(n, ef, dim=768, metric="cos"):
     vs, torch, ix, base, q = _setup(n, ef, dim, metric)
     k = 10
     assert ix.size() == n
     qh = q.cpu().numpy()
     keys, dist, found = ix.search_batch(qh, k)
+    _oracle_parity(ix, qh, keys, dist, k, ef)
     # sorted, complete, duplicate-free, in range
     assert (found == k).all()
     assert (np.diff(dist, axis=1) >= 0).all()
@@ -97,6 +122,32 @@ def test_configs2_10m_x_1536_l2():
     _check(10_000_000, 320, dim=1536, metric="l2sq")
 
 
+@pytest.mark.parametrize("kind,ef", [("i8", 208), ("b1", 280)])
+def test_headline_size_integer_storage_walk_ids_equal_the_oracle(kind, ef):
+    """10M x 768 with i8 / b1 storage (the usearch-order walk serves these): ids and distance bits identical to the CPU
+    restatement's on the same graph, 1,000 queries -- at the headline size, where round 2 only checked properties."""
+    import torch
+
+    import vector_store_amd as vs
+    from bench import make_data
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2**30:
+        pytest.skip("needs 100 GiB of free HBM")
+    n, dim, k = 10_000_000, 768, 10
+    dev = torch.device("cuda:0")
+    base = make_data(n, dim, "lowrank", 1234, dev, 24)
+    qh = make_data(1000, dim, "lowrank", 4321, dev, 24).cpu().numpy()
+    ix = vs.HipUsearchIndex(dim, vs.COS, expansion_search=ef, quantization=vs.SCALARS[kind])
+    ix.reserve(n)
+    ix.add_batch_device(np.arange(n, dtype=np.uint64), base.data_ptr(), n, dim)
+    del base
+    torch.cuda.empty_cache()
+    keys, dist, found = ix.search_batch(qh, k)
+    assert (found == k).all()
+    rep = _oracle_parity(ix, qh, keys, dist, k, ef, exact=True)
+    assert rep is not None and rep["identical_rows"] == 1000, rep
+
+
 def test_configs4_batched_q256_10m_x_768_inner_product():
     """BASELINE configs[4]: batches of q = 256 over 10M x 768 inner product: the MFMA block-distance path (exact) against the
     graph walk on the same index -- the walk reaches the recall the metric is quoted at, its distances are the exact
@@ -120,6 +171,8 @@ def test_configs4_batched_q256_10m_x_768_inner_product():
     assert recall >= 0.95, recall
     same = wk[:, 0] == tk2[:, 0]
     assert same.mean() > 0.9 and np.allclose(wd[same, 0], td2[same, 0], rtol=1e-5, atol=1e-5)
+    st = ix.exact_stats()  # round 3: the one-product pass over the bf16 plane served every batch, none was handed on
+    assert st["plane_batches"] >= 2 and st["plane_fallbacks"] == 0
 
 
 def test_one_index_beyond_2_pow_26_members():

@@ -440,10 +440,18 @@ struct SelArrays<false> {};
 // TEAM > 1: a workgroup of TEAM waves serves ONE query (small batches, where most of the chip would idle):
 // wave 0 walks the graph, all waves evaluate each hop's neighbour batch.  team_m is the mailbox.
 constexpr uint32_t kTeamExit = 0xFFFFFFFFu;
+constexpr uint32_t kTeamSpec = 0xFFFFFFFEu;  // team_q: the batch is e_slot[0 .. team_m) -> e_dist (beam_search_spec), not u_slot
 template <int TM>
 struct TeamBox {
     uint32_t team_m;
-    uint32_t team_q;  // kInvalid: distances from the walker's own query to u_slot[]; else from stored row team_q to sel_s[] (refine)
+    uint32_t team_q;  // kInvalid: distances from the walker's own query to u_slot[]; kTeamSpec: to e_slot[]; else from stored row team_q to sel_s[] (refine)
+    // Speculative evaluation (beam_search_spec, lone queries): while the walker merges hop h, the helper waves already measure
+    // the unvisited neighbours of the runner-up; when that node is indeed expanded next its distances are waiting.
+    uint32_t team_async;   // 1: the walker does not take part in this batch (it goes on with its merge and joins the barrier later)
+    uint32_t e_slot[128];  // a batch: [the hop's own fresh neighbours | the runner-up's unvisited neighbours]
+    float e_dist[128];
+    uint32_t spec_slot[64];  // the runner-up's unvisited neighbours as of the last hop, in adjacency order, and their distances
+    float spec_dist[64];
 };
 template <>
 struct TeamBox<1> {};
@@ -556,7 +564,12 @@ __device__ __forceinline__ void team_helper_loop(const IndexView& ix, const Quer
             const uint32_t* list = qs == kInvalid ? sh.u_slot : sh.sel_s;
             if (mine) eval_batch<AR, I, Sh::kTeam>(ix, use, list, sh.u_dist, m, lane, w);
         } else {
-            eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, w);
+            if (sh.team_q == kTeamSpec) {
+                if (sh.team_async) eval_batch<AR, I, Sh::kTeam - 1, Sh::kNT>(ix, q, sh.e_slot, sh.e_dist, m, lane, w - 1u);  // the walker is busy merging
+                else eval_batch<AR, I, Sh::kTeam, Sh::kNT>(ix, q, sh.e_slot, sh.e_dist, m, lane, w);
+            } else {
+                eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, w);
+            }
         }
         __syncthreads();
     }
@@ -667,6 +680,33 @@ __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
     // results never contain duplicates and no node is ever lost -- only evaluations are repeated.
     sh.overflowed = 1;
     return false;
+}
+
+// The lookup half of visited_test_and_set: is `slot` in the set?  Nothing is inserted (speculative evaluation must not mark).
+template <class Sh>
+__device__ __forceinline__ bool visited_contains(const Sh& sh, uint32_t slot) {
+    constexpr int NB = Sh::kNB, CH = Sh::kChoices;
+    using C = VisitedCfg<NB, CH, Sh::kWideTags>;
+    const uint32_t m = (slot * 0x9E3779B1u) & C::domain_mask;
+    const uint32_t b1 = m >> (C::tag_bits + C::hi_bits);
+    const uint32_t tag = m & ((1u << C::tag_bits) - 1u);
+    const uint32_t hi = (m >> C::tag_bits) & ((1u << C::hi_bits) - 1u);
+    const uint32_t c1 = (sh.vis_cnt[b1 >> 2] >> ((b1 & 3u) * 8u)) & 0xFFu;
+    bool found = bucket_has(sh, b1, c1, tag, hi);
+    if (CH == 2) {
+        const uint32_t alt = ((tag * 0x5BD1u) >> 3) & (uint32_t)(NB - 1);
+        const uint32_t b2 = b1 ^ alt;
+        if (b2 != b1) {
+            const uint32_t c2 = (sh.vis_cnt[b2 >> 2] >> ((b2 & 3u) * 8u)) & 0xFFu;
+            found |= bucket_has(sh, b2, c2, tag | 0x8000u, hi);
+        }
+    }
+    if (!found) {
+        constexpr uint32_t ovf_cap = Sh::kOvfCap;
+        const uint32_t oc = sh.ovf_cnt < ovf_cap ? sh.ovf_cnt : ovf_cap;
+        for (uint32_t j = 0; j < oc; ++j) found |= sh.vis_ovf[j] == slot;
+    }
+    return found;
 }
 
 __device__ __forceinline__ const uint32_t* adjacency(const IndexView& ix, uint32_t slot, int level, uint32_t& cap) {
@@ -936,6 +976,219 @@ __device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>&
             live = sz;
         }
     }
+    if (sh.overflowed) cnt.overflow += 1;
+    out_cur = cur;
+    return sz;
+}
+
+// beam_search for a TEAM serving ONE query (lone callers: the reference issues one query per FFI call), with SPECULATIVE
+// evaluation.  A lone walk is a chain of dependent hops, each an HBM round trip (5 us at 10M x 768); bandwidth is free at this
+// load, so while hop h is merged the helper waves already measure the unvisited neighbours of the RUNNER-UP (whose adjacency
+// row was prefetched one hop earlier, like the runner-up's own row in beam_search).  When the runner-up is indeed expanded
+// next -- no closer candidate arrived -- its neighbours' distances are waiting and the hop costs a list merge instead of a
+// round trip.  Every decision is the walker's and is taken exactly as in beam_search: speculation only measures (the visited
+// set is consulted, never marked), the real test-and-set happens when the node is popped, and since nothing is marked in
+// between, the fresh neighbours then ARE the speculated list, in the same order; distances come from the same eval_batch code.
+// Same ids, same distance bits, same evaluation and hop counts (tests/test_gpu_team.py).
+template <int AR, int I, class Sh>
+__device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR, I>& q, uint32_t start, uint32_t ef, Counters& cnt, int lane,
+                                     int& out_cur, bool tomb) {
+    static_assert(Sh::kTeam > 1 && !Sh::kSel, "team search kernels only");
+    constexpr int EFCAP = Sh::kEfCap;
+    constexpr int level = 0;
+    visited_clear(sh, lane);
+    wsync<Sh>();
+    const int cur = 0;
+    uint32_t sz = 0, live = 0;
+    if (lane == 0) {
+        visited_test_and_set(sh, start);
+        sh.u_slot[0] = start;
+    }
+    wsync<Sh>();
+    eval_shared<AR, I>(ix, q, sh, 1, lane);
+    cnt.evals += 1;
+    {
+        const bool start_dead = tomb && ix.keys[start] == kFreeKey;
+        if (lane == 0) {
+            sh.lst_d[0][0] = sh.u_dist[0];
+            sh.lst_s[0][0] = start | (start_dead ? kDead : 0u);
+        }
+        sz = 1;
+        live = start_dead ? 0 : 1;
+    }
+    wsync<Sh>();
+    // adjacency rows of the second and third unexpanded candidates, one id per lane (prefetched a hop ahead)
+    uint32_t pfa_slot = kInvalid, pfa_n = kInvalid, pfb_slot = kInvalid, pfb_n = kInvalid;
+    uint32_t spec_src = kInvalid, spec_m = 0;  // whose unvisited neighbours sh.spec_slot / spec_dist hold
+    bool spec_pending = false;                 // an asynchronous batch is out: its closing barrier has not been joined yet
+    uint32_t pend_off = 0, pend_m = 0;         // where in e_dist its speculated part lies
+    auto collect = [&]() {                     // join the batch that is still out and take its speculated distances
+        if (spec_pending) {
+            __syncthreads();
+            spec_pending = false;
+        }
+        if (pend_m) {
+            if ((uint32_t)lane < pend_m) sh.spec_dist[lane] = sh.e_dist[pend_off + lane];
+            pend_m = 0;
+            wsync<Sh>();
+        }
+    };
+    for (;;) {
+        // the three closest unexpanded entries
+        int pick = -1, pick2 = -1, pick3 = -1;
+#pragma unroll
+        for (int r = 0; r < EFCAP / kWave; ++r) {
+            uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+            bool un = p < sz && !(sh.lst_s[cur][p] & kExpanded);
+            uint64_t mask = __ballot(un);
+            if (pick < 0 && mask) {
+                pick = r * kWave + (int)__builtin_ctzll(mask);
+                mask &= mask - 1;
+            }
+            if (pick >= 0 && pick2 < 0 && mask) {
+                pick2 = r * kWave + (int)__builtin_ctzll(mask);
+                mask &= mask - 1;
+            }
+            if (pick2 >= 0 && pick3 < 0 && mask) pick3 = r * kWave + (int)__builtin_ctzll(mask);
+        }
+        if (pick < 0) break;
+        const uint32_t c_entry = sh.lst_s[cur][pick];
+        const uint32_t c_slot = c_entry & kSlotMask;
+        const uint32_t c2_slot = pick2 >= 0 ? (sh.lst_s[cur][pick2] & kSlotMask) : kInvalid;
+        const uint32_t c3_slot = pick3 >= 0 ? (sh.lst_s[cur][pick3] & kSlotMask) : kInvalid;
+        wsync<Sh>();
+        if (lane == 0) sh.lst_s[cur][pick] = c_entry | kExpanded;
+        cnt.hops += 1;
+        uint32_t cap;
+        const uint32_t* row = adjacency(ix, c_slot, level, cap);
+        uint32_t n;
+        if (c_slot == pfa_slot) n = pfa_n;
+        else if (c_slot == pfb_slot) n = pfb_n;
+        else n = (uint32_t)lane < cap ? row[lane] : kInvalid;
+        // rows of the next two candidates: kept when already here, else on their way for the next hop
+        uint32_t n2 = kInvalid, n3 = kInvalid;
+        bool have2 = false;
+        if (c2_slot != kInvalid) {
+            if (c2_slot == pfa_slot) { n2 = pfa_n; have2 = true; }
+            else if (c2_slot == pfb_slot) { n2 = pfb_n; have2 = true; }
+            else {
+                uint32_t cap2;
+                const uint32_t* row2 = adjacency(ix, c2_slot, level, cap2);
+                n2 = (uint32_t)lane < cap2 ? row2[lane] : kInvalid;
+            }
+        }
+        if (c3_slot != kInvalid) {
+            if (c3_slot == pfa_slot) n3 = pfa_n;
+            else if (c3_slot == pfb_slot) n3 = pfb_n;
+            else {
+                uint32_t cap3;
+                const uint32_t* row3 = adjacency(ix, c3_slot, level, cap3);
+                n3 = (uint32_t)lane < cap3 ? row3[lane] : kInvalid;
+            }
+        }
+        pfa_slot = c2_slot;
+        pfa_n = n2;
+        pfb_slot = c3_slot;
+        pfb_n = n3;
+        collect();  // the speculated distances of the previous hop are in sh.spec_dist now
+        const bool fresh = n != kInvalid && !visited_test_and_set(sh, n);
+        const uint64_t fmask = __ballot(fresh);
+        const uint32_t m = (uint32_t)__popcll(fmask);
+        const bool hit = c_slot == spec_src && m == spec_m;  // (m == spec_m always holds then; kept as a guard)
+        if (fresh) sh.u_slot[mbcnt(fmask)] = n;
+        // next speculation: the runner-up's neighbours that are unvisited NOW (after this hop's marks)
+        uint32_t ms = 0;
+        uint64_t smask = 0;
+        if (have2) {
+            const bool sf = n2 != kInvalid && !visited_contains(sh, n2);
+            smask = __ballot(sf);
+            ms = (uint32_t)__popcll(smask);
+        }
+        wsync<Sh>();
+        if (hit && (uint32_t)lane < m) sh.u_dist[lane] = sh.spec_dist[lane];  // (u_slot[lane] == spec_slot[lane])
+        wsync<Sh>();
+        if (have2 && ((smask >> lane) & 1ull)) sh.spec_slot[mbcnt(smask)] = n2;
+        spec_src = have2 ? c2_slot : kInvalid;
+        spec_m = ms;
+        const uint32_t main_m = hit ? 0u : m;
+        if (main_m + ms) {
+            if (!hit && fresh) sh.e_slot[mbcnt(fmask)] = n;
+            if (have2 && ((smask >> lane) & 1ull)) sh.e_slot[main_m + mbcnt(smask)] = n2;
+            if (lane == 0) {
+                sh.team_m = main_m + ms;
+                sh.team_q = kTeamSpec;
+                sh.team_async = hit ? 1u : 0u;
+            }
+            __syncthreads();  // releases the helpers (team_helper_loop)
+            pend_off = main_m;
+            pend_m = ms;
+            if (!hit) {
+                eval_batch<AR, I, Sh::kTeam, Sh::kNT>(ix, q, sh.e_slot, sh.e_dist, main_m + ms, lane, 0);
+                __syncthreads();  // every wave's distances are in LDS
+                if ((uint32_t)lane < m) sh.u_dist[lane] = sh.e_dist[lane];
+                wsync<Sh>();
+            } else {
+                spec_pending = true;  // the helpers measure; the walker merges meanwhile and joins their barrier in collect()
+            }
+        }
+        if (m == 0) continue;
+        cnt.evals += m;
+        // ---- admission and merge: exactly beam_search's ----
+        float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
+        uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
+        bool admit = (uint32_t)lane < m;
+        if (tomb) {
+            if (admit && ix.keys[ns] == kFreeKey) ns |= kDead;
+            if (live >= ef) admit = admit && nd < sh.lst_d[cur][sz - 1];
+        } else if (sz + m > ef) {
+            if (sz == ef) admit = admit && nd < sh.lst_d[cur][ef - 1];
+        }
+        if (sh.overflowed) {  // wave-uniform; see visited_test_and_set: re-evaluated nodes are dropped here
+            uint32_t lo = 0, hi = admit ? sz : 0;
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (key_less_in(sh, sh.lst_d[cur][mid], sh.lst_s[cur][mid], nd, ns)) lo = mid + 1; else hi = mid;
+            }
+            if (admit && lo < sz && (sh.lst_s[cur][lo] & kSlotMask) == (ns & kSlotMask) && sh.lst_d[cur][lo] == nd) admit = false;
+        }
+        uint64_t amask = __ballot(admit);
+        uint32_t ma = (uint32_t)__popcll(amask);
+        if (ma == 0) continue;
+        wsync<Sh>();
+        if (admit) {
+            uint32_t r = mbcnt(amask);
+            sh.u_dist[r] = nd;
+            sh.u_slot[r] = ns;
+        }
+        wsync<Sh>();
+        nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
+        ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
+        sz = list_merge(sh, cur, sz, tomb ? (uint32_t)EFCAP : ef, nd, ns, ma, lane);
+        wsync<Sh>();
+        if (tomb) {  // cut after the ef-th live entry
+            uint32_t cum = 0, cut = sz;
+            bool found = false;
+#pragma unroll
+            for (int r = 0; r < EFCAP / kWave; ++r) {
+                uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
+                bool lv = p < sz && !(sh.lst_s[cur][p] & kDead);
+                uint64_t mask = __ballot(lv);
+                uint32_t c = (uint32_t)__popcll(mask);
+                if (!found && cum + c >= ef) {
+                    uint32_t need = ef - cum;
+                    for (uint32_t i = 1; i < need; ++i) mask &= mask - 1;
+                    cut = (uint32_t)r * kWave + (uint32_t)__builtin_ctzll(mask) + 1u;
+                    found = true;
+                }
+                cum += c;
+            }
+            live = found ? ef : cum;
+            sz = cut;
+        } else {
+            live = sz;
+        }
+    }
+    if (spec_pending) __syncthreads();  // the last batch's closing barrier
     if (sh.overflowed) cnt.overflow += 1;
     out_cur = cur;
     return sz;

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
     // usearch index_gt::search: search_for_one_ down to level 1, then the base-level beam.
     uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
     int cur = 0;
-    uint32_t sz = beam_search<AR, I>(ix, sh, q, start, 0, a.ef, kInvalid, cnt, lane, cur, a.has_removed != 0);
+    uint32_t sz;
+    if constexpr (TEAM > 1) sz = beam_search_spec<AR, I>(ix, sh, q, start, a.ef, cnt, lane, cur, a.has_removed != 0);  // lone queries: speculative evaluation
+    else sz = beam_search<AR, I>(ix, sh, q, start, 0, a.ef, kInvalid, cnt, lane, cur, a.has_removed != 0);
     team_release(sh, lane);
     wsync<Sh>();
     // top.sort_ascending(); top.shrink(wanted); removed members (free key) are never results.

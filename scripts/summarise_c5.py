@@ -14,7 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarise_profiles import kernel_sources_sha16  # noqa: E402
 
-KERNELS = ("block_dist_bf16x3_kernel", "block_merge_kernel", "exact_select_kernel", "exact_finish_kernel", "block_rescore_kernel", "block_final_kernel",
+KERNELS = ("p1_tile_kernel", "p1_plane_rows_kernel", "p1_round_queries_kernel", "block_dist_bf16x3_kernel", "block_merge_kernel", "exact_select_kernel", "exact_finish_kernel", "block_rescore_kernel", "block_final_kernel",
            "split_queries_kernel", "exact_dist_mfma_kernel")
 
 
@@ -36,6 +36,9 @@ def per_kernel(path, counter):
     for k, rs in rows.items():
         g = max(int(r["Grid_Size"]) for r in rs)
         rs = [r for r in rs if int(r["Grid_Size"]) == g]
+        if k == "p1_tile_kernel":  # persistent launches share one grid: keep the long ones (the last chunk of every batch)
+            longest = max(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs)
+            rs = [r for r in rs if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 0.6 * longest]
         out[k] = (len(rs), sum(float(r["Counter_Value"]) for r in rs) / len(rs),
                   sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / len(rs) / 1e6, g, int(rs[0]["Workgroup_Size"]))
     return out
@@ -89,6 +92,28 @@ def main():
                 _, busy, bms, _, _ = pmc["SQ_VALU_MFMA_BUSY_CYCLES"][k]
                 e["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = busy
                 e["expected_busy_cycles_32_per_mfma"] = mfma * 32
+                e["launch_ms_in_the_mfma_pass"] = bms
+        if k == "p1_tile_kernel" and "grid_threads" in e:
+            # the persistent launch with the largest grid that runs longest is the last chunk: rows [32^2 * 1024, N) of the plane
+            rows = a.vectors - 1048576 if a.vectors > 1048576 else a.vectors
+            kp = (a.dim + 63) // 64 * 64
+            e["rows_of_the_largest_launch"] = rows
+            e["mfma_instructions_per_launch"] = 256 * rows * kp // (16 * 16 * 32)   # v_mfma_f32_16x16x32_bf16, ONE product per score
+            e["bf16_flops_per_launch"] = 2 * 256 * rows * kp
+            e["algorithmic_bytes_per_launch"] = rows * kp * 2 + 256 * kp * 2          # the plane's rows once + the query block once
+            ms = max(e.get("launch_ms_in_the_pmc_pass", 0.0), 1e-9)
+            if k in pmc["FETCH_SIZE"]:
+                ms = pmc["FETCH_SIZE"][k][2]
+            e["achieved_bf16_TFLOPs"] = e["bf16_flops_per_launch"] / (ms * 1e-3) / 1e12
+            e["frac_of_2500_TFLOPs_dense_bf16"] = e["achieved_bf16_TFLOPs"] / 2500.0
+            e["achieved_hbm_TBps_algorithmic"] = e["algorithmic_bytes_per_launch"] / (ms * 1e-3) / 1e12
+            e["frac_of_8_TBps"] = e["achieved_hbm_TBps_algorithmic"] / 8.0
+            if "hbm_bytes_per_launch" in e:
+                e["ratio_traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"]
+            if k in pmc["SQ_VALU_MFMA_BUSY_CYCLES"]:
+                _, busy, bms, _, _ = pmc["SQ_VALU_MFMA_BUSY_CYCLES"][k]
+                e["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = busy
+                e["expected_busy_cycles_16_per_mfma"] = e["mfma_instructions_per_launch"] * 16
                 e["launch_ms_in_the_mfma_pass"] = bms
         rec["kernels"][k] = e
     json.dump(rec, open(os.path.join(a.out, f"{a.tag}_c5_kernels.json"), "w"), indent=1)

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--stats-dir")
     ap.add_argument("--fetch-dir")
     ap.add_argument("--write-dir")
+    ap.add_argument("--tcc-dir", help="a pass with --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum (one pass: four TCC slots)")
     ap.add_argument("--bench-json", help="JSON line of the bench run made under --stats-dir (workload string, algorithmic bytes)")
     ap.add_argument("--out", required=True)
     ap.add_argument("--tag", required=True)
@@ -99,6 +100,28 @@ def main():
                     rec["workload"] = b["config"]["workload"]
                     rec["algorithmic_bytes_per_launch"] = b["roofline"]["bytes_per_query"] * nq
                     rec["ratio_traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
+        # How much of the traffic is served by the XCDs' L2s and how much leaves them (MI355X_MICROARCH.md 'L2': hit rate =
+        # TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum); TCC_EA0_RDREQ = read requests on the L2's memory side, _DRAM = those that
+        # target HBM (behind the Infinity Cache, whose hits no counter of this list separates)
+        if a.tcc_dir:
+            cc = find(a.tcc_dir, "_counter_collection.csv")
+            tcc = {}
+            for name in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_sum"):
+                if not cc:
+                    break
+                _, rows = search_rows(cc, name)
+                rows = rows[-a.timed_launches:]
+                if rows:
+                    tcc[name] = sum(float(x["Counter_Value"]) for x in rows) / len(rows)
+            if len(tcc) == 4:
+                hit, miss = tcc["TCC_HIT_sum"], tcc["TCC_MISS_sum"]
+                rec["dram"] = {"counters_per_launch": tcc, "l2_hit_rate": hit / max(hit + miss, 1.0),
+                               "l2_requests_served_in_l2_frac": hit / max(hit + miss, 1.0),
+                               "memory_side_read_requests_to_dram_frac": tcc["TCC_EA0_RDREQ_DRAM_sum"] / max(tcc["TCC_EA0_RDREQ_sum"], 1.0),
+                               "bytes_beyond_l2_per_launch_64B_per_request_x2": tcc["TCC_EA0_RDREQ_sum"] * 64 * 2,
+                               "note": "L2 hits are served on the XCD; every memory-side read request (TCC_EA0_RDREQ, tallied at 64 B for 128-B requests on "
+                                       "gfx950: x2) leaves the XCD for the Infinity Cache / HBM; no counter of rocprofv3 -L separates Infinity-Cache hits from "
+                                       "HBM reads, so 'beyond L2' is the upper bound of the DRAM traffic"}
         rec["kernel_sources_sha16"] = kernel_sources_sha16()
         json.dump(rec, open(os.path.join(a.out, f"{a.tag}_traffic.json"), "w"), indent=1)
     # the other two hot kernels of the same run: the build's insert kernel (HBM-bound) and the exact path's MFMA tile kernel

@@ -1166,6 +1166,8 @@ struct Engine {
                  : (team_mode == 0 && on_device <= 3 * team_max_nq)               ? (uint32_t)kSearchTeamMid  // measured: 4 waves win up to ~800
                  : (team_mode == 3)                                               ? (uint32_t)kSearchTeamMid
                                                                                   : 1u;
+        static const bool no_spec = std::getenv("VS_HNSW_SPEC") && std::getenv("VS_HNSW_SPEC")[0] == '0';
+        if (no_spec && a.team > 1) a.team |= 0x100u;  // team kernels without speculative evaluation (A/B measurements)
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;

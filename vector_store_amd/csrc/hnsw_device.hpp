@@ -992,7 +992,7 @@ __device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>&
 // Same ids, same distance bits, same evaluation and hop counts (tests/test_gpu_team.py).
 template <int AR, int I, class Sh>
 __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR, I>& q, uint32_t start, uint32_t ef, Counters& cnt, int lane,
-                                     int& out_cur, bool tomb) {
+                                     int& out_cur, bool tomb, bool speculate = true) {
     static_assert(Sh::kTeam > 1 && !Sh::kSel, "team search kernels only");
     constexpr int EFCAP = Sh::kEfCap;
     constexpr int level = 0;
@@ -1021,6 +1021,13 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
     uint32_t pfa_slot = kInvalid, pfa_n = kInvalid, pfb_slot = kInvalid, pfb_n = kInvalid;
     uint32_t spec_src = kInvalid, spec_m = 0;  // whose unvisited neighbours sh.spec_slot / spec_dist hold
     bool spec_pending = false;                 // an asynchronous batch is out: its closing barrier has not been joined yet
+#ifdef VS_SPEC_DEBUG
+    uint32_t dbg_hits = 0, dbg_have2 = 0, dbg_hops = 0, dbg_wait = 0, dbg_m0 = 0;
+    uint64_t dbg_t_collect = 0, dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = __builtin_amdgcn_s_memtime();
+#define SPEC_STAMP(i) do { const uint64_t now__ = __builtin_amdgcn_s_memtime(); dbg_ph[i] += now__ - dbg_last; dbg_last = now__; } while (0)
+#else
+#define SPEC_STAMP(i) do {} while (0)
+#endif
     uint32_t pend_off = 0, pend_m = 0;         // where in e_dist its speculated part lies
     auto collect = [&]() {                     // join the batch that is still out and take its speculated distances
         if (spec_pending) {
@@ -1052,6 +1059,7 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
             if (pick2 >= 0 && pick3 < 0 && mask) pick3 = r * kWave + (int)__builtin_ctzll(mask);
         }
         if (pick < 0) break;
+        SPEC_STAMP(0);  // pick
         const uint32_t c_entry = sh.lst_s[cur][pick];
         const uint32_t c_slot = c_entry & kSlotMask;
         const uint32_t c2_slot = pick2 >= 0 ? (sh.lst_s[cur][pick2] & kSlotMask) : kInvalid;
@@ -1069,8 +1077,8 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
         uint32_t n2 = kInvalid, n3 = kInvalid;
         bool have2 = false;
         if (c2_slot != kInvalid) {
-            if (c2_slot == pfa_slot) { n2 = pfa_n; have2 = true; }
-            else if (c2_slot == pfb_slot) { n2 = pfb_n; have2 = true; }
+            if (c2_slot == pfa_slot) { n2 = pfa_n; have2 = speculate; }
+            else if (c2_slot == pfb_slot) { n2 = pfb_n; have2 = speculate; }
             else {
                 uint32_t cap2;
                 const uint32_t* row2 = adjacency(ix, c2_slot, level, cap2);
@@ -1090,11 +1098,26 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
         pfa_n = n2;
         pfb_slot = c3_slot;
         pfb_n = n3;
+        SPEC_STAMP(1);  // candidate, adjacency issue
+#ifdef VS_SPEC_DEBUG
+        const uint64_t t0__ = __builtin_amdgcn_s_memtime();
+        dbg_wait += spec_pending ? 1u : 0u;
+#endif
         collect();  // the speculated distances of the previous hop are in sh.spec_dist now
+#ifdef VS_SPEC_DEBUG
+        dbg_t_collect += __builtin_amdgcn_s_memtime() - t0__;
+#endif
         const bool fresh = n != kInvalid && !visited_test_and_set(sh, n);
         const uint64_t fmask = __ballot(fresh);
         const uint32_t m = (uint32_t)__popcll(fmask);
         const bool hit = c_slot == spec_src && m == spec_m;  // (m == spec_m always holds then; kept as a guard)
+#ifdef VS_SPEC_DEBUG
+        dbg_hops += 1;
+        dbg_hits += hit ? 1u : 0u;
+        dbg_have2 += have2 ? 1u : 0u;
+        dbg_m0 += m == 0 ? 1u : 0u;
+#endif
+        SPEC_STAMP(2);  // collect + visited test-and-set (waits for the adjacency row)
         if (fresh) sh.u_slot[mbcnt(fmask)] = n;
         // next speculation: the runner-up's neighbours that are unvisited NOW (after this hop's marks)
         uint32_t ms = 0;
@@ -1111,6 +1134,7 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
         spec_src = have2 ? c2_slot : kInvalid;
         spec_m = ms;
         const uint32_t main_m = hit ? 0u : m;
+        SPEC_STAMP(3);  // speculation list (visited_contains), compaction
         if (main_m + ms) {
             if (!hit && fresh) sh.e_slot[mbcnt(fmask)] = n;
             if (have2 && ((smask >> lane) & 1ull)) sh.e_slot[main_m + mbcnt(smask)] = n2;
@@ -1131,6 +1155,7 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
                 spec_pending = true;  // the helpers measure; the walker merges meanwhile and joins their barrier in collect()
             }
         }
+        SPEC_STAMP(4);  // post, evaluation (miss), barriers
         if (m == 0) continue;
         cnt.evals += m;
         // ---- admission and merge: exactly beam_search's ----
@@ -1154,6 +1179,11 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
         uint64_t amask = __ballot(admit);
         uint32_t ma = (uint32_t)__popcll(amask);
         if (ma == 0) continue;
+        // The adjacency row of a candidate admitted now is needed two dependent loads before its neighbours' distances when it
+        // becomes the closest unexpanded entry at once (a "miss" of the speculation).  One dword per admitted candidate pulls
+        // its 128-byte row into the cache hierarchy while the list is merged; the value itself is not used.
+        uint32_t touch = 0;
+        if (speculate && admit) touch = __builtin_nontemporal_load(ix.adj0 + (size_t)(ns & kSlotMask) * ix.M0);
         wsync<Sh>();
         if (admit) {
             uint32_t r = mbcnt(amask);
@@ -1187,8 +1217,19 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
         } else {
             live = sz;
         }
+        asm volatile("" ::"v"(touch));  // (keeps the load; by now it has long landed)
+        SPEC_STAMP(5);  // admission + merge
     }
     if (spec_pending) __syncthreads();  // the last batch's closing barrier
+#ifdef VS_SPEC_DEBUG
+    if (lane == 0 && blockIdx.x == 0)
+        printf("[spec] hops %u hits %u have2 %u empty %u collect-waits %u collect clocks/100MHz %llu\n", dbg_hops, dbg_hits, dbg_have2, dbg_m0, dbg_wait,
+               (unsigned long long)dbg_t_collect);
+    if (lane == 0 && blockIdx.x == 0)
+        printf("[spec] clocks: pick %llu cand %llu collect+visit %llu spec-list %llu post+eval %llu merge %llu\n", (unsigned long long)dbg_ph[0],
+               (unsigned long long)dbg_ph[1], (unsigned long long)dbg_ph[2], (unsigned long long)dbg_ph[3], (unsigned long long)dbg_ph[4],
+               (unsigned long long)dbg_ph[5]);
+#endif
     if (sh.overflowed) cnt.overflow += 1;
     out_cur = cur;
     return sz;

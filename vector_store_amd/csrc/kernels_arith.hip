@@ -56,8 +56,11 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
     uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
     int cur = 0;
     uint32_t sz;
-    if constexpr (TEAM > 1) sz = beam_search_spec<AR, I>(ix, sh, q, start, a.ef, cnt, lane, cur, a.has_removed != 0);  // lone queries: speculative evaluation
-    else sz = beam_search<AR, I>(ix, sh, q, start, 0, a.ef, kInvalid, cnt, lane, cur, a.has_removed != 0);
+    if constexpr (TEAM > 1) {  // lone queries: speculative evaluation (bit 8 of `team`: off -- VS_HNSW_SPEC=0, A/B measurements)
+        sz = beam_search_spec<AR, I>(ix, sh, q, start, a.ef, cnt, lane, cur, a.has_removed != 0, (a.team & 0x100u) == 0u);
+    } else {
+        sz = beam_search<AR, I>(ix, sh, q, start, 0, a.ef, kInvalid, cnt, lane, cur, a.has_removed != 0);
+    }
     team_release(sh, lane);
     wsync<Sh>();
     // top.sort_ascending(); top.shrink(wanted); removed members (free key) are never results.
@@ -377,7 +380,8 @@ static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 512, 2048, 2, 1, true, true>), grid, block, 0, s, a);
         return hipGetLastError();
     }
-    if (a.team == kSearchTeamMid && a.ef <= 256 && !a.stress_small_table) {
+    const uint32_t team = a.team & 0xFFu;  // (bit 8: speculation off)
+    if (team == kSearchTeamMid && a.ef <= 256 && !a.stress_small_table) {
         dim3 tblock(64 * kSearchTeamMid);
         if (a.ef <= 128)
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, kSearchTeamMid>), grid, tblock, 0, s, a);
@@ -385,7 +389,7 @@ static hipError_t search_ef(const SearchArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 256, 1024, 2, kSearchTeamMid>), grid, tblock, 0, s, a);
         return hipGetLastError();
     }
-    if (a.team == kSearchTeam && !a.stress_small_table) {
+    if (team == kSearchTeam && !a.stress_small_table) {
         dim3 tblock(64 * kSearchTeam);
         if (a.ef <= 128)
             hipLaunchKernelGGL((hnsw_search_kernel<AR, I, 128, 1024, 1, kSearchTeam>), grid, tblock, 0, s, a);

@@ -43,7 +43,7 @@ class _GraphInfo(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libvs_hnsw.so")
+    return os.environ.get("VS_HNSW_LIB") or os.path.join(_HERE, "libvs_hnsw.so")  # VS_HNSW_LIB: an instrumented build (development)
 
 
 _lib = None

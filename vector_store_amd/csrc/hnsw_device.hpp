@@ -445,13 +445,16 @@ template <int TM>
 struct TeamBox {
     uint32_t team_m;
     uint32_t team_q;  // kInvalid: distances from the walker's own query to u_slot[]; kTeamSpec: to e_slot[]; else from stored row team_q to sel_s[] (refine)
-    // Speculative evaluation (beam_search_spec, lone queries): while the walker merges hop h, the helper waves already measure
-    // the unvisited neighbours of the runner-up; when that node is indeed expanded next its distances are waiting.
+#ifdef VS_TEAM_SPEC
+    // Speculative evaluation (beam_search_spec, lone queries; an experiment, see kernels_arith.hip): while the walker merges hop h,
+    // the helper waves already measure the unvisited neighbours of the runner-up; when that node is indeed expanded next its
+    // distances are waiting.
     uint32_t team_async;   // 1: the walker does not take part in this batch (it goes on with its merge and joins the barrier later)
     uint32_t e_slot[128];  // a batch: [the hop's own fresh neighbours | the runner-up's unvisited neighbours]
     float e_dist[128];
     uint32_t spec_slot[64];  // the runner-up's unvisited neighbours as of the last hop, in adjacency order, and their distances
     float spec_dist[64];
+#endif
 };
 template <>
 struct TeamBox<1> {};
@@ -564,10 +567,13 @@ __device__ __forceinline__ void team_helper_loop(const IndexView& ix, const Quer
             const uint32_t* list = qs == kInvalid ? sh.u_slot : sh.sel_s;
             if (mine) eval_batch<AR, I, Sh::kTeam>(ix, use, list, sh.u_dist, m, lane, w);
         } else {
+#ifdef VS_TEAM_SPEC
             if (sh.team_q == kTeamSpec) {
                 if (sh.team_async) eval_batch<AR, I, Sh::kTeam - 1, Sh::kNT>(ix, q, sh.e_slot, sh.e_dist, m, lane, w - 1u);  // the walker is busy merging
                 else eval_batch<AR, I, Sh::kTeam, Sh::kNT>(ix, q, sh.e_slot, sh.e_dist, m, lane, w);
-            } else {
+            } else
+#endif
+            {
                 eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, w);
             }
         }
@@ -981,6 +987,7 @@ __device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>&
     return sz;
 }
 
+#ifdef VS_TEAM_SPEC
 // beam_search for a TEAM serving ONE query (lone callers: the reference issues one query per FFI call), with SPECULATIVE
 // evaluation.  A lone walk is a chain of dependent hops, each an HBM round trip (5 us at 10M x 768); bandwidth is free at this
 // load, so while hop h is merged the helper waves already measure the unvisited neighbours of the RUNNER-UP (whose adjacency
@@ -1234,6 +1241,8 @@ __device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR
     out_cur = cur;
     return sz;
 }
+
+#endif  // VS_TEAM_SPEC
 
 // usearch refine_: neighbour-selection heuristic over the sorted candidates in
 // sh.lst_*[cur][0..sz).  Accept c iff for every already accepted a: d(c, a) >= d(c, centre).

@@ -879,6 +879,9 @@ __global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t 
         const uint32_t slot = e.y;
         bool ok = i < n;
         if (ok && sz == C) ok = key_less(d, slot, sh.lst_d[0][C - 1], sh.lst_s[0][C - 1]);
+        // one-product pass: a score more than 2 eps behind the k-th best so far cannot belong to a true top-k row (see the
+        // threshold below), so it need not be listed either -- the lists stay short and the merges cheap
+        if (ok && band_eps && band_k && sz >= band_k) ok = d <= sh.lst_d[0][band_k - 1] + 2.0f * band_eps[ql];
         ok = ok && ix.keys[ok ? slot : 0] != kFreeKey;
         const uint64_t mask = __ballot(ok);
         if (!mask) continue;

@@ -151,3 +151,82 @@ def test_construction_beam_above_512_is_refused_with_a_status():
     with pytest.raises(v.VsError) as e:
         v.HipUsearchIndex(16, v.COS, 16, 513, 64)
     assert e.value.code == -7
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("M", [48, 64])
+def test_connectivity_up_to_64(M):
+    """`maximum_node_connections` above 32: level-0 rows of up to 128 ids are taken two per lane.  (1) a graph built by the
+    oracle at that connectivity, imported: the fused-list search, the usearch-order walk and an i8 index return the oracle's ids;
+    (2) one add per call on exactly representable data builds the oracle's graph row for row; (3) the batched GPU build is as good
+    as the CPU restatement's."""
+    v = vs()
+    dim, n, k = 32, 6000, 10
+    data = _dataset(n + 100, dim, 5)
+    base, q = data[:n], data[n:]
+    o = OracleIndex(dim, oracle.COS, M, 128, 64)
+    o.reserve(n)
+    o.add_batch(np.arange(n, dtype=np.uint64), base, threads=1)
+    g = o.export_graph()
+    assert g["adj0"].shape[1] == 2 * M and (g["adj0"][:, 64:] != 0xFFFFFFFF).any()  # rows really use the second half
+    for stress in (0, 16):  # fused list; usearch-order walk
+        ix = v.HipUsearchIndex(dim, v.COS, M, 128, 64, _stress=stress)
+        ix.import_graph(g)
+        ties = 0
+        for ef in (64, 200):
+            o.set_expansion_search(ef)
+            ix.set_expansion_search(ef)
+            gk, gd, gf = ix.search_batch(q, k)
+            for i in range(len(q)):
+                ok_, od_ = o.search(q[i], k)
+                ties += assert_same_results(gk[i, : gf[i]], gd[i, : gf[i]], ok_, od_, lambda key, i=i: o.distance_to_slot(q[i], int(key)), what=(M, stress, ef, i))
+        assert ties <= 6, ties
+    # i8 storage (always the walk): bit-identical
+    o8 = OracleIndex(dim, oracle.COS, M, 128, 100, quantization=oracle.I8)
+    o8.reserve(n)
+    o8.add_batch(np.arange(n, dtype=np.uint64), base, threads=1)
+    i8 = v.HipUsearchIndex(dim, v.COS, M, 128, 100, quantization=v.I8)
+    i8.import_graph(o8.export_graph())
+    gk, gd, gf = i8.search_batch(q, k)
+    for i in range(len(q)):
+        ok_, od_ = o8.search(q[i], k)
+        assert_same_results(gk[i, : gf[i]], gd[i, : gf[i]], ok_, od_, exact=True, what=("i8", M, i))
+    # (2) sequential adds on a lattice: the graph itself
+    m2 = 900
+    lat = lattice(m2, 8, 9, span=500)
+    os_ = OracleIndex(8, oracle.L2SQ, M, 128, 64)
+    os_.reserve(m2)
+    gs = v.HipUsearchIndex(8, v.L2SQ, M, 128, 64)
+    gs.reserve(m2)
+    for i in range(m2):
+        os_.add(i, lat[i])
+        gs.add(i, lat[i])
+        assert gs.size() == i + 1
+    go, gg = os_.export_graph(), gs.export_graph()
+    assert (go["levels"] == gg["levels"]).all() and go["entry_slot"] == gg["entry_slot"]
+    differ = [s_ for s_ in range(m2) if set(go["adj0"][s_].tolist()) != set(gg["adj0"][s_].tolist())]
+    for s_ in differ[:20]:
+        d = ((lat - lat[s_]) ** 2).sum(1)
+        cand = set(go["adj0"][s_].tolist()) ^ set(gg["adj0"][s_].tolist())
+        cand.discard(0xFFFFFFFF)
+        assert any(np.sum(d == d[c]) > 1 for c in cand), (s_, "rows differ without an exact tie")
+    assert len(differ) <= m2 // 50, len(differ)
+    # (3) batched GPU build
+    gb = v.HipUsearchIndex(dim, v.COS, M, 128, 64)
+    gb.reserve(n)
+    gb.add_batch(np.arange(n, dtype=np.uint64), base)
+    tk, _, _ = gb.exact_search_batch(q, k)
+    bk, _, _ = gb.search_batch(q, k)
+    o.set_expansion_search(64)
+    r_gpu = np.mean([len(set(tk[i].tolist()) & set(bk[i].tolist())) / k for i in range(len(q))])
+    r_cpu = np.mean([len(set(tk[i].tolist()) & set(o.search(q[i], k)[0].tolist())) / k for i in range(len(q))])
+    assert r_gpu >= r_cpu - 0.03, (r_gpu, r_cpu)
+    info = gb.graph_info()
+    assert info["connectivity"] == M and info["connectivity_base"] == 2 * M
+
+
+def test_connectivity_above_64_is_refused_with_a_status():
+    v = vs()
+    with pytest.raises(v.VsError) as e:
+        v.HipUsearchIndex(16, v.COS, 65, 128, 64)
+    assert e.value.code == -7

@@ -496,7 +496,7 @@ struct Engine {
         max_sub_batch = std::min(max_sub_batch, chunk_rows);
         if (const char* t = std::getenv("VS_HNSW_TEAM")) team_mode = !std::strcmp(t, "always") ? 1 : !std::strcmp(t, "never") ? 2 : !std::strcmp(t, "mid") ? 3 : team_mode;
         M = o.connectivity ? (uint32_t)o.connectivity : 16;  // usearch default_connectivity
-        if (M < 2 || M > 32) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 32]");
+        if (M < 2 || M > 64) fail(VS_ERR_UNSUPPORTED, "connectivity must be in [2, 64]");  // level-0 rows of up to 128 ids: two per lane
         M0 = 2 * M;
         ef_add = o.expansion_add ? (uint32_t)o.expansion_add : 128;
         ef_search = o.expansion_search ? (uint32_t)o.expansion_search : 64;

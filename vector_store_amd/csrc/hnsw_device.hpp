@@ -908,6 +908,11 @@ __device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>&
             const uint32_t* row2 = adjacency(ix, c2_slot, level, cap2);
             pf_n = (uint32_t)lane < cap2 ? row2[lane] : kInvalid;
         }
+        // connectivity above 32: a level-0 row holds up to 128 ids -- two per lane -- and is taken 64 at a time, in adjacency order
+        // (the CPU loop takes the neighbours one at a time, so two batches are as equivalent to it as one)
+        const uint32_t n_hi = cap > (uint32_t)kWave && (uint32_t)kWave + (uint32_t)lane < cap ? row[kWave + lane] : kInvalid;
+        for (uint32_t half = 0; half < (cap > (uint32_t)kWave ? 2u : 1u); ++half) {
+        if (half) n = n_hi;
         bool fresh = n != kInvalid && !visited_test_and_set(sh, n);
         uint64_t fmask = __ballot(fresh);
         uint32_t m = (uint32_t)__popcll(fmask);
@@ -981,6 +986,7 @@ __device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>&
         } else {
             live = sz;
         }
+        }  // half
     }
     if (sh.overflowed) cnt.overflow += 1;
     out_cur = cur;
@@ -1252,9 +1258,9 @@ __device__ uint32_t refine(const IndexView& ix, Sh& sh, int cur, uint32_t sz, ui
                            Counters& cnt, int lane) {
     if (sz < needed || sz == 0) {
         wsync<Sh>();
-        if ((uint32_t)lane < sz) {
-            sh.sel_s[lane] = sh.lst_s[cur][lane] & kSlotMask;
-            sh.sel_d[lane] = sh.lst_d[cur][lane];
+        for (uint32_t e = (uint32_t)lane; e < sz; e += kWave) {
+            sh.sel_s[e] = sh.lst_s[cur][e] & kSlotMask;
+            sh.sel_d[e] = sh.lst_d[cur][e];
         }
         wsync<Sh>();
         return sz;
@@ -1273,7 +1279,8 @@ __device__ uint32_t refine(const IndexView& ix, Sh& sh, int cur, uint32_t sz, ui
         query_from_row<AR, I>(ix, cs, cv, lane);
         eval_selected<AR, I>(ix, cs, cv, sh, nsel, lane);
         cnt.evals += nsel;
-        bool bad = (uint32_t)lane < nsel && sh.u_dist[lane] < cd;
+        bool bad = false;
+        for (uint32_t b0 = 0; b0 < nsel; b0 += kWave) bad = bad || (b0 + (uint32_t)lane < nsel && sh.u_dist[b0 + lane] < cd);  // (more than 64 accepted: link kernel, connectivity above 32)
         bool reject = __ballot(bad) != 0ull;
         wsync<Sh>();
         if (!reject) {

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_insert_kernel(InsertArgs a) {
         uint32_t cap;
         uint32_t* row = const_cast<uint32_t*>(adjacency(ix, slot, l, cap));
         if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < nsel ? sh.sel_s[lane] : kInvalid;
+        if ((uint32_t)kWave + (uint32_t)lane < cap) row[kWave + lane] = kInvalid;  // (connectivity above 32: level-0 rows of up to 128 ids; nsel <= M <= 64)
         if ((uint32_t)lane < ix.M) {
             bool on = (uint32_t)lane < nsel;
             a.req_key[req + lane] = on ? (((uint64_t)(uint32_t)l << 32) | sh.sel_s[lane]) : ~0ull;
@@ -159,16 +160,16 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_insert_kernel(InsertArgs a) {
     }
 }
 
-struct LinkShared {
+struct LinkShared {  // sized for a level-0 row of 128 ids (connectivity 64) + 64 new requests
     static constexpr int kTeam = 1;
-    float lst_d[1][128];
-    uint32_t lst_s[1][128];
-    float t_d[128];
-    uint32_t t_s[128];
-    uint32_t u_slot[64];
-    float u_dist[64];
-    uint32_t sel_s[64];
-    float sel_d[64];
+    float lst_d[1][192];
+    uint32_t lst_s[1][192];
+    float t_d[192];
+    uint32_t t_s[192];
+    uint32_t u_slot[128];
+    float u_dist[128];
+    uint32_t sel_s[128];
+    float sel_d[128];
 };
 
 constexpr uint32_t kMaxNewPerTarget = 64;
@@ -195,9 +196,9 @@ __device__ uint32_t refine_cached(const IndexView& ix, LinkShared& sh, uint4* ro
     if (sz == 0) return 0;
     __syncthreads();
     if (sz < needed) {  // usearch: fewer candidates than slots -> all of them
-        if ((uint32_t)lane < sz) {
-            sh.sel_s[lane] = sh.lst_s[0][lane] & kSlotMask;
-            sh.sel_d[lane] = sh.lst_d[0][lane];
+        for (uint32_t e = (uint32_t)lane; e < sz; e += kWave) {
+            sh.sel_s[e] = sh.lst_s[0][e] & kSlotMask;
+            sh.sel_d[e] = sh.lst_d[0][e];
         }
         __syncthreads();
         return sz;
@@ -239,7 +240,8 @@ __device__ uint32_t refine_cached(const IndexView& ix, LinkShared& sh, uint4* ro
         if (!reject && nsel > in_lds) {  // accepted beyond the cache: measured from HBM as before
             eval_batch<AR, I>(ix, cv, sh.sel_s + in_lds, sh.u_dist, nsel - in_lds, lane);
             __syncthreads();
-            bool bad2 = (uint32_t)lane < nsel - in_lds && sh.u_dist[lane] < cd;
+            bool bad2 = false;
+            for (uint32_t b0 = 0; b0 < nsel - in_lds; b0 += kWave) bad2 = bad2 || (b0 + (uint32_t)lane < nsel - in_lds && sh.u_dist[b0 + lane] < cd);
             reject = __ballot(bad2) != 0ull;
             __syncthreads();
         }
@@ -290,21 +292,24 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
             src = (uint32_t)v;
             src_d = __uint_as_float((uint32_t)(v >> 32));
         }
-        // existing links; a link to a source being (re)inserted is superseded by the new request
+        // existing links (up to 128 at connectivity 64: two per lane); a link to a source being (re)inserted is superseded by the new request
         uint32_t ex = (uint32_t)lane < cap ? row[lane] : kInvalid;
+        uint32_t ex2 = (uint32_t)kWave + (uint32_t)lane < cap ? row[kWave + lane] : kInvalid;
         for (uint32_t j = 0; j < n_new; ++j) {
             uint32_t sj = (uint32_t)__shfl((int)src, (int)j);
             if (ex == sj) ex = kInvalid;
+            if (ex2 == sj) ex2 = kInvalid;
         }
-        uint64_t emask = __ballot(ex != kInvalid);
-        const uint32_t cnt = (uint32_t)__popcll(emask);
+        const uint64_t emask = __ballot(ex != kInvalid), emask2 = __ballot(ex2 != kInvalid);
+        const uint32_t cnt1 = (uint32_t)__popcll(emask), cnt = cnt1 + (uint32_t)__popcll(emask2);
         __syncthreads();
         if (ex != kInvalid) sh.u_slot[mbcnt(emask)] = ex;
+        if (ex2 != kInvalid) sh.u_slot[cnt1 + mbcnt(emask2)] = ex2;
         __syncthreads();
         if (cnt + n_new <= cap) {  // usearch: close_header.push_back(new_slot)
-            const bool is_new = lane >= (int)cnt && lane < (int)(cnt + n_new);
-            const uint32_t from_new = (uint32_t)__shfl((int)src, is_new ? lane - (int)cnt : 0);
-            if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < cnt ? sh.u_slot[lane] : (is_new ? from_new : kInvalid);
+            if (lane < (int)n_new) sh.u_slot[cnt + lane] = src;  // (cnt + n_new <= cap <= 128)
+            __syncthreads();
+            for (uint32_t e = (uint32_t)lane; e < cap; e += kWave) row[e] = e < cnt + n_new ? sh.u_slot[e] : kInvalid;
         } else {
             // usearch: top = {new} U existing, all measured from `close_slot`; refine_(connectivity_max)
             Query<AR, I> q;
@@ -312,10 +317,10 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
             eval_batch<AR, I>(ix, q, sh.u_slot, sh.u_dist, cnt, lane);
             __syncthreads();
             c.evals += cnt;
-            const uint32_t total = cnt + n_new;  // <= 32 + 64
-            if ((uint32_t)lane < cnt) {
-                sh.t_d[lane] = sh.u_dist[lane];
-                sh.t_s[lane] = sh.u_slot[lane];
+            const uint32_t total = cnt + n_new;  // <= 128 + 64
+            for (uint32_t e = (uint32_t)lane; e < cnt; e += kWave) {
+                sh.t_d[e] = sh.u_dist[e];
+                sh.t_s[e] = sh.u_slot[e];
             }
             if ((uint32_t)lane < n_new) {
                 sh.t_d[cnt + lane] = src_d;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(64) void hnsw_link_kernel(LinkArgs a) {
             extern __shared__ uint4 link_rowbuf[];
             uint32_t nsel = a.cache_rows ? refine_cached<AR, I>(ix, sh, link_rowbuf, a.cache_rows, total, cap, c, lane)
                                          : refine<AR, I>(ix, sh, 0, total, cap, c, lane);
-            if ((uint32_t)lane < cap) row[lane] = (uint32_t)lane < nsel ? sh.sel_s[lane] : kInvalid;
+            for (uint32_t e = (uint32_t)lane; e < cap; e += kWave) row[e] = e < nsel ? sh.sel_s[e] : kInvalid;
         }
         if (n_new < kMaxNewPerTarget) break;
         __syncthreads();

@@ -341,6 +341,16 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         }
         if (cs == self) continue;
         WALK_STAMP(1);  // candidate, pop, prefetch issue
+        // connectivity above 32: a level-0 row holds up to 128 ids, taken 64 at a time in adjacency order (as the CPU loop would)
+        uint32_t n_hi = kInvalid;
+        {
+            uint32_t capc;
+            const uint32_t* rowc = adjacency(ix, cs, level, capc);
+            if (capc > (uint32_t)kWave) n_hi = (uint32_t)kWave + (uint32_t)lane < capc ? rowc[kWave + lane] : kInvalid;
+        }
+        const uint32_t halves = (level == 0 ? ix.M0 : ix.M) > (uint32_t)kWave ? 2u : 1u;
+        for (uint32_t half = 0; half < halves && !exhausted; ++half) {
+        if (half) n = n_hi;
         const bool fresh = mark(n);
         const uint64_t fmask = __ballot(fresh);
         const uint32_t m = (uint32_t)__popcll(fmask);
@@ -530,6 +540,8 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         }
         sz = T + a;
         wsync<Sh>();
+        }  // half
+        if (exhausted) break;
     }
     if (debug && lane == 0) {
         debug[0] = dbg_max_hn;

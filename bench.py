@@ -45,7 +45,9 @@ import sys
 import time
 
 import numpy as np
-import torch
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # before the HIP runtime initialises: concurrent filtered searches (see csrc/engine.hip HwQueuesDefault)
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -1010,6 +1010,7 @@ struct Engine {
         uint32_t* unknown_list = nullptr;
         uint32_t* unknown_count = nullptr;
         uint32_t cap = 0, budget = 0;
+        uint32_t* consulted = nullptr;
     };
     void search_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
                        hipStream_t st, size_t load = 0, const uint32_t* allow = nullptr, uint32_t allow_stride = 0,
@@ -1036,6 +1037,7 @@ struct Engine {
             a.unknown_count = lazy ? lazy->unknown_count : nullptr;
             a.unknown_cap = lazy ? lazy->cap : 0u;
             a.unknown_budget = lazy ? lazy->budget : 0u;
+            a.consulted = lazy ? lazy->consulted : nullptr;
             a.qlist = nullptr;
             a.qcount = nullptr;
             a.retry_list = nullptr;
@@ -1440,7 +1442,7 @@ struct Engine {
         uint32_t* d_unknown = (uint32_t*)w->f.ensure(((size_t)cap + 64) * 4);  // [count, 63 pad | list]
         HIP_OK(hipMemcpyAsync(d_q, q, (size_t)dim * 4, hipMemcpyHostToDevice, st));
         const uint32_t hint = lazy_need_hint.load();
-        const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 4));
+        const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
         uint64_t listed_total = 0;
         for (int round = 0; round < 20; ++round) {
             HIP_OK(hipMemcpyAsync(d_bits, allow_h.data(), words * 4, hipMemcpyHostToDevice, st));
@@ -1451,12 +1453,14 @@ struct Engine {
             lf.unknown_list = d_unknown + 64;
             lf.unknown_count = d_unknown;
             lf.cap = cap;
-            // The first round's budget follows what recent filtered queries of this index needed (+ 25 %): filters of one
-            // workload tend to be alike, and a first round that lists enough makes the second the exact one -- two walks instead
-            // of four at 10 % selectivity, for at most a quarter more predicate calls.  It doubles from there as before.
+            lf.consulted = d_unknown + 1;  // (a pad word of the count block)
+            // The first round's budget follows the number of verdicts the exact walks of recent filtered queries of this index
+            // consulted (+ 50 %): filters of one workload tend to be alike, and a first round that lists enough makes the second
+            // the exact one -- two walks instead of four at 10 % selectivity.  It doubles from there as before.
             lf.budget = (uint32_t)std::min<size_t>(cap, (size_t)first_budget << round);
             search_device(d_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
-            uint32_t count = 0, found = 0;
+            uint32_t count = 0, found = 0, consulted = 0;
+            HIP_OK(hipMemcpyAsync(&consulted, d_unknown + 1, 4, hipMemcpyDeviceToHost, st));
             HIP_OK(hipMemcpyAsync(&count, d_unknown, 4, hipMemcpyDeviceToHost, st));
             HIP_OK(hipMemcpyAsync(&found, d_f, 4, hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));
@@ -1465,8 +1469,8 @@ struct Engine {
                 HIP_OK(hipMemcpy(keys, d_k, (size_t)found * 8, hipMemcpyDeviceToHost));
                 HIP_OK(hipMemcpy(dist, d_d, (size_t)found * 4, hipMemcpyDeviceToHost));
                 lazy_rounds += (uint64_t)round + 1;
-                // two launches sufficed: try a little less next time; more were needed: what this query took in all
-                lazy_need_hint = round <= 1 && hint ? hint - hint / 16 : (uint32_t)std::min<uint64_t>(cap, listed_total);
+                // what the exact walk (this last round) consulted, smoothed over the recent queries of this index
+                lazy_need_hint = hint ? (3 * hint + consulted) / 4 : consulted;
                 return found;
             }
             const uint32_t m = std::min(count, cap);

@@ -79,6 +79,7 @@ struct WalkArgs {
     uint32_t* unknown_list;   // unknown_cap entries per query
     uint32_t* unknown_count;  // one per query; the walk stops once it has listed unknown_budget slots
     uint32_t unknown_cap, unknown_budget;
+    uint32_t* consulted;      // nullptr, or one word per query: verdicts the walk asked for (known or not) -- sizes the first lazy round of later queries
     const uint32_t* qlist;   // retry instance: serve queries qlist[0 .. *qcount) instead of 0 .. nq
     const uint32_t* qcount;
     uint32_t* retry_list;    // LDS instances: queries whose visited table or heap ran out are appended here ...

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
                                          a.debug ? a.debug + (size_t)qi * 12 : nullptr,
                                          a.known ? a.known + (size_t)qi * a.allow_stride : nullptr,
                                          a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
-                                         a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget);
+                                         a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget,
+                                         a.consulted ? a.consulted + qi : nullptr);
         if (exhausted) {
             if (lane == 0) {
                 if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;  // the global-bitmap instance takes it

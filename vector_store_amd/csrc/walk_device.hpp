@@ -243,7 +243,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
                                  uint32_t ef, uint32_t self, bool tomb, const uint32_t* allow, Counters& cnt, int lane,
                                  bool& exhausted, uint32_t* debug = nullptr, const uint32_t* known = nullptr,
                                  uint32_t* unknown_list = nullptr, uint32_t* unknown_count = nullptr, uint32_t unknown_cap = 0,
-                                 uint32_t unknown_budget = 0) {
+                                 uint32_t unknown_budget = 0, uint32_t* consulted_out = nullptr) {
     uint32_t dbg_max_hn = 0, dbg_pushed = 0;
 #ifdef VS_WALK_PROFILE
     uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -260,10 +260,12 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
     // May slot s be a result?  Wave-level (every lane calls it, `valid` says whether the lane holds a slot): with a lazy
     // predicate the slots whose verdict is not known yet are listed for the host and count as rejected for this launch.
     bool over_budget = false;
+    uint32_t consulted = 0;
     auto allowed = [&](uint32_t s, bool valid) -> bool {
         bool ok = valid;
         if (tomb) ok = ok && ix.keys[valid ? s : 0u] != kFreeKey;
         if (allow) {
+            consulted += (uint32_t)__popcll(__ballot(ok));
             if (known) {
                 const bool kn = ok && ((known[s >> 5] >> (s & 31u)) & 1u) != 0u;
                 const bool unk = ok && !kn;  // (removed members need no verdict)
@@ -543,6 +545,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         }  // half
         if (exhausted) break;
     }
+    if (consulted_out && lane == 0) *consulted_out = consulted;
     if (debug && lane == 0) {
         debug[0] = dbg_max_hn;
         debug[1] = (uint32_t)cnt.evals;

@@ -1443,7 +1443,6 @@ struct Engine {
         HIP_OK(hipMemcpyAsync(d_q, q, (size_t)dim * 4, hipMemcpyHostToDevice, st));
         const uint32_t hint = lazy_need_hint.load();
         const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
-        uint64_t listed_total = 0;
         for (int round = 0; round < 20; ++round) {
             HIP_OK(hipMemcpyAsync(d_bits, allow_h.data(), words * 4, hipMemcpyHostToDevice, st));
             HIP_OK(hipMemcpyAsync(d_bits + words, known_h.data(), words * 4, hipMemcpyHostToDevice, st));
@@ -1474,7 +1473,6 @@ struct Engine {
                 return found;
             }
             const uint32_t m = std::min(count, cap);
-            listed_total += m;
             HIP_OK(hipMemcpy(list.data(), d_unknown + 64, (size_t)m * 4, hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < m; ++i) {
                 const uint32_t s = list[i];

@@ -119,6 +119,15 @@ struct HostExchange {
         base = (char*)p;
         registered = hipHostRegister(base, bytes, hipHostRegisterDefault) == hipSuccess;  // pageable copies work too, only slower
         ctl()->attached.fetch_add(1);
+        // collective, like ncclCommInitRank: every rank of the world has attached when this returns
+        const auto t0 = std::chrono::steady_clock::now();
+        while (ctl()->attached.load(std::memory_order_acquire) < (uint32_t)world) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kWaitSeconds)) {
+                close_segment();
+                throw Fail{VS_ERR_DEVICE, "host exchange: the other ranks did not attach within " + std::to_string(kWaitSeconds) + " s"};
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
     }
     void close_segment() {
         if (!base) return;

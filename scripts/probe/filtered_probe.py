@@ -1,5 +1,5 @@
 """Filtered search through the C ABI with the reference's call pattern (blocking callers, native counted predicate):
-QPS, latency, predicate calls, walk launches, evaluations and hops per query.   python scripts/probe/filtered_probe.py [vectors] [ef]"""
+QPS, latency, predicate calls, walk launches, evaluations and hops per query.   python scripts/probe/filtered_probe.py [vectors] [ef] [threads,threads,...]"""
 import ctypes as C, os, sys, time, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import vector_store_amd as vs
@@ -23,12 +23,12 @@ class Res(C.Structure):
 
 L = C.CDLL(os.path.join("vector_store_amd", "libvs_callers.so"))
 L.vs_callers_run_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double, C.POINTER(Res), C.POINTER(C.c_uint64)]
-for threads in (1, 17):
+for threads in ([int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1, 17)):
     for mod in (2, 10, 100):
         r, extra = Res(), (C.c_uint64 * 4)()
         ix.stats(reset=True)
         f0 = ix.filter_stats()
-        rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], dim, k, mod, threads, 3.0, C.byref(r), extra)
+        rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], dim, k, mod, threads, 2.0, C.byref(r), extra)
         f1, st = ix.filter_stats(), ix.stats(reset=True)
         nq = max(int(r.queries), 1)
         print(f"n {n} ef {ef} threads {threads} selectivity 1/{mod}: {r.qps:.1f} QPS, latency min {r.latency_min_ns/1e6:.1f} ms max {r.latency_max_ns/1e6:.1f} ms, "

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 USEARCH_ORDER, GLOBAL_WALK, TINY_HEAP = 16, 32, 128
-WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512, WALK_LDS_320 = 1, 2, 3, 8
+WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512, WALK_LDS_320, WALK_LDS_256_DENSE = 1, 2, 3, 8, 9
 
 
 def vs():
@@ -92,6 +92,41 @@ def test_walk_instance_is_chosen_by_its_own_visited_domain(monkeypatch):
     assert instances == [WALK_LDS_320, WALK_LDS_512, WALK_GLOBAL_512], instances
     for keys, dist, found in results[1:]:
         assert np.array_equal(keys, results[0][0]) and np.array_equal(dist.view(np.uint32), results[0][1].view(np.uint32))
+
+
+@pytest.mark.timeout(600)
+def test_dense_visited_table_instance_returns_what_the_256_instance_returns(monkeypatch):
+    """Beams of 129..256 below 2^24 slots take the dense instance (512 buckets x 12 tags, 600 entries of `next`: 8 walks per
+    CU); beyond 2^24 slots its 24-bit domain does not tell slots apart and the 256 instance runs.  Same ids, same distances,
+    bit for bit, and both equal the CPU restatement's walk."""
+    v = vs()
+    from oracle import OracleIndex
+    n, dim, k, ef = 40000, 96, 10, 200
+    base = _data(n, dim, 31)
+    q = _data(600, dim, 32)
+    results, instances = [], []
+    graph = None
+    for pretend in (0, (1 << 24) + 1):
+        if pretend:
+            monkeypatch.setenv("VS_HNSW_WALK_DOMAIN_SLOTS", str(pretend))
+        else:
+            monkeypatch.delenv("VS_HNSW_WALK_DOMAIN_SLOTS", raising=False)
+        ix = v.HipUsearchIndex(dim, v.L2SQ, expansion_search=ef, quantization=v.I8)
+        if graph is None:
+            ix.reserve(n)
+            ix.add_batch(np.arange(n, dtype=np.uint64), base)
+            graph = ix.export_graph()
+        else:
+            ix.import_graph(graph)
+        results.append(ix.search_batch(q, k))
+        instances.append(ix.walk_info()["last_instance"])
+    assert instances == [WALK_LDS_256_DENSE, WALK_LDS_256], instances
+    assert np.array_equal(results[0][0], results[1][0])
+    assert np.array_equal(results[0][1].view(np.uint32), results[1][1].view(np.uint32))
+    o = OracleIndex(dim, v.L2SQ, expansion_search=ef, quantization=v.I8)
+    o.import_graph(graph)
+    ok, od, _ = o.search_batch(q[:200], k, threads=8)
+    assert np.array_equal(ok, results[0][0][:200]) and np.array_equal(od, results[0][1][:200])
 
 
 @pytest.mark.timeout(600)

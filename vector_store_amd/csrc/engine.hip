@@ -269,6 +269,11 @@ struct Arena {
 struct WorkCtx {
     hipStream_t stream = nullptr;
     DeviceBuf a, b, c, d, e, f;
+    // one-query calls (Engine::search_one): a pinned, device-mapped block the kernel reads its query from and writes its
+    // answer to, and the event the caller polls
+    char* pin = nullptr;
+    size_t pin_bytes = 0;
+    hipEvent_t ev = nullptr;
 };
 
 struct DevicePool {
@@ -378,6 +383,7 @@ struct Engine {
     std::atomic<uint32_t> lazy_need_hint{0};  // verdicts the recent filtered queries of this index needed (moving average): sizes the first round
     std::atomic<bool> lds_walk_bad[16] = {};  // per walk instance: more than a quarter of a batch outgrew its LDS structures -> global-bitmap instance at once
     std::atomic<bool> small_table_ok{true};  // usearch-order walk, beams <= 128: the half-size visited table is paying off
+    std::atomic<bool> dense_table_ok{true};  // beams of 129..256: the dense instance (8 walks per CU) is paying off
     bool force_wide_tags = false;     // reserved bit 6 (tests): wide visited tags although the index is small
     bool force_global_walk = false;   // reserved bit 5 (tests): every search takes the global-bitmap walk instance
     uint64_t walk_domain_override = 0;  // VS_HNSW_WALK_DOMAIN_SLOTS (tests): the slot count the walk's instance choice assumes
@@ -1079,11 +1085,15 @@ struct Engine {
             if (wr.retry_seen_valid && wr.retry_seen_owner == this && hipEventQuery(wr.retry_seen_ev) == hipSuccess) {
                 const uint32_t seen = wr.retry_seen[0], of = wr.retry_seen[1], which = wr.retry_seen[2] & 15u;
                 if (of >= 64 && which == WALK_LDS_128_SMALL && seen * 20 > of) small_table_ok = false;
+                else if (of >= 64 && which == WALK_LDS_256_DENSE && seen * 20 > of) dense_table_ok = false;  // > 5 % of a batch outgrew it
                 else if (of >= 64 && which != WALK_LDS_128_SMALL && which != WALK_LDS_128_TINY && seen * 4 > of) lds_walk_bad[which] = true;
             }
             wr.retry_seen_valid = false;
             const bool small = ef <= 128 && small_table_ok.load() && slots <= (1ull << walk_small_table_bits()) && !stress_small_table;
-            uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : ef <= 256 ? WALK_LDS_256 : ef <= kWalk320MaxBeam ? WALK_LDS_320 : WALK_LDS_512;
+            static const bool no_team_global = std::getenv("VS_HNSW_TEAM_GLOBAL") && std::getenv("VS_HNSW_TEAM_GLOBAL")[0] == '0';  // A/B measurements
+            static const bool dense_off = std::getenv("VS_HNSW_WALK_DENSE") && std::getenv("VS_HNSW_WALK_DENSE")[0] == '0';  // A/B measurements
+            const bool dense = ef > 128 && ef <= 256 && !dense_off && dense_table_ok.load() && std::max<uint64_t>(slots, walk_domain_override) <= (1ull << walk_instance_domain_bits(WALK_LDS_256_DENSE));
+            uint32_t inst = (stress_small_table && iters == 1 && ef <= 128) ? WALK_LDS_128_TINY : small ? WALK_LDS_128_SMALL : ef <= 128 ? WALK_LDS_128 : dense ? WALK_LDS_256_DENSE : ef <= 256 ? WALK_LDS_256 : ef <= kWalk320MaxBeam ? WALK_LDS_320 : WALK_LDS_512;
             // The visited tags of the instance actually chosen must tell every slot apart (needs_global_walk asks by beam, and
             // the 320-entry instance carries the 256 instance's 25-bit table, not the 512 instance's 26 bits): a wider
             // instance first, the global bitmap beyond that.  walk_domain_override: test hook (pretends the index is larger).
@@ -1092,9 +1102,15 @@ struct Engine {
             const bool out_of_domain = inst != WALK_LDS_128_TINY && domain_slots > (1ull << walk_instance_domain_bits(inst));
             last_walk_instance = (global || out_of_domain || lds_walk_bad[inst].load()) ? g_inst : inst;
             if (global || out_of_domain || lds_walk_bad[inst].load()) {
-                const uint32_t grid = global_space(a, g_inst, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
+                // a lone query (every filtered one is: the predicate is the caller's) takes a team of waves here too -- one
+                // workgroup, one workspace per query
+                const bool team_g = g_inst == WALK_GLOBAL_512 && iters < 12 && nq <= 32 && !no_team_global &&
+                                    (team_mode == 1 || (team_mode == 0 && std::max(nq, load) <= team_max_nq));
+                const uint32_t gi = team_g ? (g_inst | kWalkTeamFlag) : g_inst;
+                const uint32_t grid = global_space(a, gi, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
+                if (team_g && grid != nq) fail(VS_ERR_DEVICE, "team walk: workspace");
                 a.work_counter = retry + 1;
-                HIP_OK(launch_walk(a, iters, g_inst, grid, st, nullptr));
+                HIP_OK(launch_walk(a, iters, gi, grid, st, nullptr));
                 return;
             }
             // LDS visited table; queries that exhaust it (or the heap workspace) go to a global-bitmap launch behind
@@ -1107,6 +1123,7 @@ struct Engine {
             a.heap_cap = 8192;
             a.space_stride = walk_space_stride(0, 0, a.heap_cap);
             // batches too small to fill the chip (lone callers): a team of waves per query, as the fused-list kernel does
+            if (inst == WALK_LDS_256_DENSE && (team_mode == 1 || (team_mode == 0 && std::max(nq, load) <= team_max_nq))) inst = WALK_LDS_256;  // (lone callers: the team form)
             const bool team_walk = inst != WALK_LDS_512 && inst != WALK_LDS_128_TINY &&
                                    (team_mode == 1 || (team_mode == 0 && std::max(nq, load) <= team_max_nq));
             const uint32_t launch_inst = team_walk ? (inst | kWalkTeamFlag) : inst;
@@ -1330,6 +1347,8 @@ struct Engine {
 
     // One query per FFI call (reference usearch.rs:212): handled by the per-device SearchService below.
     int search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found);
+    bool search_direct(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found);
+    std::atomic<uint64_t> lone_walk_ns{0};  // what a one-query call's walk took lately (launch to event), search_direct's sleep
     void search_async(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found,
                       void (*cb)(void*, int), void* ctx);
 
@@ -1429,24 +1448,36 @@ struct Engine {
             n = slots;
         }
         const size_t words = (n + 31) / 32;
-        std::vector<uint32_t> known_h(words, 0u), allow_h(words, 0u);
         const uint32_t cap = 1u << 17;
-        std::vector<uint32_t> list(cap);
         Lease w(device);
         hipStream_t st = w->stream;
         float* d_q = (float*)w->a.ensure((size_t)dim * 4);
         uint64_t* d_k = (uint64_t*)w->b.ensure(k * 8);
         float* d_d = (float*)w->c.ensure(k * 4);
         uint32_t* d_f = (uint32_t*)w->d.ensure(64);
-        uint32_t* d_bits = (uint32_t*)w->e.ensure(words * 8);              // [allow | known]
-        uint32_t* d_unknown = (uint32_t*)w->f.ensure(((size_t)cap + 64) * 4);  // [count, 63 pad | list]
+        uint32_t* d_bits = (uint32_t*)w->e.ensure(words * 8);                           // [allow | known], on the device for the whole query
+        uint32_t* d_unknown = (uint32_t*)w->f.ensure(((size_t)cap + 64) * 4 + cap);  // [count, consulted, 62 pad | list | verdicts]
+        uint8_t* d_verdict = (uint8_t*)(d_unknown + 64 + cap);
+        // pinned staging: [counters 64 B | list cap x 4 | verdicts cap | keys k x 8 | dist k x 4]
+        const size_t pin_need = 64 + (size_t)cap * 5 + k * 12 + 64;
+        if (w->pin_bytes < pin_need) {
+            if (w->pin) (void)hipHostFree(w->pin);
+            w->pin = nullptr;
+            w->pin_bytes = 0;
+            HIP_OK(hipHostMalloc((void**)&w->pin, pin_need, hipHostMallocDefault));
+            w->pin_bytes = pin_need;
+        }
+        uint32_t* h_cnt = (uint32_t*)w->pin;
+        uint32_t* h_list = (uint32_t*)(w->pin + 64);
+        uint8_t* h_verdict = (uint8_t*)(w->pin + 64 + (size_t)cap * 4);
+        uint64_t* h_k = (uint64_t*)(w->pin + 64 + (size_t)cap * 5);
+        float* h_d = (float*)(h_k + k);
         HIP_OK(hipMemcpyAsync(d_q, q, (size_t)dim * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(d_bits, 0, words * 8, st));
         const uint32_t hint = lazy_need_hint.load();
         const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
         for (int round = 0; round < 20; ++round) {
-            HIP_OK(hipMemcpyAsync(d_bits, allow_h.data(), words * 4, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(d_bits + words, known_h.data(), words * 4, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemsetAsync(d_unknown, 0, 4, st));
+            HIP_OK(hipMemsetAsync(d_unknown, 0, 8, st));
             LazyFilter lf;
             lf.known = d_bits + words;
             lf.unknown_list = d_unknown + 64;
@@ -1458,30 +1489,42 @@ struct Engine {
             // the exact one -- two walks instead of four at 10 % selectivity.  It doubles from there as before.
             lf.budget = (uint32_t)std::min<size_t>(cap, (size_t)first_budget << round);
             search_device(d_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
-            uint32_t count = 0, found = 0, consulted = 0;
-            HIP_OK(hipMemcpyAsync(&consulted, d_unknown + 1, 4, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipMemcpyAsync(&count, d_unknown, 4, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipMemcpyAsync(&found, d_f, 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(h_cnt, d_unknown, 8, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(h_cnt + 2, d_f, 4, hipMemcpyDeviceToHost, st));
+            // the answer and the head of the list ride along: one wait per round unless the list is long
+            HIP_OK(hipMemcpyAsync(h_k, d_k, k * 8, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(h_d, d_d, k * 4, hipMemcpyDeviceToHost, st));
+            const uint32_t head = std::min<uint32_t>(lf.budget, cap);
+            HIP_OK(hipMemcpyAsync(h_list, d_unknown + 64, (size_t)head * 4, hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));
+            const uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
             if (count == 0) {
                 if (found == kWalkFailed) return (size_t)-1;
-                HIP_OK(hipMemcpy(keys, d_k, (size_t)found * 8, hipMemcpyDeviceToHost));
-                HIP_OK(hipMemcpy(dist, d_d, (size_t)found * 4, hipMemcpyDeviceToHost));
+                std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
+                std::memcpy(dist, h_d, (size_t)std::min<size_t>(found, k) * 4);
                 lazy_rounds += (uint64_t)round + 1;
                 // what the exact walk (this last round) consulted, smoothed over the recent queries of this index
                 lazy_need_hint = hint ? (3 * hint + consulted) / 4 : consulted;
                 return found;
             }
             const uint32_t m = std::min(count, cap);
-            HIP_OK(hipMemcpy(list.data(), d_unknown + 64, (size_t)m * 4, hipMemcpyDeviceToHost));
-            for (uint32_t i = 0; i < m; ++i) {
-                const uint32_t s = list[i];
-                if (s >= n || ((known_h[s >> 5] >> (s & 31)) & 1u)) continue;
-                known_h[s >> 5] |= 1u << (s & 31);
-                const uint64_t key = h_keys[s];
-                ++lazy_predicate_calls;
-                if (key != kFreeKey && pred(key, pctx)) allow_h[s >> 5] |= 1u << (s & 31);
+            if (m > head) {  // (a hop's worth beyond the budget)
+                HIP_OK(hipMemcpyAsync(h_list + head, d_unknown + 64 + head, (size_t)(m - head) * 4, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
             }
+            // a walk evaluates a node once, so a list names a slot once, and slots with a verdict are never listed again
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint32_t s = h_list[i];
+                uint8_t v = 0;
+                if (s < n) {
+                    const uint64_t key = h_keys[s];
+                    ++lazy_predicate_calls;
+                    v = key != kFreeKey && pred(key, pctx) ? 1 : 0;
+                }
+                h_verdict[i] = v;
+            }
+            HIP_OK(hipMemcpyAsync(d_verdict, h_verdict, m, hipMemcpyHostToDevice, st));
+            HIP_OK(launch_apply_verdicts(d_unknown + 64, d_verdict, m, (uint32_t)n, d_bits, d_bits + words, st));
         }
         return (size_t)-1;
     }
@@ -1571,14 +1614,25 @@ class SearchService {
         {
             std::lock_guard<std::mutex> g(mu_);
             pending_.push_back(std::move(r));
+            n_pending_.store(pending_.size(), std::memory_order_release);
         }
         cv_.notify_one();
     }
 
    private:
-    static constexpr int kSlots = 2;
+    // Pipeline slots.  Blocking callers (the reference's num_workers() + 1 threads, one query each) come back in ones and
+    // twos as their results are delivered: with two slots most of them found both busy and waited out half a walk on
+    // average (1.5 walks per round trip); with eight a free slot is there when the query is, and the round trip is one
+    // walk (team kernels of different streams run side by side: GPU_MAX_HW_QUEUES).  VS_HNSW_SERVICE_SLOTS: 1..16.
+    static constexpr int kSlots = 16;
+    int n_slots_ = 8;
+    // While a batch is in flight the dispatcher polls its event and the queue instead of sleeping in timer steps (a
+    // 20 us condition-variable wait is 70 us of timer slack and wake-up on Linux): VS_HNSW_SERVICE_SPIN=0 sleeps instead.
+    bool spin_ = true;
+    std::atomic<size_t> n_pending_{0};
     static constexpr size_t kMaxBatch = 8192;
     static constexpr size_t kZeroCopyBatch = 256;
+    static constexpr size_t kHeavyLoad = 512;  // queries in flight beyond which only two slots are used
     struct Slot {
         hipStream_t st = nullptr;
         hipEvent_t ev = nullptr;
@@ -1604,6 +1658,8 @@ class SearchService {
     Slot slots_[kSlots];
 
     explicit SearchService(int device) : device_(device) {
+        if (const char* v = std::getenv("VS_HNSW_SERVICE_SLOTS")) n_slots_ = std::min(kSlots, std::max(1, std::atoi(v)));
+        if (const char* v = std::getenv("VS_HNSW_SERVICE_SPIN")) spin_ = v[0] != '0';
         std::thread([this] { run(); }).detach();
     }
 
@@ -1644,7 +1700,7 @@ class SearchService {
             grow(s, nb, dim, k);
             for (size_t i = 0; i < nb; ++i) std::memcpy(s.h_q + i * dim, s.reqs[i].q.data(), dim * 4);
             size_t load = 0;  // this batch + the batches of the other slots still in flight
-            for (const Slot& o : slots_) load += o.busy ? o.reqs.size() : 0;
+            for (int i = 0; i < n_slots_; ++i) load += slots_[i].busy ? slots_[i].reqs.size() : 0;
             // Small batches skip the copy engine: the kernel reads its queries from, and writes its results to, the
             // pinned host block directly (device-mapped) -- 3 KB in and 124 B out per query over PCIe, two API calls
             // and two copy-engine latencies less per launch (the dispatcher thread is what bounds small batches).
@@ -1712,7 +1768,8 @@ class SearchService {
         for (;;) {
             bool progressed = false;
             // reap
-            for (Slot& s : slots_) {
+            for (int si = 0; si < n_slots_; ++si) {
+                Slot& s = slots_[si];
                 if (!s.busy) continue;
                 bool done = s.status != VS_OK || hipEventQuery(s.ev) == hipSuccess;
                 if (done) {
@@ -1725,8 +1782,19 @@ class SearchService {
             }
             // launch
             if (!pending_.empty()) {
-                for (Slot& s : slots_) {
+                // under load (the non-blocking entry point with thousands of queries in flight) two batches in flight keep
+                // the chip full and large batches are the efficient ones: the other slots are for the trickle of lone callers
+                size_t in_flight = 0;
+                int busy_n = 0;
+                for (int si = 0; si < n_slots_; ++si)
+                    if (slots_[si].busy) {
+                        in_flight += slots_[si].reqs.size();
+                        ++busy_n;
+                    }
+                for (int si = 0; si < n_slots_; ++si) {
+                    Slot& s = slots_[si];
                     if (s.busy || pending_.empty()) continue;
+                    if (busy_n >= 2 && in_flight >= kHeavyLoad) break;
                     Engine* e = pending_.front().e;
                     const size_t k = pending_.front().k;
                     std::deque<SearchReq> rest;
@@ -1737,7 +1805,10 @@ class SearchService {
                         pending_.pop_front();
                     }
                     pending_.swap(rest);
+                    n_pending_.store(pending_.size(), std::memory_order_release);
                     s.busy = true;
+                    in_flight += s.reqs.size();
+                    ++busy_n;
                     lk.unlock();
                     launch(s);
                     lk.lock();
@@ -1745,10 +1816,42 @@ class SearchService {
                 }
             }
             if (progressed) continue;
-            bool any_busy = false;
-            for (Slot& s : slots_) any_busy |= s.busy;
-            if (any_busy) cv_.wait_for(lk, std::chrono::microseconds(20));
-            else cv_.wait(lk, [this] { return !pending_.empty(); });
+            bool any_busy = false, any_free = false;
+            {
+                size_t in_flight = 0;
+                int busy_n = 0;
+                for (int si = 0; si < n_slots_; ++si) {
+                    any_busy |= slots_[si].busy;
+                    any_free |= !slots_[si].busy;
+                    if (slots_[si].busy) {
+                        in_flight += slots_[si].reqs.size();
+                        ++busy_n;
+                    }
+                }
+                if (busy_n >= 2 && in_flight >= kHeavyLoad) any_free = false;  // (no launch before one of them is back)
+            }
+            if (!any_busy) {
+                cv_.wait(lk, [this] { return !pending_.empty(); });
+                continue;
+            }
+            if (!spin_) {
+                cv_.wait_for(lk, std::chrono::microseconds(20));
+                continue;
+            }
+            // poll the events of the batches in flight and the queue (`busy` is written by this thread only); a batch
+            // that takes longer than 2 ms (large batches of the non-blocking entry point) is slept on in timer steps
+            lk.unlock();
+            bool woke = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 1; !woke; ++it) {
+                if (any_free && n_pending_.load(std::memory_order_acquire) > 0) woke = true;
+                for (int si = 0; si < n_slots_ && !woke; ++si)
+                    if (slots_[si].busy && (slots_[si].status != VS_OK || hipEventQuery(slots_[si].ev) == hipSuccess)) woke = true;
+                if (woke || ((it & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))) break;
+                for (int p = 0; p < 16; ++p) __builtin_ia32_pause();
+            }
+            lk.lock();
+            if (!woke) cv_.wait_for(lk, std::chrono::microseconds(50));
         }
     }
 
@@ -1774,7 +1877,91 @@ void Engine::search_async(const float* q, size_t k, uint64_t* keys, float* dist,
     SearchService::get(device).submit(std::move(r));
 }
 
+// One blocking caller, one walk, no thread hand-over: while few calls are in flight (the reference's num_workers() + 1
+// blocking threads, usearch.rs:203-222 / worker.rs:44-118) the calling thread launches the team kernel for its own query
+// on a leased stream -- query and answer in a pinned block the kernel addresses directly -- and waits for it itself:
+// it sleeps through most of the walk's expected time (what the last walks took) and polls the event for the rest.
+// Through the dispatcher the same query pays two thread wake-ups (caller -> dispatcher -> caller: 0.3-0.4 ms beside
+// a 0.6 ms walk); beyond kDirectCallers calls in flight batches are what fills the chip, and the dispatcher forms them.
+static std::atomic<int> g_direct_active{0};
+static std::atomic<int64_t> g_direct_off_until_ns{0};
+static int direct_callers_limit() {
+    static const int v = [] {
+        const char* s = std::getenv("VS_HNSW_DIRECT_CALLERS");
+        return s ? std::max(0, std::atoi(s)) : 20;  // + the dispatcher's slots: within GPU_MAX_HW_QUEUES, so no two lone walks share a hardware queue
+    }();
+    return v;
+}
+
+bool Engine::search_direct(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
+    const int limit = direct_callers_limit();
+    if (limit <= 0) return false;
+    // more callers than that: for the next 50 ms everybody goes through the dispatcher, whose batches serve many callers
+    // better than many lone walks side by side do (measured: 33 / 65 blocking callers 24k / 48k QPS batched, 16k / 24k mixed)
+    const int64_t now_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (now_ns < g_direct_off_until_ns.load(std::memory_order_relaxed)) return false;
+    const int ahead = g_direct_active.fetch_add(1, std::memory_order_acq_rel);
+    struct Leave {
+        ~Leave() { g_direct_active.fetch_sub(1, std::memory_order_acq_rel); }
+    } leave;
+    if (ahead >= limit) {
+        g_direct_off_until_ns.store(now_ns + 50000000, std::memory_order_relaxed);
+        return false;
+    }
+    use_device();
+    Lease w(device);
+    const size_t need_bytes = (size_t)dim * 4 + k * 12 + 64;
+    if (w->pin_bytes < need_bytes) {
+        if (w->pin) (void)hipHostFree(w->pin);
+        w->pin = nullptr;
+        w->pin_bytes = 0;
+        HIP_OK(hipHostMalloc((void**)&w->pin, need_bytes * 2, hipHostMallocDefault));
+        w->pin_bytes = need_bytes * 2;
+    }
+    if (!w->ev) HIP_OK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
+    float* h_q = (float*)w->pin;
+    uint64_t* h_k = (uint64_t*)(w->pin + (((size_t)dim * 4 + 15) & ~(size_t)15));
+    float* h_d = (float*)(h_k + k);
+    uint32_t* h_f = (uint32_t*)(h_d + k);
+    std::memcpy(h_q, q, (size_t)dim * 4);
+    *h_f = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    search_device(h_q, 1, k, h_k, h_d, h_f, w->stream, (size_t)ahead + 1);
+    HIP_OK(hipEventRecord(w->ev, w->stream));
+    // sleep through the first part of the walk (timer slack and wake-up cost ~70 us: leave 150), poll the rest
+    const uint64_t expect = lone_walk_ns.load(std::memory_order_relaxed);
+    if (expect > 250000) std::this_thread::sleep_for(std::chrono::nanoseconds(expect - 150000));
+    for (unsigned it = 1;; ++it) {
+        const hipError_t st = hipEventQuery(w->ev);
+        if (st == hipSuccess) break;
+        if (st != hipErrorNotReady) HIP_OK(st);
+        if ((it & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            HIP_OK(hipEventSynchronize(w->ev));  // not a lone walk any more (the device is busy with batches): block
+            break;
+        }
+        for (int p = 0; p < 32; ++p) __builtin_ia32_pause();
+    }
+    const uint64_t took = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    // what the next caller sleeps by: follows the walks down at once, up slowly (a walk that waited behind a batch is no guide)
+    lone_walk_ns.store(took < expect || expect == 0 ? took : expect + (std::min<uint64_t>(took, 4 * expect) - expect) / 8, std::memory_order_relaxed);
+    SearchService::n_batches += 1;
+    SearchService::n_queries += 1;
+    SearchService::n_team_batches += 1;
+    SearchService::n_team_queries += 1;
+    if (*h_f == kWalkFailed) {
+        *found = rank_all(q, k, keys, dist);
+        SearchService::n_ranked_fallbacks += 1;
+        return true;
+    }
+    const size_t f = std::min<size_t>(*h_f, k);
+    std::memcpy(keys, h_k, f * 8);
+    std::memcpy(dist, h_d, f * 4);
+    *found = f;
+    return true;
+}
+
 int Engine::search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
+    if (search_direct(q, k, keys, dist, found)) return VS_OK;
     struct Waiter {
         std::mutex m;
         std::condition_variable c;

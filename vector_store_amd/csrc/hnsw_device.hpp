@@ -476,6 +476,7 @@ struct BeamShared : SelArrays<SEL>, TeamBox<TM>, VisitedHi<WT, NB> {
     static constexpr int kChoices = CH;
     static constexpr int kEfCap = EFCAP;
     static constexpr int kNB = NB;
+    static constexpr int kBucket = 8;  // tags per bucket of the visited table
     static constexpr int kTeam = TM;
     static constexpr bool kSel = SEL;
     static constexpr uint32_t kOvfCap = (uint32_t)kOvf - 2u;  // entries of vis_ovf
@@ -612,14 +613,26 @@ __device__ __forceinline__ void visited_clear(Sh& sh, int lane) {
 // Tags of one bucket that match `want` among its first min(cnt, 8) entries.
 template <class Sh>
 __device__ __forceinline__ bool bucket_has(const Sh& sh, uint32_t b, uint32_t cnt, uint32_t want, uint32_t want_hi) {
-    const uint4 t4 = *reinterpret_cast<const uint4*>(&sh.vis_tag[b * 8]);
-    const uint32_t w[4] = {t4.x, t4.y, t4.z, t4.w};
-    const uint32_t n = cnt < 8u ? cnt : 8u;
+    constexpr int BS = Sh::kBucket;  // 8 tags = one 16-byte read; 12 tags (the dense table of the walk) = three 8-byte reads
+    static_assert(BS == 8 || (BS == 12 && !Sh::kWideTags), "bucket sizes");
+    uint32_t w[BS / 2];
+    if constexpr (BS == 8) {
+        const uint4 t4 = *reinterpret_cast<const uint4*>(&sh.vis_tag[b * 8]);
+        w[0] = t4.x; w[1] = t4.y; w[2] = t4.z; w[3] = t4.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < BS / 4; ++i) {
+            const uint2 t2 = *reinterpret_cast<const uint2*>(&sh.vis_tag[b * BS + 4 * i]);
+            w[2 * i] = t2.x;
+            w[2 * i + 1] = t2.y;
+        }
+    }
+    const uint32_t n = cnt < (uint32_t)BS ? cnt : (uint32_t)BS;
     uint32_t hw = 0;
     if constexpr (Sh::kWideTags) hw = sh.vis_hi[b];
     bool found = false;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < BS; ++j) {
         uint32_t tj = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
         bool eq = tj == want;
         if constexpr (Sh::kWideTags) eq = eq && ((hw >> (4 * j)) & 15u) == want_hi;
@@ -670,9 +683,10 @@ __device__ __forceinline__ bool visited_test_and_set(Sh& sh, uint32_t slot) {
     }
     if (found) return true;
     // a full bucket is not incremented further: the byte counter can never wrap
-    uint32_t pos = cb >= 8u ? 8u : (atomicAdd(&sh.vis_cnt[b >> 2], 1u << sb) >> sb) & 0xFFu;
-    if (pos < 8u) {
-        sh.vis_tag[b * 8 + pos] = (uint16_t)stored;
+    constexpr uint32_t BS = (uint32_t)Sh::kBucket;
+    uint32_t pos = cb >= BS ? BS : (atomicAdd(&sh.vis_cnt[b >> 2], 1u << sb) >> sb) & 0xFFu;
+    if (pos < BS) {
+        sh.vis_tag[b * BS + pos] = (uint16_t)stored;
         if constexpr (Sh::kWideTags) atomicOr(&sh.vis_hi[b], hi << (4u * pos));
         return false;
     }

@@ -58,8 +58,9 @@ struct LinkArgs {
 enum : uint32_t { WALK_LDS_128 = 0, WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512, WALK_GLOBAL_2048, WALK_GLOBAL_10240,
                   WALK_LDS_128_TINY /* test hook: 256-bucket visited table (1-chunk rows only), forces the retry path */,
                   WALK_LDS_128_SMALL /* 512-bucket two-choice table (4,096 entries, slots < 2^24): 14.6 KB of LDS, 10 walks per CU */,
-                  WALK_LDS_320 /* beams of 257..288 (`top` of 320): the 256 instance's visited table, 5 walks per CU instead of 3 */ };
-constexpr uint32_t kWalkTeamFlag = 0x100;      // instance | flag: one workgroup of kSearchTeam waves per query (LDS instances up to 320, unfiltered)
+                  WALK_LDS_320 /* beams of 257..288 (`top` of 320): the 256 instance's visited table, 5 walks per CU instead of 3 */,
+                  WALK_LDS_256_DENSE /* beams of 129..256 below 2^24 slots: 512 x 12-tag buckets instead of 1,024 x 8: 22.0 KB, 7 walks per CU */ };
+constexpr uint32_t kWalkTeamFlag = 0x100;      // instance | flag: one workgroup of kSearchTeam waves per query (LDS instances up to 320, unfiltered; WALK_GLOBAL_512, filtered too)
 constexpr uint32_t kWalk320MaxBeam = 288;      // ~23.6 evaluations per beam entry: 6,800 of the table's 8,192 entries
 constexpr uint32_t kWalkFailed = 0xFFFFFFFFu;  // out_found: the walk outgrew its workspace, the query was not answered
 constexpr uint32_t kMaxWalkBeam = 10240;       // widest `top` of the walk instances
@@ -164,6 +165,9 @@ hipError_t launch_block1_plane_rows(const IndexView& ix, uint16_t* plane, uint32
 hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_t* plane, float rho, float max_row_norm, uint32_t* d_uncertified,
                                 hipStream_t s);
 hipError_t launch_row_norm_max(const IndexView& ix, uint32_t first, uint32_t n, uint32_t* d_max_bits, hipStream_t s);
+// filtered search, lazily evaluated predicate: verdict[i] (0 / 1) of slot list[i] -> the device-resident known / allow bitmaps
+hipError_t launch_apply_verdicts(const uint32_t* list, const uint8_t* verdict, uint32_t m, uint32_t slots, uint32_t* allow, uint32_t* known,
+                                 hipStream_t s);
 
 // out[s] = distance(query, row s) for s in [0, n): one wave per row; result copied to host_out.
 // d_scratch: n + dim + 64 floats.

@@ -28,7 +28,8 @@ uint32_t walk_small_table_bits() { return VisitedCfg<512, 2>::domain_bits; }
 uint32_t walk_instance_domain_bits(uint32_t instance) {
     switch (instance & ~kWalkTeamFlag) {
         case WALK_LDS_128: return VisitedCfg<1024, 1>::domain_bits;
-        case WALK_LDS_128_SMALL: return VisitedCfg<512, 2>::domain_bits;
+        case WALK_LDS_128_SMALL:
+        case WALK_LDS_256_DENSE: return VisitedCfg<512, 2>::domain_bits;
         case WALK_LDS_128_TINY: return VisitedCfg<256, 1>::domain_bits;
         case WALK_LDS_256:
         case WALK_LDS_320: return VisitedCfg<1024, 2>::domain_bits;

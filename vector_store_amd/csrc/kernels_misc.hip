@@ -1018,6 +1018,25 @@ size_t block_scratch_bytes(uint32_t nq, uint32_t dim) {
            (size_t)nq * kpad * 8 + (size_t)nq * kBlockC * 16 + (size_t)nq * 4 + 4096;
 }
 
+// Filtered search with a lazily evaluated predicate (engine.hip filtered_lazy): the host's verdicts for the slots the last
+// walk listed go into the query's `known` / `allow` bitmaps, which live on the device for the whole query.
+__global__ void apply_verdicts_kernel(const uint32_t* __restrict__ list, const uint8_t* __restrict__ verdict, uint32_t m, uint32_t slots,
+                                      uint32_t* __restrict__ allow, uint32_t* __restrict__ known) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t s = list[i];
+    if (s >= slots) return;
+    atomicOr(&known[s >> 5], 1u << (s & 31u));
+    if (verdict[i]) atomicOr(&allow[s >> 5], 1u << (s & 31u));
+}
+
+hipError_t launch_apply_verdicts(const uint32_t* list, const uint8_t* verdict, uint32_t m, uint32_t slots, uint32_t* allow, uint32_t* known,
+                                 hipStream_t s) {
+    if (!m) return hipSuccess;
+    hipLaunchKernelGGL(apply_verdicts_kernel, dim3((m + 255) / 256), dim3(256), 0, s, list, verdict, m, slots, allow, known);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_norm_max(const IndexView& ix, uint32_t first, uint32_t n, uint32_t* d_max_bits, hipStream_t s) {
     if (!n) return hipSuccess;
     const uint32_t kpad = (ix.dim + 31u) & ~31u;

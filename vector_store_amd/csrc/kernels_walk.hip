@@ -24,9 +24,9 @@
 
 namespace vs {
 
-template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, bool VISG>
+template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, bool VISG, int BS = 8>
 __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
-    using Sh = WalkShared<EFCAP, LCAP, NB, CH, VISG>;
+    using Sh = WalkShared<EFCAP, LCAP, NB, CH, VISG, 1, false, false, BS>;
     __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
@@ -159,6 +159,84 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_kernel(WalkArgs a) {
     }
 }
 
+// The global-bitmap walk (filtered search, beams and indexes beyond the LDS tables) for a lone query: the same team of waves.
+// Wave 0 walks with the visited bitmap, the visited log and the deep levels of `next` in its workspace (a.space, one per
+// workgroup) and consults the predicate's verdicts exactly as the one-wave kernel does; the helpers only measure distances.
+template <int AR, int I, int EFCAP, int LCAP, int TEAM>
+__global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_global_kernel(WalkArgs a) {
+    using Sh = WalkShared<EFCAP, LCAP, 256, 1, true, TEAM>;
+    __shared__ Sh sh;
+    const IndexView& ix = a.ix;
+    const int lane = lane_id();
+    const uint32_t qi = blockIdx.x, w = threadIdx.x >> 6;
+    uint64_t* ok = a.out_keys + (size_t)qi * a.k;
+    float* od = a.out_dist + (size_t)qi * a.k;
+    if (ix.max_level < 0) {  // empty index
+        if (w == 0) {
+            for (uint32_t i = lane; i < a.k; i += kWave) {
+                ok[i] = kFreeKey;
+                od[i] = __builtin_inff();
+            }
+            if (lane == 0) a.out_found[qi] = 0;
+        }
+        return;
+    }
+    Query<AR, I> q;
+    query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
+    if (w != 0) {
+        team_helper_loop<AR, I>(ix, q, sh, lane, w);
+        return;
+    }
+    WalkSpace ws;
+    {
+        char* base = a.space + (size_t)blockIdx.x * a.space_stride;
+        ws.bitmap = reinterpret_cast<uint32_t*>(base);
+        ws.vlog = ws.bitmap + a.bitmap_words;
+        ws.heap = reinterpret_cast<uint2*>(ws.vlog + a.vlog_cap);
+        ws.bitmap_words = a.bitmap_words;
+        ws.vlog_cap = a.vlog_cap;
+        ws.heap_cap = a.heap_cap;
+    }
+    Counters cnt = {0, 0, 0};
+    const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
+    bool exhausted = false;
+    const uint32_t* allow = a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
+    const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, allow, cnt, lane, exhausted, nullptr,
+                                     a.known ? a.known + (size_t)qi * a.allow_stride : nullptr,
+                                     a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
+                                     a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget,
+                                     a.consulted ? a.consulted + qi : nullptr);
+    team_release(sh, lane);
+    wsync<Sh>();
+    if (exhausted) {
+        if (lane == 0) a.out_found[qi] = kWalkFailed;  // workspace too small: the host ranks exhaustively
+        return;
+    }
+    const uint32_t found = sz < a.k ? sz : a.k;
+    for (uint32_t i = lane; i < a.k; i += kWave) {
+        const bool in = i < found;
+        ok[i] = in ? ix.keys[sh.lst_s[i]] : kFreeKey;
+        od[i] = in ? sh.lst_d[i] : __builtin_inff();
+    }
+    if (lane == 0) {
+        a.out_found[qi] = found;
+        atomicAdd(&a.stats[ST_SEARCH_EVALS], cnt.evals);
+        atomicAdd(&a.stats[ST_SEARCH_HOPS], cnt.hops);
+        atomicAdd(&a.stats[ST_QUERIES], 1ull);
+    }
+}
+
+template <int AR, int I, int EFCAP, int LCAP>
+static hipError_t walk_team_global_launch(const WalkArgs& a, hipStream_t s, uint32_t* grid_out) {
+    if (grid_out) {
+        *grid_out = a.nq ? a.nq : 1;
+        return hipSuccess;
+    }
+    if (!a.nq || a.qlist) return a.nq ? hipErrorInvalidValue : hipSuccess;
+    hipLaunchKernelGGL((hnsw_walk_team_global_kernel<AR, I, EFCAP, LCAP, kSearchTeam>), dim3(a.nq), dim3(64 * kSearchTeam), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int AR, int I, int EFCAP, int LCAP, int NB, int CH>
 static hipError_t walk_team_launch(const WalkArgs& a, hipStream_t s, uint32_t* grid_out) {
     if (grid_out) {
@@ -185,9 +263,9 @@ static uint32_t resident_workgroups(K kernel, int device) {  // workgroups of `k
     return (uint32_t)per_cu * (uint32_t)cus;
 }
 
-template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, bool VISG>
+template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, bool VISG, int BS = 8>
 static hipError_t walk_launch(const WalkArgs& a, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out) {
-    auto kernel = hnsw_walk_kernel<AR, I, EFCAP, LCAP, NB, CH, VISG>;
+    auto kernel = hnsw_walk_kernel<AR, I, EFCAP, LCAP, NB, CH, VISG, BS>;
     static std::atomic<uint32_t> resident_cache{0};  // per instance; the engine serves one device model
     uint32_t resident = resident_cache.load(std::memory_order_relaxed);
     if (!resident) {
@@ -221,6 +299,7 @@ static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_ca
             case WALK_LDS_128_SMALL:
             case WALK_LDS_128_TINY: return walk_launch<AR, I, 128, kWalkHeapLds, 1024, 1, false>(a, grid_cap, s, grid_out);
             case WALK_LDS_256:
+            case WALK_LDS_256_DENSE:
             case WALK_LDS_320:
             case WALK_LDS_512: return walk_launch<AR, I, 512, 1690, 2048, 2, false>(a, grid_cap, s, grid_out);
             case WALK_GLOBAL_512: return walk_launch<AR, I, 512, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
@@ -243,11 +322,18 @@ static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_ca
         case WALK_GLOBAL_2048: return walk_launch<AR, I, 2048, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_GLOBAL_10240: return walk_launch<AR, I, 10240, 1024, 256, 1, true>(a, grid_cap, s, grid_out);
         case WALK_LDS_128_SMALL: return walk_launch<AR, I, 128, kWalkHeapLds, 512, 2, false>(a, grid_cap, s, grid_out);
+        // beams of 129..256 below 2^24 slots: 512 buckets x 12 tags (6,144 entries, two choices; a beam of 208 visits ~4,900
+        // nodes, 5,500 at most) instead of 1,024 x 8: 22,004 B of LDS = 7 walks per CU instead of 6.  (`next` keeps its 796
+        // entries: with 600 -- 8 walks per CU -- a quarter of the headline's queries outgrew it, p50 569 / p99 679 / max 772.)
+        // A query that outgrows the table goes to the retry instance, and an index on which many do goes back to the 256
+        // instance (engine.hip).
+        case WALK_LDS_256_DENSE: return walk_launch<AR, I, 256, 796, 512, 2, false, 12>(a, grid_cap, s, grid_out);
         // team forms (small batches) of the instances above
         case WALK_LDS_128 | kWalkTeamFlag: return walk_team_launch<AR, I, 128, kWalkHeapLds, 1024, 1>(a, s, grid_out);
         case WALK_LDS_128_SMALL | kWalkTeamFlag: return walk_team_launch<AR, I, 128, kWalkHeapLds, 512, 2>(a, s, grid_out);
         case WALK_LDS_256 | kWalkTeamFlag: return walk_team_launch<AR, I, 256, 796, 1024, 2>(a, s, grid_out);
         case WALK_LDS_320 | kWalkTeamFlag: return walk_team_launch<AR, I, 320, 990, 1024, 2>(a, s, grid_out);
+        case WALK_GLOBAL_512 | kWalkTeamFlag: return walk_team_global_launch<AR, I, 512, 1024>(a, s, grid_out);
         case WALK_LDS_128_TINY:
             if constexpr (I == 1) return walk_launch<AR, 1, 128, kWalkHeapLds, 256, 1, false>(a, grid_cap, s, grid_out);
             return hipErrorInvalidValue;

@@ -45,26 +45,29 @@ struct WalkSpace {
 };
 
 constexpr int kWalkOvf = 62;  // overflow list of the walk's visited table (the 128-entry `top` instance then fits 7 per CU)
-template <bool ON, int NB>
+template <bool ON, int NB, int BS = 8>
 struct VisitedLds {
-    alignas(16) uint16_t vis_tag[NB * 8];
+    alignas(16) uint16_t vis_tag[NB * BS];
     uint32_t vis_cnt[NB / 4];
     uint32_t vis_ovf[kWalkOvf];
     uint32_t ovf_cnt;
     uint32_t overflowed;
 };
-template <int NB>
-struct VisitedLds<false, NB> {};
+template <int NB, int BS>
+struct VisitedLds<false, NB, BS> {};
 
 // EFCAP: capacity of `top`; LCAP: entries of `next` kept in LDS (the first levels of the heap -- every pop walks from the
 // root, the deep levels are touched once per pop); VISG: visited set = bitmap in global memory (no limit on the index
 // size or on the number of visited nodes) instead of the LDS tag table of hnsw_device.hpp.
-template <int EFCAP, int LCAP, int NB, int CH, bool VISG, int TM = 1, bool NT = false, bool SEL = false>
-struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB> {
+// BS: tags per bucket of the visited table (8; 12 = the DENSE table: 512 buckets x 12 hold the 6,144 nodes a beam of up to 256 visits
+// in 12.5 KB instead of 17: 7 walks per CU instead of 6).
+template <int EFCAP, int LCAP, int NB, int CH, bool VISG, int TM = 1, bool NT = false, bool SEL = false, int BS = 8>
+struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB, BS> {
     static constexpr bool kNT = NT;
     static constexpr int kChoices = CH;
     static constexpr int kEfCap = EFCAP;
     static constexpr int kNB = NB;
+    static constexpr int kBucket = BS;
     static constexpr int kTeam = TM;
     static constexpr bool kSel = SEL;
     static constexpr int kHeapLds = LCAP;

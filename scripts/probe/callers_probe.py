@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: what blocking / non-blocking callers get through the C ABI on one index, for A/B runs of the
 dispatcher's settings (VS_HNSW_SERVICE_SLOTS, VS_HNSW_SERVICE_SPIN) -- the loop is libvs_callers' (bench.py's `boundary`).
-    python scripts/probe/callers_probe.py [vectors] [ef] [seconds] [quantization]"""
+    python scripts/probe/callers_probe.py [vectors] [ef] [seconds] [quantization] [threadsxinflight,...]"""
 import ctypes as C
 import os
 import sys
@@ -39,7 +39,8 @@ L = C.CDLL(os.path.join(ROOT, "vector_store_amd", "libvs_callers.so"))
 L.vs_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint,
                              C.c_double, C.POINTER(Res)]
 print(f"n {n} ef {ef} slots {os.environ.get('VS_HNSW_SERVICE_SLOTS', 'default')} spin {os.environ.get('VS_HNSW_SERVICE_SPIN', 'default')}", flush=True)
-for threads, inflight in ((1, 1), (4, 1), (17, 1), (33, 1), (65, 1), (16, 16), (16, 256)):
+legs = [tuple(int(x) for x in leg.split("x")) for leg in sys.argv[5].split(",")] if len(sys.argv) > 5 else ((1, 1), (4, 1), (17, 1), (33, 1), (65, 1), (16, 16), (16, 256))
+for threads, inflight in legs:
     r = Res()
     rc = L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], dim, k, truth.ctypes.data, threads, inflight, seconds, C.byref(r))
     print(f"  threads {threads:3d} x {inflight:3d} in flight: {r.qps:10.0f} QPS  min {r.latency_min_ns / 1e6:.3f} ms  agreement {r.recall_avg:.4f}  "

@@ -269,8 +269,8 @@ struct Arena {
 struct WorkCtx {
     hipStream_t stream = nullptr;
     DeviceBuf a, b, c, d, e, f;
-    // one-query calls (Engine::search_one): a pinned, device-mapped block the kernel reads its query from and writes its
-    // answer to, and the event the caller polls
+    // filtered search with a lazily evaluated predicate (Engine::filtered_lazy): pinned staging for the lists and verdicts
+    // of a round, and the event a crowd of callers sleeps on
     char* pin = nullptr;
     size_t pin_bytes = 0;
     hipEvent_t ev = nullptr;
@@ -1347,8 +1347,6 @@ struct Engine {
 
     // One query per FFI call (reference usearch.rs:212): handled by the per-device SearchService below.
     int search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found);
-    bool search_direct(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found);
-    std::atomic<uint64_t> lone_walk_ns{0};  // what a one-query call's walk took lately (launch to event), search_direct's sleep
     void search_async(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found,
                       void (*cb)(void*, int), void* ctx);
 
@@ -1474,6 +1472,31 @@ struct Engine {
         float* h_d = (float*)(h_k + k);
         HIP_OK(hipMemcpyAsync(d_q, q, (size_t)dim * 4, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemsetAsync(d_bits, 0, words * 8, st));
+        // Waiting for a round: hipStreamSynchronize polls, which is the fastest wake-up while every caller has a core; with
+        // more filtered calls in flight than cores (the reference runs each on a spawn_blocking thread, usearch.rs:937-948:
+        // as many as there are requests) polling callers starve the ones that have verdicts to compute, so the crowd sleeps
+        // in 100 us steps on the round's event instead (measured with 64 callers on 16 cores: 70 QPS polling, 17 callers: 241).
+        static std::atomic<int> filtered_active{0};
+        struct Active {
+            std::atomic<int>& n;
+            explicit Active(std::atomic<int>& c) : n(c) { n.fetch_add(1, std::memory_order_relaxed); }
+            ~Active() { n.fetch_sub(1, std::memory_order_relaxed); }
+        } active(filtered_active);
+        if (!w->ev) HIP_OK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
+        auto wait_round = [&] {
+            static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+            if (filtered_active.load(std::memory_order_relaxed) < cores) {
+                HIP_OK(hipStreamSynchronize(st));
+                return;
+            }
+            HIP_OK(hipEventRecord(w->ev, st));
+            for (;;) {
+                const hipError_t e = hipEventQuery(w->ev);
+                if (e == hipSuccess) break;
+                if (e != hipErrorNotReady) HIP_OK(e);
+                std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+        };
         const uint32_t hint = lazy_need_hint.load();
         const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
         for (int round = 0; round < 20; ++round) {
@@ -1496,7 +1519,7 @@ struct Engine {
             HIP_OK(hipMemcpyAsync(h_d, d_d, k * 4, hipMemcpyDeviceToHost, st));
             const uint32_t head = std::min<uint32_t>(lf.budget, cap);
             HIP_OK(hipMemcpyAsync(h_list, d_unknown + 64, (size_t)head * 4, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipStreamSynchronize(st));
+            wait_round();
             const uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
             if (count == 0) {
                 if (found == kWalkFailed) return (size_t)-1;
@@ -1510,7 +1533,7 @@ struct Engine {
             const uint32_t m = std::min(count, cap);
             if (m > head) {  // (a hop's worth beyond the budget)
                 HIP_OK(hipMemcpyAsync(h_list + head, d_unknown + 64 + head, (size_t)(m - head) * 4, hipMemcpyDeviceToHost, st));
-                HIP_OK(hipStreamSynchronize(st));
+                wait_round();
             }
             // a walk evaluates a node once, so a list names a slot once, and slots with a verdict are never listed again
             for (uint32_t i = 0; i < m; ++i) {
@@ -1877,91 +1900,7 @@ void Engine::search_async(const float* q, size_t k, uint64_t* keys, float* dist,
     SearchService::get(device).submit(std::move(r));
 }
 
-// One blocking caller, one walk, no thread hand-over: while few calls are in flight (the reference's num_workers() + 1
-// blocking threads, usearch.rs:203-222 / worker.rs:44-118) the calling thread launches the team kernel for its own query
-// on a leased stream -- query and answer in a pinned block the kernel addresses directly -- and waits for it itself:
-// it sleeps through most of the walk's expected time (what the last walks took) and polls the event for the rest.
-// Through the dispatcher the same query pays two thread wake-ups (caller -> dispatcher -> caller: 0.3-0.4 ms beside
-// a 0.6 ms walk); beyond kDirectCallers calls in flight batches are what fills the chip, and the dispatcher forms them.
-static std::atomic<int> g_direct_active{0};
-static std::atomic<int64_t> g_direct_off_until_ns{0};
-static int direct_callers_limit() {
-    static const int v = [] {
-        const char* s = std::getenv("VS_HNSW_DIRECT_CALLERS");
-        return s ? std::max(0, std::atoi(s)) : 20;  // + the dispatcher's slots: within GPU_MAX_HW_QUEUES, so no two lone walks share a hardware queue
-    }();
-    return v;
-}
-
-bool Engine::search_direct(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
-    const int limit = direct_callers_limit();
-    if (limit <= 0) return false;
-    // more callers than that: for the next 50 ms everybody goes through the dispatcher, whose batches serve many callers
-    // better than many lone walks side by side do (measured: 33 / 65 blocking callers 24k / 48k QPS batched, 16k / 24k mixed)
-    const int64_t now_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (now_ns < g_direct_off_until_ns.load(std::memory_order_relaxed)) return false;
-    const int ahead = g_direct_active.fetch_add(1, std::memory_order_acq_rel);
-    struct Leave {
-        ~Leave() { g_direct_active.fetch_sub(1, std::memory_order_acq_rel); }
-    } leave;
-    if (ahead >= limit) {
-        g_direct_off_until_ns.store(now_ns + 50000000, std::memory_order_relaxed);
-        return false;
-    }
-    use_device();
-    Lease w(device);
-    const size_t need_bytes = (size_t)dim * 4 + k * 12 + 64;
-    if (w->pin_bytes < need_bytes) {
-        if (w->pin) (void)hipHostFree(w->pin);
-        w->pin = nullptr;
-        w->pin_bytes = 0;
-        HIP_OK(hipHostMalloc((void**)&w->pin, need_bytes * 2, hipHostMallocDefault));
-        w->pin_bytes = need_bytes * 2;
-    }
-    if (!w->ev) HIP_OK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
-    float* h_q = (float*)w->pin;
-    uint64_t* h_k = (uint64_t*)(w->pin + (((size_t)dim * 4 + 15) & ~(size_t)15));
-    float* h_d = (float*)(h_k + k);
-    uint32_t* h_f = (uint32_t*)(h_d + k);
-    std::memcpy(h_q, q, (size_t)dim * 4);
-    *h_f = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    search_device(h_q, 1, k, h_k, h_d, h_f, w->stream, (size_t)ahead + 1);
-    HIP_OK(hipEventRecord(w->ev, w->stream));
-    // sleep through the first part of the walk (timer slack and wake-up cost ~70 us: leave 150), poll the rest
-    const uint64_t expect = lone_walk_ns.load(std::memory_order_relaxed);
-    if (expect > 250000) std::this_thread::sleep_for(std::chrono::nanoseconds(expect - 150000));
-    for (unsigned it = 1;; ++it) {
-        const hipError_t st = hipEventQuery(w->ev);
-        if (st == hipSuccess) break;
-        if (st != hipErrorNotReady) HIP_OK(st);
-        if ((it & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
-            HIP_OK(hipEventSynchronize(w->ev));  // not a lone walk any more (the device is busy with batches): block
-            break;
-        }
-        for (int p = 0; p < 32; ++p) __builtin_ia32_pause();
-    }
-    const uint64_t took = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    // what the next caller sleeps by: follows the walks down at once, up slowly (a walk that waited behind a batch is no guide)
-    lone_walk_ns.store(took < expect || expect == 0 ? took : expect + (std::min<uint64_t>(took, 4 * expect) - expect) / 8, std::memory_order_relaxed);
-    SearchService::n_batches += 1;
-    SearchService::n_queries += 1;
-    SearchService::n_team_batches += 1;
-    SearchService::n_team_queries += 1;
-    if (*h_f == kWalkFailed) {
-        *found = rank_all(q, k, keys, dist);
-        SearchService::n_ranked_fallbacks += 1;
-        return true;
-    }
-    const size_t f = std::min<size_t>(*h_f, k);
-    std::memcpy(keys, h_k, f * 8);
-    std::memcpy(dist, h_d, f * 4);
-    *found = f;
-    return true;
-}
-
 int Engine::search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
-    if (search_direct(q, k, keys, dist, found)) return VS_OK;
     struct Waiter {
         std::mutex m;
         std::condition_variable c;

@@ -333,7 +333,9 @@ static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_ca
         case WALK_LDS_128_SMALL | kWalkTeamFlag: return walk_team_launch<AR, I, 128, kWalkHeapLds, 512, 2>(a, s, grid_out);
         case WALK_LDS_256 | kWalkTeamFlag: return walk_team_launch<AR, I, 256, 796, 1024, 2>(a, s, grid_out);
         case WALK_LDS_320 | kWalkTeamFlag: return walk_team_launch<AR, I, 320, 990, 1024, 2>(a, s, grid_out);
-        case WALK_GLOBAL_512 | kWalkTeamFlag: return walk_team_global_launch<AR, I, 512, 1024>(a, s, grid_out);
+        // lone filtered queries: `next` grows to thousands of entries (rejected nodes are expanded too); a team workgroup has
+        // its CU's LDS nearly to itself, so 6,144 entries of it (12 levels) stay there: 54 KB
+        case WALK_GLOBAL_512 | kWalkTeamFlag: return walk_team_global_launch<AR, I, 512, 6144>(a, s, grid_out);
         case WALK_LDS_128_TINY:
             if constexpr (I == 1) return walk_launch<AR, 1, 128, kWalkHeapLds, 256, 1, false>(a, grid_cap, s, grid_out);
             return hipErrorInvalidValue;

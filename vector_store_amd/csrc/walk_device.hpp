@@ -115,6 +115,22 @@ __device__ __forceinline__ void heap_set(Sh& sh, const WalkSpace& ws, uint32_t i
     }
 }
 
+// per-lane access to entry i of a heap whose deep levels live in global memory (lanes of one wave may hit both)
+template <class Sh>
+__device__ __forceinline__ uint2 heap_lane_load(const Sh& sh, const WalkSpace& ws, uint32_t i, bool valid) {
+    uint2 e = make_uint2(0u, 0u);
+    if (valid) {
+        if (i < (uint32_t)Sh::kHeapLds) e = sh.hp[i];
+        else e = ws.heap[i - (uint32_t)Sh::kHeapLds];
+    }
+    return e;
+}
+template <class Sh>
+__device__ __forceinline__ void heap_lane_store(Sh& sh, const WalkSpace& ws, uint32_t i, uint2 e) {
+    if (i < (uint32_t)Sh::kHeapLds) sh.hp[i] = e;
+    else ws.heap[i - (uint32_t)Sh::kHeapLds] = e;
+}
+
 // emplace + shift_up: the new entry climbs while its parent is strictly farther.
 // LDS-only heaps (LDS instances): the ancestors of the insertion point are known up front -- ((pos + 1) >> k) - 1 --, so
 // lane k loads ancestor k, one ballot says how far the entry climbs, and the entries on that stretch move down one
@@ -136,16 +152,20 @@ __device__ __forceinline__ void heap_push(Sh& sh, const WalkSpace& ws, uint32_t&
         if (lane == 0) sh.hp[((pos + 1u) >> climb) - 1u] = make_uint2(__float_as_uint(d), slot);
         return;
     } else {
-        uint32_t i = uni(hn);
-        hn = i + 1u;
-        while (i) {
-            const uint32_t p = (i - 1u) >> 1;
-            const uint2 e = heap_get(sh, ws, p);
-            if (!(__uint_as_float(e.x) > d)) break;
-            heap_set(sh, ws, i, e, lane);
-            i = p;
-        }
-        heap_set(sh, ws, i, make_uint2(__float_as_uint(d), slot), lane);
+        // the same with the deep levels in global memory: every lane reads ITS ancestor from wherever it lives, so a push is
+        // one LDS and (for a deep heap) one global round trip, whatever the depth (a filtered walk's `next` holds thousands of
+        // entries: one dependent global read per level made the heap the larger part of a hop)
+        const uint32_t pos = uni(hn);
+        hn = pos + 1u;
+        const uint32_t depth = 32u - (uint32_t)__builtin_clz(pos + 1u) - 1u;
+        const uint32_t k = (uint32_t)lane;
+        const bool on = k >= 1u && k <= depth;
+        const uint32_t anc = ((pos + 1u) >> (on ? k : 0u)) - 1u;
+        const uint2 e = heap_lane_load(sh, ws, anc, on);
+        const uint64_t far = __ballot(on && __uint_as_float(e.x) > d) >> 1;
+        const uint32_t climb = (uint32_t)__builtin_ctzll(~far);  // <= depth
+        if (on && k <= climb) heap_lane_store(sh, ws, ((pos + 1u) >> (k - 1u)) - 1u, e);
+        if (lane == 0) heap_lane_store(sh, ws, ((pos + 1u) >> climb) - 1u, make_uint2(__float_as_uint(d), slot));
     }
 }
 
@@ -203,22 +223,45 @@ __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& 
         if (lane == 0) sh.hp[sink ? land : 0u] = make_uint2(last.x, last.y);
         return;
     } else {
+        // Heaps with their deep levels in global memory: the descendants of node i down to five levels are the 62 entries
+        // (i + 1) 2^j - 1 + t (j = 1..5, t < 2^j): lane L = 2^j - 1 + t loads its entry from LDS or global memory, whichever
+        // holds it -- one round trip --, and the sift then runs five levels on registers (in lane space the children of L are
+        // 2 L + 1 and 2 L + 2 again).  Same comparisons in the same order as the level-by-level loop.
         const uint2 last = heap_get(sh, ws, n);
         const float ld = __uint_as_float(last.x);
-        uint32_t i = 0;
+        uint32_t i = 0;  // the node the last entry is sinking from (absolute index, wave-uniform)
         for (;;) {
-            const uint32_t l = 2u * i + 1u;
-            if (l >= n) break;
-            uint2 ec = heap_get(sh, ws, l);
-            uint2 er = l + 1u < n ? heap_get(sh, ws, l + 1u) : ec;
-            uint32_t c = l;
-            if (l + 1u < n && __uint_as_float(ec.x) > __uint_as_float(er.x)) {
-                ec = er;
-                c = l + 1u;
+            if (2u * i + 1u >= n) break;
+            const uint32_t L = (uint32_t)lane;
+            const uint32_t j = 31u - (uint32_t)__builtin_clz(L + 1u);
+            const uint64_t idx64 = (((uint64_t)i + 1ull) << j) - 1ull + (uint64_t)(L + 1u - (1u << j));
+            const bool valid = L >= 1u && L <= 62u && idx64 < (uint64_t)n;
+            const uint2 e = heap_lane_load(sh, ws, (uint32_t)idx64, valid);
+            uint32_t pos = 0, a_pos = i;
+            bool done = false;
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) {
+                const uint32_t l = 2u * pos + 1u, a_l = 2u * a_pos + 1u;
+                if (a_l >= n) {
+                    done = true;
+                    break;
+                }
+                const bool two = a_l + 1u < n;
+                const float dl = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)l));
+                const float dr = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)(l + 1u)));
+                const uint32_t c = (two && dl > dr) ? l + 1u : l;
+                const uint32_t a_c = a_l + (c - l);
+                const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)c), cy = (uint32_t)__builtin_amdgcn_readlane((int)e.y, (int)c);
+                if (!(ld > __uint_as_float(cx))) {
+                    done = true;
+                    break;
+                }
+                heap_set(sh, ws, a_pos, make_uint2(cx, cy), lane);
+                pos = c;
+                a_pos = a_c;
             }
-            if (!(ld > __uint_as_float(ec.x))) break;
-            heap_set(sh, ws, i, ec, lane);
-            i = c;
+            i = a_pos;
+            if (done) break;
         }
         heap_set(sh, ws, i, last, lane);
     }

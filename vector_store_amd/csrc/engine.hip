@@ -28,6 +28,7 @@
 
 #include "../../include/vs_hnsw.h"
 #include "kernels.hpp"
+#include "filter_rounds.hpp"
 
 #define VS_VERSION "0.1.0"
 
@@ -1449,15 +1450,14 @@ struct Engine {
         const uint32_t cap = 1u << 17;
         Lease w(device);
         hipStream_t st = w->stream;
-        float* d_q = (float*)w->a.ensure((size_t)dim * 4);
         uint64_t* d_k = (uint64_t*)w->b.ensure(k * 8);
         float* d_d = (float*)w->c.ensure(k * 4);
         uint32_t* d_f = (uint32_t*)w->d.ensure(64);
         uint32_t* d_bits = (uint32_t*)w->e.ensure(words * 8);                           // [allow | known], on the device for the whole query
-        uint32_t* d_unknown = (uint32_t*)w->f.ensure(((size_t)cap + 64) * 4 + cap);  // [count, consulted, 62 pad | list | verdicts]
-        uint8_t* d_verdict = (uint8_t*)(d_unknown + 64 + cap);
-        // pinned staging: [counters 64 B | list cap x 4 | verdicts cap | keys k x 8 | dist k x 4]
-        const size_t pin_need = 64 + (size_t)cap * 5 + k * 12 + 64;
+        uint32_t* d_unknown = (uint32_t*)w->f.ensure(((size_t)cap + 64) * 4);  // [count, consulted, 62 pad | list]
+        // pinned, device-mapped: [counters 64 B | list cap x 4 | verdicts cap | keys k x 8 | dist k x 4 | the query]: the device reads the
+        // query and the verdicts from it and writes each round's outcome into it -- no copy engine on this path
+        const size_t pin_need = 64 + (size_t)cap * 5 + k * 12 + 64 + (size_t)dim * 4;
         if (w->pin_bytes < pin_need) {
             if (w->pin) (void)hipHostFree(w->pin);
             w->pin = nullptr;
@@ -1470,8 +1470,10 @@ struct Engine {
         uint8_t* h_verdict = (uint8_t*)(w->pin + 64 + (size_t)cap * 4);
         uint64_t* h_k = (uint64_t*)(w->pin + 64 + (size_t)cap * 5);
         float* h_d = (float*)(h_k + k);
-        HIP_OK(hipMemcpyAsync(d_q, q, (size_t)dim * 4, hipMemcpyHostToDevice, st));
+        float* h_q = (float*)(w->pin + ((64 + (size_t)cap * 5 + k * 12 + 63) & ~(size_t)63));
+        std::memcpy(h_q, q, (size_t)dim * 4);
         HIP_OK(hipMemsetAsync(d_bits, 0, words * 8, st));
+        HIP_OK(hipMemsetAsync(d_unknown, 0, 8, st));
         // Waiting for a round: hipStreamSynchronize polls, which is the fastest wake-up while every caller has a core; with
         // more filtered calls in flight than cores (the reference runs each on a spawn_blocking thread, usearch.rs:937-948:
         // as many as there are requests) polling callers starve the ones that have verdicts to compute, so the crowd sleeps
@@ -1500,7 +1502,6 @@ struct Engine {
         const uint32_t hint = lazy_need_hint.load();
         const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
         for (int round = 0; round < 20; ++round) {
-            HIP_OK(hipMemsetAsync(d_unknown, 0, 8, st));
             LazyFilter lf;
             lf.known = d_bits + words;
             lf.unknown_list = d_unknown + 64;
@@ -1511,14 +1512,9 @@ struct Engine {
             // consulted (+ 50 %): filters of one workload tend to be alike, and a first round that lists enough makes the second
             // the exact one -- two walks instead of four at 10 % selectivity.  It doubles from there as before.
             lf.budget = (uint32_t)std::min<size_t>(cap, (size_t)first_budget << round);
-            search_device(d_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
-            HIP_OK(hipMemcpyAsync(h_cnt, d_unknown, 8, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipMemcpyAsync(h_cnt + 2, d_f, 4, hipMemcpyDeviceToHost, st));
-            // the answer and the head of the list ride along: one wait per round unless the list is long
-            HIP_OK(hipMemcpyAsync(h_k, d_k, k * 8, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipMemcpyAsync(h_d, d_d, k * 4, hipMemcpyDeviceToHost, st));
-            const uint32_t head = std::min<uint32_t>(lf.budget, cap);
-            HIP_OK(hipMemcpyAsync(h_list, d_unknown + 64, (size_t)head * 4, hipMemcpyDeviceToHost, st));
+            search_device(h_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
+            // counters, answer and list reach the pinned block by a kernel: one wait per round
+            HIP_OK(launch_export_round(d_unknown, cap, d_k, d_d, d_f, (uint32_t)k, h_cnt, h_list, h_k, h_d, st));
             wait_round();
             const uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
             if (count == 0) {
@@ -1531,10 +1527,6 @@ struct Engine {
                 return found;
             }
             const uint32_t m = std::min(count, cap);
-            if (m > head) {  // (a hop's worth beyond the budget)
-                HIP_OK(hipMemcpyAsync(h_list + head, d_unknown + 64 + head, (size_t)(m - head) * 4, hipMemcpyDeviceToHost, st));
-                wait_round();
-            }
             // a walk evaluates a node once, so a list names a slot once, and slots with a verdict are never listed again
             for (uint32_t i = 0; i < m; ++i) {
                 const uint32_t s = h_list[i];
@@ -1546,8 +1538,7 @@ struct Engine {
                 }
                 h_verdict[i] = v;
             }
-            HIP_OK(hipMemcpyAsync(d_verdict, h_verdict, m, hipMemcpyHostToDevice, st));
-            HIP_OK(launch_apply_verdicts(d_unknown + 64, d_verdict, m, (uint32_t)n, d_bits, d_bits + words, st));
+            HIP_OK(launch_apply_verdicts(d_unknown, h_verdict, m, (uint32_t)n, d_bits, d_bits + words, st));
         }
         return (size_t)-1;
     }

@@ -165,9 +165,6 @@ hipError_t launch_block1_plane_rows(const IndexView& ix, uint16_t* plane, uint32
 hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_t* plane, float rho, float max_row_norm, uint32_t* d_uncertified,
                                 hipStream_t s);
 hipError_t launch_row_norm_max(const IndexView& ix, uint32_t first, uint32_t n, uint32_t* d_max_bits, hipStream_t s);
-// filtered search, lazily evaluated predicate: verdict[i] (0 / 1) of slot list[i] -> the device-resident known / allow bitmaps
-hipError_t launch_apply_verdicts(const uint32_t* list, const uint8_t* verdict, uint32_t m, uint32_t slots, uint32_t* allow, uint32_t* known,
-                                 hipStream_t s);
 
 // out[s] = distance(query, row s) for s in [0, n): one wave per row; result copied to host_out.
 // d_scratch: n + dim + 64 floats.

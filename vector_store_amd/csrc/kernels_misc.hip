@@ -1,5 +1,6 @@
 // kernels_misc.hip -- row staging, norms, exact (brute-force) top-k and the multi-GPU top-k merge.
 #include "kernels.hpp"
+#include "filter_rounds.hpp"
 
 namespace vs {
 
@@ -1029,11 +1030,40 @@ __global__ void apply_verdicts_kernel(const uint32_t* __restrict__ list, const u
     atomicOr(&known[s >> 5], 1u << (s & 31u));
     if (verdict[i]) atomicOr(&allow[s >> 5], 1u << (s & 31u));
 }
+__global__ void reset_round_kernel(uint32_t* unknown) {  // [listed, consulted]: zero for the next walk (after the apply kernel has read the list)
+    if (threadIdx.x < 2) unknown[threadIdx.x] = 0u;
+}
 
-hipError_t launch_apply_verdicts(const uint32_t* list, const uint8_t* verdict, uint32_t m, uint32_t slots, uint32_t* allow, uint32_t* known,
+// One round's outcome -> the caller's pinned block, written by the device itself: counters, the answer, the listed slots.  (Five
+// small copies through the copy engines instead: each waits for its stream's walk on a shared engine queue, and with many
+// filtered calls in flight the copies of all of them queued up behind whichever walk was slowest.)
+__global__ void export_round_kernel(const uint32_t* __restrict__ unknown, uint32_t cap, const uint64_t* __restrict__ d_k,
+                                    const float* __restrict__ d_d, const uint32_t* __restrict__ d_f, uint32_t k, uint32_t* __restrict__ h_cnt,
+                                    uint32_t* __restrict__ h_list, uint64_t* __restrict__ h_k, float* __restrict__ h_d) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, total = gridDim.x * blockDim.x;
+    const uint32_t count = unknown[0] < cap ? unknown[0] : cap;
+    for (uint32_t i = tid; i < count; i += total) h_list[i] = unknown[64 + i];
+    for (uint32_t i = tid; i < k; i += total) {
+        h_k[i] = d_k[i];
+        h_d[i] = d_d[i];
+    }
+    if (tid == 0) {
+        h_cnt[0] = unknown[0];
+        h_cnt[1] = unknown[1];
+        h_cnt[2] = d_f[0];
+    }
+}
+
+hipError_t launch_export_round(const uint32_t* unknown, uint32_t cap, const uint64_t* d_k, const float* d_d, const uint32_t* d_f, uint32_t k,
+                               uint32_t* h_cnt, uint32_t* h_list, uint64_t* h_k, float* h_d, hipStream_t s) {
+    hipLaunchKernelGGL(export_round_kernel, dim3(32), dim3(256), 0, s, unknown, cap, d_k, d_d, d_f, k, h_cnt, h_list, h_k, h_d);
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_verdicts(uint32_t* unknown, const uint8_t* verdict, uint32_t m, uint32_t slots, uint32_t* allow, uint32_t* known,
                                  hipStream_t s) {
-    if (!m) return hipSuccess;
-    hipLaunchKernelGGL(apply_verdicts_kernel, dim3((m + 255) / 256), dim3(256), 0, s, list, verdict, m, slots, allow, known);
+    if (m) hipLaunchKernelGGL(apply_verdicts_kernel, dim3((m + 255) / 256), dim3(256), 0, s, unknown + 64, verdict, m, slots, allow, known);
+    hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(64), 0, s, unknown);
     return hipGetLastError();
 }
 

@@ -444,13 +444,16 @@ def boundary_record(ix, queries_host, truth, k, seconds):
         L.vs_callers_run_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double,
                                               C.POINTER(Res), C.POINTER(C.c_uint64)]
         out["filtered"] = {}
-        for name, modulus in (("selectivity_10pct", 10), ("selectivity_1pct", 100)):
+        # the third record: the reference puts EVERY filtered query on a blocking thread (spawn_blocking), so under load there are
+        # far more of them than cores
+        for name, modulus, callers in (("selectivity_10pct", 10, cores + 1), ("selectivity_1pct", 100, cores + 1),
+                                       ("selectivity_10pct_64_callers", 10, 64)):
             r = Res()
             extra = (C.c_uint64 * 4)()
             f0 = ix.filter_stats()
-            rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, cores + 1, max(seconds / 2, 1.0), C.byref(r), extra)
+            rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, max(seconds / 2, 1.0), C.byref(r), extra)
             f1 = ix.filter_stats()
-            fr = rec_of(r, rc, cores + 1, 1)
+            fr = rec_of(r, rc, callers, 1)
             fr.pop("recall_at_10", None)
             nqd = max(int(r.queries), 1)
             fr.update({"predicate": f"key % {modulus} == 0", "predicate_calls_per_query": extra[0] / nqd, "results_per_query": extra[1] / nqd,

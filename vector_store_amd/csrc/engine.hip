@@ -1111,7 +1111,27 @@ struct Engine {
                 const uint32_t grid = global_space(a, gi, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
                 if (team_g && grid != nq) fail(VS_ERR_DEVICE, "team walk: workspace");
                 a.work_counter = retry + 1;
+                static const bool walk_debug_g = std::getenv("VS_HNSW_WALK_DEBUG") != nullptr;  // measurement aid, as below
+                uint32_t* d_dbg_g = nullptr;
+                if (walk_debug_g) {
+                    HIP_OK(hipMalloc((void**)&d_dbg_g, nq * 48));
+                    HIP_OK(hipMemsetAsync(d_dbg_g, 0, nq * 48, st));
+                    a.debug = d_dbg_g;
+                }
                 HIP_OK(launch_walk(a, iters, gi, grid, st, nullptr));
+                if (walk_debug_g) {
+                    std::vector<uint32_t> h(nq * 12);
+                    HIP_OK(hipMemcpyAsync(h.data(), d_dbg_g, nq * 48, hipMemcpyDeviceToHost, st));
+                    HIP_OK(hipStreamSynchronize(st));
+                    (void)hipFree(d_dbg_g);
+                    static const char* names[12] = {"max_next", "evals", "hops", "pushed", "clk/16 startup", "clk/16 pop", "clk/16 visited",
+                                                    "clk/16 distances", "clk/16 admission", "clk/16 pushes", "clk/16 merge", "clk/16 -"};
+                    for (size_t i = 0; i < std::min<size_t>(nq, 4); ++i) {
+                        fprintf(stderr, "[walk global%s] query %zu:", team_g ? " team" : "", i);
+                        for (int c = 0; c < 12; ++c) fprintf(stderr, " %s %u;", names[c], h[i * 12 + c]);
+                        fprintf(stderr, "\n");
+                    }
+                }
                 return;
             }
             // LDS visited table; queries that exhaust it (or the heap workspace) go to a global-bitmap launch behind

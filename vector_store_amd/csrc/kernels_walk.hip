@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_global_kernel(WalkAr
     const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
     bool exhausted = false;
     const uint32_t* allow = a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
-    const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, allow, cnt, lane, exhausted, nullptr,
+    const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, allow, cnt, lane, exhausted,
+                                     a.debug ? a.debug + (size_t)qi * 12 : nullptr,
                                      a.known ? a.known + (size_t)qi * a.allow_stride : nullptr,
                                      a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
                                      a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget,

@@ -115,20 +115,35 @@ __device__ __forceinline__ void heap_set(Sh& sh, const WalkSpace& ws, uint32_t i
     }
 }
 
-// per-lane access to entry i of a heap whose deep levels live in global memory (lanes of one wave may hit both)
-template <class Sh>
+// per-lane access to entry i of a heap whose deep levels live in global memory (lanes of one wave may hit both).  LDS_ONLY: the
+// caller knows (wave-uniformly) that every index of this access is below kHeapLds -- no global load in the code path, so no
+// s_waitcnt vmcnt(0) that would also wait for the adjacency row and the vectors in flight.
+template <bool LDS_ONLY, class Sh>
 __device__ __forceinline__ uint2 heap_lane_load(const Sh& sh, const WalkSpace& ws, uint32_t i, bool valid) {
     uint2 e = make_uint2(0u, 0u);
     if (valid) {
-        if (i < (uint32_t)Sh::kHeapLds) e = sh.hp[i];
+        if (LDS_ONLY || i < (uint32_t)Sh::kHeapLds) e = sh.hp[i];
         else e = ws.heap[i - (uint32_t)Sh::kHeapLds];
     }
     return e;
 }
-template <class Sh>
+template <bool LDS_ONLY, class Sh>
 __device__ __forceinline__ void heap_lane_store(Sh& sh, const WalkSpace& ws, uint32_t i, uint2 e) {
-    if (i < (uint32_t)Sh::kHeapLds) sh.hp[i] = e;
+    if (LDS_ONLY || i < (uint32_t)Sh::kHeapLds) sh.hp[i] = e;
     else ws.heap[i - (uint32_t)Sh::kHeapLds] = e;
+}
+
+template <bool LDS_ONLY, class Sh>
+__device__ __forceinline__ void heap_push_spill(Sh& sh, const WalkSpace& ws, uint32_t pos, float d, uint32_t slot, int lane) {
+    const uint32_t depth = 32u - (uint32_t)__builtin_clz(pos + 1u) - 1u;
+    const uint32_t k = (uint32_t)lane;
+    const bool on = k >= 1u && k <= depth;
+    const uint32_t anc = ((pos + 1u) >> (on ? k : 0u)) - 1u;
+    const uint2 e = heap_lane_load<LDS_ONLY>(sh, ws, anc, on);
+    const uint64_t far = __ballot(on && __uint_as_float(e.x) > d) >> 1;
+    const uint32_t climb = (uint32_t)__builtin_ctzll(~far);  // <= depth
+    if (on && k <= climb) heap_lane_store<LDS_ONLY>(sh, ws, ((pos + 1u) >> (k - 1u)) - 1u, e);
+    if (lane == 0) heap_lane_store<LDS_ONLY>(sh, ws, ((pos + 1u) >> climb) - 1u, make_uint2(__float_as_uint(d), slot));
 }
 
 // emplace + shift_up: the new entry climbs while its parent is strictly farther.
@@ -157,16 +172,67 @@ __device__ __forceinline__ void heap_push(Sh& sh, const WalkSpace& ws, uint32_t&
         // entries: one dependent global read per level made the heap the larger part of a hop)
         const uint32_t pos = uni(hn);
         hn = pos + 1u;
-        const uint32_t depth = 32u - (uint32_t)__builtin_clz(pos + 1u) - 1u;
-        const uint32_t k = (uint32_t)lane;
-        const bool on = k >= 1u && k <= depth;
-        const uint32_t anc = ((pos + 1u) >> (on ? k : 0u)) - 1u;
-        const uint2 e = heap_lane_load(sh, ws, anc, on);
-        const uint64_t far = __ballot(on && __uint_as_float(e.x) > d) >> 1;
-        const uint32_t climb = (uint32_t)__builtin_ctzll(~far);  // <= depth
-        if (on && k <= climb) heap_lane_store(sh, ws, ((pos + 1u) >> (k - 1u)) - 1u, e);
-        if (lane == 0) heap_lane_store(sh, ws, ((pos + 1u) >> climb) - 1u, make_uint2(__float_as_uint(d), slot));
+        if (pos < (uint32_t)Sh::kHeapLds) heap_push_spill<true>(sh, ws, pos, d, slot, lane);  // (scalar branch)
+        else heap_push_spill<false>(sh, ws, pos, d, slot, lane);
     }
+}
+
+// shift_down of a heap whose deep levels may live in global memory: where the entry with distance `ld` lands when it sinks from the
+// root of a heap of n entries; the entries it passes move up on the way (see heap_pop).
+template <bool LDS_ONLY, class Sh>
+__device__ __forceinline__ uint32_t heap_sink_windows(Sh& sh, const WalkSpace& ws, uint32_t n, float ld, int lane) {
+    const uint32_t L = (uint32_t)lane;
+    const uint32_t j = 31u - (uint32_t)__builtin_clz(L + 1u);  // depth of lane L below the window's root (lane 0: the root)
+    const uint32_t t = L + 1u - (1u << j);
+    uint32_t i = 0;  // the node the last entry is sinking from (absolute index, wave-uniform)
+    for (;;) {
+        if (2u * i + 1u >= n) break;
+        const uint64_t idx64 = (((uint64_t)i + 1ull) << j) - 1ull + (uint64_t)t;
+        const bool valid = L <= 62u && idx64 < (uint64_t)n;
+        const uint2 e = heap_lane_load<LDS_ONLY>(sh, ws, (uint32_t)idx64, valid && L >= 1u);
+        const uint64_t vmask = __ballot(valid);
+        // preference of every internal lane (0..30): the right child only when it exists and the left one is strictly farther
+        const uint32_t cl = 2u * L + 1u;
+        const float dl = __uint_as_float((uint32_t)__shfl((int)e.x, (int)(cl & 63u)));
+        const float dr = __uint_as_float((uint32_t)__shfl((int)e.x, (int)((cl + 1u) & 63u)));
+        const bool has_l = L <= 30u && ((vmask >> cl) & 1ull) != 0ull, has_r = L <= 30u && ((vmask >> (cl + 1u)) & 1ull) != 0ull;
+        const uint32_t pref = (has_r && dl > dr) ? cl + 1u : cl;
+        const uint64_t hc = __ballot(has_l);
+        // the preferred path through the window: path[0] = lane 0 (node i), up to five more
+        uint32_t path[6];
+        path[0] = 0;
+        uint32_t len = 0;
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const uint32_t p = path[s5];
+            const bool go = len == (uint32_t)s5 && ((hc >> p) & 1ull) != 0ull;
+            path[s5 + 1] = go ? (uint32_t)__builtin_amdgcn_readlane((int)pref, (int)p) : 0u;
+            len += go ? 1u : 0u;
+        }
+        // lane k (1..len) takes the k-th node of the path, and the node above it
+        uint32_t mine = 0, above = 0;
+#pragma unroll
+        for (int k5 = 1; k5 <= 5; ++k5) {
+            mine = L == (uint32_t)k5 ? path[k5] : mine;
+            above = L == (uint32_t)k5 ? path[k5 - 1] : above;
+        }
+        const bool on = L >= 1u && L <= len;
+        const uint32_t px = (uint32_t)__shfl((int)e.x, (int)mine), py = (uint32_t)__shfl((int)e.y, (int)mine);
+        const uint64_t closer = __ballot(on && ld > __uint_as_float(px)) >> 1;  // bit k - 1: the last entry sinks past path node k
+        const uint32_t sink = (uint32_t)__builtin_ctzll(~closer);                // <= len
+        // absolute index of a window lane
+        auto abs_of = [&](uint32_t wl) -> uint32_t {
+            const uint32_t dj = 31u - (uint32_t)__builtin_clz(wl + 1u);
+            return (uint32_t)((((uint64_t)i + 1ull) << dj) - 1ull + (uint64_t)(wl + 1u - (1u << dj)));
+        };
+        if (on && L <= sink) heap_lane_store<LDS_ONLY>(sh, ws, abs_of(above), make_uint2(px, py));  // path node k moves up to node k - 1
+        uint32_t land = 0;  // the entry lands on path node `sink` (the window's root when it does not sink at all)
+#pragma unroll
+        for (int k5 = 1; k5 <= 5; ++k5) land = sink == (uint32_t)k5 ? path[k5] : land;
+        i = uni(abs_of(land));
+        if (sink < 5u) break;  // stopped inside the window: at a closer node, or at a leaf (sink <= len <= 5); else on with the next five levels
+    }
+    return i;
 }
 
 // pop: swap(first, last), shrink, shift_down(0): the larger child is the right one only when the left one is strictly
@@ -225,44 +291,14 @@ __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& 
     } else {
         // Heaps with their deep levels in global memory: the descendants of node i down to five levels are the 62 entries
         // (i + 1) 2^j - 1 + t (j = 1..5, t < 2^j): lane L = 2^j - 1 + t loads its entry from LDS or global memory, whichever
-        // holds it -- one round trip --, and the sift then runs five levels on registers (in lane space the children of L are
-        // 2 L + 1 and 2 L + 2 again).  Same comparisons in the same order as the level-by-level loop.
+        // holds it -- one round trip for five levels.  In lane space the children of L are 2 L + 1 and 2 L + 2 again, and, as
+        // in the LDS-only form, which child a node prefers does not depend on the sinking entry: every lane computes its
+        // preference, five scalar steps follow the preferred path through the window, one ballot says how far the last entry
+        // sinks along it, one parallel store moves that stretch up.  Same comparisons, same order as the level-by-level loop.
         const uint2 last = heap_get(sh, ws, n);
         const float ld = __uint_as_float(last.x);
-        uint32_t i = 0;  // the node the last entry is sinking from (absolute index, wave-uniform)
-        for (;;) {
-            if (2u * i + 1u >= n) break;
-            const uint32_t L = (uint32_t)lane;
-            const uint32_t j = 31u - (uint32_t)__builtin_clz(L + 1u);
-            const uint64_t idx64 = (((uint64_t)i + 1ull) << j) - 1ull + (uint64_t)(L + 1u - (1u << j));
-            const bool valid = L >= 1u && L <= 62u && idx64 < (uint64_t)n;
-            const uint2 e = heap_lane_load(sh, ws, (uint32_t)idx64, valid);
-            uint32_t pos = 0, a_pos = i;
-            bool done = false;
-#pragma unroll
-            for (int s5 = 0; s5 < 5; ++s5) {
-                const uint32_t l = 2u * pos + 1u, a_l = 2u * a_pos + 1u;
-                if (a_l >= n) {
-                    done = true;
-                    break;
-                }
-                const bool two = a_l + 1u < n;
-                const float dl = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)l));
-                const float dr = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)(l + 1u)));
-                const uint32_t c = (two && dl > dr) ? l + 1u : l;
-                const uint32_t a_c = a_l + (c - l);
-                const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)c), cy = (uint32_t)__builtin_amdgcn_readlane((int)e.y, (int)c);
-                if (!(ld > __uint_as_float(cx))) {
-                    done = true;
-                    break;
-                }
-                heap_set(sh, ws, a_pos, make_uint2(cx, cy), lane);
-                pos = c;
-                a_pos = a_c;
-            }
-            i = a_pos;
-            if (done) break;
-        }
+        const uint32_t i = n <= (uint32_t)Sh::kHeapLds ? heap_sink_windows<true>(sh, ws, n, ld, lane)  // (scalar branch)
+                                                        : heap_sink_windows<false>(sh, ws, n, ld, lane);
         heap_set(sh, ws, i, last, lane);
     }
 }
@@ -312,8 +348,11 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         if (tomb) ok = ok && ix.keys[valid ? s : 0u] != kFreeKey;
         if (allow) {
             consulted += (uint32_t)__popcll(__ballot(ok));
+            // both words are requested before either is looked at: one round trip, not two (a slot without a verdict has a 0 in `allow`)
+            const uint32_t word = (ok ? s : 0u) >> 5;
+            const uint32_t allow_w = allow[word], known_w = known ? known[word] : ~0u;
             if (known) {
-                const bool kn = ok && ((known[s >> 5] >> (s & 31u)) & 1u) != 0u;
+                const bool kn = ok && ((known_w >> (s & 31u)) & 1u) != 0u;
                 const bool unk = ok && !kn;  // (removed members need no verdict)
                 const uint64_t um = __ballot(unk);
                 if (um) {
@@ -326,7 +365,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
                 }
                 ok = kn;
             }
-            ok = ok && ((allow[(ok ? s : 0u) >> 5] >> (s & 31u)) & 1u) != 0u;
+            ok = ok && ((allow_w >> (s & 31u)) & 1u) != 0u;
         }
         return ok;
     };

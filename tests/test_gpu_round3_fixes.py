@@ -157,3 +157,57 @@ def test_ip_certificate_follows_a_reused_slots_norm():
         order = np.argsort(d[i], kind="stable")[:k]
         assert keys[i].tolist() == ids[order].tolist(), (i, keys[i], ids[order])
         assert np.allclose(dist[i], d[i][order], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.timeout(900)
+def test_crowds_of_callers_get_the_batch_paths_answers():
+    """The reference's call patterns through the C ABI, with more callers than host cores: blocking single-query callers (the
+    dispatcher's eight pipeline slots), the non-blocking entry point under load (two slots, large batches), and a crowd of
+    blocking FILTERED callers (each its own rounds of walks; beyond the core count they sleep on the round's event).  Every
+    answer equals the batch path's, no call fails, every filtered call returns k admitted members."""
+    import ctypes as C
+    v = vs()
+    n, dim, k = 200000, 64, 10
+    base = _data(n, dim, 51)
+    q = np.ascontiguousarray(_data(2000, dim, 52))
+    ix = v.HipUsearchIndex(dim, v.COS, expansion_search=96)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    truth, _, _ = ix.search_batch(q, k)
+    truth = np.ascontiguousarray(truth, dtype=np.uint64)
+
+    class Res(C.Structure):
+        _fields_ = [("seconds", C.c_double), ("queries", C.c_uint64), ("qps", C.c_double), ("latency_min_ns", C.c_int64),
+                    ("latency_max_ns", C.c_int64)] + [(f"p{p:02d}_ns", C.c_int64) for p in (1, 10, 25, 50, 75, 90, 99)] + [
+                    ("recall_avg", C.c_double), ("errors", C.c_uint64), ("launches", C.c_uint64), ("team_launches", C.c_uint64)]
+
+    L = C.CDLL(os.path.join(os.path.dirname(v.__file__), "libvs_callers.so"))
+    L.vs_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint,
+                                 C.c_double, C.POINTER(Res)]
+    L.vs_callers_run_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double,
+                                          C.POINTER(Res), C.POINTER(C.c_uint64)]
+    for threads, inflight in ((3, 1), (40, 1), (16, 128)):
+        r = Res()
+        rc = L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], dim, k, truth.ctypes.data, threads, inflight, 1.0, C.byref(r))
+        assert rc == 0 and r.errors == 0 and r.queries > 0, (threads, inflight, rc, r.errors)
+        assert r.recall_avg > 0.9999, (threads, inflight, r.recall_avg)  # agreement with the batch path's ids
+    for threads, modulus in ((5, 10), (48, 10), (48, 50)):
+        r, extra = Res(), (C.c_uint64 * 4)()
+        rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], dim, k, modulus, threads, 1.5, C.byref(r), extra)
+        assert rc == 0 and r.errors == 0 and r.queries > 0, (threads, modulus, rc, r.errors)
+        assert extra[1] == r.queries * k, (threads, modulus, extra[1], r.queries)
+    # the same filtered answers whether one caller asks or a crowd does (24 threads: beyond the core count of the pool's boxes)
+    pred = lambda key: key % 7 == 3
+    want = [ix.filtered_search(q[i], k, pred) for i in range(24)]
+    got = [None] * 24
+
+    def ask(i):
+        got[i] = ix.filtered_search(q[i], k, pred)
+    th = [threading.Thread(target=ask, args=(i,)) for i in range(24)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(24):
+        assert got[i] is not None and got[i][0].tolist() == want[i][0].tolist(), i
+        assert np.array_equal(got[i][1].view(np.uint32), want[i][1].view(np.uint32)), i

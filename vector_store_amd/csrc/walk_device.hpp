@@ -115,35 +115,20 @@ __device__ __forceinline__ void heap_set(Sh& sh, const WalkSpace& ws, uint32_t i
     }
 }
 
-// per-lane access to entry i of a heap whose deep levels live in global memory (lanes of one wave may hit both).  LDS_ONLY: the
-// caller knows (wave-uniformly) that every index of this access is below kHeapLds -- no global load in the code path, so no
-// s_waitcnt vmcnt(0) that would also wait for the adjacency row and the vectors in flight.
-template <bool LDS_ONLY, class Sh>
+// per-lane access to entry i of a heap whose deep levels live in global memory (lanes of one wave may hit both)
+template <class Sh>
 __device__ __forceinline__ uint2 heap_lane_load(const Sh& sh, const WalkSpace& ws, uint32_t i, bool valid) {
     uint2 e = make_uint2(0u, 0u);
     if (valid) {
-        if (LDS_ONLY || i < (uint32_t)Sh::kHeapLds) e = sh.hp[i];
+        if (i < (uint32_t)Sh::kHeapLds) e = sh.hp[i];
         else e = ws.heap[i - (uint32_t)Sh::kHeapLds];
     }
     return e;
 }
-template <bool LDS_ONLY, class Sh>
+template <class Sh>
 __device__ __forceinline__ void heap_lane_store(Sh& sh, const WalkSpace& ws, uint32_t i, uint2 e) {
-    if (LDS_ONLY || i < (uint32_t)Sh::kHeapLds) sh.hp[i] = e;
+    if (i < (uint32_t)Sh::kHeapLds) sh.hp[i] = e;
     else ws.heap[i - (uint32_t)Sh::kHeapLds] = e;
-}
-
-template <bool LDS_ONLY, class Sh>
-__device__ __forceinline__ void heap_push_spill(Sh& sh, const WalkSpace& ws, uint32_t pos, float d, uint32_t slot, int lane) {
-    const uint32_t depth = 32u - (uint32_t)__builtin_clz(pos + 1u) - 1u;
-    const uint32_t k = (uint32_t)lane;
-    const bool on = k >= 1u && k <= depth;
-    const uint32_t anc = ((pos + 1u) >> (on ? k : 0u)) - 1u;
-    const uint2 e = heap_lane_load<LDS_ONLY>(sh, ws, anc, on);
-    const uint64_t far = __ballot(on && __uint_as_float(e.x) > d) >> 1;
-    const uint32_t climb = (uint32_t)__builtin_ctzll(~far);  // <= depth
-    if (on && k <= climb) heap_lane_store<LDS_ONLY>(sh, ws, ((pos + 1u) >> (k - 1u)) - 1u, e);
-    if (lane == 0) heap_lane_store<LDS_ONLY>(sh, ws, ((pos + 1u) >> climb) - 1u, make_uint2(__float_as_uint(d), slot));
 }
 
 // emplace + shift_up: the new entry climbs while its parent is strictly farther.
@@ -172,14 +157,21 @@ __device__ __forceinline__ void heap_push(Sh& sh, const WalkSpace& ws, uint32_t&
         // entries: one dependent global read per level made the heap the larger part of a hop)
         const uint32_t pos = uni(hn);
         hn = pos + 1u;
-        if (pos < (uint32_t)Sh::kHeapLds) heap_push_spill<true>(sh, ws, pos, d, slot, lane);  // (scalar branch)
-        else heap_push_spill<false>(sh, ws, pos, d, slot, lane);
+        const uint32_t depth = 32u - (uint32_t)__builtin_clz(pos + 1u) - 1u;
+        const uint32_t k = (uint32_t)lane;
+        const bool on = k >= 1u && k <= depth;
+        const uint32_t anc = ((pos + 1u) >> (on ? k : 0u)) - 1u;
+        const uint2 e = heap_lane_load(sh, ws, anc, on);
+        const uint64_t far = __ballot(on && __uint_as_float(e.x) > d) >> 1;
+        const uint32_t climb = (uint32_t)__builtin_ctzll(~far);  // <= depth
+        if (on && k <= climb) heap_lane_store(sh, ws, ((pos + 1u) >> (k - 1u)) - 1u, e);
+        if (lane == 0) heap_lane_store(sh, ws, ((pos + 1u) >> climb) - 1u, make_uint2(__float_as_uint(d), slot));
     }
 }
 
 // shift_down of a heap whose deep levels may live in global memory: where the entry with distance `ld` lands when it sinks from the
 // root of a heap of n entries; the entries it passes move up on the way (see heap_pop).
-template <bool LDS_ONLY, class Sh>
+template <class Sh>
 __device__ __forceinline__ uint32_t heap_sink_windows(Sh& sh, const WalkSpace& ws, uint32_t n, float ld, int lane) {
     const uint32_t L = (uint32_t)lane;
     const uint32_t j = 31u - (uint32_t)__builtin_clz(L + 1u);  // depth of lane L below the window's root (lane 0: the root)
@@ -189,7 +181,7 @@ __device__ __forceinline__ uint32_t heap_sink_windows(Sh& sh, const WalkSpace& w
         if (2u * i + 1u >= n) break;
         const uint64_t idx64 = (((uint64_t)i + 1ull) << j) - 1ull + (uint64_t)t;
         const bool valid = L <= 62u && idx64 < (uint64_t)n;
-        const uint2 e = heap_lane_load<LDS_ONLY>(sh, ws, (uint32_t)idx64, valid && L >= 1u);
+        const uint2 e = heap_lane_load(sh, ws, (uint32_t)idx64, valid && L >= 1u);
         const uint64_t vmask = __ballot(valid);
         // preference of every internal lane (0..30): the right child only when it exists and the left one is strictly farther
         const uint32_t cl = 2u * L + 1u;
@@ -225,7 +217,7 @@ __device__ __forceinline__ uint32_t heap_sink_windows(Sh& sh, const WalkSpace& w
             const uint32_t dj = 31u - (uint32_t)__builtin_clz(wl + 1u);
             return (uint32_t)((((uint64_t)i + 1ull) << dj) - 1ull + (uint64_t)(wl + 1u - (1u << dj)));
         };
-        if (on && L <= sink) heap_lane_store<LDS_ONLY>(sh, ws, abs_of(above), make_uint2(px, py));  // path node k moves up to node k - 1
+        if (on && L <= sink) heap_lane_store(sh, ws, abs_of(above), make_uint2(px, py));  // path node k moves up to node k - 1
         uint32_t land = 0;  // the entry lands on path node `sink` (the window's root when it does not sink at all)
 #pragma unroll
         for (int k5 = 1; k5 <= 5; ++k5) land = sink == (uint32_t)k5 ? path[k5] : land;
@@ -297,8 +289,7 @@ __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& 
         // sinks along it, one parallel store moves that stretch up.  Same comparisons, same order as the level-by-level loop.
         const uint2 last = heap_get(sh, ws, n);
         const float ld = __uint_as_float(last.x);
-        const uint32_t i = n <= (uint32_t)Sh::kHeapLds ? heap_sink_windows<true>(sh, ws, n, ld, lane)  // (scalar branch)
-                                                        : heap_sink_windows<false>(sh, ws, n, ld, lane);
+        const uint32_t i = heap_sink_windows(sh, ws, n, ld, lane);
         heap_set(sh, ws, i, last, lane);
     }
 }
@@ -348,11 +339,8 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         if (tomb) ok = ok && ix.keys[valid ? s : 0u] != kFreeKey;
         if (allow) {
             consulted += (uint32_t)__popcll(__ballot(ok));
-            // both words are requested before either is looked at: one round trip, not two (a slot without a verdict has a 0 in `allow`)
-            const uint32_t word = (ok ? s : 0u) >> 5;
-            const uint32_t allow_w = allow[word], known_w = known ? known[word] : ~0u;
             if (known) {
-                const bool kn = ok && ((known_w >> (s & 31u)) & 1u) != 0u;
+                const bool kn = ok && ((known[s >> 5] >> (s & 31u)) & 1u) != 0u;
                 const bool unk = ok && !kn;  // (removed members need no verdict)
                 const uint64_t um = __ballot(unk);
                 if (um) {
@@ -365,7 +353,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
                 }
                 ok = kn;
             }
-            ok = ok && ((allow_w >> (s & 31u)) & 1u) != 0u;
+            ok = ok && ((allow[(ok ? s : 0u) >> 5] >> (s & 31u)) & 1u) != 0u;
         }
         return ok;
     };

@@ -46,7 +46,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # before the HIP runtime initialises: concurrent filtered searches (see csrc/engine.hip HwQueuesDefault)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")  # before the HIP runtime initialises: concurrent filtered searches (see csrc/engine.hip HwQueuesDefault)
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

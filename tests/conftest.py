@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # as vector_store_amd sets it; here before anything can initialise the HIP runtime
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")  # as vector_store_amd sets it; here before anything can initialise the HIP runtime
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

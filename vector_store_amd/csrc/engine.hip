@@ -37,12 +37,16 @@ namespace vs {
 // Filtered searches run one walk launch per caller on the caller's own stream (the predicate is the caller's), and the
 // reference runs every filtered query on a blocking thread (usearch.rs:937-948): dozens of small kernels must be able to run
 // side by side.  ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels that share a
-// queue run one after the other: 17 callers got 2.8 x one caller's rate.  The library therefore asks for 24 queues unless the
+// queue run one after the other: 17 callers got 2.8 x one caller's rate.  The library therefore asks for 20 queues unless the
 // process has chosen a value -- effective when it is loaded before the HIP runtime initialises (a Rust service linking it; the
 // Python binding and bench.py set the variable themselves before touching the GPU).  Measured at 2M x 768, 10 % selective
 // filter, 17 blocking callers: 35 -> 210 queries/s (scripts/probe/filtered_probe.py).
+// 20, not more: the device has 24 hardware queue slots for user queues; once a process holds more queues than that (24 of
+// its own + the runtime's internal ones) the hardware scheduler time-slices them, and EVERY kernel of the process runs
+// ~20 % slower from then on, busy queue or idle (scripts/probe/aftermath_probe.py: the 10,000-query batch kernel 13.5 -> 16.3 ms
+// after 17 filtered callers had each opened their stream; 12 / 16 / 20 queues: unchanged).
 struct HwQueuesDefault {
-    HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+    HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
 };
 static HwQueuesDefault g_hw_queues_default;
 

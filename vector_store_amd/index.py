@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # concurrent filtered searches are one small kernel launch per caller: see HwQueuesDefault in csrc/engine.hip (only effective
 # while the HIP runtime has not initialised yet -- importing torch does not initialise it, the first CUDA call does)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 COS, L2SQ, IP, HAMMING = 0, 1, 2, 3
 METRICS = {"cos": COS, "l2sq": L2SQ, "ip": IP, "hamming": HAMMING}
 F32, F16, BF16, I8, B1 = 0, 1, 2, 3, 4

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_kernel(WalkArgs a) {
     Counters cnt = {0, 0, 0};
     const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
     bool exhausted = false;
-    const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, nullptr, cnt, lane, exhausted);
+    const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, a.ef, kInvalid, a.has_removed != 0, nullptr, cnt, lane, exhausted,
+                                     a.debug ? a.debug + (size_t)qi * 12 : nullptr);
     team_release(sh, lane);
     wsync<Sh>();
     if (exhausted) {

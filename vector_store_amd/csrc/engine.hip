@@ -1525,6 +1525,7 @@ struct Engine {
         };
         const uint32_t hint = lazy_need_hint.load();
         const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
+        uint64_t n_known = 0, n_allowed = 0;  // verdicts of this query so far
         for (int round = 0; round < 20; ++round) {
             LazyFilter lf;
             lf.known = d_bits + words;
@@ -1536,6 +1537,10 @@ struct Engine {
             // consulted (+ 50 %): filters of one workload tend to be alike, and a first round that lists enough makes the second
             // the exact one -- two walks instead of four at 10 % selectivity.  It doubles from there as before.
             lf.budget = (uint32_t)std::min<size_t>(cap, (size_t)first_budget << round);
+            // exploratory rounds after the first guess unknown verdicts at half the selectivity seen so far (walk_device.hpp `guess_t`)
+            static const int guess_pct = std::getenv("VS_HNSW_FILTER_GUESS") ? std::atoi(std::getenv("VS_HNSW_FILTER_GUESS")) : 50;  // % of the observed selectivity; 0 = off
+            if (n_known > 0 && guess_pct > 0)
+                lf.budget |= std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * n_allowed * (uint64_t)guess_pct / (100 * n_known))) << 24;
             search_device(h_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
             // counters, answer and list reach the pinned block by a kernel: one wait per round
             HIP_OK(launch_export_round(d_unknown, cap, d_k, d_d, d_f, (uint32_t)k, h_cnt, h_list, h_k, h_d, st));
@@ -1561,7 +1566,9 @@ struct Engine {
                     v = key != kFreeKey && pred(key, pctx) ? 1 : 0;
                 }
                 h_verdict[i] = v;
+                n_allowed += v;
             }
+            n_known += m;
             HIP_OK(launch_apply_verdicts(d_unknown, h_verdict, m, (uint32_t)n, d_bits, d_bits + words, st));
         }
         return (size_t)-1;

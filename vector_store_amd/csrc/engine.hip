@@ -385,6 +385,7 @@ struct Engine {
     std::atomic<uint64_t> plane_batches{0}, plane_fallbacks{0};
     bool eager_filter = false;               // VS_HNSW_FILTER=eager: always one predicate call per live member (the full bitmap)
     std::atomic<uint64_t> lazy_rounds{0}, lazy_predicate_calls{0};  // filtered_lazy: rounds / predicate calls so far (tests)
+    std::atomic<uint32_t> lazy_sel_hint{0};   // fraction of the asked-about slots the recent filters admitted (1 / 65,536; moving average)
     std::atomic<uint32_t> lazy_need_hint{0};  // verdicts the recent filtered queries of this index needed (moving average): sizes the first round
     std::atomic<bool> lds_walk_bad[16] = {};  // per walk instance: more than a quarter of a batch outgrew its LDS structures -> global-bitmap instance at once
     std::atomic<bool> small_table_ok{true};  // usearch-order walk, beams <= 128: the half-size visited table is paying off
@@ -1524,6 +1525,7 @@ struct Engine {
             }
         };
         const uint32_t hint = lazy_need_hint.load();
+        const uint32_t sel_hint = lazy_sel_hint.load();  // selectivity of recent filtered queries, in 1 / 65,536
         const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
         uint64_t n_known = 0, n_allowed = 0;  // verdicts of this query so far
         for (int round = 0; round < 20; ++round) {
@@ -1539,8 +1541,15 @@ struct Engine {
             lf.budget = (uint32_t)std::min<size_t>(cap, (size_t)first_budget << round);
             // exploratory rounds after the first guess unknown verdicts at half the selectivity seen so far (walk_device.hpp `guess_t`)
             static const int guess_pct = std::getenv("VS_HNSW_FILTER_GUESS") ? std::atoi(std::getenv("VS_HNSW_FILTER_GUESS")) : 50;  // % of the observed selectivity; 0 = off
-            if (n_known > 0 && guess_pct > 0)
+            static const bool guess_first = std::getenv("VS_HNSW_FILTER_GUESS_FIRST") && std::getenv("VS_HNSW_FILTER_GUESS_FIRST")[0] == '1';  // experiment
+            if (n_known > 0 && guess_pct > 0) {
                 lf.budget |= std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * n_allowed * (uint64_t)guess_pct / (100 * n_known))) << 24;
+            } else if (round == 0 && guess_first && guess_pct > 0 && sel_hint > 0) {
+                // the first round too: at the selectivity recent filtered queries of this index showed, and with room for everything
+                // such a walk consults (it lists every slot it asks about)
+                lf.budget = (uint32_t)std::min<size_t>(cap, std::max<size_t>(lf.budget, 3 * (size_t)hint));
+                lf.budget |= std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * sel_hint * (uint64_t)guess_pct / (100ull * 65536ull))) << 24;
+            }
             search_device(h_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
             // counters, answer and list reach the pinned block by a kernel: one wait per round
             HIP_OK(launch_export_round(d_unknown, cap, d_k, d_d, d_f, (uint32_t)k, h_cnt, h_list, h_k, h_d, st));
@@ -1553,6 +1562,10 @@ struct Engine {
                 lazy_rounds += (uint64_t)round + 1;
                 // what the exact walk (this last round) consulted, smoothed over the recent queries of this index
                 lazy_need_hint = hint ? (3 * hint + consulted) / 4 : consulted;
+                if (n_known) {
+                    const uint32_t sel = (uint32_t)std::min<uint64_t>(65536, n_allowed * 65536ull / n_known);
+                    lazy_sel_hint = sel_hint ? (3 * sel_hint + sel) / 4 : sel;
+                }
                 return found;
             }
             const uint32_t m = std::min(count, cap);

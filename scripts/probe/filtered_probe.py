@@ -1,5 +1,5 @@
 """Filtered search through the C ABI with the reference's call pattern (blocking callers, native counted predicate):
-QPS, latency, predicate calls, walk launches, evaluations and hops per query.   python scripts/probe/filtered_probe.py [vectors] [ef] [threads,threads,...]"""
+QPS, latency, predicate calls, walk launches, evaluations and hops per query.   python scripts/probe/filtered_probe.py [vectors] [ef] [threads,threads,...] [pre]"""
 import ctypes as C, os, sys, time, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import vector_store_amd as vs
@@ -23,6 +23,13 @@ class Res(C.Structure):
 
 L = C.CDLL(os.path.join("vector_store_amd", "libvs_callers.so"))
 L.vs_callers_run_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double, C.POINTER(Res), C.POINTER(C.c_uint64)]
+if len(sys.argv) > 4 and sys.argv[4] == "pre":  # as bench.py does: the unfiltered legs first (the dispatcher's streams exist before the callers' own)
+    L.vs_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_double, C.POINTER(Res)]
+    truth = np.zeros((q.shape[0], k), dtype=np.uint64)
+    for threads, inflight in ((17, 1), (16, 256)):
+        r = Res()
+        L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], dim, k, truth.ctypes.data, threads, inflight, 1.0, C.byref(r))
+        print(f"pre: {threads} x {inflight}: {r.qps:.0f} QPS", flush=True)
 for threads in ([int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1, 17)):
     for mod in (2, 10, 100):
         r, extra = Res(), (C.c_uint64 * 4)()

@@ -72,7 +72,9 @@ typedef struct vs_hnsw_options {
                          i8 / b1 storage only), bit 5 = always the global-bitmap instance of that walk,
                          bit 6 = wide visited tags (the instances for indexes above 2^25 / 2^26 slots) on a small index,
                          bit 7 = 64-entry global heap for the global-bitmap walk (a flooding walk then reports "outgrew its
-                         workspace", which the host entry points answer by ranking exhaustively) */
+                         workspace", which the host entry points answer by ranking exhaustively),
+                         bit 8 = lone queries never take the pipelined walk (kernels_pipe.hip): the team kernels serve them, as
+                         before round 4 (A/B in tests) */
 } vs_hnsw_options;
 
 /* -- lifecycle: usearch::Index::new (usearch.rs:172), drop ------------------------------- */
@@ -152,6 +154,10 @@ VS_API int vs_hnsw_walk_info(vs_hnsw* index, uint64_t out[2]);
 /* Filtered search on indexes above 65,536 slots asks the predicate lazily (only for members a walk needs a verdict for, in
  * rounds): [0] walk launches and [1] predicate calls spent that way so far. */
 VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
+
+/* Lone queries (one vector per call, usearch.rs:212 / :236) on float indexes take the pipelined walk (kernels_pipe.hip):
+ * [0] launches of it so far, [1] reserved. */
+VS_API int vs_hnsw_pipe_stats(vs_hnsw* index, uint64_t out[2]);
 
 /* Exact search on float storage (cos / ip, k <= 64, >= 65,536 slots) nominates with split-bf16 MFMA tiles, re-scores the nominees
  * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's

@@ -73,6 +73,7 @@ def lib():
         L.orc_filtered_search.argtypes = [vp, vp, sz, PRED, vp, u64p, f32p, C.POINTER(sz)]
         L.orc_add_batch.argtypes = [vp, vp, vp, sz, sz]
         L.orc_search_batch.argtypes = [vp, vp, sz, sz, vp, vp, vp, sz]
+        L.orc_filtered_search_timed.argtypes = [vp, vp, sz, sz, C.c_uint64, vp, vp, vp, sz, C.c_double, vp]
         L.orc_stats.argtypes = [vp, u64p, C.c_int]
         L.orc_exact_search.argtypes = [vp, vp, sz, u64p, f32p, C.POINTER(sz)]
         L.orc_distance_to_slot.restype = C.c_float
@@ -234,6 +235,19 @@ class OracleIndex:
         found = np.zeros(nq, dtype=np.uint64)
         self._check(self.L.orc_search_batch(self.h, _ptr(q), nq, k, _ptr(keys), _ptr(d), _ptr(found), threads))
         return keys, d, found.astype(np.int64)
+
+    def filtered_search_timed(self, queries, k: int, modulus: int, threads: int = 1, seconds: float = 5.0):
+        """filtered_search with the predicate `key % modulus == 0` from `threads` threads, one query per call, for at most
+        `seconds`: (keys, distances, found, queries answered, predicate calls, wall seconds)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq = q.shape[0]
+        keys = np.zeros((nq, k), dtype=np.uint64)
+        d = np.zeros((nq, k), dtype=np.float32)
+        found = np.zeros(nq, dtype=np.uint64)
+        out = np.zeros(3, dtype=np.uint64)
+        self._check(self.L.orc_filtered_search_timed(self.h, _ptr(q), nq, k, modulus, _ptr(keys), _ptr(d), _ptr(found), threads,
+                                                     float(seconds), _ptr(out)))
+        return keys, d, found.astype(np.int64), int(out[0]), int(out[1]), out[2] / 1e9
 
     def exact_search(self, vector, k: int):
         v = self._vec(vector)

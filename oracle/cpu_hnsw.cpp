@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -893,6 +894,56 @@ int orc_search_batch(void* h, const void* Q, size_t nq, size_t k, uint64_t* keys
         ix->batch_distances += c.computed_distances;
         ix->batch_cycles += c.iteration_cycles;
     }
+    return 0;
+}
+
+// The same driver for filtered_search (reference filtered_ann, usearch.rs:1107-1154: every filtered query runs on a blocking
+// thread, :937-948): predicate key % modulus == 0 -- what libvs_callers' filtered run asks the GPU engine -- for `seconds`
+// of wall time or until `nq` queries are answered, whichever comes first.  out3: [0] queries answered, [1] predicate calls,
+// [2] nanoseconds of wall time.
+int orc_filtered_search_timed(void* h, const void* Q, size_t nq, size_t k, uint64_t modulus, uint64_t* keys, float* d,
+                              size_t* found, size_t threads, double seconds, uint64_t* out3) {
+    Index* ix = (Index*)h;
+    if (threads < 1) threads = 1;
+    if (!modulus) return -1;
+    std::atomic<size_t> next{0};
+    std::atomic<uint64_t> calls{0}, done{0};
+    std::atomic<bool> stop{false};
+    std::vector<Context> local(threads);
+    struct Local {
+        uint64_t modulus;
+        uint64_t calls;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](size_t t) {
+        Context& c = local[t];
+        Local l{modulus, 0};
+        auto pred = [](uint64_t key, void* p) -> int {
+            Local* x = (Local*)p;
+            ++x->calls;
+            return key % x->modulus == 0 ? 1 : 0;
+        };
+        while (!stop.load(std::memory_order_relaxed)) {
+            size_t i = next.fetch_add(1);
+            if (i >= nq) break;
+            found[i] = ix->search((const float*)Q + i * ix->dim, k, pred, &l, keys + i * k, d + i * k, c, nullptr);
+            done.fetch_add(1);
+            if (t == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) stop = true;
+        }
+        calls += l.calls;
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < threads; ++t) th.emplace_back(work, t);
+    work(0);
+    stop = true;
+    for (auto& x : th) x.join();
+    for (auto& c : local) {
+        ix->batch_distances += c.computed_distances;
+        ix->batch_cycles += c.iteration_cycles;
+    }
+    out3[0] = done.load();
+    out3[1] = calls.load();
+    out3[2] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
 

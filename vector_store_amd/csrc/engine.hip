@@ -422,6 +422,8 @@ struct Engine {
     int exact_mode = 0;                      // VS_HNSW_EXACT: 0 = bf16 plane -> split bf16 -> f32; 1 = "bf16x3": split bf16 -> f32; 2 = "f32"
     std::atomic<uint64_t> plane_batches{0}, plane_fallbacks{0};
     bool eager_filter = false;               // VS_HNSW_FILTER=eager: always one predicate call per live member (the full bitmap)
+    std::atomic<uint64_t> pipe_launches{0};  // launches of the pipelined walk (tests)
+    bool no_pipe = false;                    // options.reserved bit 8: lone queries never take the pipelined walk (A/B in tests)
     std::atomic<uint64_t> lazy_rounds{0}, lazy_predicate_calls{0};  // filtered_lazy: rounds / predicate calls so far (tests)
     std::atomic<uint32_t> lazy_sel_hint{0};   // fraction of the asked-about slots the recent filters admitted (1 / 65,536; moving average)
     std::atomic<uint32_t> lazy_need_hint{0};  // verdicts the recent filtered queries of this index needed (moving average): sizes the first round
@@ -545,6 +547,7 @@ struct Engine {
         force_global_walk = (o.reserved & 32) != 0;
         force_wide_tags = (o.reserved & 64) != 0;
         tiny_walk_heap = (o.reserved & 128) != 0;
+        no_pipe = (o.reserved & 256) != 0;
         if (const char* ff = std::getenv("VS_HNSW_FILTER")) eager_filter = !std::strcmp(ff, "eager");
         if (const char* xf = std::getenv("VS_HNSW_EXACT")) {
             exact_f32_only = !std::strcmp(xf, "f32");
@@ -1040,6 +1043,14 @@ struct Engine {
     //   fused-list kernel (hnsw_search_kernel)   float metrics, beam <= 512, index within the LDS tags' reach;
     //   usearch-order walk, LDS visited table     i8 / b1 (ties are the rule there) or order_mode 1, beam <= 512;
     //   usearch-order walk, global visited bitmap filtered search, beams 513..10,240, indexes beyond the LDS tags.
+    // lone queries on float indexes: the pipelined walk (kernels_pipe.hip) serves them
+    bool pipe_usable(uint32_t ef) const {
+        static const bool pipe_off = std::getenv("VS_HNSW_PIPE") && std::getenv("VS_HNSW_PIPE")[0] == '0';  // A/B measurements
+        IndexView v{};
+        v.scalar = scalar;
+        v.M0 = (uint32_t)M0;
+        return !pipe_off && !no_pipe && !tiny_walk_heap && iters < 12 && pipe_walk_supported(v, iters, ef);
+    }
     bool usearch_order() const { return order_mode == 1 || (order_mode == 0 && (scalar == VS_SCALAR_I8 || scalar == VS_SCALAR_B1)); }
     void check_search(size_t k, uint32_t& ef) const {
         if (k == 0) fail(VS_ERR_INVALID_ARGUMENT, "k must be > 0");
@@ -1061,6 +1072,7 @@ struct Engine {
         uint32_t* unknown_count = nullptr;
         uint32_t cap = 0, budget = 0;
         uint32_t* consulted = nullptr;
+        bool explore = false;  // an exploring round of the pipelined walk (kernels_pipe.hip): lists missing verdicts, answers nothing
     };
     void search_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
                        hipStream_t st, size_t load = 0, const uint32_t* allow = nullptr, uint32_t allow_stride = 0,
@@ -1088,6 +1100,7 @@ struct Engine {
             a.unknown_cap = lazy ? lazy->cap : 0u;
             a.unknown_budget = lazy ? lazy->budget : 0u;
             a.consulted = lazy ? lazy->consulted : nullptr;
+            a.pipe_explore = (lazy && lazy->explore) ? 1u : 0u;
             a.qlist = nullptr;
             a.qcount = nullptr;
             a.retry_list = nullptr;
@@ -1154,6 +1167,45 @@ struct Engine {
                 const uint32_t grid = global_space(a, gi, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
                 if (team_g && grid != nq) fail(VS_ERR_DEVICE, "team walk: workspace");
                 a.work_counter = retry + 1;
+                // Lone queries on float indexes: the PIPELINED walk first (kernels_pipe.hip: the walker decides on registers, the other
+                // waves measure candidates ahead of it -- a fifth of the team walk's chain per hop); a query in which two equal
+                // distances meet is handed to the team form of the usearch-order walk right behind (same stream, same workspace).
+                static const uint32_t pipe_pool = std::getenv("VS_HNSW_PIPE_POOL") ? (uint32_t)std::atoi(std::getenv("VS_HNSW_PIPE_POOL")) : 12288u;
+                if (team_g && pipe_usable(ef)) {
+                    WalkArgs p = a;
+                    p.retry_count = retry;
+                    p.retry_list = retry + 64;
+                    p.pipe_pool_cap = std::min<uint32_t>(std::max<uint32_t>(pipe_pool, 256u), 16384u);
+                    static const bool walk_debug_p = std::getenv("VS_HNSW_WALK_DEBUG") != nullptr;
+                    uint32_t* d_dbg_p = nullptr;
+                    if (walk_debug_p) {
+                        HIP_OK(hipMalloc((void**)&d_dbg_p, nq * 48));
+                        HIP_OK(hipMemsetAsync(d_dbg_p, 0, nq * 48, st));
+                        p.debug = d_dbg_p;
+                    }
+                    HIP_OK(launch_pipe_walk(p, iters, st));
+                    WalkArgs r = a;  // second chance: only the queries the pipelined walk listed
+                    r.qlist = p.retry_list;
+                    r.qcount = p.retry_count;
+                    HIP_OK(launch_walk(r, iters, gi, grid, st, nullptr));
+                    if (walk_debug_p) {
+                        std::vector<uint32_t> h(nq * 12);
+                        uint32_t redone = 0;
+                        HIP_OK(hipMemcpyAsync(h.data(), d_dbg_p, nq * 48, hipMemcpyDeviceToHost, st));
+                        HIP_OK(hipMemcpyAsync(&redone, retry, 4, hipMemcpyDeviceToHost, st));
+                        HIP_OK(hipStreamSynchronize(st));
+                        (void)hipFree(d_dbg_p);
+                        static const char* names[12] = {"max_next (prof: clk/16 entry wait)", "evals (prof: hops that waited)", "hops", "early+windows<<16", "clk/16 pop", "clk/16 read+issue+early", "clk/16 atomics",
+                                                        "clk/16 verdicts", "clk/16 push+top", "clk/16 schedule", "misses (prof: clk per job part)", "refills"};
+                        for (size_t i = 0; i < std::min<size_t>(nq, 4); ++i) {
+                            fprintf(stderr, "[walk pipe] query %zu:", i);
+                            for (int c = 0; c < 12; ++c) fprintf(stderr, " %s %u;", names[c], h[i * 12 + c]);
+                            fprintf(stderr, " redone %u of %zu\n", redone, nq);
+                        }
+                    }
+                    pipe_launches.fetch_add(1, std::memory_order_relaxed);
+                    return;
+                }
                 static const bool walk_debug_g = std::getenv("VS_HNSW_WALK_DEBUG") != nullptr;  // measurement aid, as below
                 uint32_t* d_dbg_g = nullptr;
                 if (walk_debug_g) {
@@ -1566,34 +1618,53 @@ struct Engine {
         const uint32_t sel_hint = lazy_sel_hint.load();  // selectivity of recent filtered queries, in 1 / 65,536
         const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
         uint64_t n_known = 0, n_allowed = 0;  // verdicts of this query so far
-        for (int round = 0; round < 20; ++round) {
+        // Rounds, round 4: on float indexes the pipelined walk (kernels_pipe.hip) first EXPLORES -- several candidates at a time, no
+        // order kept, verdicts it misses guessed at half the selectivity seen so far (of this query, else of recent queries of the
+        // index) and listed --, the host answers the list, and the next round is the exact walk, which as a rule meets no slot
+        // without a verdict.  An index that has seen no filtered query yet has no selectivity to guess with: its first exploring
+        // round takes every unknown slot as rejected and stops after first_budget of them; the second one guesses.
+        uint32_t ef_now = 0;
+        check_search(k, ef_now);
+        const bool can_explore = pipe_usable(ef_now);
+        bool explored = false;  // an exploring round that could guess has run (or two that could not)
+        int exact_rounds = 0, explore_rounds = 0;
+        for (int round = 0; round < 24; ++round) {
             LazyFilter lf;
             lf.known = d_bits + words;
             lf.unknown_list = d_unknown + 64;
             lf.unknown_count = d_unknown;
             lf.cap = cap;
             lf.consulted = d_unknown + 1;  // (a pad word of the count block)
-            // The first round's budget follows the number of verdicts the exact walks of recent filtered queries of this index
-            // consulted (+ 50 %): filters of one workload tend to be alike, and a first round that lists enough makes the second
-            // the exact one -- two walks instead of four at 10 % selectivity.  It doubles from there as before.
-            lf.budget = (uint32_t)std::min<size_t>(cap, (size_t)first_budget << round);
-            // exploratory rounds after the first guess unknown verdicts at half the selectivity seen so far (walk_device.hpp `guess_t`)
             static const int guess_pct = std::getenv("VS_HNSW_FILTER_GUESS") ? std::atoi(std::getenv("VS_HNSW_FILTER_GUESS")) : 50;  // % of the observed selectivity; 0 = off
             static const bool guess_first = std::getenv("VS_HNSW_FILTER_GUESS_FIRST") && std::getenv("VS_HNSW_FILTER_GUESS_FIRST")[0] == '1';  // experiment
-            if (n_known > 0 && guess_pct > 0) {
-                lf.budget |= std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * n_allowed * (uint64_t)guess_pct / (100 * n_known))) << 24;
-            } else if (round == 0 && guess_first && guess_pct > 0 && sel_hint > 0) {
-                // the first round too: at the selectivity recent filtered queries of this index showed, and with room for everything
-                // such a walk consults (it lists every slot it asks about)
-                lf.budget = (uint32_t)std::min<size_t>(cap, std::max<size_t>(lf.budget, 3 * (size_t)hint));
-                lf.budget |= std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * sel_hint * (uint64_t)guess_pct / (100ull * 65536ull))) << 24;
+            static const bool explore_off = std::getenv("VS_HNSW_FILTER_EXPLORE") && std::getenv("VS_HNSW_FILTER_EXPLORE")[0] == '0';  // A/B measurements
+            uint32_t guess = 0;  // of 256
+            if (n_known > 0 && guess_pct > 0) guess = std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * n_allowed * (uint64_t)guess_pct / (100 * n_known)));
+            else if (sel_hint > 0 && guess_pct > 0) guess = std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * sel_hint * (uint64_t)guess_pct / (100ull * 65536ull)));
+            lf.explore = can_explore && !explore_off && !explored && guess_pct > 0;
+            if (lf.explore) {
+                lf.budget = guess ? cap / 2 : first_budget;
+                lf.budget |= guess << 24;
+                explored = guess != 0 || ++explore_rounds >= 2;
+            } else {
+                // The first exact round's budget follows the number of verdicts the exact walks of recent filtered queries of this index
+                // consulted (+ 50 %): filters of one workload tend to be alike.  It doubles from there.
+                lf.budget = (uint32_t)std::min<size_t>(cap, (size_t)first_budget << exact_rounds);
+                // a round that meets unknown slots after all guesses them at half the selectivity seen so far (walk_device.hpp `guess_t`)
+                if (n_known > 0) {
+                    lf.budget |= guess << 24;
+                } else if (round == 0 && guess_first && guess) {
+                    lf.budget = (uint32_t)std::min<size_t>(cap, std::max<size_t>(lf.budget, 3 * (size_t)hint));
+                    lf.budget |= guess << 24;
+                }
+                ++exact_rounds;
             }
             search_device(h_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
             // counters, answer and list reach the pinned block by a kernel: one wait per round
             HIP_OK(launch_export_round(d_unknown, cap, d_k, d_d, d_f, (uint32_t)k, h_cnt, h_list, h_k, h_d, st));
             wait_round();
             const uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
-            if (count == 0) {
+            if (count == 0 && !lf.explore) {
                 if (found == kWalkFailed) return (size_t)-1;
                 std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
                 std::memcpy(dist, h_d, (size_t)std::min<size_t>(found, k) * 4);
@@ -1606,6 +1677,7 @@ struct Engine {
                 }
                 return found;
             }
+            if (count == 0) continue;  // (an exploring round that found every verdict it wanted)
             const uint32_t m = std::min(count, cap);
             // a walk evaluates a node once, so a list names a slot once, and slots with a verdict are never listed again
             for (uint32_t i = 0; i < m; ++i) {
@@ -2261,6 +2333,13 @@ int vs_hnsw_filter_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.lazy_rounds.load();
     out[1] = h->e.lazy_predicate_calls.load();
+    return VS_OK;
+}
+
+int vs_hnsw_pipe_stats(vs_hnsw* h, uint64_t out[2]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.pipe_launches.load();
+    out[1] = 0;
     return VS_OK;
 }
 

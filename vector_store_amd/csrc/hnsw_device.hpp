@@ -741,7 +741,7 @@ __device__ __forceinline__ const uint32_t* adjacency(const IndexView& ix, uint32
 // usearch search_for_one_: greedy walk on levels (from_level .. to_level+1].
 template <int AR, int I, class Sh>
 __device__ uint32_t greedy_descent(const IndexView& ix, Sh& sh, const Query<AR, I>& q,
-                                   uint32_t start, int from_level, int to_level, Counters& cnt, int lane) {
+                                   uint32_t start, int from_level, int to_level, Counters& cnt, int lane, float* out_d = nullptr) {
     uint32_t cur = start;
     if (lane == 0) sh.u_slot[0] = cur;
     wsync<Sh>();
@@ -780,6 +780,7 @@ __device__ uint32_t greedy_descent(const IndexView& ix, Sh& sh, const Query<AR, 
             }
         }
     }
+    if (out_d) *out_d = cur_d;
     return cur;
 }
 

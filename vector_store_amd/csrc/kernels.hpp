@@ -95,6 +95,8 @@ struct WalkArgs {
     uint32_t* out_found;
     unsigned long long* stats;
     uint32_t* debug;         // nullptr, or nq x 12 words: largest `next`, nodes evaluated, hops, admitted, 8 phase clocks (VS_HNSW_WALK_DEBUG)
+    uint32_t pipe_explore = 0;   // pipelined walk, lazy filter: an exploring round (lists missing verdicts, several candidates at a time; its answer is not one)
+    uint32_t pipe_pool_cap = 0;  // pipelined walk (kernels_pipe.hip): entries of `next` behind the front, in LDS (8 B each, <= 16,384)
 };
 inline size_t walk_space_stride(uint32_t bitmap_words, uint32_t vlog_cap, uint32_t heap_cap) {
     return (((size_t)bitmap_words + vlog_cap) * 4 + (size_t)heap_cap * 8 + 255) / 256 * 256;
@@ -105,6 +107,12 @@ inline size_t walk_space_stride(uint32_t bitmap_words, uint32_t vlog_cap, uint32
 template <int AR> hipError_t launch_walk_ar(const WalkArgs& a, uint32_t iters, uint32_t instance, uint32_t grid_cap, hipStream_t s,
                                             uint32_t* grid_out);
 hipError_t launch_walk(const WalkArgs& a, uint32_t iters, uint32_t instance, uint32_t grid_cap, hipStream_t s, uint32_t* grid_out);
+// The pipelined walk for lone queries (pipe_device.hpp / kernels_pipe.hip): float arithmetics, M0 <= 64, beams <= 512, rows of up to
+// 8 wave-loads; one workgroup and one WalkSpace (a.space) per query.  out_found == kPipeRedo: the usearch-order walk must answer.
+template <int AR> hipError_t launch_pipe_walk_ar(const WalkArgs& a, uint32_t iters, hipStream_t s);
+bool pipe_walk_supported(const IndexView& ix, uint32_t iters, uint32_t ef);
+hipError_t launch_pipe_walk(const WalkArgs& a, uint32_t iters, hipStream_t s);
+constexpr uint32_t kPipeRedoFound = 0xFFFFFFFEu;  // == kPipeRedo (pipe_device.hpp)
 template <int AR> hipError_t launch_search_ar(const SearchArgs& a, uint32_t iters, hipStream_t s);
 template <int AR> hipError_t launch_insert_ar(const InsertArgs& a, uint32_t iters, hipStream_t s);
 template <int AR> hipError_t launch_link_ar(const LinkArgs& a, uint32_t iters, hipStream_t s);

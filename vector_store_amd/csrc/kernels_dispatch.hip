@@ -68,6 +68,24 @@ hipError_t launch_walk(const WalkArgs& a, uint32_t iters, uint32_t instance, uin
     VS_DISPATCH(launch_walk_ar, (a, iters, instance, grid_cap, s, grid_out))
 }
 
+bool pipe_walk_supported(const IndexView& ix, uint32_t iters, uint32_t ef) {
+    return ix.scalar != SC_I8 && ix.scalar != SC_B1 && ix.M0 <= 64u && ef >= 1 && ef <= 512 &&
+           (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8);
+}
+
+hipError_t launch_pipe_walk(const WalkArgs& a, uint32_t iters, hipStream_t s) {
+    if (!pipe_walk_supported(a.ix, iters, a.ef)) return hipErrorInvalidValue;
+    switch (arith_of(a.ix.scalar, a.ix.metric)) {
+        case AR_F32_DOT: return launch_pipe_walk_ar<AR_F32_DOT>(a, iters, s);
+        case AR_F32_L2: return launch_pipe_walk_ar<AR_F32_L2>(a, iters, s);
+        case AR_F16_DOT: return launch_pipe_walk_ar<AR_F16_DOT>(a, iters, s);
+        case AR_F16_L2: return launch_pipe_walk_ar<AR_F16_L2>(a, iters, s);
+        case AR_BF16_DOT: return launch_pipe_walk_ar<AR_BF16_DOT>(a, iters, s);
+        case AR_BF16_L2: return launch_pipe_walk_ar<AR_BF16_L2>(a, iters, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     if (!search_supported(iters, a.ef_add)) return hipErrorInvalidValue;

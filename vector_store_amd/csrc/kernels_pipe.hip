@@ -1,0 +1,152 @@
+// kernels_pipe.hip -- hnsw_pipe_walk_kernel for ONE float arithmetic (-DVS_AR=0..5): the pipelined walk of pipe_device.hpp
+// behind usearch::Index::search / filtered_search for LONE queries (the reference issues one query per FFI call:
+// crates/vector-store/src/vs_index/usearch.rs:210-212, :233-236; filtered queries each on their own blocking thread, :937-948).
+// One workgroup of kPipeTeam waves per query: wave 0 walks, the others evaluate candidates ahead of it.  A query this kernel
+// cannot answer exactly as usearch orders it (two equal distances met, or `next` outgrew the pool) is flagged kPipeRedo and
+// served by the usearch-order walk (kernels_walk.hip).
+#include <mutex>
+
+#include "kernels.hpp"
+#include "pipe_device.hpp"
+
+#ifndef VS_AR
+#error "compile with -DVS_AR=<arithmetic>"
+#endif
+
+namespace vs {
+
+template <int AR, int I, int EFCAP>
+__global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs a) {
+    using Sh = PipeShared<EFCAP, kPipeTeam, false>;
+    __shared__ Sh sh;
+    extern __shared__ uint2 pipe_pool[];
+    const IndexView& ix = a.ix;
+    const int lane = lane_id();
+    const uint32_t w = threadIdx.x >> 6;
+    uint32_t qi = blockIdx.x;
+    if (a.qlist) {  // second-chance launches name their queries
+        if (qi >= *a.qcount) return;
+        qi = a.qlist[qi];
+    }
+    uint64_t* ok = a.out_keys + (size_t)qi * a.k;
+    float* od = a.out_dist + (size_t)qi * a.k;
+    if (ix.max_level < 0) {  // empty index
+        if (w == 0) {
+            for (uint32_t i = lane; i < a.k; i += kWave) {
+                ok[i] = kFreeKey;
+                od[i] = __builtin_inff();
+            }
+            if (lane == 0) a.out_found[qi] = 0;
+        }
+        return;
+    }
+    if (threadIdx.x < (uint32_t)kPipeTeam) {
+        sh.job_state[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) {
+            sh.stop = 0u;
+            sh.prof_jobs[0] = sh.prof_jobs[1] = 0u;
+        }
+    }
+    if (threadIdx.x < (uint32_t)kPipeCache) sh.c_ready[threadIdx.x] = 0u;
+    WalkSpace ws;
+    {
+        char* base = a.space + (size_t)blockIdx.x * a.space_stride;
+        ws.bitmap = reinterpret_cast<uint32_t*>(base);
+        ws.vlog = ws.bitmap + a.bitmap_words;
+        ws.heap = reinterpret_cast<uint2*>(ws.vlog + a.vlog_cap);
+        ws.bitmap_words = a.bitmap_words;
+        ws.vlog_cap = a.vlog_cap;
+        ws.heap_cap = a.heap_cap;
+    }
+    const bool tomb = a.has_removed != 0;
+    const uint32_t* allow = a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
+    const uint32_t* known = a.known ? a.known + (size_t)qi * a.allow_stride : nullptr;
+    Query<AR, I> q;
+    query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
+    if (w != 0) {
+        team_helper_loop<AR, I>(ix, q, sh, lane, w);  // the descent through the upper levels: the team form, with barriers
+        pipe_helper_loop<AR, I>(ix, q, sh, ws, tomb, allow, known, lane, w);
+        return;
+    }
+    Counters cnt = {0, 0, 0};
+    float start_d = 0.f;
+    const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane, &start_d);
+    team_release(sh, lane);  // the last barrier: from here on the waves meet through LDS words only
+    PipeTop<EFCAP / 64> top;
+    const PipeOut r = pipe_walk<AR, I>(ix, sh, pipe_pool, a.pipe_pool_cap, ws, start, start_d, a.ef, tomb, allow, known,
+                                       a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
+                                       a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget,
+                                       a.consulted ? a.consulted + qi : nullptr, cnt, lane, top, a.debug ? a.debug + (size_t)qi * 12 : nullptr,
+                                       a.pipe_explore != 0u);
+    if (r.status == 1u) {  // the usearch-order walk answers it (and lists the verdicts IT misses: this walk's list is dropped)
+        if (lane == 0) {
+            if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;
+            a.out_found[qi] = kPipeRedo;
+            if (a.unknown_count) a.unknown_count[qi] = 0u;
+            if (a.consulted) a.consulted[qi] = 0u;
+        }
+        return;
+    }
+    // top.shrink(wanted): `top` holds admitted, live members only (a round that ran out of budget reports what it has; the host
+    // looks at the listed slots first and walks again)
+    constexpr uint32_t R = EFCAP / 64;
+    const uint32_t found = r.sz < a.k ? r.sz : a.k;
+#pragma unroll
+    for (uint32_t j = 0; j < R; ++j) {
+        const uint32_t pos = (uint32_t)lane * R + j;
+        if (pos < found) {
+            ok[pos] = ix.keys[top.s[j]];
+            od[pos] = top.d[j];
+        }
+    }
+    for (uint32_t i = found + (uint32_t)lane; i < a.k; i += kWave) {
+        ok[i] = kFreeKey;
+        od[i] = __builtin_inff();
+    }
+    if (lane == 0) {
+        a.out_found[qi] = found;
+        atomicAdd(&a.stats[ST_SEARCH_EVALS], cnt.evals);
+        atomicAdd(&a.stats[ST_SEARCH_HOPS], cnt.hops);
+        atomicAdd(&a.stats[ST_QUERIES], 1ull);
+    }
+}
+
+template <int AR, int I, int EFCAP>
+static hipError_t pipe_launch(const WalkArgs& a, hipStream_t s) {
+    auto kernel = hnsw_pipe_walk_kernel<AR, I, EFCAP>;
+    const size_t dyn = (size_t)a.pipe_pool_cap * sizeof(uint2);
+    static std::once_flag once[16];  // the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t attr = hipSuccess;
+    std::call_once(once[dev & 15], [&] {
+        attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(kernel, dim3(a.nq), dim3(64 * kPipeTeam), dyn, s, a);
+    return hipGetLastError();
+}
+
+template <int AR, int I>
+static hipError_t pipe_ef(const WalkArgs& a, hipStream_t s) {
+    if (a.ef <= 256) return pipe_launch<AR, I, 256>(a, s);
+    if (a.ef <= 512) return pipe_launch<AR, I, 512>(a, s);
+    return hipErrorInvalidValue;
+}
+
+template <>
+hipError_t launch_pipe_walk_ar<VS_AR>(const WalkArgs& a, uint32_t iters, hipStream_t s) {
+    if (!a.nq) return hipSuccess;
+    if (a.ix.M0 > 64u || !a.space || a.pipe_pool_cap < 256u) return hipErrorInvalidValue;
+    switch (iters) {
+        case 1: return pipe_ef<VS_AR, 1>(a, s);
+        case 2: return pipe_ef<VS_AR, 2>(a, s);
+        case 3: return pipe_ef<VS_AR, 3>(a, s);
+        case 4: return pipe_ef<VS_AR, 4>(a, s);
+        case 6: return pipe_ef<VS_AR, 6>(a, s);
+        case 8: return pipe_ef<VS_AR, 8>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace vs

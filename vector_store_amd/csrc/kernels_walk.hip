@@ -169,7 +169,12 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_global_kernel(WalkAr
     __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
-    const uint32_t qi = blockIdx.x, w = threadIdx.x >> 6;
+    uint32_t qi = blockIdx.x;
+    const uint32_t w = threadIdx.x >> 6;
+    if (a.qlist) {  // second chance behind the pipelined walk (kernels_pipe.hip): only the queries it handed over
+        if (qi >= *a.qcount) return;
+        qi = a.qlist[qi];
+    }
     uint64_t* ok = a.out_keys + (size_t)qi * a.k;
     float* od = a.out_dist + (size_t)qi * a.k;
     if (ix.max_level < 0) {  // empty index
@@ -234,7 +239,7 @@ static hipError_t walk_team_global_launch(const WalkArgs& a, hipStream_t s, uint
         *grid_out = a.nq ? a.nq : 1;
         return hipSuccess;
     }
-    if (!a.nq || a.qlist) return a.nq ? hipErrorInvalidValue : hipSuccess;
+    if (!a.nq) return hipSuccess;
     hipLaunchKernelGGL((hnsw_walk_team_global_kernel<AR, I, EFCAP, LCAP, kSearchTeam>), dim3(a.nq), dim3(64 * kSearchTeam), 0, s, a);
     return hipGetLastError();
 }

@@ -1,0 +1,807 @@
+// pipe_device.hpp -- the PIPELINED walk: usearch's search_to_find_in_base_ (reference call sites
+// crates/vector-store/src/vs_index/usearch.rs:210-212 search, :233-236 filtered_search) for a LONE query, served by one
+// workgroup of waves that no longer meet at barriers.
+//
+// Why: a lone walk is a chain of dependent hops.  The team kernels (hnsw_device.hpp / walk_device.hpp) spread a hop's
+// distances over eight waves, but every hop still pays, one after the other: heap pop, adjacency read, visited
+// test-and-set, the HBM round trip of the rows, verdict words, admission, heap pushes, list merge -- 14k shader clocks
+// (profiles/r03_walk_phase_clocks.txt), of which the row round trip is a quarter and the rest a chain of LDS / global
+// round trips on wave 0.  A filtered walk at 10 % selectivity is 3,300 such hops.
+//
+// Here wave 0 (the WALKER) only takes decisions, on structures that live in its registers, and waves 1.. (the HELPERS)
+// evaluate candidates AHEAD of it:
+//
+//   next   = [front: the 64 closest unexpanded candidates, one per lane of wave 0, sorted] + [pool: the rest, unsorted, in
+//            LDS].  pop = a lane shift, push = a ballot rank + a lane shift (or an append to the pool); the front is refilled
+//            from the pool by a radix select when it runs empty (rare: every push below the front's worst goes to it).
+//   top    = usearch's sorted buffer, <= 512 entries in wave 0's registers (consecutive positions per lane); an insertion
+//            is R ballots + a lane shift, so admission is the CPU loop as written: one neighbour at a time, in adjacency
+//            order, against the moving radius.
+//   helpers: the walker publishes jobs "evaluate candidate X into cache entry e" for the first kPipeAhead entries of the
+//            front that have no entry yet.  A helper loads X's adjacency row, drops the neighbours the visited bitmap
+//            already holds, fetches their verdict bits, measures the rest (eval_batch: the same code as every other
+//            kernel, so the same distance bits) and stores (neighbour, distance, flags) in adjacency order.  Speculation
+//            only MEASURES: the visited set is marked by the walker alone, when X is really popped, and the bitmap only
+//            grows during a query, so a neighbour a helper skipped is visited then too and what it measured is a superset
+//            of what the pop needs.  A candidate that falls back in the queue keeps its entry; one that is never popped
+//            cost bandwidth, which a lone walk has to spare.
+//
+// Per hop the walker is left with: shift the front, find the entry (a ballot over tags in registers), one returning
+// atomicOr on the visited bitmap, the admission loop, the pushes -- about a fifth of the old chain.
+//
+// Order among EQUAL distances is the one thing these structures do not reproduce (usearch's array heap and lower_bound
+// insertion decide it, walk_device.hpp emulates them swap for swap).  Every insertion therefore checks for an equal
+// distance among the entries it is ranked against; the first tie ends the walk with status kPipeRedo and the query is
+// answered by the usearch-order walk instead.  Float metrics on real data never tie; lattice data, duplicates, i8 and b1
+// go to the old kernels (the host does not even try the integer metrics here).  Tie-free, the decisions -- and with the
+// shared distance code the ids and distance bits -- equal walk_usearch's.
+#pragma once
+#include "walk_device.hpp"
+
+namespace vs {
+
+#ifndef VS_PIPE_TEAM
+#define VS_PIPE_TEAM 12
+#endif
+constexpr int kPipeTeam = VS_PIPE_TEAM;  // waves per query: the walker + the helpers (165 registers: three waves per SIMD, twelve per CU)
+constexpr int kPipeCache = 16;  // evaluated-candidate entries (LDS)
+constexpr int kPipeAhead = 8;   // front positions the helpers keep evaluated
+#ifndef VS_PIPE_PARTS
+#define VS_PIPE_PARTS 3
+#endif
+constexpr uint32_t kPipeParts = VS_PIPE_PARTS;  // helpers that share one candidate measured ahead (the one needed at once: four)
+constexpr uint32_t kPipeRedo = 0xFFFFFFFEu;  // out_found: not answered here (a tie, or a structure outgrown): the usearch-order walk must answer
+
+// flags of a cache entry's neighbour
+constexpr uint32_t kPfEvaluated = 1u;  // c_dist holds its distance
+constexpr uint32_t kPfLive = 2u;       // not a removed member (asks for a verdict when a filter is on)
+constexpr uint32_t kPfKnown = 4u;      // the filter's verdict is known ...
+constexpr uint32_t kPfAllowed = 8u;    // ... and admits it (no filter: every live member)
+
+template <int EFCAP, int TM, bool NT>
+struct PipeShared : TeamBox<TM> {
+    static constexpr bool kNT = NT;
+    static constexpr int kEfCap = EFCAP;
+    static constexpr int kTeam = TM;
+    static constexpr bool kSel = false;
+    // the team phase (greedy descent through the upper levels: eval_shared / team_helper_loop)
+    uint32_t u_slot[64];
+    float u_dist[64];
+    // jobs: walker -> helper w
+    uint32_t job_state[TM];  // 0 idle, 1 posted
+    uint32_t job_slot[TM];
+    uint32_t job_entry[TM];
+    uint32_t job_part[TM];   // part | parts << 8: the helper takes the neighbours whose adjacency position % parts == part
+    uint32_t stop;
+    // evaluated candidates
+    uint32_t c_ready[kPipeCache];  // parts still out (0: complete, or not in use)
+    uint32_t c_slot[kPipeCache][64];
+    float c_dist[kPipeCache][64];
+    uint32_t c_flag[kPipeCache][64];
+    // helper scratch: the compacted list eval_batch works on
+    uint32_t h_slot[TM][64];
+    float h_dist[TM][64];
+    // refill
+    uint32_t hist[256];
+    uint2 stage[64];
+    uint32_t prof_jobs[2];  // profile builds: job parts done, their clocks
+};
+
+__device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The WALKER's flag traffic.  LDS executes one wave's instructions in order, so a flag stored after its payload is seen after it, and
+// payload read after a flag is read after it -- no s_waitcnt needed; what must not happen is the compiler moving them across each
+// other (wavefront-scope fences: ordering only).  A workgroup-scope release / acquire here would also wait for every global store the
+// walker has in flight (visited log, unknown list) and for the visited atomics it issued on purpose ahead of the bookkeeping.
+__device__ __forceinline__ void lds_flag_store(uint32_t* p, uint32_t v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_flag_load(const uint32_t* p) {
+    const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return v;
+}
+
+// lane l <- lane l - 1 (lane 0 keeps `fill`); lane l <- lane l + 1 (lane 63 keeps `fill`)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float rl_f(float v, uint32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l)); }
+__device__ __forceinline__ uint32_t rl_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// order-preserving key of a distance (NaN never gets here: group_reduce ranks it as +inf)
+__device__ __forceinline__ uint32_t dist_key(uint32_t bits) { return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+// minimum over the wave, in every lane: four DPP rotations inside the rows of 16, then the four row results on the scalar side
+__device__ __forceinline__ float wave_min(float v) {
+    v = fminf(v, VS_DPP_ROR(v, 8));
+    v = fminf(v, VS_DPP_ROR(v, 4));
+    v = fminf(v, VS_DPP_ROR(v, 2));
+    v = fminf(v, VS_DPP_ROR(v, 1));
+    return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
+}
+
+// ---- helper waves --------------------------------------------------------------------------------------------------
+template <int AR, int I, class Sh>
+__device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Query<AR, I>& q, Sh& sh, const WalkSpace& ws, bool tomb,
+                                                 const uint32_t* allow, const uint32_t* known, int lane, uint32_t w) {
+    for (;;) {
+        while (lds_load_acquire(&sh.job_state[w]) == 0u) {
+            if (lds_load_relaxed(&sh.stop)) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+#ifdef VS_WALK_PROFILE
+        const uint64_t job_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        const uint32_t slot = uni(sh.job_slot[w]), e = uni(sh.job_entry[w]), pp = uni(sh.job_part[w]);
+        const uint32_t part = pp & 255u, parts = (pp >> 8) & 255u;
+        const bool claim = (pp >> 16) != 0u;  // exploring rounds: the helper itself marks what it measures (no order to keep)
+        const uint32_t cap = ix.M0;  // <= 64 (host-checked)
+        const uint32_t* row = ix.adj0 + (size_t)slot * ix.M0;
+        const bool mine = (uint32_t)lane % parts == part;  // the positions of the adjacency row this helper answers for
+        const uint32_t n = (mine && (uint32_t)lane < cap) ? row[lane] : kInvalid;
+        const bool valid = n != kInvalid;
+        // Everything that depends on the neighbour ids alone leaves together: the visited word (read past L1: the walker's atomics live
+        // in L2), the verdict words, the key (removed members), and one dword of the neighbour's own adjacency row -- should it become
+        // the closest candidate at once, that row is two dependent loads away from ITS neighbours' distances; the touch pulls it into
+        // L2 meanwhile (the value is not used).
+        uint32_t vw = 0, kw = ~0u, aw = ~0u, touch = 0;
+        uint64_t key = 0;
+        if (valid) {
+            if (claim) vw = atomicOr(&ws.bitmap[n >> 5], 1u << (n & 31u));
+            else vw = __hip_atomic_load(&ws.bitmap[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            touch = ix.adj0[(size_t)n * ix.M0];
+            if (tomb) key = ix.keys[n];
+            if (allow) {
+                aw = allow[n >> 5];
+                if (known) kw = known[n >> 5];
+            }
+        }
+        // The bitmap only grows during a query, so "seen" stays true; "not seen" is re-tested by the walker when the candidate is popped.
+        const bool seen = valid && ((vw >> (n & 31u)) & 1u) != 0u;
+        const bool need = valid && !seen;
+        uint32_t fl = 0;
+        if (need) {
+            const bool live = !tomb || key != kFreeKey;
+            const bool kn = ((kw >> (n & 31u)) & 1u) != 0u, al = ((aw >> (n & 31u)) & 1u) != 0u;
+            fl = kPfEvaluated | (live ? kPfLive : 0u);
+            if (live) fl |= (kn ? kPfKnown : 0u) | ((kn && al) ? kPfAllowed : 0u);
+        }
+        const uint64_t nm = __ballot(need);
+        const uint32_t m = (uint32_t)__popcll(nm);
+        if (need) sh.h_slot[w][mbcnt(nm)] = n;
+        if (mine) {
+            sh.c_slot[e][lane] = n;
+            sh.c_flag[e][lane] = fl;
+        }
+        // (the list is this wave's own: LDS keeps one wave's accesses in order, only the compiler must be held -- a workgroup-scope fence
+        // would also wait for the touch loads, a full HBM round trip, before the first row load is issued)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        eval_batch<AR, I, 1, Sh::kNT>(ix, q, sh.h_slot[w], sh.h_dist[w], m, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (need) sh.c_dist[e][lane] = sh.h_dist[w][mbcnt(nm)];
+#ifdef VS_WALK_PROFILE
+        if (lane == 0) {
+            atomicAdd(&sh.prof_jobs[0], 1u);
+            atomicAdd(&sh.prof_jobs[1], (uint32_t)(__builtin_amdgcn_s_memtime() - job_t0));
+        }
+#endif
+        if (lane == 0) {
+            __hip_atomic_fetch_sub(&sh.c_ready[e], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_store_release(&sh.job_state[w], 0u);
+        }
+        asm volatile("" ::"v"(touch));
+    }
+}
+
+// ---- the walker ----------------------------------------------------------------------------------------------------
+// EFCAP / 64 consecutive positions of `top` per lane.
+template <int R>
+struct PipeTop {
+    float d[R];
+    uint32_t s[R];
+};
+
+struct PipeOut {
+    uint32_t status;  // 0 answered; 1 redo (an order-relevant tie / structure outgrown); 2 the round's budget of unknown verdicts is spent (lazy filter)
+    uint32_t sz;
+};
+
+template <int AR, int I, class Sh>
+__device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2* pool, uint32_t pool_cap, const WalkSpace& ws, uint32_t start,
+                                             float start_d, uint32_t ef, bool tomb, const uint32_t* allow, const uint32_t* known,
+                                             uint32_t* unknown_list, uint32_t* unknown_count, uint32_t unknown_cap, uint32_t unknown_budget,
+                                             uint32_t* consulted_out, Counters& cnt, int lane, PipeTop<Sh::kEfCap / 64>& top, uint32_t* debug,
+                                             bool explore) {
+    constexpr int R = Sh::kEfCap / 64;
+    constexpr uint32_t TM = (uint32_t)Sh::kTeam;
+    constexpr uint32_t K = (uint32_t)kPipeCache;
+    const uint32_t L = (uint32_t)lane;
+    const float INF = __builtin_inff();
+#ifdef VS_WALK_PROFILE
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prof_t = __builtin_amdgcn_s_memtime();
+#endif
+    uint32_t dbg_max_next = 0, dbg_pushed = 0, dbg_miss = 0, dbg_refill = 0, dbg_early = 0, dbg_windows = 0, dbg_waits = 0;
+    bool redo = false, over_budget = false;
+    const uint32_t guess_t = unknown_budget >> 24;
+    unknown_budget &= 0xFFFFFFu;
+    uint32_t ucount = 0, consulted = 0, vcount = 0;
+    bool vlog_lost = false;
+    // front / pool / top
+    float f_d = INF;
+    uint32_t f_s = kInvalid, f_c = 0, nf = 0, np = 0;  // f_c: 1 = a cache entry (complete or being measured) belongs to this candidate
+    float pool_lb = INF;  // the smallest distance in the pool
+    uint32_t sz = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        top.d[j] = INF;
+        top.s[j] = kInvalid;
+    }
+    uint32_t tag = kInvalid;  // lane e < kPipeCache: the candidate cache entry e belongs to
+    // Order among EQUAL distances: the one thing these structures do not reproduce.  While two candidates with one distance v wait in
+    // `next` together ("window": from the pop of the first of them until the head of `next` lies beyond v) usearch's heap decides who goes
+    // first.  The sets the walk works on -- visited, `next`, `top` -- come out the same either way as long as no comparison against the
+    // radius can tell the orders apart and no two equal distances are inserted into `top` in an order-dependent sequence: i.e. while,
+    // inside the window, `top` is not full, does not fill up, and no insertion meets an equal distance there.  Anything else inside a
+    // window hands the query to the usearch-order walk (status redo).
+    bool tie_active = false;
+    float tie_v = 0.f;
+
+    // distance at position p of `top` (wave-uniform p): one readlane per register row, chosen on the scalar side (a select chain over
+    // the rows themselves is turned into an indexed load from a scratch copy of the array)
+    auto top_at = [&](uint32_t p) -> float {
+        const uint32_t pl = p / (uint32_t)R, pr = p % (uint32_t)R;
+        float v = rl_f(top.d[0], pl);
+#pragma unroll
+        for (int j = 1; j < R; ++j) {
+            const float x = rl_f(top.d[j], pl);
+            v = pr == (uint32_t)j ? x : v;
+        }
+        return v;
+    };
+    float radius = INF;  // top's last distance once it is full
+    auto top_insert = [&](float d, uint32_t s) {  // top.insert({d, s}, ef) with d below the radius when full: in front of equal entries
+        uint32_t rank = 0;
+        bool eq = false;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const bool in = L * (uint32_t)R + (uint32_t)j < sz;
+            rank += (uint32_t)__popcll(__ballot(in && top.d[j] < d));
+            eq = eq || (in && top.d[j] == d);
+        }
+        if (tie_active && (sz + 1u >= ef || __ballot(eq) != 0ull)) redo = true;
+        const float cd = __uint_as_float(wave_shr1(__float_as_uint(top.d[R - 1]), 0u));
+        const uint32_t cs = wave_shr1(top.s[R - 1], 0u);
+#pragma unroll
+        for (int j = R - 1; j >= 0; --j) {
+            const uint32_t pos = L * (uint32_t)R + (uint32_t)j;
+            const float pd = j ? top.d[j > 0 ? j - 1 : 0] : cd;
+            const uint32_t ps = j ? top.s[j > 0 ? j - 1 : 0] : cs;
+            top.d[j] = pos > rank ? pd : pos == rank ? d : top.d[j];
+            top.s[j] = pos > rank ? ps : pos == rank ? s : top.s[j];
+        }
+        sz = sz < ef ? sz + 1u : ef;
+        if (sz == ef) radius = top_at(ef - 1u);
+    };
+    auto pool_append = [&](bool mine, float d, uint32_t s) {  // every lane with `mine` appends its entry
+        const uint64_t mk = __ballot(mine);
+        if (!mk) return;
+        const uint32_t c = (uint32_t)__popcll(mk);
+        if (np + c > pool_cap) {
+            redo = true;
+            return;
+        }
+        if (mine) pool[np + mbcnt(mk)] = make_uint2(__float_as_uint(d), s);
+        np += c;
+        pool_lb = fminf(pool_lb, wave_min(mine ? d : INF));
+    };
+    auto pool_append_one = [&](float d, uint32_t s) {  // one wave-uniform entry
+        if (np + 1u > pool_cap) {
+            redo = true;
+            return;
+        }
+        if (L == 0u) pool[np] = make_uint2(__float_as_uint(d), s);
+        np += 1u;
+        pool_lb = fminf(pool_lb, d);
+    };
+    auto free_entry_of = [&](uint32_t s) {  // the candidate lost its place among the cached ones
+        if (L < K && tag == s) tag = kInvalid;
+    };
+    auto front_insert = [&](float d, uint32_t s, uint32_t c) {  // one entry (wave-uniform) into the sorted front; the displaced worst goes to the pool
+        const bool in = L < nf;
+        const uint32_t rank = (uint32_t)__popcll(__ballot(in && f_d <= d));  // (behind equal ones: any order among them is as good)
+        const bool full = nf == 64u;
+        if (full && rank >= 64u) {  // (an earlier insertion of the same hop moved the front's reach below it)
+            pool_append_one(d, s);
+            if (c) free_entry_of(s);
+            return;
+        }
+        const float ev_d = rl_f(f_d, 63);
+        const uint32_t ev_s = rl_u(f_s, 63), ev_c = rl_u(f_c, 63);
+        const float sd = __uint_as_float(wave_shr1(__float_as_uint(f_d), 0u));
+        const uint32_t ss = wave_shr1(f_s, 0u), sc = wave_shr1(f_c, 0u);
+        f_d = L > rank ? sd : L == rank ? d : f_d;
+        f_s = L > rank ? ss : L == rank ? s : f_s;
+        f_c = L > rank ? sc : L == rank ? c : f_c;
+        if (full) {
+            pool_append_one(ev_d, ev_s);
+            if (ev_c) free_entry_of(ev_s);
+        } else {
+            nf += 1u;
+        }
+    };
+    // next.insert for the lanes in `mask` (their own nd / ns): below the front's reach -> the front, one at a time; the rest -> the pool
+    auto push_lanes = [&](uint64_t mask, float nd, uint32_t ns) {
+        const float reach = nf == 64u ? rl_f(f_d, 63) : pool_lb;  // closer than this: belongs to the front
+        const bool mine = ((mask >> L) & 1ull) != 0ull;
+        const uint64_t fm = __ballot(mine && nd < reach);
+        pool_append(mine && !(nd < reach), nd, ns);
+        for (uint64_t r = fm; r; r &= r - 1ull) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(r);
+            front_insert(rl_f(nd, j), rl_u(ns, j), 0u);
+        }
+        dbg_pushed += (uint32_t)__popcll(mask);
+    };
+    // the front ran empty: the closest entries of the pool move up (radix select on the order-preserving distance bits)
+    auto refill = [&]() {
+        ++dbg_refill;
+        uint32_t thr = 0xFFFFFFFFu;  // entries with key < thr move (all: every entry)
+        const bool all = np <= 64u;
+        if (!all) {
+            uint32_t prefix = 0, below = 0;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sh.hist[L * 4u + (uint32_t)i] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = L; i < np; i += 64u) {
+                    const uint32_t k = dist_key(pool[i].x);
+                    if (shift == 24 || (k >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t h0 = sh.hist[L * 4u], h1 = sh.hist[L * 4u + 1u], h2 = sh.hist[L * 4u + 2u], h3 = sh.hist[L * 4u + 3u];
+                uint32_t incl = h0 + h1 + h2 + h3;  // inclusive scan over lanes
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                    if (L >= (uint32_t)o) incl += up;
+                }
+                const uint32_t excl = incl - (h0 + h1 + h2 + h3);
+                const uint32_t room = 64u - below;  // entries that may still move
+                const uint64_t over = __ballot(incl > room);  // first bucket whose inclusive count exceeds the room
+                if (!over) {  // (cannot happen: the first pass sees np > 64 entries, a later one a bucket that exceeded the room)
+                    redo = true;
+                    return;
+                }
+                const uint32_t ol = (uint32_t)__builtin_ctzll(over);
+                const uint32_t e0 = rl_u(excl, ol), a0 = rl_u(h0, ol), a1 = rl_u(h1, ol), a2 = rl_u(h2, ol);
+                uint32_t c = e0, b = ol * 4u;
+                if (c + a0 <= room) { c += a0; ++b; if (c + a1 <= room) { c += a1; ++b; if (c + a2 <= room) { c += a2; ++b; } } }
+                below += c;
+                thr = shift == 24 ? (b << 24) : ((prefix << (shift + 8)) | (b << shift));
+                if (below >= 16u) break;
+                if (shift == 0) {
+                    // thr is a full 32-bit key now.  Nothing below it: more than 64 - below entries share the smallest distance;
+                    // that run moves up whole when it fits (the front takes equal entries as they come), else the other walk serves
+                    if (below == 0u) {
+                        const uint32_t a3 = rl_u(h3, ol);
+                        const uint32_t run = (b & 3u) == 0u ? a0 : (b & 3u) == 1u ? a1 : (b & 3u) == 2u ? a2 : a3;
+                        if (run > 64u) {
+                            redo = true;
+                            return;
+                        }
+                        thr = thr + 1u;  // (0xFFFFFFFF is the key of no distance: +inf maps below it)
+                    }
+                    break;
+                }
+                prefix = shift == 24 ? b : ((prefix << 8) | b);
+            }
+        }
+        uint32_t taken = 0, kept = 0;
+        float lb = INF;
+        for (uint32_t base = 0; base < np; base += 64u) {
+            const bool valid = base + L < np;
+            const uint2 e = valid ? pool[base + L] : make_uint2(0u, 0u);
+            const bool take = valid && (all || dist_key(e.x) < thr);
+            const bool keep = valid && !take;
+            const uint64_t tm = __ballot(take), km = __ballot(keep);
+            if (taken + (uint32_t)__popcll(tm) > 64u) {  // (cannot happen: the select counted them)
+                redo = true;
+                return;
+            }
+            if (take) sh.stage[taken + mbcnt(tm)] = e;
+            if (keep) {
+                pool[kept + mbcnt(km)] = e;
+                lb = fminf(lb, __uint_as_float(e.x));
+            }
+            taken += (uint32_t)__popcll(tm);
+            kept += (uint32_t)__popcll(km);
+        }
+        np = kept;
+        pool_lb = wave_min(lb);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint2 me = L < taken ? sh.stage[L] : make_uint2(__float_as_uint(INF), kInvalid);
+        const float md = __uint_as_float(me.x);
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < taken; ++j) {
+            const float dj = rl_f(md, j);
+            rank += (dj < md || (dj == md && j < L)) ? 1u : 0u;
+        }
+        // lane l sends its entry to lane rank (a permutation of 0 .. taken - 1)
+        f_d = __int_as_float(__builtin_amdgcn_ds_permute((int)(rank << 2), __float_as_int(md)));
+        f_s = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)me.y);
+        if (L >= taken) {
+            f_d = INF;
+            f_s = kInvalid;
+        }
+        f_c = 0u;
+        nf = taken;
+    };
+
+    // ---- jobs ----
+    uint64_t idle = 0, freem = 0;  // helpers without a job / cache entries that can take one, as of the hop's start minus what the hop used
+    auto refresh_jobs = [&]() {
+        uint32_t js = 1u, cr = 1u;
+        if (L >= 1u && L < TM) js = lds_load_relaxed(&sh.job_state[L]);
+        if (L < K) cr = lds_load_relaxed(&sh.c_ready[L]);
+        idle = __ballot(L >= 1u && L < TM && js == 0u);
+        freem = __ballot(L < K && tag == kInvalid && cr == 0u);
+    };
+    // "measure candidate s", split over up to `want` helpers; the entry, or kInvalid when no helper or no entry is to be had
+    auto post_job = [&](uint32_t s, uint32_t want, uint32_t claim = 0u) -> uint32_t {
+        const uint32_t avail = (uint32_t)__popcll(idle);
+        if (!avail || !freem) return kInvalid;
+        const uint32_t parts = want < avail ? want : avail;
+        const uint32_t e = (uint32_t)__builtin_ctzll(freem);
+        freem &= freem - 1ull;
+        if (L == e) tag = s;
+        if (L == 0u) sh.c_ready[e] = parts;
+        // lane h of the first `parts` idle helpers writes helper h's job: four stores for the whole post, the flag last
+        const uint32_t rank = mbcnt(idle);
+        const bool pick = ((idle >> L) & 1ull) != 0ull && rank < parts;
+        if (pick) {
+            sh.job_slot[L] = s;
+            sh.job_entry[L] = e;
+            sh.job_part[L] = rank | (parts << 8) | (claim << 16);
+            lds_flag_store(&sh.job_state[L], 1u);
+        }
+        idle &= ~__ballot(pick);
+        return e;
+    };
+    // keep the first kPipeAhead entries of the front measured (two helpers stay in reserve for the candidate a hop needs at once)
+    auto schedule = [&]() {
+        const uint32_t want = nf < (uint32_t)kPipeAhead ? nf : (uint32_t)kPipeAhead;
+        uint64_t missing = __ballot(L < want && f_c == 0u);
+        for (; missing; missing &= missing - 1ull) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(missing);
+            const uint32_t avail = (uint32_t)__popcll(idle);
+            if (i == 0u ? avail == 0u : avail < kPipeParts + 2u) break;
+            const uint32_t e = post_job(rl_u(f_s, i), i == 0u ? 4u : kPipeParts);
+            if (e == kInvalid) break;
+            if (L == i) f_c = 1u;
+        }
+    };
+
+    // ---- start: visits.set(start); next.insert(start); top.insert(start) if it may be a result ----
+    auto mark = [&](uint32_t n, bool valid) -> bool {  // true: n is new to the visited set
+        bool fresh = false;
+        if (valid) {
+            const uint32_t bit = 1u << (n & 31u);
+            fresh = (atomicOr(&ws.bitmap[n >> 5], bit) & bit) == 0u;
+        }
+        const uint64_t fm = __ballot(fresh);
+        const uint32_t c = (uint32_t)__popcll(fm);
+        if (vcount + c <= ws.vlog_cap) {
+            if (fresh) ws.vlog[vcount + mbcnt(fm)] = n;
+        } else {
+            vlog_lost = true;
+        }
+        vcount += c;
+        return fresh;
+    };
+    // verdict bookkeeping of the lanes in `ask` (flags fl): consulted / unknown listing / guess; returns the admitted lanes
+    auto verdicts = [&](uint64_t ask, uint32_t n, uint32_t fl) -> uint64_t {
+        const bool mine = ((ask >> L) & 1ull) != 0ull;
+        const bool live = mine && (fl & kPfLive) != 0u;
+        if (!allow) return __ballot(live);
+        consulted += (uint32_t)__popcll(__ballot(live));
+        const bool unk = live && !(fl & kPfKnown);
+        const uint64_t um = __ballot(unk);
+        if (um) {
+            const uint32_t c = (uint32_t)__popcll(um);
+            if (unk && ucount + mbcnt(um) < unknown_cap) unknown_list[ucount + mbcnt(um)] = n;
+            ucount += c;
+            if (ucount >= unknown_budget) over_budget = true;
+        }
+        const bool guess = unk && guess_t != 0u && ((n * 2654435761u) >> 24) < guess_t;
+        return __ballot((live && (fl & kPfAllowed) != 0u) || guess);
+    };
+    (void)mark(start, L == 0u);
+    cnt.evals += 1;  // (the walk measures its start, as walk_usearch does; here the descent's value is reused -- same code, same bits)
+    {
+        uint32_t fl0 = 0;
+        if (L == 0u) {
+            const bool live = !tomb || ix.keys[start] != kFreeKey;
+            fl0 = live ? kPfLive : 0u;
+            if (live) {
+                if (!allow) fl0 |= kPfKnown | kPfAllowed;
+                else {
+                    const bool kn = !known || ((known[start >> 5] >> (start & 31u)) & 1u) != 0u;
+                    const bool al = ((allow[start >> 5] >> (start & 31u)) & 1u) != 0u;
+                    fl0 |= (kn ? kPfKnown : 0u) | ((kn && al) ? kPfAllowed : 0u);
+                }
+            }
+        }
+        const uint64_t ok0 = verdicts(1ull, start, fl0);
+        front_insert(start_d, start, 0u);
+        if (ok0 & 1ull) top_insert(start_d, start);
+    }
+    // ---- exploring round (lazy filter): no answer is taken from it, so no order has to be kept.  The closest candidates are expanded
+    // several at a time, each by one helper that also marks what it measures; the walker only merges: verdict bookkeeping (which lists
+    // the slots whose verdict is missing -- what the round is for), pushes, `top` (with guessed verdicts, so that the radius behaves
+    // as the exact walk's will).  Two batches are kept in flight: the next one is posted before the last one is merged.
+    if (explore) {
+        constexpr uint32_t kBatch = (TM - 1u) / 2u;
+        auto post_batch = [&]() -> uint64_t {
+            refresh_jobs();
+            uint64_t ents = 0;
+            for (uint32_t c = 0; c < kBatch && nf && idle && freem; ++c) {
+                const float cd = rl_f(f_d, 0);
+                const uint32_t cs = rl_u(f_s, 0);
+                if (sz == ef && cd > radius) break;
+                f_d = __uint_as_float(wave_shl1(__float_as_uint(f_d), __float_as_uint(INF)));
+                f_s = wave_shl1(f_s, kInvalid);
+                f_c = wave_shl1(f_c, 0u);
+                nf -= 1u;
+                cnt.hops += 1;
+                const uint32_t e = post_job(cs, 1u, 1u);
+                ents |= 1ull << e;
+            }
+            return ents;
+        };
+        auto merge = [&](uint64_t ents) {
+            for (; ents && !redo; ents &= ents - 1ull) {
+                const uint32_t e = (uint32_t)__builtin_ctzll(ents);
+                for (uint32_t spins = 0; lds_flag_load(&sh.c_ready[e]) != 0u; ++spins) {
+                    if (spins > (1u << 22)) {
+                        redo = true;
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const uint32_t n = sh.c_slot[e][lane];
+                const uint32_t fl = sh.c_flag[e][lane];
+                float nd = sh.c_dist[e][lane];
+                if (L == e) tag = kInvalid;
+                const bool evd = n != kInvalid && (fl & kPfEvaluated) != 0u;  // claimed by the helper: new to the visited set
+                if (!evd) nd = INF;
+                cnt.evals += (uint32_t)__popcll(__ballot(evd));
+                if (over_budget) continue;  // (the entries of a batch in flight are still drained)
+                const uint64_t cand = __ballot(evd && (sz < ef || nd < radius));
+                const uint64_t okmask = verdicts(cand, n, fl);
+                push_lanes(cand, nd, n);
+                for (uint64_t r = okmask; r; r &= r - 1ull) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(r);
+                    const float dj = rl_f(nd, j);
+                    if (sz < ef || dj < radius) top_insert(dj, rl_u(n, j));
+                }
+            }
+        };
+        uint64_t flying = 0;
+        for (;;) {
+            if (nf == 0u && np != 0u && !over_budget) refill();
+            const uint64_t posted = (redo || over_budget) ? 0ull : post_batch();
+            if (flying) merge(flying);
+            flying = posted;
+            dbg_max_next = nf + np > dbg_max_next ? nf + np : dbg_max_next;
+            if (redo) break;
+            if (!flying) {
+                if (over_budget || (nf == 0u && np == 0u)) break;
+                if (nf && sz == ef && rl_f(f_d, 0) > radius) break;
+                if (nf == 0u) continue;  // (refill next)
+                __builtin_amdgcn_s_sleep(1);  // (no helper or entry free although nothing is in flight: cannot last)
+            }
+        }
+        // every helper must have finished marking before the bitmap is wiped (the visited log was not kept: the helpers marked)
+        for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+            refresh_jobs();
+            if ((uint32_t)__popcll(idle) == TM - 1u) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        vlog_lost = true;
+    }
+    refresh_jobs();
+    if (!explore) schedule();
+    WALK_STAMP(0);
+    while (!explore && !redo && !over_budget) {
+        if (nf == 0u) {
+            if (np == 0u) break;
+            refill();
+            if (redo || nf == 0u) break;
+        }
+        const float cd = rl_f(f_d, 0);
+        const uint32_t cs = rl_u(f_s, 0);
+        if (sz == ef && cd > radius) break;  // `candidate.distance > radius && top.size() == top_limit`
+        // pop
+        f_d = __uint_as_float(wave_shl1(__float_as_uint(f_d), __float_as_uint(INF)));
+        f_s = wave_shl1(f_s, kInvalid);
+        f_c = wave_shl1(f_c, 0u);
+        nf -= 1u;
+        cnt.hops += 1;
+        const float next_d = nf ? rl_f(f_d, 0) : pool_lb;  // (pool_lb: +inf when the pool is empty)
+        if (tie_active && cd > tie_v) tie_active = false;
+        if (!tie_active && next_d == cd) {
+            tie_active = true;
+            tie_v = cd;
+            ++dbg_windows;
+        }
+        // its evaluated neighbours
+        uint64_t hitm = __ballot(L < K && tag == cs);
+        if (!hitm) {  // not even posted (every helper was busy, or it arrived with this very hop): post it now, first in line
+            ++dbg_miss;
+            for (uint32_t spins = 0;; ++spins) {
+                if (spins > (1u << 22)) {
+                    redo = true;
+                    break;
+                }
+                refresh_jobs();
+                const uint32_t e = post_job(cs, 4u);
+                if (e != kInvalid) {
+                    hitm = 1ull << e;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (redo) break;
+        const uint32_t e = (uint32_t)__builtin_ctzll(hitm);
+        WALK_STAMP(1);  // pop, lookup
+        for (uint32_t spins = 0; lds_flag_load(&sh.c_ready[e]) != 0u; ++spins) {
+            if (spins > (1u << 22)) {  // (a helper that never answers: give the query to the other walk rather than hang the device)
+                redo = true;
+                break;
+            }
+            if (spins == 0) ++dbg_waits;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (redo) break;
+        WALK_STAMP(7);  // wait for the entry
+        const uint32_t n = sh.c_slot[e][lane];
+        const uint32_t fl = sh.c_flag[e][lane];
+        float nd = sh.c_dist[e][lane];
+        if (L == e) tag = kInvalid;  // the entry is free again
+        refresh_jobs();
+        // visited test-and-set: the atomics are on their way while the next candidate is looked for
+        bool fresh = false;
+        if (n != kInvalid) {
+            const uint32_t bit = 1u << (n & 31u);
+            fresh = (atomicOr(&ws.bitmap[n >> 5], bit) & bit) == 0u;
+        }
+        // The closest neighbour measured for this candidate, when it is closer than everything that waits in `next`, is the very next
+        // candidate (if it is new, which the atomics will tell): its own measurement starts NOW, not after this hop's bookkeeping.
+        const bool evd = n != kInvalid && (fl & kPfEvaluated) != 0u;
+        if (!evd) nd = INF;
+        uint32_t early_slot = kInvalid, early_e = kInvalid;
+        {
+            const float best = wave_min(nd);
+            if (best < next_d && (sz < ef || best < radius)) {
+                const uint64_t bm = __ballot(evd && nd == best);
+                early_slot = rl_u(n, (uint32_t)__builtin_ctzll(bm));
+                early_e = post_job(early_slot, 4u);
+                if (early_e == kInvalid) early_slot = kInvalid;
+                else ++dbg_early;
+            }
+        }
+        WALK_STAMP(2);  // entry read, atomics issued, early post
+        const uint64_t fmask = __ballot(fresh);
+        WALK_STAMP(3);  // the atomics' round trip
+        {
+            const uint32_t c = (uint32_t)__popcll(fmask);
+            if (vcount + c <= ws.vlog_cap) {
+                if (fresh) ws.vlog[vcount + mbcnt(fmask)] = n;
+            } else {
+                vlog_lost = true;
+            }
+            vcount += c;
+        }
+        const uint32_t m = (uint32_t)__popcll(fmask);
+        if (__ballot(fresh && !(fl & kPfEvaluated))) {  // (cannot happen: the bitmap only grows) -- never trust a distance that is not there
+            redo = true;
+            break;
+        }
+        cnt.evals += m;
+        if (m) {
+            if (!fresh) nd = INF;
+            // verdicts are needed only for neighbours that can still be admitted: once `top` is full, those below the hop's first radius
+            const float radius0 = sz == ef ? radius : INF;
+            const uint64_t cand = __ballot(fresh && (sz < ef || nd < radius0));
+            const uint64_t okmask = verdicts(cand, n, fl);
+            if (over_budget) break;  // enough unknown slots listed for one round: the host evaluates them and launches again
+            WALK_STAMP(4);  // verdicts
+            const uint32_t oks = (uint32_t)__popcll(okmask);
+            bool done = false;
+            if (sz + oks <= ef && sz < ef) {
+                // `top` cannot outgrow its limit during this hop: every fresh neighbour is pushed, the admitted ones enter `top` -- unless
+                // the one that fills `top` exactly has neighbours behind it, which then meet a finite radius: the literal loop below
+                bool filled_early = false;
+                if (sz + oks == ef) {
+                    const uint32_t last_ok = 63u - (uint32_t)__builtin_clzll(okmask | 1ull);
+                    filled_early = oks != 0u && (cand >> last_ok) > 1ull;
+                }
+                if (!filled_early) {
+                    push_lanes(cand, nd, n);
+                    for (uint64_t r = okmask; r; r &= r - 1ull) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(r);
+                        top_insert(rl_f(nd, j), rl_u(n, j));
+                    }
+                    done = true;
+                }
+            }
+            // the CPU loop as written: one neighbour at a time, in adjacency order, against the moving radius
+            for (uint64_t r = done ? 0ull : cand; r; r &= r - 1ull) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(r);
+                const float dj = rl_f(nd, j);
+                if (sz == ef && !(dj < radius)) continue;  // `top.size() < top_limit || d < radius`
+                push_lanes(1ull << j, nd, n);
+                if ((okmask >> j) & 1ull) top_insert(dj, rl_u(n, j));
+            }
+        }
+        if (early_slot != kInvalid) {  // where the candidate measured ahead went: the front (it keeps its entry), or nowhere (visited already / beyond the radius)
+            const bool here = L < nf && f_s == early_slot;
+            if (here) f_c = 1u;
+            if (!__ballot(here)) free_entry_of(early_slot);
+        }
+        WALK_STAMP(5);  // pushes, top
+        dbg_max_next = nf + np > dbg_max_next ? nf + np : dbg_max_next;
+        schedule();
+        WALK_STAMP(6);  // scheduling
+    }
+    if (L == 0u) lds_flag_store(&sh.stop, 1u);
+    if (unknown_count && L == 0u) *unknown_count = ucount;
+    if (consulted_out && L == 0u) *consulted_out = consulted;
+    if (debug && L == 0u) {
+        debug[0] = dbg_max_next;
+        debug[1] = (uint32_t)cnt.evals;
+        debug[2] = (uint32_t)cnt.hops;
+        debug[3] = dbg_early | (dbg_windows << 16);
+#ifdef VS_WALK_PROFILE
+        for (int i = 0; i < 6; ++i) debug[4 + i] = (uint32_t)(prof[1 + i] >> 4);
+        debug[0] = (uint32_t)(prof[7] >> 4);                      // (profile builds: the wait for the entry instead of the largest `next`)
+        debug[1] = dbg_waits;                                     // (hops that waited)
+        debug[10] = sh.prof_jobs[0] ? sh.prof_jobs[1] / sh.prof_jobs[0] : 0u;  // (helpers: clocks per job part)
+#endif
+#ifndef VS_WALK_PROFILE
+        debug[10] = dbg_miss;
+#endif
+        debug[11] = dbg_refill;
+    }
+    // leave the bitmap all zero for the next query that gets this workspace
+    if (vlog_lost) {
+        uint4* b4 = reinterpret_cast<uint4*>(ws.bitmap);  // (the workspace is 256-byte aligned)
+        const uint32_t quads = ws.bitmap_words / 4u;
+        for (uint32_t i = L; i < quads; i += 64u) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t wd = quads * 4u + L; wd < ws.bitmap_words; wd += 64u) ws.bitmap[wd] = 0u;
+    } else {
+        for (uint32_t i = L; i < vcount; i += 64u) ws.bitmap[ws.vlog[i] >> 5] = 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PipeOut out;
+    out.status = redo ? 1u : explore ? 3u : over_budget ? 2u : 0u;
+    out.sz = sz;
+    return out;
+}
+
+}  // namespace vs

@@ -95,6 +95,7 @@ def lib():
     L.vs_hnsw_stats.argtypes = [vp, vp, C.c_int]
     L.vs_hnsw_memory_info.argtypes = [vp, vp]
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
+    L.vs_hnsw_pipe_stats.argtypes = [vp, vp]
     L.vs_hnsw_exact_stats.argtypes = [vp, vp]
     L.vs_hnsw_walk_info.argtypes = [vp, vp]
     L.vs_hnsw_exact_stats2.argtypes = [vp, vp]
@@ -284,6 +285,11 @@ class HipUsearchIndex:
         out = np.zeros(2, dtype=np.uint64)
         _check(self.L.vs_hnsw_filter_stats(self.h, _p(out)))
         return {"lazy_rounds": int(out[0]), "lazy_predicate_calls": int(out[1])}
+
+    def pipe_stats(self) -> dict:
+        out = np.zeros(2, dtype=np.uint64)
+        _check(self.L.vs_hnsw_pipe_stats(self.h, _p(out)))
+        return {"pipe_launches": int(out[0])}
 
     def exact_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)

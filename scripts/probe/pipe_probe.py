@@ -20,7 +20,7 @@ t0 = time.time()
 ix.add_batch_device(np.arange(n, dtype=np.uint64), base.data_ptr(), n, dim)
 print(f"built {n} in {time.time() - t0:.1f} s", flush=True)
 del base
-big = n > 2_000_000  # (no second copy of a large index: run again with VS_HNSW_PIPE=0 for the other side)
+big = n > 2_000_000 or os.environ.get('PIPE_PROBE_FAST') == '1'  # (no second copy of a large index: run again with VS_HNSW_PIPE=0 for the other side)
 old = None
 if not big:
     old = vs.HipUsearchIndex(dim, vs.COS, expansion_search=ef, _stress=256)  # never the pipelined walk
@@ -50,7 +50,7 @@ L = C.CDLL(os.path.join("vector_store_amd", "libvs_callers.so"))
 L.vs_callers_run_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double, C.POINTER(Res), C.POINTER(C.c_uint64)]
 for name, index in ((("pipe" if os.environ.get("VS_HNSW_PIPE", "1") != "0" else "team"), ix),) + (() if big else (("team", old),)):
     for threads in threads_list:
-        for mod in (2, 10, 100):
+        for mod in [int(m) for m in os.environ.get('PIPE_PROBE_MODS', '2,10,100').split(',')]:
             r, extra = Res(), (C.c_uint64 * 4)()
             L.vs_callers_run_filtered(index.h, q.ctypes.data, q.shape[0], dim, k, mod, threads, 0.3, C.byref(Res()), (C.c_uint64 * 4)())
             index.stats(reset=True)

@@ -1083,7 +1083,13 @@ struct Engine {
         std::shared_lock<std::shared_mutex> vg(view_mu);
         // plain tags -> wide tags (fused kernel only) -> global bitmap, as the index outgrows what each can tell apart
         const bool global = allow || needs_global_walk(ef);
-        if (global || usearch_order()) {
+        // Lone queries on float indexes (the reference issues one query per FFI call, usearch.rs:212; the dispatcher hands over what
+        // queued since the last launch): the pipelined walk (kernels_pipe.hip) instead of the team form of the fused-list kernel --
+        // the walker decides on registers while the other waves measure candidates ahead of it.
+        static const bool lone_pipe_off = std::getenv("VS_HNSW_PIPE_LONE") && std::getenv("VS_HNSW_PIPE_LONE")[0] == '0';  // A/B measurements
+        const bool lone_pipe = !allow && !global && !usearch_order() && !lone_pipe_off && pipe_usable(ef) && team_mode != 2 && team_mode != 3 &&
+                               std::max(nq, load) <= team_max_nq && !stress_small_table && !force_wide_tags;
+        if (global || usearch_order() || lone_pipe) {
             WalkArgs a;
             a.ix = view();
             a.queries = d_q;
@@ -1157,14 +1163,14 @@ struct Engine {
             const uint64_t domain_slots = std::max<uint64_t>(slots, walk_domain_override);
             if (inst == WALK_LDS_320 && domain_slots > (1ull << walk_instance_domain_bits(inst))) inst = WALK_LDS_512;
             const bool out_of_domain = inst != WALK_LDS_128_TINY && domain_slots > (1ull << walk_instance_domain_bits(inst));
-            last_walk_instance = (global || out_of_domain || lds_walk_bad[inst].load()) ? g_inst : inst;
-            if (global || out_of_domain || lds_walk_bad[inst].load()) {
+            last_walk_instance = (global || lone_pipe || out_of_domain || lds_walk_bad[inst].load()) ? g_inst : inst;
+            if (global || lone_pipe || out_of_domain || lds_walk_bad[inst].load()) {
                 // a lone query (every filtered one is: the predicate is the caller's) takes a team of waves here too -- one
                 // workgroup, one workspace per query
-                const bool team_g = g_inst == WALK_GLOBAL_512 && iters < 12 && nq <= 32 && !no_team_global &&
+                const bool team_g = g_inst == WALK_GLOBAL_512 && iters < 12 && nq <= (lone_pipe ? team_max_nq : (size_t)32) && !no_team_global &&
                                     (team_mode == 1 || (team_mode == 0 && std::max(nq, load) <= team_max_nq));
                 const uint32_t gi = team_g ? (g_inst | kWalkTeamFlag) : g_inst;
-                const uint32_t grid = global_space(a, gi, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256);
+                const uint32_t grid = global_space(a, gi, (uint32_t)std::min<size_t>(nq, 1u << 20), nq <= 256 && !lone_pipe);  // (lone_pipe: `next` lives in LDS; the heap only serves the rare second chance)
                 if (team_g && grid != nq) fail(VS_ERR_DEVICE, "team walk: workspace");
                 a.work_counter = retry + 1;
                 // Lone queries on float indexes: the PIPELINED walk first (kernels_pipe.hip: the walker decides on registers, the other

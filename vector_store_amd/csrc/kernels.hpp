@@ -96,6 +96,7 @@ struct WalkArgs {
     unsigned long long* stats;
     uint32_t* debug;         // nullptr, or nq x 12 words: largest `next`, nodes evaluated, hops, admitted, 8 phase clocks (VS_HNSW_WALK_DEBUG)
     uint32_t pipe_explore = 0;   // pipelined walk, lazy filter: an exploring round (lists missing verdicts, several candidates at a time; its answer is not one)
+    uint32_t pipe_lds_visited = 0;  // pipelined walk: the visited set is the LDS tag table (unfiltered; slots < 2^25 at beams <= 256, 2^26 beyond) instead of the bitmap in a.space
     uint32_t pipe_pool_cap = 0;  // pipelined walk (kernels_pipe.hip): entries of `next` behind the front, in LDS (8 B each, <= 16,384)
 };
 inline size_t walk_space_stride(uint32_t bitmap_words, uint32_t vlog_cap, uint32_t heap_cap) {

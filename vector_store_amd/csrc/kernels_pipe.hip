@@ -15,9 +15,9 @@
 
 namespace vs {
 
-template <int AR, int I, int EFCAP>
+template <int AR, int I, int EFCAP, bool VISG>
 __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs a) {
-    using Sh = PipeShared<EFCAP, kPipeTeam, false>;
+    using Sh = PipeShared<EFCAP, kPipeTeam, false, VISG>;
     __shared__ Sh sh;
     extern __shared__ uint2 pipe_pool[];
     const IndexView& ix = a.ix;
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
         }
     }
     if (threadIdx.x < (uint32_t)kPipeCache) sh.c_ready[threadIdx.x] = 0u;
-    WalkSpace ws;
-    {
+    WalkSpace ws = {nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    if constexpr (VISG) {
         char* base = a.space + (size_t)blockIdx.x * a.space_stride;
         ws.bitmap = reinterpret_cast<uint32_t*>(base);
         ws.vlog = ws.bitmap + a.bitmap_words;
@@ -65,6 +65,12 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
     query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
     if (w != 0) {
         team_helper_loop<AR, I>(ix, q, sh, lane, w);  // the descent through the upper levels: the team form, with barriers
+#ifdef VS_PIPE_SOLO
+        if ((w & 3u) == 0u) {  // (experiment: the walker has its SIMD to itself)
+            if (lane == 0) sh.job_state[w] = 1u;
+            return;
+        }
+#endif
         pipe_helper_loop<AR, I>(ix, q, sh, ws, tomb, allow, known, lane, w);
         return;
     }
@@ -111,9 +117,9 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
     }
 }
 
-template <int AR, int I, int EFCAP>
+template <int AR, int I, int EFCAP, bool VISG>
 static hipError_t pipe_launch(const WalkArgs& a, hipStream_t s) {
-    auto kernel = hnsw_pipe_walk_kernel<AR, I, EFCAP>;
+    auto kernel = hnsw_pipe_walk_kernel<AR, I, EFCAP, VISG>;
     const size_t dyn = (size_t)a.pipe_pool_cap * sizeof(uint2);
     static std::once_flag once[16];  // the attribute is per device
     int dev = 0;
@@ -129,15 +135,18 @@ static hipError_t pipe_launch(const WalkArgs& a, hipStream_t s) {
 
 template <int AR, int I>
 static hipError_t pipe_ef(const WalkArgs& a, hipStream_t s) {
-    if (a.ef <= 256) return pipe_launch<AR, I, 256>(a, s);
-    if (a.ef <= 512) return pipe_launch<AR, I, 512>(a, s);
+    // (the LDS tag table as the visited set -- PipeShared<..., VISG = false> -- was measured for unfiltered lone walks and dropped: its
+    // test-and-set costs the walker as much as the returning global atomic, which runs under the early post: 0.80 against 0.74 ms)
+    if (a.pipe_lds_visited) return hipErrorInvalidValue;
+    if (a.ef <= 256) return pipe_launch<AR, I, 256, true>(a, s);
+    if (a.ef <= 512) return pipe_launch<AR, I, 512, true>(a, s);
     return hipErrorInvalidValue;
 }
 
 template <>
 hipError_t launch_pipe_walk_ar<VS_AR>(const WalkArgs& a, uint32_t iters, hipStream_t s) {
     if (!a.nq) return hipSuccess;
-    if (a.ix.M0 > 64u || !a.space || a.pipe_pool_cap < 256u) return hipErrorInvalidValue;
+    if (a.ix.M0 > 64u || (!a.space && !a.pipe_lds_visited) || a.pipe_pool_cap < 256u) return hipErrorInvalidValue;
     switch (iters) {
         case 1: return pipe_ef<VS_AR, 1>(a, s);
         case 2: return pipe_ef<VS_AR, 2>(a, s);

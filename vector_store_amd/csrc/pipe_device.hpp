@@ -45,11 +45,22 @@ namespace vs {
 #endif
 constexpr int kPipeTeam = VS_PIPE_TEAM;  // waves per query: the walker + the helpers (165 registers: three waves per SIMD, twelve per CU)
 constexpr int kPipeCache = 16;  // evaluated-candidate entries (LDS)
-constexpr int kPipeAhead = 8;   // front positions the helpers keep evaluated
+#ifndef VS_PIPE_AHEAD
+#define VS_PIPE_AHEAD 8
+#endif
+constexpr int kPipeAhead = VS_PIPE_AHEAD;  // front positions the helpers keep evaluated
 #ifndef VS_PIPE_PARTS
 #define VS_PIPE_PARTS 3
 #endif
-constexpr uint32_t kPipeParts = VS_PIPE_PARTS;  // helpers that share one candidate measured ahead (the one needed at once: four)
+constexpr uint32_t kPipeParts = VS_PIPE_PARTS;  // helpers that share one candidate measured ahead
+#ifndef VS_PIPE_URGENT
+#define VS_PIPE_URGENT 4
+#endif
+constexpr uint32_t kPipeUrgentParts = VS_PIPE_URGENT;  // ... and the one the walker needs at once
+#ifndef VS_PIPE_URGENT_FLAGS
+#define VS_PIPE_URGENT_FLAGS 2
+#endif
+constexpr uint32_t kPipeUrgentFlags = VS_PIPE_URGENT_FLAGS;  // 2: an urgent job measures every neighbour without waiting for the visited word
 constexpr uint32_t kPipeRedo = 0xFFFFFFFEu;  // out_found: not answered here (a tie, or a structure outgrown): the usearch-order walk must answer
 
 // flags of a cache entry's neighbour
@@ -57,13 +68,23 @@ constexpr uint32_t kPfEvaluated = 1u;  // c_dist holds its distance
 constexpr uint32_t kPfLive = 2u;       // not a removed member (asks for a verdict when a filter is on)
 constexpr uint32_t kPfKnown = 4u;      // the filter's verdict is known ...
 constexpr uint32_t kPfAllowed = 8u;    // ... and admits it (no filter: every live member)
+constexpr uint32_t kPfSeen = 16u;      // measured although the visited set held it already (urgent jobs measure every neighbour)
 
-template <int EFCAP, int TM, bool NT>
-struct PipeShared : TeamBox<TM> {
+// VISG: the visited set is a bitmap over all slots in global memory (filtered walks visit tens of thousands of nodes; any index size);
+// else the exact LDS tag table of hnsw_device.hpp (unfiltered lone walks: a beam of 200 visits ~5,000 nodes) -- the walker's
+// test-and-set is then an LDS round trip instead of a returning global atomic, and nothing has to be wiped afterwards.
+template <int EFCAP, int TM, bool NT, bool VISG>
+struct PipeShared : TeamBox<TM>, VisitedLds<!VISG, (EFCAP <= 256 ? 1024 : 2048), 8> {
     static constexpr bool kNT = NT;
     static constexpr int kEfCap = EFCAP;
     static constexpr int kTeam = TM;
     static constexpr bool kSel = false;
+    static constexpr bool kVisGlobal = VISG;
+    static constexpr int kNB = EFCAP <= 256 ? 1024 : 2048;
+    static constexpr int kChoices = 2;
+    static constexpr int kBucket = 8;
+    static constexpr bool kWideTags = false;
+    static constexpr uint32_t kOvfCap = (uint32_t)kWalkOvf;
     // the team phase (greedy descent through the upper levels: eval_shared / team_helper_loop)
     uint32_t u_slot[64];
     float u_dist[64];
@@ -144,7 +165,9 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
 #endif
         const uint32_t slot = uni(sh.job_slot[w]), e = uni(sh.job_entry[w]), pp = uni(sh.job_part[w]);
         const uint32_t part = pp & 255u, parts = (pp >> 8) & 255u;
-        const bool claim = (pp >> 16) != 0u;  // exploring rounds: the helper itself marks what it measures (no order to keep)
+        const bool claim = ((pp >> 16) & 1u) != 0u;  // exploring rounds: the helper itself marks what it measures (no order to keep)
+        const bool nofilter = ((pp >> 17) & 1u) != 0u;  // the candidate is needed at once: every neighbour is measured, visited or not
+                                                      // (the visited word's round trip would come before the first row load)
         const uint32_t cap = ix.M0;  // <= 64 (host-checked)
         const uint32_t* row = ix.adj0 + (size_t)slot * ix.M0;
         const bool mine = (uint32_t)lane % parts == part;  // the positions of the adjacency row this helper answers for
@@ -153,7 +176,7 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
         // Everything that depends on the neighbour ids alone leaves together: the visited word (read past L1: the walker's atomics live
         // in L2), the verdict words, the key (removed members), and one dword of the neighbour's own adjacency row -- should it become
         // the closest candidate at once, that row is two dependent loads away from ITS neighbours' distances; the touch pulls it into
-        // L2 meanwhile (the value is not used).
+        // L2 meanwhile (the value is not used).  Only the visited word is waited for before the rows are asked for.
         uint32_t vw = 0, kw = ~0u, aw = ~0u, touch = 0;
         uint64_t key = 0;
         if (valid) {
@@ -167,22 +190,11 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
             }
         }
         // The bitmap only grows during a query, so "seen" stays true; "not seen" is re-tested by the walker when the candidate is popped.
-        const bool seen = valid && ((vw >> (n & 31u)) & 1u) != 0u;
-        const bool need = valid && !seen;
-        uint32_t fl = 0;
-        if (need) {
-            const bool live = !tomb || key != kFreeKey;
-            const bool kn = ((kw >> (n & 31u)) & 1u) != 0u, al = ((aw >> (n & 31u)) & 1u) != 0u;
-            fl = kPfEvaluated | (live ? kPfLive : 0u);
-            if (live) fl |= (kn ? kPfKnown : 0u) | ((kn && al) ? kPfAllowed : 0u);
-        }
+        // (an urgent job does not wait for the visited word: it is looked at after the rows, as a hint for the walker)
+        const bool need = valid && (nofilter || ((vw >> (n & 31u)) & 1u) == 0u);
         const uint64_t nm = __ballot(need);
         const uint32_t m = (uint32_t)__popcll(nm);
         if (need) sh.h_slot[w][mbcnt(nm)] = n;
-        if (mine) {
-            sh.c_slot[e][lane] = n;
-            sh.c_flag[e][lane] = fl;
-        }
         // (the list is this wave's own: LDS keeps one wave's accesses in order, only the compiler must be held -- a workgroup-scope fence
         // would also wait for the touch loads, a full HBM round trip, before the first row load is issued)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -190,6 +202,18 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
         eval_batch<AR, I, 1, Sh::kNT>(ix, q, sh.h_slot[w], sh.h_dist[w], m, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        uint32_t fl = 0;
+        if (need) {
+            const bool live = !tomb || key != kFreeKey;
+            const bool kn = ((kw >> (n & 31u)) & 1u) != 0u, al = ((aw >> (n & 31u)) & 1u) != 0u;
+            fl = kPfEvaluated | (live ? kPfLive : 0u);
+            if (live) fl |= (kn ? kPfKnown : 0u) | ((kn && al) ? kPfAllowed : 0u);
+            if (((vw >> (n & 31u)) & 1u) != 0u) fl |= kPfSeen;
+        }
+        if (mine) {
+            sh.c_slot[e][lane] = n;
+            sh.c_flag[e][lane] = fl;
+        }
         if (need) sh.c_dist[e][lane] = sh.h_dist[w][mbcnt(nm)];
 #ifdef VS_WALK_PROFILE
         if (lane == 0) {
@@ -233,7 +257,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t prof_t = __builtin_amdgcn_s_memtime();
 #endif
-    uint32_t dbg_max_next = 0, dbg_pushed = 0, dbg_miss = 0, dbg_refill = 0, dbg_early = 0, dbg_windows = 0, dbg_waits = 0;
+    [[maybe_unused]] uint32_t dbg_max_next = 0, dbg_pushed = 0, dbg_miss = 0, dbg_refill = 0, dbg_early = 0, dbg_windows = 0, dbg_waits = 0;
     bool redo = false, over_budget = false;
     const uint32_t guess_t = unknown_budget >> 24;
     unknown_budget &= 0xFFFFFFu;
@@ -354,11 +378,17 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         }
         dbg_pushed += (uint32_t)__popcll(mask);
     };
+    auto push_one = [&](float d, uint32_t s) {  // next.insert of one wave-uniform entry
+        const float reach = nf == 64u ? rl_f(f_d, 63) : pool_lb;
+        if (d < reach) front_insert(d, s, 0u);
+        else pool_append_one(d, s);
+        dbg_pushed += 1u;
+    };
     // the front ran empty: the closest entries of the pool move up (radix select on the order-preserving distance bits)
-    auto refill = [&]() {
+    auto refill = [&](uint32_t limit = 64u) {  // limit: at most this many move up (exploring rounds: small batches keep the order near best-first)
         ++dbg_refill;
         uint32_t thr = 0xFFFFFFFFu;  // entries with key < thr move (all: every entry)
-        const bool all = np <= 64u;
+        const bool all = np <= limit;
         if (!all) {
             uint32_t prefix = 0, below = 0;
             for (int shift = 24; shift >= 0; shift -= 8) {
@@ -379,7 +409,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                     if (L >= (uint32_t)o) incl += up;
                 }
                 const uint32_t excl = incl - (h0 + h1 + h2 + h3);
-                const uint32_t room = 64u - below;  // entries that may still move
+                const uint32_t room = limit - below;  // entries that may still move
                 const uint64_t over = __ballot(incl > room);  // first bucket whose inclusive count exceeds the room
                 if (!over) {  // (cannot happen: the first pass sees np > 64 entries, a later one a bucket that exceeded the room)
                     redo = true;
@@ -391,9 +421,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 if (c + a0 <= room) { c += a0; ++b; if (c + a1 <= room) { c += a1; ++b; if (c + a2 <= room) { c += a2; ++b; } } }
                 below += c;
                 thr = shift == 24 ? (b << 24) : ((prefix << (shift + 8)) | (b << shift));
-                if (below >= 16u) break;
+                if (below >= limit / 4u) break;
                 if (shift == 0) {
-                    // thr is a full 32-bit key now.  Nothing below it: more than 64 - below entries share the smallest distance;
+                    // thr is a full 32-bit key now.  Nothing below it: more than limit - below entries share the smallest distance;
                     // that run moves up whole when it fits (the front takes equal entries as they come), else the other walk serves
                     if (below == 0u) {
                         const uint32_t a3 = rl_u(h3, ol);
@@ -402,6 +432,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                             redo = true;
                             return;
                         }
+                        if (run > limit) limit = run;
                         thr = thr + 1u;  // (0xFFFFFFFF is the key of no distance: +inf maps below it)
                     }
                     break;
@@ -415,7 +446,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             const bool valid = base + L < np;
             const uint2 e = valid ? pool[base + L] : make_uint2(0u, 0u);
             const bool take = valid && (all || dist_key(e.x) < thr);
-            const bool keep = valid && !take;
+            // (once `top` is full the radius only shrinks: a candidate beyond it can never be expanded -- `candidate.distance > radius` ends
+            // the walk when it is the closest -- so it is dropped here instead of being carried along)
+            const bool keep = valid && !take && !(sz == ef && __uint_as_float(e.x) > radius);
             const uint64_t tm = __ballot(take), km = __ballot(keep);
             if (taken + (uint32_t)__popcll(tm) > 64u) {  // (cannot happen: the select counted them)
                 redo = true;
@@ -461,7 +494,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         freem = __ballot(L < K && tag == kInvalid && cr == 0u);
     };
     // "measure candidate s", split over up to `want` helpers; the entry, or kInvalid when no helper or no entry is to be had
-    auto post_job = [&](uint32_t s, uint32_t want, uint32_t claim = 0u) -> uint32_t {
+    auto post_job = [&](uint32_t s, uint32_t want, uint32_t flags = 0u) -> uint32_t {  // flags: 1 claim (exploring), 2 measure every neighbour (urgent)
         const uint32_t avail = (uint32_t)__popcll(idle);
         if (!avail || !freem) return kInvalid;
         const uint32_t parts = want < avail ? want : avail;
@@ -475,7 +508,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (pick) {
             sh.job_slot[L] = s;
             sh.job_entry[L] = e;
-            sh.job_part[L] = rank | (parts << 8) | (claim << 16);
+            sh.job_part[L] = rank | (parts << 8) | (flags << 16);
             lds_flag_store(&sh.job_state[L], 1u);
         }
         idle &= ~__ballot(pick);
@@ -489,7 +522,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             const uint32_t i = (uint32_t)__builtin_ctzll(missing);
             const uint32_t avail = (uint32_t)__popcll(idle);
             if (i == 0u ? avail == 0u : avail < kPipeParts + 2u) break;
-            const uint32_t e = post_job(rl_u(f_s, i), i == 0u ? 4u : kPipeParts);
+            const uint32_t e = post_job(rl_u(f_s, i), i == 0u ? kPipeUrgentParts : kPipeParts, i == 0u ? kPipeUrgentFlags : 0u);
             if (e == kInvalid) break;
             if (L == i) f_c = 1u;
         }
@@ -498,6 +531,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     // ---- start: visits.set(start); next.insert(start); top.insert(start) if it may be a result ----
     auto mark = [&](uint32_t n, bool valid) -> bool {  // true: n is new to the visited set
         bool fresh = false;
+        if constexpr (!Sh::kVisGlobal) {
+            return valid && !visited_test_and_set(sh, n);
+        }
         if (valid) {
             const uint32_t bit = 1u << (n & 31u);
             fresh = (atomicOr(&ws.bitmap[n >> 5], bit) & bit) == 0u;
@@ -529,6 +565,11 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         const bool guess = unk && guess_t != 0u && ((n * 2654435761u) >> 24) < guess_t;
         return __ballot((live && (fl & kPfAllowed) != 0u) || guess);
     };
+    if constexpr (!Sh::kVisGlobal) {
+        visited_clear(sh, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     (void)mark(start, L == 0u);
     cnt.evals += 1;  // (the walk measures its start, as walk_usearch does; here the descent's value is reused -- same code, same bits)
     {
@@ -609,9 +650,12 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             dbg_max_next = nf + np > dbg_max_next ? nf + np : dbg_max_next;
             if (redo) break;
             if (!flying) {
-                if (over_budget || (nf == 0u && np == 0u)) break;
-                if (nf && sz == ef && rl_f(f_d, 0) > radius) break;
-                if (nf == 0u) continue;  // (refill next)
+                if (over_budget) break;
+                if (nf && sz == ef && rl_f(f_d, 0) > radius) nf = 0u;  // (the batch's rest lies beyond the radius: dropped)
+                if (nf == 0u) {
+                    if (np == 0u || (sz == ef && pool_lb > radius)) break;
+                    continue;  // (refill next)
+                }
                 __builtin_amdgcn_s_sleep(1);  // (no helper or entry free although nothing is in flight: cannot last)
             }
         }
@@ -658,7 +702,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                     break;
                 }
                 refresh_jobs();
-                const uint32_t e = post_job(cs, 4u);
+                const uint32_t e = post_job(cs, kPipeUrgentParts, kPipeUrgentFlags);
                 if (e != kInvalid) {
                     hitm = 1ull << e;
                     break;
@@ -685,10 +729,13 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (L == e) tag = kInvalid;  // the entry is free again
         refresh_jobs();
         // visited test-and-set: the atomics are on their way while the next candidate is looked for
-        bool fresh = false;
-        if (n != kInvalid) {
-            const uint32_t bit = 1u << (n & 31u);
-            fresh = (atomicOr(&ws.bitmap[n >> 5], bit) & bit) == 0u;
+        // (only the atomic itself sits in the divergent block: its value is looked at after the early post, so the round trip runs under it)
+        const uint32_t vbit = 1u << (n & 31u);
+        uint32_t vold = vbit;
+        if constexpr (Sh::kVisGlobal) {
+            if (n != kInvalid) vold = atomicOr(&ws.bitmap[n >> 5], vbit);
+        } else {
+            if (n != kInvalid && !visited_test_and_set(sh, n)) vold = 0u;
         }
         // The closest neighbour measured for this candidate, when it is closer than everything that waits in `next`, is the very next
         // candidate (if it is new, which the atomics will tell): its own measurement starts NOW, not after this hop's bookkeeping.
@@ -696,19 +743,25 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (!evd) nd = INF;
         uint32_t early_slot = kInvalid, early_e = kInvalid;
         {
-            const float best = wave_min(nd);
+            const float best = wave_min((fl & kPfSeen) ? INF : nd);
             if (best < next_d && (sz < ef || best < radius)) {
-                const uint64_t bm = __ballot(evd && nd == best);
+                const uint64_t bm = __ballot(evd && !(fl & kPfSeen) && nd == best);
                 early_slot = rl_u(n, (uint32_t)__builtin_ctzll(bm));
-                early_e = post_job(early_slot, 4u);
+                early_e = post_job(early_slot, kPipeUrgentParts, kPipeUrgentFlags);
                 if (early_e == kInvalid) early_slot = kInvalid;
                 else ++dbg_early;
             }
         }
         WALK_STAMP(2);  // entry read, atomics issued, early post
+        const bool fresh = (vold & vbit) == 0u;
         const uint64_t fmask = __ballot(fresh);
         WALK_STAMP(3);  // the atomics' round trip
-        {
+        if constexpr (!Sh::kVisGlobal) {
+            if (uni(sh.overflowed)) {  // the table is full: the other walk serves the query
+                redo = true;
+                break;
+            }
+        } else {
             const uint32_t c = (uint32_t)__popcll(fmask);
             if (vcount + c <= ws.vlog_cap) {
                 if (fresh) ws.vlog[vcount + mbcnt(fmask)] = n;
@@ -755,8 +808,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 const uint32_t j = (uint32_t)__builtin_ctzll(r);
                 const float dj = rl_f(nd, j);
                 if (sz == ef && !(dj < radius)) continue;  // `top.size() < top_limit || d < radius`
-                push_lanes(1ull << j, nd, n);
-                if ((okmask >> j) & 1ull) top_insert(dj, rl_u(n, j));
+                const uint32_t sj = rl_u(n, j);
+                push_one(dj, sj);
+                if ((okmask >> j) & 1ull) top_insert(dj, sj);
             }
         }
         if (early_slot != kInvalid) {  // where the candidate measured ahead went: the front (it keeps its entry), or nowhere (visited already / beyond the radius)
@@ -789,7 +843,8 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         debug[11] = dbg_refill;
     }
     // leave the bitmap all zero for the next query that gets this workspace
-    if (vlog_lost) {
+    if constexpr (!Sh::kVisGlobal) {
+    } else if (vlog_lost) {
         uint4* b4 = reinterpret_cast<uint4*>(ws.bitmap);  // (the workspace is 256-byte aligned)
         const uint32_t quads = ws.bitmap_words / 4u;
         for (uint32_t i = L; i < quads; i += 64u) b4[i] = make_uint4(0u, 0u, 0u, 0u);

@@ -29,7 +29,8 @@ collective; scaling "weak"; value = all ranks' queries per second.  With N>1 two
 key-range shards, per-shard top-k all-gathered by ONE ncclAllGather per batch issued by libvs_ranks over RCCL, merged by
 topk_merge_kernel) are also run and reported under "sharded": `weak` (--vectors per GPU, index = N x that) and
 `fixed_total` (--vectors / N per GPU: the same index as N = 1, cut into N key ranges).  `--mode shard` makes the weak
-sharded form the timed path.  `rccl_ranks` is ncclCommCount of the library's communicator.
+sharded form the timed path.  `rccl_ranks` is ncclCommCount of the library's communicator (a run over N > 1 GPUs whose value is not N exits 4),
+`comm_ranks` the ranks that joined its exchange, `sharded_{weak,fixed_total}_queries_per_s` the sharded legs beside the replica `value`.
 
 Synthetic data: `--dist lowrank` (default) = 24-d Gaussian latent mapped by a fixed random 24 x dim matrix plus 0.05
 isotropic noise: embedding-like local intrinsic dimension, on which HNSW reaches the recall target at the reference's
@@ -54,6 +55,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+HBM_ACHIEVABLE_GBS = 6300.0  # ... and what a streaming copy measures on it (same guide)
 BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline figure is not used)
 ADJ_BYTES = 132             # level-0 adjacency record, 4 + 32*4
 
@@ -176,11 +178,15 @@ def hbm_roofline(ix, st, nq, dim, kernel_ms, kernel_name):
     b_q = e_q * ix.bytes_per_vector() + h_q * ADJ_BYTES + dim * 4
     achieved = b_q * nq / (kernel_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            # against what a streaming copy reaches on this chip (MI355X_MICROARCH.md: 6.29 TB/s; once-read random 2,304-byte rows
+            # 5.7-5.8).  A value near or above 1 does NOT mean the DRAM interface is saturated: part of the bytes counted are served by
+            # the 256 MB Infinity Cache (hub rows, upper levels, adjacency), which no counter of rocprofv3 separates from HBM reads.
+            "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "achievable": HBM_ACHIEVABLE_GBS,
             "kernel": kernel_name, "kernel_ms": kernel_ms, "bytes_per_query": b_q, "evals_per_query": e_q, "hops_per_query": h_q,
             "visited_overflow": st["visited_overflow"]}
 
 
-def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_host=None):
+def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_host=None, filtered_seconds=0.0):
     """The CPU restatement of the usearch algorithm (oracle/, kind "port") on the host cores of this box, on the
     SAME graph: searches one query per call from T threads (reference usearch.rs:212), then -- the build half of the
     metric -- inserts `extra_host` further vectors into that full-size index from T threads (usearch.rs:194-196).
@@ -217,6 +223,26 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
 
     exact = ix.scalar in (oracle.I8, oracle.B1)
     out["id_parity"] = count_parity(gpu_keys, gpu_dist, keys, dists, found, oracle_distance, exact=exact)
+    # filtered_search on the same graph, same predicate and call pattern as boundary.filtered (one query per call from T threads,
+    # reference filtered_ann usearch.rs:1107-1154): the CPU number beside the GPU's, and id parity of the engine's answers
+    if filtered_seconds > 0:
+        out["filtered"] = {}
+        for name, modulus in (("selectivity_10pct", 10), ("selectivity_1pct", 100)):
+            fk, fd, ff, answered, calls, wall = o.filtered_search_timed(queries_host, k, modulus, threads=threads, seconds=filtered_seconds)
+            rec = {"queries_per_s": answered / wall, "queries": answered, "seconds": wall, "threads": threads,
+                   "predicate": f"key % {modulus} == 0", "predicate_calls_per_query": calls / max(answered, 1)}
+            # the engine's answers for the first queries of the batch, through the C ABI with the same predicate, against the oracle's
+            m = min(answered, 24)
+            if m and not np.any(ff[:m] == 0):
+                gk = np.zeros((m, k), dtype=np.uint64)
+                gd = np.full((m, k), np.inf, dtype=np.float32)
+                for i in range(m):
+                    a_k, a_d = ix.filtered_search(queries_host[i], k, lambda key, mod=modulus: key % mod == 0)
+                    gk[i, : len(a_k)] = a_k
+                    gd[i, : len(a_d)] = a_d
+                par = count_parity(gk, gd, fk[:m], fd[:m], ff[:m], oracle_distance, exact=exact)
+                rec["id_parity"] = {kk: par[kk] for kk in ("rows", "identical_rows", "near_tie_positions", "violations")}
+            out["filtered"][name] = rec
     if extra:
         t0 = time.perf_counter()
         o.add_batch(np.arange(slots, slots + extra, dtype=np.uint64) + np.uint64(1 << 40), extra_host, threads=threads)
@@ -284,9 +310,10 @@ def side_records(vs, dev, dim, metric, k):
 
 def config_c5(vs, dev, n, dim, k, dist_kind, rank):
     """BASELINE.json configs[4]: batched search, q = 256, 10M x 768 inner product over unit vectors -- the one dense
-    contraction of the path (exact block search: split-bf16 MFMA nomination, f32 re-score, certificate).  Bound: bf16 MFMA.
-    achieved = ISSUED bf16 flops (3 split products per f32 product, 2*q*n*dim each) / batch time, the batch timed whole
-    (tile kernel + selection + re-score) with HIP events on the launch stream; the HBM floor is reported beside it."""
+    contraction of the path (exact block search: one bf16 MFMA product per score over the bf16 plane, f32 re-score,
+    certificate).  Bound: with the plane, q = 256 gives 2 * 256 flop per 2-byte element = 256 flop/B, below the ridge of the
+    bf16 peak over the HBM peak (312): the batch is HBM-bound -- achieved = the plane's bytes / batch time, the batch timed
+    whole (tile kernel + merges + re-score) with HIP events on the launch stream; the matrix-side figure is reported beside it."""
     nq, batches = 256, 8
     t0 = time.perf_counter()
     base = make_data(n, dim, dist_kind, 1234, dev, rank)
@@ -336,7 +363,16 @@ def config_c5(vs, dev, n, dim, k, dist_kind, rank):
            "ms_per_batch": exact_ms, "queries_per_s": nq / exact_ms * 1e3, "batches_timed": batches,
            "plane_batches": x1.get("plane_batches", 0) - x0.get("plane_batches", 0), "plane_fallback_batches": x1.get("plane_fallbacks", 0) - x0.get("plane_fallbacks", 0),
            "block_search_batches": x1["block_batches"] - x0["block_batches"], "f32_fallback_batches": x1["block_fallbacks"] - x0["block_fallbacks"],
-           "roofline": {"bound": "mfma", "achieved": issued, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / BF16_PEAK_TFLOPS, "traffic": None,
+           # Which roofline bounds the batch: the arithmetic intensity of the pass that served is products * 2 * q flops per row_bytes / dim
+           # bytes of a row element; against the ridge of the bf16 peak over the HBM peak (2,500 TFLOP/s / 8 TB/s = 312 flop/B) the
+           # one-product pass at q = 256 (256 flop/B) is HBM-bound, the three-product pass over f32 rows (384 flop/B) matrix-bound.
+           "roofline": ({"bound": "hbm", "achieved": float(n) * row_bytes / (exact_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": float(n) * row_bytes / (exact_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "floor_ms_per_batch": float(n) * row_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                         "intensity_flop_per_byte": products * 2.0 * nq * dim / row_bytes, "ridge_flop_per_byte": BF16_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS,
+                         "mfma": {"achieved_tflops": issued, "peak_tflops": BF16_PEAK_TFLOPS, "frac": issued / BF16_PEAK_TFLOPS}}
+                        if products * 2.0 * nq * dim / row_bytes < BF16_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else
+                        {"bound": "mfma", "achieved": issued, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / BF16_PEAK_TFLOPS, "traffic": None}) | {
                         "kernel": ("p1_tile_kernel (one bf16 product per score over the bf16 plane)" if plane else "block_dist_bf16x3_kernel (three split-bf16 products)") +
                                   " + selection, f32 re-score, certificate: the whole batch is timed",
                         "mfma_products_per_score": products, "f32_equivalent_tflops": flops / (exact_ms * 1e-3) / 1e12,
@@ -393,6 +429,18 @@ def make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, total_rows, 
     gs = None
     if dist is None:
         return ranks.RankedSearcher(ix, queries, k, None, total_rows)
+    if native:
+        # RankedSearcher's constructor is itself collective (ncclCommInitRank, or the host exchange's attach wait): a rank that cannot even
+        # load the library must say so BEFORE the others enter it, or they wait in the bootstrap for a rank that never comes
+        can_load = 1
+        try:
+            ranks.lib()
+        except Exception as e:  # noqa: BLE001
+            can_load = 0
+            print(f"[bench] libvs_ranks does not load on rank {dist.get_rank()}: {e!r}", file=sys.stderr)
+        agree = torch.tensor([can_load], device=queries.device if backend == "nccl" else "cpu")
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        native = int(agree.item()) == 1
     if native:
         try:
             gs = ranks.RankedSearcher(ix, queries, k, dist, total_rows)
@@ -589,14 +637,15 @@ def main():
                   "hops_per_add": st["add_hops"] / max(st["added"], 1)}
     se = Searcher(ix, batches, k)
     finish = lambda: None  # pipelined steppers: completes the batch still in flight
-    rccl_ranks, gs, exchange_kind = None, None, None
+    rccl_ranks, comm_ranks, gs, exchange_kind = None, None, None, None
+    rccl_failed = False
     if shard_mode:
         # native path (libvs_ranks: one ncclAllGather per batch on its own stream, overlapped with the next walk);
         # the torch.distributed twin only where RCCL is not the backend (gloo smoke tests)
         gs = make_sharded_searcher(ix, queries, k, dist, vs, ranks, sharded, n * world, a.backend)
         if hasattr(gs, "ranks"):
             ci = gs.ranks.comm_info()
-            rccl_ranks, exchange_kind = ci["rccl_ranks"], ci["exchange"]
+            rccl_ranks, comm_ranks, exchange_kind = ci["rccl_ranks"], ci["comm_ranks"], ci["exchange"]
         truth = gs.exact()
         turn = [0]
 
@@ -704,6 +753,10 @@ def main():
     if world > 1 and not shard_mode and not a.no_sharded_leg:
         out["sharded"] = {}
         for leg, per in (("weak", n), ("fixed_total", max(n // world, 1))):
+            # every rank builds its shard first and says whether it could: a rank that failed must not leave the others waiting in the
+            # collectives below (communicator creation, barriers, the all-gathers)
+            six = sq = None
+            setup_err = None
             try:
                 sbase = make_data(per, dim, a.dist, 777 + rank, dev, a.rank)
                 skeys = np.arange(per, dtype=np.uint64) + np.uint64(rank * per)
@@ -711,10 +764,18 @@ def main():
                 del sbase
                 six.set_expansion_search(ef)
                 sq = [make_data(nq, dim, a.dist, 4321 + 1000 * b, dev, a.rank) for b in range(nb)]
+            except Exception as e:  # noqa: BLE001
+                setup_err = e
+            if reduce_scalar(0.0 if setup_err is not None else 1.0, dist.ReduceOp.MIN) < 0.5:
+                out["sharded"][leg] = {"error": repr(setup_err) if setup_err is not None else "another rank could not build its shard"}
+                del six, sq
+                torch.cuda.empty_cache()
+                continue
+            try:
                 gs = make_sharded_searcher(six, sq[0], k, dist, vs, ranks, sharded, per * world, a.backend)
                 if hasattr(gs, "ranks"):
                     ci = gs.ranks.comm_info()
-                    rccl_ranks, exchange_kind = ci["rccl_ranks"], ci["exchange"]
+                    rccl_ranks, comm_ranks, exchange_kind = ci["rccl_ranks"], ci["comm_ranks"], ci["exchange"]
                 sfinish = getattr(gs, "flush", lambda: None)
                 struth = gs.exact()
                 gs.step()
@@ -742,8 +803,20 @@ def main():
                 out["sharded"][leg] = {"error": repr(e)}
         out["sharded"]["collective"] = "one ncclAllGather (RCCL, libvs_ranks) of packed per-shard top-k per batch + topk_merge_kernel, overlapped with the next walk"
     if world > 1 or shard_mode:
-        out["rccl_ranks"] = rccl_ranks  # ncclCommCount of libvs_ranks' communicator (1 at N = 1; None: the torch twin served the sharded path)
+        out["rccl_ranks"] = rccl_ranks  # ncclCommCount of libvs_ranks' communicator (0: its host exchange served; None: the torch twin did)
+        out["comm_ranks"] = comm_ranks  # ranks that joined the library's exchange, whichever it is
         out["exchange"] = exchange_kind
+        # the sharded legs beside the replica `value`: the north_star's own path (key ranges + one all-gather per batch)
+        for leg in ("weak", "fixed_total"):
+            rec = out.get("sharded", {}).get(leg)
+            if isinstance(rec, dict) and "queries_per_s" in rec:
+                out[f"sharded_{leg}_queries_per_s"] = rec["queries_per_s"]
+                out[f"sharded_{leg}_recall_at_10"] = rec["recall_at_10"]
+        # An N-GPU line is only worth reporting when RCCL itself carried the exchange between N ranks (--same-device: a testing aid on
+        # one GPU, marked as such, never a scaling number).
+        if world > 1 and not a.same_device and (exchange_kind != "rccl" or rccl_ranks != world):
+            out["error"] = f"the sharded path did not run over RCCL with {world} ranks (exchange {exchange_kind}, rccl_ranks {rccl_ranks})"
+            rccl_failed = True
     if a.same_device and world > 1:
         out["same_device"] = True  # testing aid: every rank on GPU 0 -- exercises the N > 1 code, is NOT a scaling measurement
 
@@ -763,10 +836,19 @@ def main():
             torch.cuda.synchronize()
             gk, gd = result_keys().view(np.uint64).copy(), result_dist().copy()
             extra = make_data(a.cpu_build_vectors, dim, a.dist, 97531, dev, a.rank).cpu().numpy() if a.cpu_build_vectors else None
-            cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds, gk, gd, extra)
+            want_filtered = a.quantization == "f32" and isinstance(out.get("boundary"), dict) and "filtered" in out["boundary"]
+            cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds, gk, gd, extra,
+                                     filtered_seconds=min(4.0, a.cpu_seconds / 2) if want_filtered else 0.0)
             cb["recall_at_10"] = round(recall_at_k(truth, ckeys), 4)
             out["cpu_baseline"] = cb
             violations = cb["id_parity"]["violations"]
+            # the CPU's filtered rate beside each GPU record of the same predicate (same graph, same call pattern, `cores` threads)
+            for name, crec in cb.get("filtered", {}).items():
+                violations += crec.get("id_parity", {}).get("violations", 0)
+                for gname, grec in out["boundary"]["filtered"].items():
+                    if gname.startswith(name) and isinstance(grec, dict) and crec["queries_per_s"] > 0:
+                        grec["cpu_queries_per_s"] = crec["queries_per_s"]
+                        grec["vs_cpu"] = grec["queries_per_s"] / crec["queries_per_s"]
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
 
@@ -810,6 +892,9 @@ def main():
     if violations:
         print(f"[bench] id parity against the CPU restatement: {violations} violation(s)", file=sys.stderr)
         sys.exit(3)
+    if rccl_failed:
+        print(f"[bench] {out['error']}", file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -159,6 +159,11 @@ VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
  * [0] launches of it so far, [1] reserved. */
 VS_API int vs_hnsw_pipe_stats(vs_hnsw* index, uint64_t out[2]);
 
+/* HIP streams the engine has created in this process so far, over all devices and indexes: a fixed set per device (16 unless
+ * VS_HNSW_STREAMS says otherwise) shared by every index handle -- thousands of per-partition handles (usearch.rs:704-705,
+ * 766-778) own none. */
+VS_API uint64_t vs_hnsw_streams_created(void);
+
 /* Exact search on float storage (cos / ip, k <= 64, >= 65,536 slots) nominates with split-bf16 MFMA tiles, re-scores the nominees
  * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's
  * certificate failed. */

@@ -50,9 +50,13 @@ VS_API int vs_ranks_create_ex(vs_hnsw* shard, int rank, int world, const uint8_t
 VS_API int vs_ranks_exchange_kind(const vs_ranks* r); /* vs_ranks_exchange of the handle */
 VS_API void vs_ranks_free(vs_ranks* r);
 
-/* What the handle is part of: this rank, the world it was created with, and the size of the RCCL communicator itself
- * (ncclCommCount; 1 when world == 1 and no communicator exists).  bench.py prints comm_ranks as `rccl_ranks`. */
+/* What the handle is part of: this rank, the world it was created with, and comm_ranks = the ranks that have joined its exchange
+ * (RCCL: ncclCommCount; host exchange: the processes attached to the segment). */
 VS_API int vs_ranks_world(const vs_ranks* r, int* rank, int* world, int* comm_ranks);
+/* ncclCommCount of the handle's RCCL communicator; 0 when the handle has none (host exchange).  A world of one has a
+ * communicator of one rank and issues the all-gather like any other.  bench.py prints this as `rccl_ranks` and refuses to report
+ * an N-GPU run whose value is not N. */
+VS_API int vs_ranks_rccl_ranks(const vs_ranks* r, int* n);
 /* Queries (cumulative) to which THIS rank's shard contributed no candidates: its walk outgrew its workspace (d_found =
  * 0xFFFFFFFF from vs_hnsw_search_batch_device) or its local search failed to launch.  Such rows enter the all-gather as
  * (free key, +inf), so the merge of every rank stays well defined; a non-zero count means recall was lost.  Synchronises. */

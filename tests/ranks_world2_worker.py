@@ -34,7 +34,7 @@ def main():
     q = torch.from_numpy(qh).cuda()
     rs = ranks.RankedSearcher(ix, q, k, dist, total)
     info = rs.ranks.comm_info()
-    assert info == {"rank": rank, "world": world, "rccl_ranks": world, "exchange": "hostshm"}, info
+    assert info == {"rank": rank, "world": world, "comm_ranks": world, "rccl_ranks": 0, "exchange": "hostshm"}, info
     assert rs.ranks.key_range() == (lo, hi)
     # exact: merged answer == brute force over all rows
     truth = rs.exact().view(np.uint64)

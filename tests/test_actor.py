@@ -143,3 +143,48 @@ def test_local_index_growth_and_partitions():
         assert time.time() - t0 < 120
     assert len(a.ann(1, data[1], 1)[0]) == 0 and a.count() == 2600 - 500
     a.stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_thousand_partition_handles():
+    """A local (per-partition-key) index is one usearch handle per partition, made on the partition's first add and grown by
+    1,000 slots at a time (reference usearch.rs:443, 704-705, 766-778) -- a table with thousands of partitions means
+    thousands of live handles.  2,000 partitions x 200 rows through the dispatch actor: making and reserving the handles is
+    quick, an idle handle costs little HBM, no handle owns a HIP stream, and every partition answers its own rows."""
+    import torch
+    import vector_store_amd as vs
+    from vector_store_amd.actor import IndexActor
+    parts, per, dim = 2000, 200, 64
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((per, dim)).astype(np.float32)
+    vs.HipUsearchIndex(dim, vs.COS).reserve(1000)  # (the device's one-time costs are not the handles')
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    streams0 = vs.streams_created()
+    a = IndexActor(dim, vs.COS, workers=8, local=True)
+    t0 = time.time()
+    for p in range(parts):                      # the first add of a partition makes its handle and reserves 1,000 slots
+        a.add_vector(p, (p << 20), data[0] + 1e-3 * p)
+    wait_for_count(a, parts)
+    t_handles = time.time() - t0
+    assert a.partitions() == parts and a.counters()["reserves"] == parts
+    assert all(a.partition_capacity(p) == 1000 for p in (0, 1, parts // 2, parts - 1))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    per_handle = (free0 - free1) / parts
+    assert t_handles <= 5.0, t_handles                       # create + reserve of 2,000 handles
+    assert per_handle <= 512 * 1024, per_handle              # HBM of a handle with 1,000 reserved slots of 64-d f32
+    for p in range(parts):
+        for i in range(1, per):
+            a.add_vector(p, (p << 20) + i, data[i] + 1e-3 * p)
+    wait_for_count(a, parts * per, timeout=400.0)
+    assert a.counters()["errors"] == 0
+    hits = 0
+    for p in range(parts):                      # one search per partition: its own row, not a neighbour partition's
+        keys, d = a.ann(p, data[p % per] + 1e-3 * p, 3)
+        hits += int(len(keys) == 3 and int(keys[0]) == (p << 20) + p % per)
+    assert hits == parts, hits
+    # the engine's streams are a fixed set per device (leased contexts and dispatcher slots share them): none per handle
+    assert vs.streams_created() - streams0 <= 20, (streams0, vs.streams_created())
+    a.stop()

@@ -360,6 +360,48 @@ def test_gpu_build_recall_and_invariants(metric, dim, n):
     assert ties <= 4, ties
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("generator", ["gaussian_pcg64", "clustered_pcg64"])
+def test_gpu_built_graph_on_the_surveys_generators_at_768d(generator):
+    """SURVEY.md section 8(d) names the synthetic inputs: numpy PCG64 standard_normal (seeds 1234 base / 4321 queries) -- the
+    hardest case for any graph index -- and its clustered variant (256 centres of seed 99, sigma 0.2).  At 768-d, 100,000 rows:
+    the batched GPU build (sub-batches against a frozen graph) must be as good a graph as the CPU restatement's insertion of the
+    same rows, measured as recall@10 against exact search at beams of 128 and 512 -- whatever that recall is (on i.i.d.
+    Gaussian data it is low for every HNSW: that is the data, and the point of the comparison)."""
+    v = vs()
+    n, nq, dim, k = 100_000, 300, 768, 10
+    if generator == "gaussian_pcg64":
+        base = np.random.Generator(np.random.PCG64(1234)).standard_normal((n, dim), dtype=np.float32)
+        q = np.random.Generator(np.random.PCG64(4321)).standard_normal((nq, dim), dtype=np.float32)
+    else:
+        centres = np.random.Generator(np.random.PCG64(99)).standard_normal((256, dim), dtype=np.float32)
+        g1, g2 = np.random.Generator(np.random.PCG64(1234)), np.random.Generator(np.random.PCG64(4321))
+        base = centres[g1.integers(0, 256, n)] + 0.2 * g1.standard_normal((n, dim), dtype=np.float32)
+        q = centres[g2.integers(0, 256, nq)] + 0.2 * g2.standard_normal((nq, dim), dtype=np.float32)
+    keys = np.arange(n, dtype=np.uint64)
+    ix = v.HipUsearchIndex(dim, v.COS)
+    ix.reserve(n)
+    ix.add_batch(keys, base)
+    tk, _, _ = ix.exact_search_batch(q, k)
+    o = OracleIndex(dim, oracle.COS)
+    o.reserve(n)
+    o.add_batch(keys, base, threads=8)
+    got = {}
+    for ef in (128, 512):
+        ix.set_expansion_search(ef)
+        o.set_expansion_search(ef)
+        gk, _, _ = ix.search_batch(q, k)
+        ck, _, _ = o.search_batch(q, k, threads=8)
+        rec_gpu = float(np.mean([len(set(tk[i].tolist()) & set(gk[i].tolist())) / k for i in range(nq)]))
+        rec_cpu = float(np.mean([len(set(tk[i].tolist()) & set(ck[i].tolist())) / k for i in range(nq)]))
+        got[ef] = (rec_gpu, rec_cpu)
+        assert rec_gpu >= rec_cpu - 0.03, (generator, ef, rec_gpu, rec_cpu)
+    print(f"[{generator} 100k x 768] recall@10 GPU-built / CPU-built: ef 128 {got[128][0]:.3f} / {got[128][1]:.3f}, ef 512 {got[512][0]:.3f} / {got[512][1]:.3f}")
+    assert got[512][0] >= got[128][0]
+    if generator == "clustered_pcg64":
+        assert got[512][0] >= 0.9, got
+
+
 @pytest.mark.parametrize("metric,dim,span", [("l2sq", 8, 500), ("ip", 16, 200)])
 def test_sequential_adds_build_the_oracle_graph(metric, dim, span):
     """One add at a time (a barrier after each: sub-batch of 1) is the sequential usearch algorithm.  On exactly

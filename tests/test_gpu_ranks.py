@@ -1,6 +1,7 @@
 """libvs_ranks (include/vs_ranks.h): key-range shards, one process per GPU, ONE ncclAllGather per batch + merge.
-world = 1 runs on any box (communicator-free path, same pack / merge / stream plumbing); world = 2 spawns two ranks over
-RCCL when the box has two GPUs (BASELINE.json configs[3] shrunk to what a test may take)."""
+world = 1 runs on any box and is a world like any other (round 4): a one-rank RCCL communicator, the in-place all-gather issued on
+the library's stream, the same pack / merge / pipeline; world = 2 spawns two ranks over RCCL when the box has two GPUs
+(BASELINE.json configs[3] shrunk to what a test may take), and over the host exchange on one GPU."""
 import os
 import subprocess
 import sys
@@ -28,6 +29,8 @@ def test_world_of_one_equals_the_plain_search():
     want_k, want_d, want_f = ix.search_batch(q.cpu().numpy(), k)
     rs = ranks.RankedSearcher(ix, q, k, None, n)
     assert rs.ranks.key_range() == (0, n) and rs.ranks.owner(n - 1) == 0
+    # RCCL itself is on the path: ncclCommInitRank made a communicator of one, and every step below issues ncclAllGather on it
+    assert rs.ranks.comm_info() == {"rank": 0, "world": 1, "comm_ranks": 1, "rccl_ranks": 1, "exchange": "rccl"}
     rs.step_sync()
     torch.cuda.synchronize()
     assert np.array_equal(rs.keys.cpu().numpy().view(np.uint64), want_k) and np.array_equal(rs.dists.cpu().numpy(), want_d)
@@ -116,9 +119,10 @@ def test_bench_gpus_2_on_one_device_runs_both_sharded_legs():
     print(out.stderr[-6000:])
     assert out.returncode == 0
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert rec["n_gpus"] == 2 and rec["same_device"] is True and rec["rccl_ranks"] == 2 and rec["exchange"] == "hostshm"
+    assert rec["n_gpus"] == 2 and rec["same_device"] is True and rec["comm_ranks"] == 2 and rec["rccl_ranks"] == 0 and rec["exchange"] == "hostshm"
     assert rec["sharded"]["weak"]["index_vectors_total"] == 200000 and rec["sharded"]["fixed_total"]["index_vectors_total"] == 100000
     for leg in ("weak", "fixed_total"):
+        assert rec[f"sharded_{leg}_queries_per_s"] == rec["sharded"][leg]["queries_per_s"] and rec[f"sharded_{leg}_recall_at_10"] >= 0.9
         assert rec["sharded"][leg]["path"] == "RankedSearcher" and rec["sharded"][leg]["recall_at_10"] >= 0.9
         assert rec["sharded"][leg]["unanswered_queries"] == 0 and rec["sharded"][leg]["queries_per_s"] > 0
 

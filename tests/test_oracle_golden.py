@@ -182,3 +182,21 @@ def test_export_import_roundtrip_same_results():
         ka, da = a.search(q[i], 10)
         kb, db = b.search(q[i], 10)
         assert ka.tolist() == kb.tolist() and da.tolist() == db.tolist()
+
+
+def test_filtered_timed_driver_equals_one_query_at_a_time():
+    """oracle.filtered_search_timed (bench.py's CPU baseline beside boundary.filtered): threads x one query per call with the
+    predicate key % m == 0 answers what filtered_search answers, and counts the predicate's calls."""
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((3000, 16)).astype(np.float32)
+    q = rng.standard_normal((40, 16)).astype(np.float32)
+    o = OracleIndex(16, oracle.L2SQ)
+    o.reserve(3000)
+    o.add_batch(np.arange(3000, dtype=np.uint64), base, threads=1)
+    keys, d, found, answered, calls, wall = o.filtered_search_timed(q, 5, 7, threads=3, seconds=30.0)
+    assert answered == 40 and wall > 0 and calls >= 40 * 5
+    for i in range(40):
+        ek, ed = o.filtered_search(q[i], 5, lambda key: key % 7 == 0)
+        assert found[i] == len(ek) == 5
+        assert keys[i].tolist() == ek.tolist() and d[i].tolist() == ed.tolist()
+        assert all(int(x) % 7 == 0 for x in keys[i])

@@ -7,5 +7,5 @@ back to a CPU path: if the library or a GPU is missing, it raises.
 """
 from .index import (  # noqa: F401
     B1, BF16, COS, F16, F32, HAMMING, I8, IP, L2SQ, METRICS, SCALARS, HipUsearchIndex, VsError, distance_valid, f32_to_b1x8, lib, lib_path,
-    similarity_score, topk_merge_device, version,
+    similarity_score, streams_created, topk_merge_device, version,
 )

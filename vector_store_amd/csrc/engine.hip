@@ -287,6 +287,7 @@ struct WorkCtx {
 // context AND per slot, 17 filtered callers after some unfiltered traffic made 26 streams and ran at 329 QPS where a fresh
 // process runs at 430.  Contexts beyond the set share a stream with an earlier one (their launches then run in stream order,
 // each on its own buffers).  VS_HNSW_STREAMS: 4..20 (default 16: room for the caller's own streams).
+static std::atomic<uint64_t> g_streams_created{0};  // HIP streams the engine has made in this process (every device): a fixed set per device, never one per index
 struct DeviceStreams {
     static constexpr int kMax = 20;
     std::mutex mu;
@@ -298,7 +299,10 @@ struct DeviceStreams {
     }
     hipStream_t at(int i) {  // mu held
         i = ((i % count) + count) % count;
-        if (!st[i]) HIP_OK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+        if (!st[i]) {
+            HIP_OK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+            g_streams_created.fetch_add(1, std::memory_order_relaxed);
+        }
         return st[i];
     }
     hipStream_t for_new_context() {
@@ -1182,6 +1186,7 @@ struct Engine {
                     p.retry_count = retry;
                     p.retry_list = retry + 64;
                     p.pipe_pool_cap = std::min<uint32_t>(std::max<uint32_t>(pipe_pool, 256u), 16384u);
+                    p.pipe_fused_order = lone_pipe ? 1u : 0u;
                     static const bool walk_debug_p = std::getenv("VS_HNSW_WALK_DEBUG") != nullptr;
                     uint32_t* d_dbg_p = nullptr;
                     if (walk_debug_p) {
@@ -1190,10 +1195,33 @@ struct Engine {
                         p.debug = d_dbg_p;
                     }
                     HIP_OK(launch_pipe_walk(p, iters, st));
-                    WalkArgs r = a;  // second chance: only the queries the pipelined walk listed
-                    r.qlist = p.retry_list;
-                    r.qcount = p.retry_count;
-                    HIP_OK(launch_walk(r, iters, gi, grid, st, nullptr));
+                    if (lone_pipe) {
+                        // second chance for plain queries of a float index: the team form of the fused-list kernel, i.e. exactly what a
+                        // batch of them gets -- a lone query and a batched one never differ, however many distances tie
+                        SearchArgs sa;
+                        sa.ix = a.ix;
+                        sa.queries = d_q;
+                        sa.q_stride = dim;
+                        sa.nq = (uint32_t)nq;
+                        sa.k = (uint32_t)k;
+                        sa.ef = ef;
+                        sa.has_removed = a.has_removed;
+                        sa.stress_small_table = 0u;
+                        sa.wide_tags = beyond_lds_tags(ef) ? 1u : 0u;
+                        sa.team = (uint32_t)kSearchTeam;
+                        sa.out_keys = d_keys_out;
+                        sa.out_dist = d_dist_out;
+                        sa.out_found = d_found;
+                        sa.stats = d_stats;
+                        sa.qlist = p.retry_list;
+                        sa.qcount = p.retry_count;
+                        HIP_OK(launch_search(sa, iters, st));
+                    } else {
+                        WalkArgs r = a;  // second chance: only the queries the pipelined walk listed, on the usearch-order walk
+                        r.qlist = p.retry_list;
+                        r.qcount = p.retry_count;
+                        HIP_OK(launch_walk(r, iters, gi, grid, st, nullptr));
+                    }
                     if (walk_debug_p) {
                         std::vector<uint32_t> h(nq * 12);
                         uint32_t redone = 0;
@@ -1320,8 +1348,6 @@ struct Engine {
                  : (team_mode == 0 && on_device <= 3 * team_max_nq)               ? (uint32_t)kSearchTeamMid  // measured: 4 waves win up to ~800
                  : (team_mode == 3)                                               ? (uint32_t)kSearchTeamMid
                                                                                   : 1u;
-        static const bool no_spec = std::getenv("VS_HNSW_SPEC") && std::getenv("VS_HNSW_SPEC")[0] == '0';
-        if (no_spec && a.team > 1) a.team |= 0x100u;  // team kernels without speculative evaluation (A/B measurements)
         a.out_keys = d_keys_out;
         a.out_dist = d_dist_out;
         a.out_found = d_found;
@@ -1360,10 +1386,15 @@ struct Engine {
                 HIP_OK(hipMemGetInfo(&free_b, &total_b));
                 const size_t want = rows_cap * kp * 2;
                 if (ar_plane.extra_needed(want, device) + (1ull << 30) > free_b) fail(VS_ERR_OUT_OF_MEMORY, "no HBM for the bf16 plane");
-                const size_t keep = std::min(plane_done, rows_cap) * kp * 2;
+                // The plane is tile-major (a 256-row tile is kp / 64 blocks of 256 x 128 B): the bytes of the first r rows are the WHOLE
+                // tiles below r -- a byte count of r rows would cover only the first k steps of a partial last tile, and a copying
+                // resize would leave the rest of that tile uninitialised.  Whole tiles are kept, and the partial tile is converted
+                // again (plane_done rounded down), so nothing depends on what a copy carried over.
+                const size_t whole = std::min(plane_done, rows_cap) / 256 * 256;
+                const size_t keep = whole * kp * 2;
                 ar_plane.resize(want, keep, device);
                 plane_rows_cap = rows_cap;
-                plane_done = std::min(plane_done, rows_cap);
+                plane_done = whole;
             }
             if (!d_rho) {
                 HIP_OK(hipMalloc((void**)&d_rho, 4));
@@ -1569,7 +1600,37 @@ struct Engine {
         }
         const size_t words = (n + 31) / 32;
         const uint32_t cap = 1u << 17;
-        Lease w(device);
+        // Admission: a lazily filtered query is a chain of small launches on its context's stream, and contexts beyond the device's
+        // streams share one -- their walks then take turns on it while each still holds a caller (64 callers on 16 streams measured
+        // 505 queries/s where 17 got 717).  At most one query per stream is let through; the others queue here, in arrival order
+        // as the condition variable wakes them, and lose nothing: the device is as busy as it gets.
+        struct Gate {
+            std::mutex mu;
+            std::condition_variable cv;
+            int free_permits = -1;
+        };
+        static Gate gates[16];
+        Gate& gate = gates[device & 15];
+        {
+            std::unique_lock<std::mutex> gl(gate.mu);
+            if (gate.free_permits < 0) {
+                static const int gate_env = std::getenv("VS_HNSW_FILTER_GATE") ? std::atoi(std::getenv("VS_HNSW_FILTER_GATE")) : 0;  // 0: one per stream
+                gate.free_permits = gate_env > 0 ? gate_env : device_streams(device).count;
+            }
+            gate.cv.wait(gl, [&] { return gate.free_permits > 0; });
+            --gate.free_permits;
+        }
+        struct Permit {
+            Gate& g;
+            ~Permit() {
+                {
+                    std::lock_guard<std::mutex> gl(g.mu);
+                    ++g.free_permits;
+                }
+                g.cv.notify_one();
+            }
+        } permit{gate};
+        Lease w(device);  // (taken behind the gate: the contexts in use -- each with its own stream -- are as many as the permits)
         hipStream_t st = w->stream;
         uint64_t* d_k = (uint64_t*)w->b.ensure(k * 8);
         float* d_d = (float*)w->c.ensure(k * 4);
@@ -1605,6 +1666,7 @@ struct Engine {
             explicit Active(std::atomic<int>& c) : n(c) { n.fetch_add(1, std::memory_order_relaxed); }
             ~Active() { n.fetch_sub(1, std::memory_order_relaxed); }
         } active(filtered_active);
+
         if (!w->ev) HIP_OK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
         auto wait_round = [&] {
             static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -2341,6 +2403,8 @@ int vs_hnsw_filter_stats(vs_hnsw* h, uint64_t out[2]) {
     out[1] = h->e.lazy_predicate_calls.load();
     return VS_OK;
 }
+
+uint64_t vs_hnsw_streams_created(void) { return vs::g_streams_created.load(); }
 
 int vs_hnsw_pipe_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;

@@ -440,21 +440,10 @@ struct SelArrays<false> {};
 // TEAM > 1: a workgroup of TEAM waves serves ONE query (small batches, where most of the chip would idle):
 // wave 0 walks the graph, all waves evaluate each hop's neighbour batch.  team_m is the mailbox.
 constexpr uint32_t kTeamExit = 0xFFFFFFFFu;
-constexpr uint32_t kTeamSpec = 0xFFFFFFFEu;  // team_q: the batch is e_slot[0 .. team_m) -> e_dist (beam_search_spec), not u_slot
 template <int TM>
 struct TeamBox {
     uint32_t team_m;
-    uint32_t team_q;  // kInvalid: distances from the walker's own query to u_slot[]; kTeamSpec: to e_slot[]; else from stored row team_q to sel_s[] (refine)
-#ifdef VS_TEAM_SPEC
-    // Speculative evaluation (beam_search_spec, lone queries; an experiment, see kernels_arith.hip): while the walker merges hop h,
-    // the helper waves already measure the unvisited neighbours of the runner-up; when that node is indeed expanded next its
-    // distances are waiting.
-    uint32_t team_async;   // 1: the walker does not take part in this batch (it goes on with its merge and joins the barrier later)
-    uint32_t e_slot[128];  // a batch: [the hop's own fresh neighbours | the runner-up's unvisited neighbours]
-    float e_dist[128];
-    uint32_t spec_slot[64];  // the runner-up's unvisited neighbours as of the last hop, in adjacency order, and their distances
-    float spec_dist[64];
-#endif
+    uint32_t team_q;  // kInvalid: distances from the walker's own query to u_slot[]; else from stored row team_q to sel_s[] (refine)
 };
 template <>
 struct TeamBox<1> {};
@@ -568,12 +557,6 @@ __device__ __forceinline__ void team_helper_loop(const IndexView& ix, const Quer
             const uint32_t* list = qs == kInvalid ? sh.u_slot : sh.sel_s;
             if (mine) eval_batch<AR, I, Sh::kTeam>(ix, use, list, sh.u_dist, m, lane, w);
         } else {
-#ifdef VS_TEAM_SPEC
-            if (sh.team_q == kTeamSpec) {
-                if (sh.team_async) eval_batch<AR, I, Sh::kTeam - 1, Sh::kNT>(ix, q, sh.e_slot, sh.e_dist, m, lane, w - 1u);  // the walker is busy merging
-                else eval_batch<AR, I, Sh::kTeam, Sh::kNT>(ix, q, sh.e_slot, sh.e_dist, m, lane, w);
-            } else
-#endif
             {
                 eval_batch<AR, I, Sh::kTeam>(ix, q, sh.u_slot, sh.u_dist, m, lane, w);
             }
@@ -1008,262 +991,6 @@ __device__ uint32_t beam_search(const IndexView& ix, Sh& sh, const Query<AR, I>&
     return sz;
 }
 
-#ifdef VS_TEAM_SPEC
-// beam_search for a TEAM serving ONE query (lone callers: the reference issues one query per FFI call), with SPECULATIVE
-// evaluation.  A lone walk is a chain of dependent hops, each an HBM round trip (5 us at 10M x 768); bandwidth is free at this
-// load, so while hop h is merged the helper waves already measure the unvisited neighbours of the RUNNER-UP (whose adjacency
-// row was prefetched one hop earlier, like the runner-up's own row in beam_search).  When the runner-up is indeed expanded
-// next -- no closer candidate arrived -- its neighbours' distances are waiting and the hop costs a list merge instead of a
-// round trip.  Every decision is the walker's and is taken exactly as in beam_search: speculation only measures (the visited
-// set is consulted, never marked), the real test-and-set happens when the node is popped, and since nothing is marked in
-// between, the fresh neighbours then ARE the speculated list, in the same order; distances come from the same eval_batch code.
-// Same ids, same distance bits, same evaluation and hop counts (tests/test_gpu_team.py).
-template <int AR, int I, class Sh>
-__device__ uint32_t beam_search_spec(const IndexView& ix, Sh& sh, const Query<AR, I>& q, uint32_t start, uint32_t ef, Counters& cnt, int lane,
-                                     int& out_cur, bool tomb, bool speculate = true) {
-    static_assert(Sh::kTeam > 1 && !Sh::kSel, "team search kernels only");
-    constexpr int EFCAP = Sh::kEfCap;
-    constexpr int level = 0;
-    visited_clear(sh, lane);
-    wsync<Sh>();
-    const int cur = 0;
-    uint32_t sz = 0, live = 0;
-    if (lane == 0) {
-        visited_test_and_set(sh, start);
-        sh.u_slot[0] = start;
-    }
-    wsync<Sh>();
-    eval_shared<AR, I>(ix, q, sh, 1, lane);
-    cnt.evals += 1;
-    {
-        const bool start_dead = tomb && ix.keys[start] == kFreeKey;
-        if (lane == 0) {
-            sh.lst_d[0][0] = sh.u_dist[0];
-            sh.lst_s[0][0] = start | (start_dead ? kDead : 0u);
-        }
-        sz = 1;
-        live = start_dead ? 0 : 1;
-    }
-    wsync<Sh>();
-    // adjacency rows of the second and third unexpanded candidates, one id per lane (prefetched a hop ahead)
-    uint32_t pfa_slot = kInvalid, pfa_n = kInvalid, pfb_slot = kInvalid, pfb_n = kInvalid;
-    uint32_t spec_src = kInvalid, spec_m = 0;  // whose unvisited neighbours sh.spec_slot / spec_dist hold
-    bool spec_pending = false;                 // an asynchronous batch is out: its closing barrier has not been joined yet
-#ifdef VS_SPEC_DEBUG
-    uint32_t dbg_hits = 0, dbg_have2 = 0, dbg_hops = 0, dbg_wait = 0, dbg_m0 = 0;
-    uint64_t dbg_t_collect = 0, dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = __builtin_amdgcn_s_memtime();
-#define SPEC_STAMP(i) do { const uint64_t now__ = __builtin_amdgcn_s_memtime(); dbg_ph[i] += now__ - dbg_last; dbg_last = now__; } while (0)
-#else
-#define SPEC_STAMP(i) do {} while (0)
-#endif
-    uint32_t pend_off = 0, pend_m = 0;         // where in e_dist its speculated part lies
-    auto collect = [&]() {                     // join the batch that is still out and take its speculated distances
-        if (spec_pending) {
-            __syncthreads();
-            spec_pending = false;
-        }
-        if (pend_m) {
-            if ((uint32_t)lane < pend_m) sh.spec_dist[lane] = sh.e_dist[pend_off + lane];
-            pend_m = 0;
-            wsync<Sh>();
-        }
-    };
-    for (;;) {
-        // the three closest unexpanded entries
-        int pick = -1, pick2 = -1, pick3 = -1;
-#pragma unroll
-        for (int r = 0; r < EFCAP / kWave; ++r) {
-            uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
-            bool un = p < sz && !(sh.lst_s[cur][p] & kExpanded);
-            uint64_t mask = __ballot(un);
-            if (pick < 0 && mask) {
-                pick = r * kWave + (int)__builtin_ctzll(mask);
-                mask &= mask - 1;
-            }
-            if (pick >= 0 && pick2 < 0 && mask) {
-                pick2 = r * kWave + (int)__builtin_ctzll(mask);
-                mask &= mask - 1;
-            }
-            if (pick2 >= 0 && pick3 < 0 && mask) pick3 = r * kWave + (int)__builtin_ctzll(mask);
-        }
-        if (pick < 0) break;
-        SPEC_STAMP(0);  // pick
-        const uint32_t c_entry = sh.lst_s[cur][pick];
-        const uint32_t c_slot = c_entry & kSlotMask;
-        const uint32_t c2_slot = pick2 >= 0 ? (sh.lst_s[cur][pick2] & kSlotMask) : kInvalid;
-        const uint32_t c3_slot = pick3 >= 0 ? (sh.lst_s[cur][pick3] & kSlotMask) : kInvalid;
-        wsync<Sh>();
-        if (lane == 0) sh.lst_s[cur][pick] = c_entry | kExpanded;
-        cnt.hops += 1;
-        uint32_t cap;
-        const uint32_t* row = adjacency(ix, c_slot, level, cap);
-        uint32_t n;
-        if (c_slot == pfa_slot) n = pfa_n;
-        else if (c_slot == pfb_slot) n = pfb_n;
-        else n = (uint32_t)lane < cap ? row[lane] : kInvalid;
-        // rows of the next two candidates: kept when already here, else on their way for the next hop
-        uint32_t n2 = kInvalid, n3 = kInvalid;
-        bool have2 = false;
-        if (c2_slot != kInvalid) {
-            if (c2_slot == pfa_slot) { n2 = pfa_n; have2 = speculate; }
-            else if (c2_slot == pfb_slot) { n2 = pfb_n; have2 = speculate; }
-            else {
-                uint32_t cap2;
-                const uint32_t* row2 = adjacency(ix, c2_slot, level, cap2);
-                n2 = (uint32_t)lane < cap2 ? row2[lane] : kInvalid;
-            }
-        }
-        if (c3_slot != kInvalid) {
-            if (c3_slot == pfa_slot) n3 = pfa_n;
-            else if (c3_slot == pfb_slot) n3 = pfb_n;
-            else {
-                uint32_t cap3;
-                const uint32_t* row3 = adjacency(ix, c3_slot, level, cap3);
-                n3 = (uint32_t)lane < cap3 ? row3[lane] : kInvalid;
-            }
-        }
-        pfa_slot = c2_slot;
-        pfa_n = n2;
-        pfb_slot = c3_slot;
-        pfb_n = n3;
-        SPEC_STAMP(1);  // candidate, adjacency issue
-#ifdef VS_SPEC_DEBUG
-        const uint64_t t0__ = __builtin_amdgcn_s_memtime();
-        dbg_wait += spec_pending ? 1u : 0u;
-#endif
-        collect();  // the speculated distances of the previous hop are in sh.spec_dist now
-#ifdef VS_SPEC_DEBUG
-        dbg_t_collect += __builtin_amdgcn_s_memtime() - t0__;
-#endif
-        const bool fresh = n != kInvalid && !visited_test_and_set(sh, n);
-        const uint64_t fmask = __ballot(fresh);
-        const uint32_t m = (uint32_t)__popcll(fmask);
-        const bool hit = c_slot == spec_src && m == spec_m;  // (m == spec_m always holds then; kept as a guard)
-#ifdef VS_SPEC_DEBUG
-        dbg_hops += 1;
-        dbg_hits += hit ? 1u : 0u;
-        dbg_have2 += have2 ? 1u : 0u;
-        dbg_m0 += m == 0 ? 1u : 0u;
-#endif
-        SPEC_STAMP(2);  // collect + visited test-and-set (waits for the adjacency row)
-        if (fresh) sh.u_slot[mbcnt(fmask)] = n;
-        // next speculation: the runner-up's neighbours that are unvisited NOW (after this hop's marks)
-        uint32_t ms = 0;
-        uint64_t smask = 0;
-        if (have2) {
-            const bool sf = n2 != kInvalid && !visited_contains(sh, n2);
-            smask = __ballot(sf);
-            ms = (uint32_t)__popcll(smask);
-        }
-        wsync<Sh>();
-        if (hit && (uint32_t)lane < m) sh.u_dist[lane] = sh.spec_dist[lane];  // (u_slot[lane] == spec_slot[lane])
-        wsync<Sh>();
-        if (have2 && ((smask >> lane) & 1ull)) sh.spec_slot[mbcnt(smask)] = n2;
-        spec_src = have2 ? c2_slot : kInvalid;
-        spec_m = ms;
-        const uint32_t main_m = hit ? 0u : m;
-        SPEC_STAMP(3);  // speculation list (visited_contains), compaction
-        if (main_m + ms) {
-            if (!hit && fresh) sh.e_slot[mbcnt(fmask)] = n;
-            if (have2 && ((smask >> lane) & 1ull)) sh.e_slot[main_m + mbcnt(smask)] = n2;
-            if (lane == 0) {
-                sh.team_m = main_m + ms;
-                sh.team_q = kTeamSpec;
-                sh.team_async = hit ? 1u : 0u;
-            }
-            __syncthreads();  // releases the helpers (team_helper_loop)
-            pend_off = main_m;
-            pend_m = ms;
-            if (!hit) {
-                eval_batch<AR, I, Sh::kTeam, Sh::kNT>(ix, q, sh.e_slot, sh.e_dist, main_m + ms, lane, 0);
-                __syncthreads();  // every wave's distances are in LDS
-                if ((uint32_t)lane < m) sh.u_dist[lane] = sh.e_dist[lane];
-                wsync<Sh>();
-            } else {
-                spec_pending = true;  // the helpers measure; the walker merges meanwhile and joins their barrier in collect()
-            }
-        }
-        SPEC_STAMP(4);  // post, evaluation (miss), barriers
-        if (m == 0) continue;
-        cnt.evals += m;
-        // ---- admission and merge: exactly beam_search's ----
-        float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
-        uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
-        bool admit = (uint32_t)lane < m;
-        if (tomb) {
-            if (admit && ix.keys[ns] == kFreeKey) ns |= kDead;
-            if (live >= ef) admit = admit && nd < sh.lst_d[cur][sz - 1];
-        } else if (sz + m > ef) {
-            if (sz == ef) admit = admit && nd < sh.lst_d[cur][ef - 1];
-        }
-        if (sh.overflowed) {  // wave-uniform; see visited_test_and_set: re-evaluated nodes are dropped here
-            uint32_t lo = 0, hi = admit ? sz : 0;
-            while (lo < hi) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (key_less_in(sh, sh.lst_d[cur][mid], sh.lst_s[cur][mid], nd, ns)) lo = mid + 1; else hi = mid;
-            }
-            if (admit && lo < sz && (sh.lst_s[cur][lo] & kSlotMask) == (ns & kSlotMask) && sh.lst_d[cur][lo] == nd) admit = false;
-        }
-        uint64_t amask = __ballot(admit);
-        uint32_t ma = (uint32_t)__popcll(amask);
-        if (ma == 0) continue;
-        // The adjacency row of a candidate admitted now is needed two dependent loads before its neighbours' distances when it
-        // becomes the closest unexpanded entry at once (a "miss" of the speculation).  One dword per admitted candidate pulls
-        // its 128-byte row into the cache hierarchy while the list is merged; the value itself is not used.
-        uint32_t touch = 0;
-        if (speculate && admit) touch = __builtin_nontemporal_load(ix.adj0 + (size_t)(ns & kSlotMask) * ix.M0);
-        wsync<Sh>();
-        if (admit) {
-            uint32_t r = mbcnt(amask);
-            sh.u_dist[r] = nd;
-            sh.u_slot[r] = ns;
-        }
-        wsync<Sh>();
-        nd = (uint32_t)lane < ma ? sh.u_dist[lane] : __builtin_inff();
-        ns = (uint32_t)lane < ma ? sh.u_slot[lane] : kInvalid;
-        sz = list_merge(sh, cur, sz, tomb ? (uint32_t)EFCAP : ef, nd, ns, ma, lane);
-        wsync<Sh>();
-        if (tomb) {  // cut after the ef-th live entry
-            uint32_t cum = 0, cut = sz;
-            bool found = false;
-#pragma unroll
-            for (int r = 0; r < EFCAP / kWave; ++r) {
-                uint32_t p = (uint32_t)lane + (uint32_t)r * kWave;
-                bool lv = p < sz && !(sh.lst_s[cur][p] & kDead);
-                uint64_t mask = __ballot(lv);
-                uint32_t c = (uint32_t)__popcll(mask);
-                if (!found && cum + c >= ef) {
-                    uint32_t need = ef - cum;
-                    for (uint32_t i = 1; i < need; ++i) mask &= mask - 1;
-                    cut = (uint32_t)r * kWave + (uint32_t)__builtin_ctzll(mask) + 1u;
-                    found = true;
-                }
-                cum += c;
-            }
-            live = found ? ef : cum;
-            sz = cut;
-        } else {
-            live = sz;
-        }
-        asm volatile("" ::"v"(touch));  // (keeps the load; by now it has long landed)
-        SPEC_STAMP(5);  // admission + merge
-    }
-    if (spec_pending) __syncthreads();  // the last batch's closing barrier
-#ifdef VS_SPEC_DEBUG
-    if (lane == 0 && blockIdx.x == 0)
-        printf("[spec] hops %u hits %u have2 %u empty %u collect-waits %u collect clocks/100MHz %llu\n", dbg_hops, dbg_hits, dbg_have2, dbg_m0, dbg_wait,
-               (unsigned long long)dbg_t_collect);
-    if (lane == 0 && blockIdx.x == 0)
-        printf("[spec] clocks: pick %llu cand %llu collect+visit %llu spec-list %llu post+eval %llu merge %llu\n", (unsigned long long)dbg_ph[0],
-               (unsigned long long)dbg_ph[1], (unsigned long long)dbg_ph[2], (unsigned long long)dbg_ph[3], (unsigned long long)dbg_ph[4],
-               (unsigned long long)dbg_ph[5]);
-#endif
-    if (sh.overflowed) cnt.overflow += 1;
-    out_cur = cur;
-    return sz;
-}
-
-#endif  // VS_TEAM_SPEC
 
 // usearch refine_: neighbour-selection heuristic over the sorted candidates in
 // sh.lst_*[cur][0..sz).  Accept c iff for every already accepted a: d(c, a) >= d(c, centre).

@@ -27,6 +27,8 @@ struct SearchArgs {
     float* out_dist;       // nq x k, padded with +inf
     uint32_t* out_found;   // nq
     unsigned long long* stats;
+    const uint32_t* qlist = nullptr;   // second chance behind the pipelined walk (kernels_pipe.hip): serve queries qlist[0 .. *qcount) of the
+    const uint32_t* qcount = nullptr;  // batch (grid = nq: workgroups beyond *qcount leave at once); nullptr: every query
 };
 
 struct InsertArgs {
@@ -96,6 +98,7 @@ struct WalkArgs {
     unsigned long long* stats;
     uint32_t* debug;         // nullptr, or nq x 12 words: largest `next`, nodes evaluated, hops, admitted, 8 phase clocks (VS_HNSW_WALK_DEBUG)
     uint32_t pipe_explore = 0;   // pipelined walk, lazy filter: an exploring round (lists missing verdicts, several candidates at a time; its answer is not one)
+    uint32_t pipe_fused_order = 0;  // pipelined walk: the answer must be the fused-list kernel's also among EQUAL distances (plain queries of float indexes): any tie in `top` hands the query over
     uint32_t pipe_lds_visited = 0;  // pipelined walk: the visited set is the LDS tag table (unfiltered; slots < 2^25 at beams <= 256, 2^26 beyond) instead of the bitmap in a.space
     uint32_t pipe_pool_cap = 0;  // pipelined walk (kernels_pipe.hip): entries of `next` behind the front, in LDS (8 B each, <= 16,384)
 };

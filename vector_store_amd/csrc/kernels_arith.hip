@@ -31,7 +31,11 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
     __shared__ Sh sh;
     const IndexView& ix = a.ix;
     const int lane = lane_id();
-    const uint32_t qi = blockIdx.x;
+    uint32_t qi = blockIdx.x;
+    if (a.qlist) {  // only the queries the pipelined walk handed over
+        if (qi >= *a.qcount) return;
+        qi = a.qlist[qi];
+    }
     uint64_t* ok = a.out_keys + (size_t)qi * a.k;
     float* od = a.out_dist + (size_t)qi * a.k;
     if (ix.max_level < 0) {
@@ -56,16 +60,6 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_search_kernel(SearchArgs a) {
     uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
     int cur = 0;
     uint32_t sz;
-#ifdef VS_TEAM_SPEC
-    // Experiment (make EXTRA=-DVS_TEAM_SPEC; bit 8 of `team` = VS_HNSW_SPEC=0 switches it off at run time): speculative
-    // evaluation of the runner-up's neighbours for lone queries.  Bit-identical results, but measured 3.5 % SLOWER than the
-    // plain team walk (1M x 768, ef 128: 0.617 vs 0.595 ms per lone query, same box, scripts/probe/spec_ab.sh): the next
-    // candidate is the runner-up on 52-67 % of the hops, yet the HBM round trip it saves is about a quarter of a hop -- the rest
-    // is a chain of dependent on-chip steps (pick, visited set, barriers, merge) that speculation lengthens.  DESIGN.md section 5.
-    if constexpr (TEAM > 1) {
-        sz = beam_search_spec<AR, I>(ix, sh, q, start, a.ef, cnt, lane, cur, a.has_removed != 0, (a.team & 0x100u) == 0u);
-    } else
-#endif
     {
         sz = beam_search<AR, I>(ix, sh, q, start, 0, a.ef, kInvalid, cnt, lane, cur, a.has_removed != 0);
     }

@@ -1,4 +1,6 @@
 // kernels_misc.hip -- row staging, norms, exact (brute-force) top-k and the multi-GPU top-k merge.
+#include <atomic>
+
 #include "kernels.hpp"
 #include "filter_rounds.hpp"
 
@@ -1452,16 +1454,17 @@ hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_
                                 uint32_t* d_uncertified, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
     if (!block1_supported(a.ix, a.k) || a.slots < (1u << 16)) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    // the attribute belongs to the (kernel, device) pair: libvs_shards searches several devices from concurrent threads of one process
+    static std::atomic<bool> attr_set[64];
+    if (!attr_set[dev & 63].load(std::memory_order_acquire)) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
-        attr_set = true;
+        attr_set[dev & 63].store(true, std::memory_order_release);  // (two threads setting it at once set the same value)
     }
-    int cus = 256, dev = 0;
-    (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t kpad = (a.ix.dim + 31u) & ~31u, kp = block1_plane_k(a.ix), C = kP1C;
     const uint32_t rows_pad = (a.nq + 255u) / 256u * 256u;

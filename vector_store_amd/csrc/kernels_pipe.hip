@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
                                        a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
                                        a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget,
                                        a.consulted ? a.consulted + qi : nullptr, cnt, lane, top, a.debug ? a.debug + (size_t)qi * 12 : nullptr,
-                                       a.pipe_explore != 0u);
+                                       a.pipe_explore != 0u, a.pipe_fused_order != 0u);
     if (r.status == 1u) {  // the usearch-order walk answers it (and lists the verdicts IT misses: this walk's list is dropped)
         if (lane == 0) {
             if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;

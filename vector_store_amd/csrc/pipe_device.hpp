@@ -247,7 +247,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                                              float start_d, uint32_t ef, bool tomb, const uint32_t* allow, const uint32_t* known,
                                              uint32_t* unknown_list, uint32_t* unknown_count, uint32_t unknown_cap, uint32_t unknown_budget,
                                              uint32_t* consulted_out, Counters& cnt, int lane, PipeTop<Sh::kEfCap / 64>& top, uint32_t* debug,
-                                             bool explore) {
+                                             bool explore, bool fused_order) {
     constexpr int R = Sh::kEfCap / 64;
     constexpr uint32_t TM = (uint32_t)Sh::kTeam;
     constexpr uint32_t K = (uint32_t)kPipeCache;
@@ -257,7 +257,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t prof_t = __builtin_amdgcn_s_memtime();
 #endif
-    [[maybe_unused]] uint32_t dbg_max_next = 0, dbg_pushed = 0, dbg_miss = 0, dbg_refill = 0, dbg_early = 0, dbg_windows = 0, dbg_waits = 0;
+    [[maybe_unused]] uint32_t dbg_max_next = 0, dbg_pushed = 0, dbg_miss = 0, dbg_refill = 0, dbg_early = 0, dbg_windows = 0, dbg_waits = 0, dbg_spills = 0;
     bool redo = false, over_budget = false;
     const uint32_t guess_t = unknown_budget >> 24;
     unknown_budget &= 0xFFFFFFu;
@@ -267,6 +267,14 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     float f_d = INF;
     uint32_t f_s = kInvalid, f_c = 0, nf = 0, np = 0;  // f_c: 1 = a cache entry (complete or being measured) belongs to this candidate
     float pool_lb = INF;  // the smallest distance in the pool
+    // (`next` beyond the pool: slots in global memory, see spill() below)
+    const uint32_t slot_cap = pool_cap / 2u;
+    const uint32_t n_slots = (slot_cap && ws.heap) ? (ws.heap_cap / slot_cap < 64u ? ws.heap_cap / slot_cap : 64u) : 0u;
+    uint32_t g_cnt = 0;    // lane j: entries of slot j
+    float g_min = INF;     // lane j: their smallest distance
+    float spill_lb = INF;  // the smallest distance in any slot
+    constexpr uint32_t kPoolSlack = 192u;  // room a hop in progress may still need (64 pushes and as many entries displaced from the front)
+    bool spill_now = false;
     uint32_t sz = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -305,7 +313,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             rank += (uint32_t)__popcll(__ballot(in && top.d[j] < d));
             eq = eq || (in && top.d[j] == d);
         }
-        if (tie_active && (sz + 1u >= ef || __ballot(eq) != 0ull)) redo = true;
+        // (fused_order: the caller's other kernels list equal distances by slot, this buffer newest first -- any two equal distances in
+        // `top` and the query is theirs)
+        if (__ballot(eq) != 0ull ? (tie_active || fused_order) : (tie_active && sz + 1u >= ef)) redo = true;
         const float cd = __uint_as_float(wave_shr1(__float_as_uint(top.d[R - 1]), 0u));
         const uint32_t cs = wave_shr1(top.s[R - 1], 0u);
 #pragma unroll
@@ -323,18 +333,24 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         const uint64_t mk = __ballot(mine);
         if (!mk) return;
         const uint32_t c = (uint32_t)__popcll(mk);
-        if (np + c > pool_cap) {
-            redo = true;
-            return;
+        if (np + c + kPoolSlack > pool_cap) {
+            spill_now = true;  // (the hop in progress ends first; then the pool's farther half moves to global memory: spill())
+            if (np + c > pool_cap) {
+                redo = true;
+                return;
+            }
         }
         if (mine) pool[np + mbcnt(mk)] = make_uint2(__float_as_uint(d), s);
         np += c;
         pool_lb = fminf(pool_lb, wave_min(mine ? d : INF));
     };
     auto pool_append_one = [&](float d, uint32_t s) {  // one wave-uniform entry
-        if (np + 1u > pool_cap) {
-            redo = true;
-            return;
+        if (np + 1u + kPoolSlack > pool_cap) {
+            spill_now = true;
+            if (np + 1u > pool_cap) {
+                redo = true;
+                return;
+            }
         }
         if (L == 0u) pool[np] = make_uint2(__float_as_uint(d), s);
         np += 1u;
@@ -368,7 +384,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     };
     // next.insert for the lanes in `mask` (their own nd / ns): below the front's reach -> the front, one at a time; the rest -> the pool
     auto push_lanes = [&](uint64_t mask, float nd, uint32_t ns) {
-        const float reach = nf == 64u ? rl_f(f_d, 63) : pool_lb;  // closer than this: belongs to the front
+        const float reach = nf == 64u ? rl_f(f_d, 63) : fminf(pool_lb, spill_lb);  // closer than this: belongs to the front
         const bool mine = ((mask >> L) & 1ull) != 0ull;
         const uint64_t fm = __ballot(mine && nd < reach);
         pool_append(mine && !(nd < reach), nd, ns);
@@ -379,67 +395,187 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         dbg_pushed += (uint32_t)__popcll(mask);
     };
     auto push_one = [&](float d, uint32_t s) {  // next.insert of one wave-uniform entry
-        const float reach = nf == 64u ? rl_f(f_d, 63) : pool_lb;
+        const float reach = nf == 64u ? rl_f(f_d, 63) : fminf(pool_lb, spill_lb);
         if (d < reach) front_insert(d, s, 0u);
         else pool_append_one(d, s);
         dbg_pushed += 1u;
     };
-    // the front ran empty: the closest entries of the pool move up (radix select on the order-preserving distance bits)
-    auto refill = [&](uint32_t limit = 64u) {  // limit: at most this many move up (exploring rounds: small batches keep the order near best-first)
-        ++dbg_refill;
-        uint32_t thr = 0xFFFFFFFFu;  // entries with key < thr move (all: every entry)
-        const bool all = np <= limit;
-        if (!all) {
-            uint32_t prefix = 0, below = 0;
-            for (int shift = 24; shift >= 0; shift -= 8) {
+    // Radix select on the order-preserving distance bits of pool[0 .. np): a threshold with between limit / 4 and limit keys below it
+    // (all: the whole pool is at most `limit` entries).  ok = false: more than `limit` entries share the smallest distance (count says how many).
+    struct Sel {
+        uint32_t thr, count;
+        bool all, ok;
+    };
+    auto select_thr = [&](uint32_t limit) -> Sel {
+        Sel r{0xFFFFFFFFu, np, true, true};
+        if (np <= limit) return r;
+        r.all = false;
+        uint32_t prefix = 0, below = 0;
+        for (int shift = 24; shift >= 0; shift -= 8) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sh.hist[L * 4u + (uint32_t)i] = 0u;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t i = L; i < np; i += 64u) {
-                    const uint32_t k = dist_key(pool[i].x);
-                    if (shift == 24 || (k >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
+            for (int i = 0; i < 4; ++i) sh.hist[L * 4u + (uint32_t)i] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = L; i < np; i += 64u) {
+                const uint32_t k = dist_key(pool[i].x);
+                if (shift == 24 || (k >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t h0 = sh.hist[L * 4u], h1 = sh.hist[L * 4u + 1u], h2 = sh.hist[L * 4u + 2u], h3 = sh.hist[L * 4u + 3u];
+            uint32_t incl = h0 + h1 + h2 + h3;  // inclusive scan over lanes
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if (L >= (uint32_t)o) incl += up;
+            }
+            const uint32_t excl = incl - (h0 + h1 + h2 + h3);
+            const uint32_t room = limit - below;  // entries that may still move
+            const uint64_t over = __ballot(incl > room);  // first bucket whose inclusive count exceeds the room
+            if (!over) {  // (cannot happen: the first pass sees np > limit entries, a later one a bucket that exceeded the room)
+                r.ok = false;
+                r.count = 0;
+                return r;
+            }
+            const uint32_t ol = (uint32_t)__builtin_ctzll(over);
+            const uint32_t e0 = rl_u(excl, ol), a0 = rl_u(h0, ol), a1 = rl_u(h1, ol), a2 = rl_u(h2, ol);
+            uint32_t c = e0, b = ol * 4u;
+            if (c + a0 <= room) { c += a0; ++b; if (c + a1 <= room) { c += a1; ++b; if (c + a2 <= room) { c += a2; ++b; } } }
+            below += c;
+            r.thr = shift == 24 ? (b << 24) : ((prefix << (shift + 8)) | (b << shift));
+            if (below >= limit / 4u) break;
+            if (shift == 0) {
+                // thr is a full 32-bit key now.  Nothing below it: more than `limit` entries share the smallest distance; that run is
+                // the selection (the caller decides whether it can take it whole)
+                if (below == 0u) {
+                    const uint32_t a3 = rl_u(h3, ol);
+                    below = (b & 3u) == 0u ? a0 : (b & 3u) == 1u ? a1 : (b & 3u) == 2u ? a2 : a3;
+                    r.thr = r.thr + 1u;  // (0xFFFFFFFF is the key of no distance: +inf maps below it)
+                    r.ok = false;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t h0 = sh.hist[L * 4u], h1 = sh.hist[L * 4u + 1u], h2 = sh.hist[L * 4u + 2u], h3 = sh.hist[L * 4u + 3u];
-                uint32_t incl = h0 + h1 + h2 + h3;  // inclusive scan over lanes
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-                    if (L >= (uint32_t)o) incl += up;
-                }
-                const uint32_t excl = incl - (h0 + h1 + h2 + h3);
-                const uint32_t room = limit - below;  // entries that may still move
-                const uint64_t over = __ballot(incl > room);  // first bucket whose inclusive count exceeds the room
-                if (!over) {  // (cannot happen: the first pass sees np > 64 entries, a later one a bucket that exceeded the room)
+                break;
+            }
+            prefix = shift == 24 ? b : ((prefix << 8) | b);
+        }
+        r.count = below;
+        return r;
+    };
+    // ---- `next` beyond LDS: slots of pool_cap / 2 entries in global memory (ws.heap).  A filter that admits 1 % keeps `top` short of its
+    // limit for thousands of hops, and `next` grows to tens of thousands of entries.  When the pool is full its farther half moves to one or
+    // two free slots (lane j keeps slot j's count and smallest distance); when the front needs entries that may lie beyond the pool, the
+    // slot with the smallest distance comes back whole.  Order is untouched: the front still pops the global minimum.
+    auto spill = [&]() {
+        ++dbg_spills;
+        const Sel sel = select_thr(slot_cap);
+        if (sel.all || (!sel.ok && sel.count == 0u)) {
+            redo = true;
+            return;
+        }
+        const uint64_t freem_s = __ballot(L < n_slots && g_cnt == 0u);
+        if ((uint32_t)__popcll(freem_s) < 2u) {  // global memory for `next` is used up too: the other walk (or exhaustive ranking) serves
+            redo = true;
+            return;
+        }
+        const uint32_t sa = (uint32_t)__builtin_ctzll(freem_s), sb = (uint32_t)__builtin_ctzll(freem_s & (freem_s - 1ull));
+        uint32_t kept = 0, moved = 0;
+        float lb = INF, mina = INF, minb = INF;
+        for (uint32_t base = 0; base < np; base += 64u) {
+            const bool valid = base + L < np;
+            const uint2 e = valid ? pool[base + L] : make_uint2(0u, 0u);
+            const float d = __uint_as_float(e.x);
+            const bool keep = valid && dist_key(e.x) < sel.thr;
+            const bool move = valid && !keep && !(sz == ef && d > radius);  // (beyond the radius of a full `top`: never expanded, dropped)
+            const uint64_t km = __ballot(keep), mm = __ballot(move);
+            if (keep) {
+                pool[kept + mbcnt(km)] = e;
+                lb = fminf(lb, d);
+            }
+            if (move) {
+                const uint32_t pos = moved + mbcnt(mm);
+                const bool in_a = pos < slot_cap;
+                ws.heap[(size_t)(in_a ? sa : sb) * slot_cap + (in_a ? pos : pos - slot_cap)] = e;
+                mina = in_a ? fminf(mina, d) : mina;
+                minb = in_a ? minb : fminf(minb, d);
+            }
+            kept += (uint32_t)__popcll(km);
+            moved += (uint32_t)__popcll(mm);
+        }
+        np = kept;
+        pool_lb = wave_min(lb);
+        mina = wave_min(mina);
+        minb = wave_min(minb);
+        if (L == sa) {
+            g_cnt = moved < slot_cap ? moved : slot_cap;
+            g_min = mina;
+        }
+        if (L == sb && moved > slot_cap) {
+            g_cnt = moved - slot_cap;
+            g_min = minb;
+        }
+        spill_lb = wave_min(g_cnt ? g_min : INF);
+    };
+    auto unspill = [&]() {  // the slot that holds the smallest spilled distance comes back into the pool
+        ++dbg_spills;
+        if (np > slot_cap) {
+            spill();
+            if (redo) return;
+        }
+        const uint64_t hm = __ballot(L < n_slots && g_cnt != 0u && g_min == spill_lb);
+        if (!hm) {
+            spill_lb = INF;
+            return;
+        }
+        const uint32_t sj = (uint32_t)__builtin_ctzll(hm);
+        const uint32_t cnt = rl_u(g_cnt, sj);
+        if (np + cnt > pool_cap) {  // (only when a run of equal distances kept the pool above half after a spill)
+            redo = true;
+            return;
+        }
+        float lb = INF;
+        uint32_t added = 0;
+        for (uint32_t base = 0; base < cnt; base += 64u) {
+            const bool valid = base + L < cnt;
+            uint2 e = make_uint2(0u, 0u);
+            if (valid) e = ws.heap[(size_t)sj * slot_cap + base + L];
+            const bool keep = valid && !(sz == ef && __uint_as_float(e.x) > radius);
+            const uint64_t km = __ballot(keep);
+            if (keep) {
+                pool[np + added + mbcnt(km)] = e;
+                lb = fminf(lb, __uint_as_float(e.x));
+            }
+            added += (uint32_t)__popcll(km);
+        }
+        np += added;
+        pool_lb = fminf(pool_lb, wave_min(lb));
+        if (L == sj) {
+            g_cnt = 0u;
+            g_min = INF;
+        }
+        spill_lb = wave_min(g_cnt ? g_min : INF);
+    };
+    // the front ran empty: the closest entries of the pool move up
+    auto refill = [&](uint32_t limit = 64u) {  // limit: at most this many move up
+        ++dbg_refill;
+        Sel sel;
+        for (uint32_t rounds = 0;; ++rounds) {
+            sel = select_thr(limit);
+            if (!sel.ok) {
+                if (sel.count == 0u || sel.count > 64u) {  // a run of more than 64 equal distances (or the impossible): the other walk serves
                     redo = true;
                     return;
                 }
-                const uint32_t ol = (uint32_t)__builtin_ctzll(over);
-                const uint32_t e0 = rl_u(excl, ol), a0 = rl_u(h0, ol), a1 = rl_u(h1, ol), a2 = rl_u(h2, ol);
-                uint32_t c = e0, b = ol * 4u;
-                if (c + a0 <= room) { c += a0; ++b; if (c + a1 <= room) { c += a1; ++b; if (c + a2 <= room) { c += a2; ++b; } } }
-                below += c;
-                thr = shift == 24 ? (b << 24) : ((prefix << (shift + 8)) | (b << shift));
-                if (below >= limit / 4u) break;
-                if (shift == 0) {
-                    // thr is a full 32-bit key now.  Nothing below it: more than limit - below entries share the smallest distance;
-                    // that run moves up whole when it fits (the front takes equal entries as they come), else the other walk serves
-                    if (below == 0u) {
-                        const uint32_t a3 = rl_u(h3, ol);
-                        const uint32_t run = (b & 3u) == 0u ? a0 : (b & 3u) == 1u ? a1 : (b & 3u) == 2u ? a2 : a3;
-                        if (run > 64u) {
-                            redo = true;
-                            return;
-                        }
-                        if (run > limit) limit = run;
-                        thr = thr + 1u;  // (0xFFFFFFFF is the key of no distance: +inf maps below it)
-                    }
-                    break;
-                }
-                prefix = shift == 24 ? b : ((prefix << 8) | b);
             }
+            // may a spilled entry belong among the ones selected?  (all: the pool's last entries move, whatever lies in the slots comes next)
+            const bool spilled_first = spill_lb != INF && (sel.all || dist_key(__float_as_uint(spill_lb)) < sel.thr);
+            if (!spilled_first) break;
+            if (rounds > 128u) {
+                redo = true;
+                return;
+            }
+            unspill();
+            if (redo) return;
         }
+        const uint32_t thr = sel.thr;
+        const bool all = sel.all;
         uint32_t taken = 0, kept = 0;
         float lb = INF;
         for (uint32_t base = 0; base < np; base += 64u) {
@@ -623,6 +759,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                WALK_STAMP(7);  // exploring: waiting for an entry
                 const uint32_t n = sh.c_slot[e][lane];
                 const uint32_t fl = sh.c_flag[e][lane];
                 float nd = sh.c_dist[e][lane];
@@ -633,18 +770,32 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 if (over_budget) continue;  // (the entries of a batch in flight are still drained)
                 const uint64_t cand = __ballot(evd && (sz < ef || nd < radius));
                 const uint64_t okmask = verdicts(cand, n, fl);
+                WALK_STAMP(4);  // exploring: verdicts
                 push_lanes(cand, nd, n);
+                WALK_STAMP(5);  // exploring: pushes
                 for (uint64_t r = okmask; r; r &= r - 1ull) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(r);
                     const float dj = rl_f(nd, j);
                     if (sz < ef || dj < radius) top_insert(dj, rl_u(n, j));
                 }
+                WALK_STAMP(6);  // exploring: top
+                if (spill_now && !redo) {
+                    spill();
+                    spill_now = false;
+                }
             }
         };
         uint64_t flying = 0;
         for (;;) {
-            if (nf == 0u && np != 0u && !over_budget) refill();
+            WALK_STAMP(1);
+            if (spill_now && !redo) {
+                spill();
+                spill_now = false;
+            }
+            if (nf == 0u && (np != 0u || spill_lb != INF) && !over_budget && !redo) refill();
+            WALK_STAMP(2);  // exploring: refill
             const uint64_t posted = (redo || over_budget) ? 0ull : post_batch();
+            WALK_STAMP(3);  // exploring: posting a batch
             if (flying) merge(flying);
             flying = posted;
             dbg_max_next = nf + np > dbg_max_next ? nf + np : dbg_max_next;
@@ -653,7 +804,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 if (over_budget) break;
                 if (nf && sz == ef && rl_f(f_d, 0) > radius) nf = 0u;  // (the batch's rest lies beyond the radius: dropped)
                 if (nf == 0u) {
-                    if (np == 0u || (sz == ef && pool_lb > radius)) break;
+                    if ((np == 0u && spill_lb == INF) || (sz == ef && fminf(pool_lb, spill_lb) > radius)) break;
                     continue;  // (refill next)
                 }
                 __builtin_amdgcn_s_sleep(1);  // (no helper or entry free although nothing is in flight: cannot last)
@@ -671,10 +822,16 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     if (!explore) schedule();
     WALK_STAMP(0);
     while (!explore && !redo && !over_budget) {
+        if (spill_now) {
+            spill();
+            spill_now = false;
+            if (redo) break;
+        }
         if (nf == 0u) {
-            if (np == 0u) break;
+            if (np == 0u && spill_lb == INF) break;
             refill();
-            if (redo || nf == 0u) break;
+            if (redo) break;
+            if (nf == 0u) continue;  // (what was selected lay beyond the radius and was dropped: look again)
         }
         const float cd = rl_f(f_d, 0);
         const uint32_t cs = rl_u(f_s, 0);
@@ -685,7 +842,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         f_c = wave_shl1(f_c, 0u);
         nf -= 1u;
         cnt.hops += 1;
-        const float next_d = nf ? rl_f(f_d, 0) : pool_lb;  // (pool_lb: +inf when the pool is empty)
+        const float next_d = nf ? rl_f(f_d, 0) : fminf(pool_lb, spill_lb);  // (+inf when nothing waits beyond the front)
         if (tie_active && cd > tie_v) tie_active = false;
         if (!tie_active && next_d == cd) {
             tie_active = true;
@@ -840,7 +997,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
 #ifndef VS_WALK_PROFILE
         debug[10] = dbg_miss;
 #endif
-        debug[11] = dbg_refill;
+        debug[11] = dbg_refill | (dbg_spills << 16);
     }
     // leave the bitmap all zero for the next query that gets this workspace
     if constexpr (!Sh::kVisGlobal) {

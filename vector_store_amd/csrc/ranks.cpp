@@ -240,8 +240,10 @@ struct vs_ranks {
         HIP_OK(hipGetLastError());
         HIP_OK(hipEventRecord(s.walked, st));
         HIP_OK(hipStreamWaitEvent(comm_stream, s.walked, 0));
+        // (a world of one enters the collective too: RCCL's initialisation, the in-place all-gather and its ordering against the walk and
+        // the merge run on every box, not only where several GPUs are)
         if (world > 1 && exchange == VS_RANKS_HOSTSHM) host.all_gather(si, s.gathered, block, comm_stream);
-        else if (world > 1) NCCL_OK(ncclAllGather(mine, s.gathered, block, ncclChar, comm, comm_stream));  // in place: sendbuff = recvbuff + rank * count
+        else if (comm) NCCL_OK(ncclAllGather(mine, s.gathered, block, ncclChar, comm, comm_stream));  // in place: sendbuff = recvbuff + rank * count
         VS_OK_OR_THROW(vs_topk_merge_packed_device(s.gathered, (size_t)world, block, nq, k, d_keys, d_dist, d_found, comm_stream));
         HIP_OK(hipEventRecord(s.merged, comm_stream));
         if (local_rc != VS_OK) throw Fail{local_rc, "local shard search failed (an empty block was gathered so that the other ranks go on): " + local_err};
@@ -285,9 +287,10 @@ int vs_ranks_create_ex(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_
             HIP_OK(hipMemset(r->d_failed, 0, 8));
             if (world > 1 && exchange == VS_RANKS_HOSTSHM) {
                 r->host.open(id, rank, world);
-            } else if (world > 1) {
+            } else if (exchange == VS_RANKS_RCCL) {
                 ncclUniqueId u;
-                std::memcpy(&u, id, sizeof u);
+                if (id) std::memcpy(&u, id, sizeof u);
+                else NCCL_OK(ncclGetUniqueId(&u));  // (world == 1: nobody to share it with)
                 NCCL_OK(ncclCommInitRank(&r->comm, world, u, rank));
             }
         } catch (...) {
@@ -329,6 +332,14 @@ int vs_ranks_world(const vs_ranks* r, int* rank, int* world, int* comm_ranks) {
 }
 
 int vs_ranks_exchange_kind(const vs_ranks* r) { return r ? r->exchange : -1; }
+
+int vs_ranks_rccl_ranks(const vs_ranks* r, int* n) {
+    return guarded([&] {
+        if (!r || !n) throw Fail{VS_ERR_INVALID_ARGUMENT, "null argument"};
+        *n = 0;
+        if (r->comm) NCCL_OK(ncclCommCount(r->comm, n));
+    });
+}
 
 int vs_ranks_unanswered(vs_ranks* r, uint64_t* queries) {
     return guarded([&] {

@@ -96,6 +96,8 @@ def lib():
     L.vs_hnsw_memory_info.argtypes = [vp, vp]
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
     L.vs_hnsw_pipe_stats.argtypes = [vp, vp]
+    L.vs_hnsw_streams_created.argtypes = []
+    L.vs_hnsw_streams_created.restype = C.c_uint64
     L.vs_hnsw_exact_stats.argtypes = [vp, vp]
     L.vs_hnsw_walk_info.argtypes = [vp, vp]
     L.vs_hnsw_exact_stats2.argtypes = [vp, vp]
@@ -110,6 +112,11 @@ def lib():
     L.vs_similarity_score.argtypes = [f32, C.c_int, sz]
     _lib = L
     return L
+
+
+def streams_created() -> int:
+    """HIP streams the engine has created in this process (a fixed set per device, never one per index)."""
+    return int(lib().vs_hnsw_streams_created())
 
 
 def version() -> str:

@@ -30,6 +30,7 @@ def lib():
         L.vs_ranks_create.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.POINTER(vp)]
         L.vs_ranks_create_ex.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, C.POINTER(vp)]
         L.vs_ranks_exchange_kind.argtypes = [vp]
+        L.vs_ranks_rccl_ranks.argtypes = [vp, vp]
         L.vs_ranks_free.argtypes = [vp]
         L.vs_ranks_world.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vs_ranks_unanswered.argtypes = [vp, C.POINTER(u64)]
@@ -77,10 +78,13 @@ class Ranks:
         self.close()
 
     def comm_info(self) -> dict:
-        """rank / world the handle was created with, and the RCCL communicator's own size (ncclCommCount)."""
+        """rank / world the handle was created with; comm_ranks: ranks that joined its exchange; rccl_ranks: ncclCommCount of its RCCL
+        communicator (0: the host exchange serves it)."""
         r, w, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._check(self.L.vs_ranks_world(self.h, C.byref(r), C.byref(w), C.byref(c)))
-        return {"rank": r.value, "world": w.value, "rccl_ranks": c.value,
+        n = C.c_int(0)
+        self._check(self.L.vs_ranks_rccl_ranks(self.h, C.byref(n)))
+        return {"rank": r.value, "world": w.value, "comm_ranks": c.value, "rccl_ranks": n.value,
                 "exchange": {0: "rccl", 1: "hostshm"}.get(self.L.vs_ranks_exchange_kind(self.h), "?")}
 
     def unanswered(self) -> int:

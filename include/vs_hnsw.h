@@ -156,7 +156,8 @@ VS_API int vs_hnsw_walk_info(vs_hnsw* index, uint64_t out[2]);
 VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
 
 /* Lone queries (one vector per call, usearch.rs:212 / :236) on float indexes take the pipelined walk (kernels_pipe.hip):
- * [0] launches of it so far, [1] reserved. */
+ * [0] launches of it so far for this index, [1] lone plain queries (process-wide) it handed over to the team kernels because two
+ * equal distances met where their order matters. */
 VS_API int vs_hnsw_pipe_stats(vs_hnsw* index, uint64_t out[2]);
 
 /* HIP streams the engine has created in this process so far, over all devices and indexes: a fixed set per device (16 unless

@@ -287,6 +287,9 @@ struct WorkCtx {
 // context AND per slot, 17 filtered callers after some unfiltered traffic made 26 streams and ran at 329 QPS where a fresh
 // process runs at 430.  Contexts beyond the set share a stream with an earlier one (their launches then run in stream order,
 // each on its own buffers).  VS_HNSW_STREAMS: 4..20 (default 16: room for the caller's own streams).
+// The single-query dispatcher looks at every answer on the host anyway: it asks for no second-chance launch behind the pipelined walk
+// (tl_pipe_no_second) and serves a handed-over query itself, with the pipelined walk off (tl_no_pipe).
+static thread_local bool tl_pipe_no_second = false, tl_no_pipe = false;
 static std::atomic<uint64_t> g_streams_created{0};  // HIP streams the engine has made in this process (every device): a fixed set per device, never one per index
 struct DeviceStreams {
     static constexpr int kMax = 20;
@@ -1053,7 +1056,7 @@ struct Engine {
         IndexView v{};
         v.scalar = scalar;
         v.M0 = (uint32_t)M0;
-        return !pipe_off && !no_pipe && !tiny_walk_heap && iters < 12 && pipe_walk_supported(v, iters, ef);
+        return !pipe_off && !no_pipe && !tl_no_pipe && !tiny_walk_heap && iters < 12 && pipe_walk_supported(v, iters, ef);
     }
     bool usearch_order() const { return order_mode == 1 || (order_mode == 0 && (scalar == VS_SCALAR_I8 || scalar == VS_SCALAR_B1)); }
     void check_search(size_t k, uint32_t& ef) const {
@@ -1194,8 +1197,13 @@ struct Engine {
                         HIP_OK(hipMemsetAsync(d_dbg_p, 0, nq * 48, st));
                         p.debug = d_dbg_p;
                     }
+                    static const int dbg_second = std::getenv("VS_HNSW_PIPE_SECOND") ? std::atoi(std::getenv("VS_HNSW_PIPE_SECOND")) : 1;  // measurement aid: 0 = no second-chance launch (redone queries stay unanswered)
+                    static const bool dbg_fused = !(std::getenv("VS_HNSW_PIPE_FUSED") && std::getenv("VS_HNSW_PIPE_FUSED")[0] == '0');  // measurement aid
+                    if (!dbg_fused) p.pipe_fused_order = 0u;
                     HIP_OK(launch_pipe_walk(p, iters, st));
-                    if (lone_pipe) {
+                    if (!dbg_second || (lone_pipe && tl_pipe_no_second)) {
+                        // (the caller reads out_found on the host and re-runs the queries marked kPipeRedo itself)
+                    } else if (lone_pipe) {
                         // second chance for plain queries of a float index: the team form of the fused-list kernel, i.e. exactly what a
                         // batch of them gets -- a lone query and a batched one never differ, however many distances tie
                         SearchArgs sa;
@@ -1942,6 +1950,10 @@ class SearchService {
             // and two copy-engine latencies less per launch (the dispatcher thread is what bounds small batches).
             const bool zero_copy = nb <= kZeroCopyBatch;
             if (!zero_copy) HIP_OK(hipMemcpyAsync(s.d_q, s.h_q, nb * dim * 4, hipMemcpyHostToDevice, s.st));
+            tl_pipe_no_second = true;  // deliver() serves the rare query the pipelined walk hands over
+            struct Reset {
+                ~Reset() { tl_pipe_no_second = false; }
+            } reset;
             if (zero_copy)
                 e->search_device(s.h_q, nb, k, s.h_k, s.h_d, s.h_f, s.st, load);
             else
@@ -1979,6 +1991,25 @@ class SearchService {
                     status = f.code;
                     s.err = f.msg;
                 } catch (const std::exception& x) {
+                    status = VS_ERR_DEVICE;
+                    s.err = x.what();
+                }
+            } else if (status == VS_OK && s.h_f[i] == kPipeRedoFound) {
+                // two equal distances met where their order matters: the team form of the fused-list kernel answers, as for a batch
+                try {
+                    tl_no_pipe = true;
+                    size_t f = 0;
+                    r.e->search_host(r.q.data(), 1, k, r.keys, r.dist, &f, false);
+                    tl_no_pipe = false;
+                    if (f == (size_t)-1) f = r.e->rank_all(r.q.data(), k, r.keys, r.dist);
+                    *r.found = f;
+                    n_pipe_redone += 1;
+                } catch (const Fail& f) {
+                    tl_no_pipe = false;
+                    status = f.code;
+                    s.err = f.msg;
+                } catch (const std::exception& x) {
+                    tl_no_pipe = false;
                     status = VS_ERR_DEVICE;
                     s.err = x.what();
                 }
@@ -2095,6 +2126,7 @@ class SearchService {
     static thread_local std::string g_async_err;
     // launches / queries, and how many of them went to the team kernel (process-wide; vs_search_service_stats)
     static inline std::atomic<unsigned long long> n_batches{0}, n_team_batches{0}, n_queries{0}, n_team_queries{0};
+    static inline std::atomic<unsigned long long> n_pipe_redone{0};  // lone queries the pipelined walk handed over (served by the team kernels)
     static inline std::atomic<unsigned long long> n_ranked_fallbacks{0};  // queries whose walk reported kWalkFailed and were ranked exhaustively
 };
 thread_local std::string SearchService::g_async_err;
@@ -2409,7 +2441,7 @@ uint64_t vs_hnsw_streams_created(void) { return vs::g_streams_created.load(); }
 int vs_hnsw_pipe_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.pipe_launches.load();
-    out[1] = 0;
+    out[1] = vs::SearchService::n_pipe_redone.load();
     return VS_OK;
 }
 

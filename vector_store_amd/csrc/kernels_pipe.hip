@@ -15,8 +15,9 @@
 
 namespace vs {
 
-template <int AR, int I, int EFCAP, bool VISG>
+template <int AR, int I, int EFCAP, int MODE>
 __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs a) {
+    constexpr bool VISG = true;
     using Sh = PipeShared<EFCAP, kPipeTeam, false, VISG>;
     __shared__ Sh sh;
     extern __shared__ uint2 pipe_pool[];
@@ -76,14 +77,16 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
     }
     Counters cnt = {0, 0, 0};
     float start_d = 0.f;
-    const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane, &start_d);
+    uint32_t start;
+    // (inlined whatever the size of the kernel: an out-of-line call passes the query's registers through scratch memory)
+    [[clang::always_inline]] start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane, &start_d);
     team_release(sh, lane);  // the last barrier: from here on the waves meet through LDS words only
     PipeTop<EFCAP / 64> top;
-    const PipeOut r = pipe_walk<AR, I>(ix, sh, pipe_pool, a.pipe_pool_cap, ws, start, start_d, a.ef, tomb, allow, known,
+    const PipeOut r = pipe_walk<AR, I, MODE>(ix, sh, pipe_pool, a.pipe_pool_cap, ws, start, start_d, a.ef, tomb, allow, known,
                                        a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
                                        a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget,
                                        a.consulted ? a.consulted + qi : nullptr, cnt, lane, top, a.debug ? a.debug + (size_t)qi * 12 : nullptr,
-                                       a.pipe_explore != 0u, a.pipe_fused_order != 0u);
+                                       a.pipe_fused_order != 0u);
     if (r.status == 1u) {  // the usearch-order walk answers it (and lists the verdicts IT misses: this walk's list is dropped)
         if (lane == 0) {
             if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;
@@ -117,9 +120,9 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
     }
 }
 
-template <int AR, int I, int EFCAP, bool VISG>
+template <int AR, int I, int EFCAP, int MODE>
 static hipError_t pipe_launch(const WalkArgs& a, hipStream_t s) {
-    auto kernel = hnsw_pipe_walk_kernel<AR, I, EFCAP, VISG>;
+    auto kernel = hnsw_pipe_walk_kernel<AR, I, EFCAP, MODE>;
     const size_t dyn = (size_t)a.pipe_pool_cap * sizeof(uint2);
     static std::once_flag once[16];  // the attribute is per device
     int dev = 0;
@@ -138,9 +141,11 @@ static hipError_t pipe_ef(const WalkArgs& a, hipStream_t s) {
     // (the LDS tag table as the visited set -- PipeShared<..., VISG = false> -- was measured for unfiltered lone walks and dropped: its
     // test-and-set costs the walker as much as the returning global atomic, which runs under the early post: 0.80 against 0.74 ms)
     if (a.pipe_lds_visited) return hipErrorInvalidValue;
-    if (a.ef <= 256) return pipe_launch<AR, I, 256, true>(a, s);
-    if (a.ef <= 512) return pipe_launch<AR, I, 512, true>(a, s);
-    return hipErrorInvalidValue;
+    // one instance per purpose (pipe_device.hpp `MODE`): plain lone queries, the exact walk of a filtered query, its exploring rounds
+    if (a.ef > 512) return hipErrorInvalidValue;
+    if (a.pipe_explore) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeExplore>(a, s) : pipe_launch<AR, I, 512, kPipeExplore>(a, s);
+    if (a.allow) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeFiltered>(a, s) : pipe_launch<AR, I, 512, kPipeFiltered>(a, s);
+    return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipePlain>(a, s) : pipe_launch<AR, I, 512, kPipePlain>(a, s);
 }
 
 template <>

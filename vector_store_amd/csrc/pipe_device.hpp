@@ -242,12 +242,24 @@ struct PipeOut {
     uint32_t sz;
 };
 
-template <int AR, int I, class Sh>
+// MODE: what the instance is for -- each carries only the state it needs (the walker's loop lives on scalar registers, and every
+// wave-uniform variable it does not need is one it does not have to spill):
+//   kPipePlain    plain lone queries (no filter): no verdict bookkeeping, `next` never outgrows LDS (no spilling), fused-list tie order
+//   kPipeFiltered the exact walk of a filtered query
+//   kPipeExplore  an exploring round of a lazily filtered query
+enum : int { kPipePlain = 0, kPipeFiltered = 1, kPipeExplore = 2 };
+template <int AR, int I, int MODE, class Sh>
 __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2* pool, uint32_t pool_cap, const WalkSpace& ws, uint32_t start,
                                              float start_d, uint32_t ef, bool tomb, const uint32_t* allow, const uint32_t* known,
                                              uint32_t* unknown_list, uint32_t* unknown_count, uint32_t unknown_cap, uint32_t unknown_budget,
                                              uint32_t* consulted_out, Counters& cnt, int lane, PipeTop<Sh::kEfCap / 64>& top, uint32_t* debug,
-                                             bool explore, bool fused_order) {
+                                             bool fused_order) {
+    constexpr bool explore = MODE == kPipeExplore;
+    constexpr bool kFilter = MODE != kPipePlain;
+    if constexpr (!kFilter) {
+        allow = nullptr;
+        known = nullptr;
+    }
     constexpr int R = Sh::kEfCap / 64;
     constexpr uint32_t TM = (uint32_t)Sh::kTeam;
     constexpr uint32_t K = (uint32_t)kPipeCache;
@@ -268,11 +280,11 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     uint32_t f_s = kInvalid, f_c = 0, nf = 0, np = 0;  // f_c: 1 = a cache entry (complete or being measured) belongs to this candidate
     float pool_lb = INF;  // the smallest distance in the pool
     // (`next` beyond the pool: slots in global memory, see spill() below)
-    const uint32_t slot_cap = pool_cap / 2u;
-    const uint32_t n_slots = (slot_cap && ws.heap) ? (ws.heap_cap / slot_cap < 64u ? ws.heap_cap / slot_cap : 64u) : 0u;
+    const uint32_t slot_cap = kFilter ? pool_cap / 2u : 0u;
+    const uint32_t n_slots = (kFilter && slot_cap && ws.heap) ? (ws.heap_cap / slot_cap < 64u ? ws.heap_cap / slot_cap : 64u) : 0u;
     uint32_t g_cnt = 0;    // lane j: entries of slot j
     float g_min = INF;     // lane j: their smallest distance
-    float spill_lb = INF;  // the smallest distance in any slot
+    float spill_lb = INF;  // the smallest distance in any slot (plain queries: never anything)
     constexpr uint32_t kPoolSlack = 192u;  // room a hop in progress may still need (64 pushes and as many entries displaced from the front)
     bool spill_now = false;
     uint32_t sz = 0;
@@ -310,12 +322,20 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const bool in = L * (uint32_t)R + (uint32_t)j < sz;
-            rank += (uint32_t)__popcll(__ballot(in && top.d[j] < d));
+            rank += (uint32_t)__popcll(__ballot(in && top.d[j] < d));  // usearch: a new entry goes in front of equal ones
             eq = eq || (in && top.d[j] == d);
         }
-        // (fused_order: the caller's other kernels list equal distances by slot, this buffer newest first -- any two equal distances in
-        // `top` and the query is theirs)
-        if (__ballot(eq) != 0ull ? (tie_active || fused_order) : (tie_active && sz + 1u >= ef)) redo = true;
+        const bool eq_any = __ballot(eq) != 0ull;
+        if (eq_any && fused_order) {
+            // (the caller's other kernels keep ONE list ordered by (distance, slot): among equal distances the lower slot first, as they
+            // do -- a second pass for the rare insertion that meets an equal distance, not a second comparison in every one)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const bool in = L * (uint32_t)R + (uint32_t)j < sz;
+                rank += (uint32_t)__popcll(__ballot(in && top.d[j] == d && top.s[j] < s));
+            }
+        }
+        if (tie_active && (sz + 1u >= ef || eq_any)) redo = true;
         const float cd = __uint_as_float(wave_shr1(__float_as_uint(top.d[R - 1]), 0u));
         const uint32_t cs = wave_shr1(top.s[R - 1], 0u);
 #pragma unroll
@@ -333,9 +353,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         const uint64_t mk = __ballot(mine);
         if (!mk) return;
         const uint32_t c = (uint32_t)__popcll(mk);
-        if (np + c + kPoolSlack > pool_cap) {
-            spill_now = true;  // (the hop in progress ends first; then the pool's farther half moves to global memory: spill())
-            if (np + c > pool_cap) {
+        if (np + c + (kFilter ? kPoolSlack : 0u) > pool_cap) {
+            if constexpr (kFilter) spill_now = true;  // (the hop in progress ends first; then the pool's farther half moves to global memory: spill())
+            if (!kFilter || np + c > pool_cap) {
                 redo = true;
                 return;
             }
@@ -345,9 +365,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         pool_lb = fminf(pool_lb, wave_min(mine ? d : INF));
     };
     auto pool_append_one = [&](float d, uint32_t s) {  // one wave-uniform entry
-        if (np + 1u + kPoolSlack > pool_cap) {
-            spill_now = true;
-            if (np + 1u > pool_cap) {
+        if (np + 1u + (kFilter ? kPoolSlack : 0u) > pool_cap) {
+            if constexpr (kFilter) spill_now = true;
+            if (!kFilter || np + 1u > pool_cap) {
                 redo = true;
                 return;
             }
@@ -384,7 +404,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     };
     // next.insert for the lanes in `mask` (their own nd / ns): below the front's reach -> the front, one at a time; the rest -> the pool
     auto push_lanes = [&](uint64_t mask, float nd, uint32_t ns) {
-        const float reach = nf == 64u ? rl_f(f_d, 63) : fminf(pool_lb, spill_lb);  // closer than this: belongs to the front
+        const float reach = nf == 64u ? rl_f(f_d, 63) : (kFilter ? fminf(pool_lb, spill_lb) : pool_lb);  // closer than this: belongs to the front
         const bool mine = ((mask >> L) & 1ull) != 0ull;
         const uint64_t fm = __ballot(mine && nd < reach);
         pool_append(mine && !(nd < reach), nd, ns);
@@ -395,7 +415,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         dbg_pushed += (uint32_t)__popcll(mask);
     };
     auto push_one = [&](float d, uint32_t s) {  // next.insert of one wave-uniform entry
-        const float reach = nf == 64u ? rl_f(f_d, 63) : fminf(pool_lb, spill_lb);
+        const float reach = nf == 64u ? rl_f(f_d, 63) : (kFilter ? fminf(pool_lb, spill_lb) : pool_lb);
         if (d < reach) front_insert(d, s, 0u);
         else pool_append_one(d, s);
         dbg_pushed += 1u;
@@ -464,6 +484,10 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     // two free slots (lane j keeps slot j's count and smallest distance); when the front needs entries that may lie beyond the pool, the
     // slot with the smallest distance comes back whole.  Order is untouched: the front still pops the global minimum.
     auto spill = [&]() {
+        if constexpr (!kFilter) {
+            redo = true;  // (a plain walk's `next` stays below four times the beam: a pool that fills up is handed over)
+            return;
+        } else {
         ++dbg_spills;
         const Sel sel = select_thr(slot_cap);
         if (sel.all || (!sel.ok && sel.count == 0u)) {
@@ -512,8 +536,13 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             g_min = minb;
         }
         spill_lb = wave_min(g_cnt ? g_min : INF);
+        }
     };
     auto unspill = [&]() {  // the slot that holds the smallest spilled distance comes back into the pool
+        if constexpr (!kFilter) {
+            redo = true;
+            return;
+        } else {
         ++dbg_spills;
         if (np > slot_cap) {
             spill();
@@ -551,6 +580,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             g_min = INF;
         }
         spill_lb = wave_min(g_cnt ? g_min : INF);
+        }
     };
     // the front ran empty: the closest entries of the pool move up
     auto refill = [&](uint32_t limit = 64u) {  // limit: at most this many move up
@@ -565,7 +595,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 }
             }
             // may a spilled entry belong among the ones selected?  (all: the pool's last entries move, whatever lies in the slots comes next)
-            const bool spilled_first = spill_lb != INF && (sel.all || dist_key(__float_as_uint(spill_lb)) < sel.thr);
+            const bool spilled_first = kFilter && spill_lb != INF && (sel.all || dist_key(__float_as_uint(spill_lb)) < sel.thr);
             if (!spilled_first) break;
             if (rounds > 128u) {
                 redo = true;
@@ -730,7 +760,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     // several at a time, each by one helper that also marks what it measures; the walker only merges: verdict bookkeeping (which lists
     // the slots whose verdict is missing -- what the round is for), pushes, `top` (with guessed verdicts, so that the radius behaves
     // as the exact walk's will).  Two batches are kept in flight: the next one is posted before the last one is merged.
-    if (explore) {
+    if constexpr (explore) {
         constexpr uint32_t kBatch = (TM - 1u) / 2u;
         auto post_batch = [&]() -> uint64_t {
             refresh_jobs();
@@ -819,16 +849,19 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         vlog_lost = true;
     }
     refresh_jobs();
-    if (!explore) schedule();
+    if constexpr (!explore) schedule();
     WALK_STAMP(0);
-    while (!explore && !redo && !over_budget) {
-        if (spill_now) {
-            spill();
-            spill_now = false;
-            if (redo) break;
+    if constexpr (!explore)
+    while (!redo && !over_budget) {
+        if constexpr (kFilter) {
+            if (spill_now) {
+                spill();
+                spill_now = false;
+                if (redo) break;
+            }
         }
         if (nf == 0u) {
-            if (np == 0u && spill_lb == INF) break;
+            if (np == 0u && (!kFilter || spill_lb == INF)) break;
             refill();
             if (redo) break;
             if (nf == 0u) continue;  // (what was selected lay beyond the radius and was dropped: look again)
@@ -842,7 +875,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         f_c = wave_shl1(f_c, 0u);
         nf -= 1u;
         cnt.hops += 1;
-        const float next_d = nf ? rl_f(f_d, 0) : fminf(pool_lb, spill_lb);  // (+inf when nothing waits beyond the front)
+        const float next_d = nf ? rl_f(f_d, 0) : (kFilter ? fminf(pool_lb, spill_lb) : pool_lb);  // (+inf when nothing waits beyond the front)
         if (tie_active && cd > tie_v) tie_active = false;
         if (!tie_active && next_d == cd) {
             tie_active = true;

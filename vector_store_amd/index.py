@@ -96,8 +96,9 @@ def lib():
     L.vs_hnsw_memory_info.argtypes = [vp, vp]
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
     L.vs_hnsw_pipe_stats.argtypes = [vp, vp]
-    L.vs_hnsw_streams_created.argtypes = []
-    L.vs_hnsw_streams_created.restype = C.c_uint64
+    if hasattr(L, "vs_hnsw_streams_created"):  # (VS_HNSW_LIB may name an older build: A/B measurements)
+        L.vs_hnsw_streams_created.argtypes = []
+        L.vs_hnsw_streams_created.restype = C.c_uint64
     L.vs_hnsw_exact_stats.argtypes = [vp, vp]
     L.vs_hnsw_walk_info.argtypes = [vp, vp]
     L.vs_hnsw_exact_stats2.argtypes = [vp, vp]
@@ -296,7 +297,7 @@ class HipUsearchIndex:
     def pipe_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)
         _check(self.L.vs_hnsw_pipe_stats(self.h, _p(out)))
-        return {"pipe_launches": int(out[0])}
+        return {"pipe_launches": int(out[0]), "lone_queries_handed_over": int(out[1])}
 
     def exact_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)

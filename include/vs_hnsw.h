@@ -155,6 +155,11 @@ VS_API int vs_hnsw_walk_info(vs_hnsw* index, uint64_t out[2]);
  * rounds): [0] walk launches and [1] predicate calls spent that way so far. */
 VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
 
+/* A crowd of lazily filtered queries (more callers than the device has streams; the reference runs every filtered query on a blocking
+ * thread of its own, usearch.rs:937-948) shares launches: [0] launches that served rounds of several callers at once, [1] rounds served
+ * that way. */
+VS_API int vs_hnsw_filter_batch_stats(vs_hnsw* index, uint64_t out[2]);
+
 /* Lone queries (one vector per call, usearch.rs:212 / :236) on float indexes take the pipelined walk (kernels_pipe.hip):
  * [0] launches of it so far for this index, [1] lone plain queries (process-wide) it handed over to the team kernels because two
  * equal distances met where their order matters. */

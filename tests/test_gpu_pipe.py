@@ -150,3 +150,38 @@ def test_heavily_duplicated_vectors_and_tiny_indexes():
     tiny.add_batch(np.arange(20, dtype=np.uint64), uniq[:20])
     fk, fd = tiny.search(q[0], 50)
     assert len(fk) == 20 and fk[0] == 0
+
+
+def test_a_crowd_of_filtered_callers_shares_launches_and_gets_the_same_answers():
+    """More filtered callers than the device has streams (the reference puts every filtered query on a blocking thread of its own,
+    usearch.rs:937-948): their rounds are batched into shared launches.  Same answers, bit for bit, as one caller at a time."""
+    import threading
+    import vector_store_amd as vs
+    n, dim, k, nq, callers = 200_000, 96, 10, 48, 40
+    data = _dataset(n + nq, dim, 31)
+    base, q = data[:n], data[n:]
+    ix = vs.HipUsearchIndex(dim, vs.COS, expansion_search=128)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    pred = lambda key: key % 10 == 3
+    want = [ix.filtered_search(q[i], k, pred) for i in range(nq)]   # one at a time (and the index learns the filter's appetite)
+    assert ix.filter_batch_stats()["batched_rounds"] == 0
+    got = [None] * (callers * 3)
+    errs = []
+
+    def caller(t):
+        try:
+            for r in range(3):
+                i = (t * 3 + r) % nq
+                got[t * 3 + r] = (i, ix.filtered_search(q[i], k, pred))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(callers)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for i, a in got:
+        _same_bits(a, want[i], ("crowd", i))
+    st = ix.filter_batch_stats()
+    assert st["batched_rounds"] > 0 and st["batched_launches"] <= st["batched_rounds"], st

@@ -279,6 +279,11 @@ struct WorkCtx {
     char* pin = nullptr;
     size_t pin_bytes = 0;
     hipEvent_t ev = nullptr;
+    // batched rounds (Engine::filtered_batched): this context's visited bitmap / log / spill slots -- all zero between rounds --, and
+    // what it was laid out for
+    DeviceBuf ws;
+    size_t ws_zeroed = 0;
+    uint32_t round_seq = 0;
 };
 
 // The engine's streams on one device: a fixed set, shared by the leased contexts (from index 0 up) and the single-query
@@ -312,6 +317,11 @@ struct DeviceStreams {
         std::lock_guard<std::mutex> g(mu);
         return at((int)(next_ctx++));
     }
+    hipStream_t round_robin() {  // batched filtered rounds: launches take the device's streams in turn
+        std::lock_guard<std::mutex> g(mu);
+        return at((int)(next_rr++));
+    }
+    unsigned next_rr = 0;
     hipStream_t for_slot(int slot) {
         std::lock_guard<std::mutex> g(mu);
         return at(count - 1 - slot);
@@ -1058,6 +1068,7 @@ struct Engine {
         v.M0 = (uint32_t)M0;
         return !pipe_off && !no_pipe && !tl_no_pipe && !tiny_walk_heap && iters < 12 && pipe_walk_supported(v, iters, ef);
     }
+    bool needs_global_walk_beyond_pipe(uint32_t ef) const { return ef > 512; }
     bool usearch_order() const { return order_mode == 1 || (order_mode == 0 && (scalar == VS_SCALAR_I8 || scalar == VS_SCALAR_B1)); }
     void check_search(size_t k, uint32_t& ef) const {
         if (k == 0) fail(VS_ERR_INVALID_ARGUMENT, "k must be > 0");
@@ -1598,8 +1609,324 @@ struct Engine {
     // for exactly those, and the walk runs again.  A round that lists nothing used only true verdicts: it IS the walk
     // with the full predicate, so its result is exact.  The per-round budget doubles, predicate calls total a small
     // multiple of what the final walk needs.  (size_t)-1: gave up (caller falls back to the full bitmap).
+    // ---- batched rounds (round 4) -----------------------------------------------------------------------------------------------------
+    // Every lazily filtered query is a chain of rounds, and the reference puts each query on a blocking thread of its own (usearch.rs:937-948:
+    // as many as there are requests).  One launch per caller and round means one small kernel per stream at a time -- 16 streams, 16 walks
+    // in flight on 256 CUs.  Here the callers' rounds share launches: a caller queues its round (one PipeQuery: its buffers, the verdicts
+    // of its last round, its budget) and waits on a flag in its own pinned block; whoever finds no launch in progress takes everything
+    // queued -- exact walks and exploring rounds are different kernels -- and launches it, one workgroup per query, the device's streams
+    // in turn.  The kernel does the round's whole exchange (kernels_pipe.hip): no export / apply launches, no copy engine, no
+    // hipStreamSynchronize -- and as many walks in flight as callers.
+    struct FilterBatcher {
+        struct Req {
+            PipeQuery pq;
+            int explore;
+            uint32_t ef;  // max(expansion_search, k) of the caller: one launch serves one beam
+        };
+        std::mutex mu;
+        std::vector<Req> pending;
+        bool launching = false;
+        static constexpr int kTables = 64, kMaxBatch = 128;  // (a table is reused 64 launches later: not even a 1 % filter's walk is still running then)
+        PipeQuery* table[kTables] = {};
+        hipEvent_t ev[kTables] = {};
+        bool used[kTables] = {};
+        int next_table = 0;
+        unsigned next_stream = 0;
+        hipEvent_t stream_ev[DeviceStreams::kMax] = {};  // the last batch launched on each of the device's streams
+        std::atomic<uint64_t> launches{0}, rounds{0};
+        ~FilterBatcher() {
+            for (int i = 0; i < kTables; ++i) {
+                if (table[i]) (void)hipHostFree(table[i]);
+                if (ev[i]) (void)hipEventDestroy(ev[i]);
+            }
+            for (auto& e : stream_ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    };
+    FilterBatcher batcher;
+    static constexpr uint32_t kBatchVlogCap = 1u << 16, kBatchHeapCap = 1u << 18;
+    size_t batch_space_bytes(size_t n_slots) const { return walk_space_stride((uint32_t)((n_slots + 31) / 32), kBatchVlogCap, kBatchHeapCap); }
+
+    void launch_rounds(std::vector<FilterBatcher::Req>& take, size_t n_slots) {
+        FilterBatcher& b = batcher;
+        std::vector<uint32_t> efs;
+        for (auto& r : take)
+            if (std::find(efs.begin(), efs.end(), r.ef) == efs.end()) efs.push_back(r.ef);
+        for (uint32_t ef : efs)
+        for (int explore = 0; explore < 2; ++explore) {
+            std::vector<const PipeQuery*> group;
+            for (auto& r : take)
+                if (r.explore == explore && r.ef == ef) group.push_back(&r.pq);
+            for (size_t off = 0; off < group.size(); off += FilterBatcher::kMaxBatch) {
+                const size_t n = std::min<size_t>(FilterBatcher::kMaxBatch, group.size() - off);
+                const int t = b.next_table++ % FilterBatcher::kTables;
+                if (!b.table[t]) {
+                    HIP_OK(hipHostMalloc((void**)&b.table[t], sizeof(PipeQuery) * FilterBatcher::kMaxBatch, hipHostMallocDefault));
+                    HIP_OK(hipEventCreateWithFlags(&b.ev[t], hipEventDisableTiming));
+                }
+                if (b.used[t]) HIP_OK(hipEventSynchronize(b.ev[t]));  // (the launch that read this table is long done)
+                for (size_t i = 0; i < n; ++i) b.table[t][i] = *group[off + i];
+                WalkArgs a{};
+                {
+                    std::shared_lock<std::shared_mutex> vg(view_mu);
+                    a.ix = view();
+                }
+                a.nq = (uint32_t)n;
+                a.ef = ef;
+                a.k = 0;
+                a.has_removed = removed.load() ? 1u : 0u;
+                a.bitmap_words = (uint32_t)((n_slots + 31) / 32);
+                a.vlog_cap = kBatchVlogCap;
+                a.heap_cap = kBatchHeapCap;
+                a.stats = d_stats;
+                a.pipe_qtable = b.table[t];
+                a.pipe_explore = explore ? 1u : 0u;
+                a.pipe_pool_cap = 12288u;
+                // A stream whose last batch has finished: a launch behind a running batch would wait for ALL of that batch's walks (stream
+                // order), however many streams sit idle.  When every stream is busy the launcher waits for the first to finish -- the rounds
+                // that queue meanwhile join the next launch.
+                DeviceStreams& ds = device_streams(device);
+                int si = -1;
+                for (uint32_t spins = 0; si < 0; ++spins) {
+                    for (int probe = 0; probe < ds.count && si < 0; ++probe) {
+                        const int c = (int)((b.next_stream + (unsigned)probe) % (unsigned)ds.count);
+                        if (!b.stream_ev[c] || hipEventQuery(b.stream_ev[c]) == hipSuccess) si = c;
+                    }
+                    if (si < 0) {
+                        if (spins > 2000000u) si = (int)(b.next_stream % (unsigned)ds.count);  // (seconds: something is stuck; stream order will do)
+                        else if (spins > 50) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                        else __builtin_ia32_pause();
+                    }
+                }
+                b.next_stream = (unsigned)si + 1u;
+                hipStream_t st;
+                {
+                    std::lock_guard<std::mutex> g(ds.mu);
+                    st = ds.at(si);
+                }
+                if (!b.stream_ev[si]) HIP_OK(hipEventCreateWithFlags(&b.stream_ev[si], hipEventDisableTiming));
+                HIP_OK(launch_pipe_walk(a, iters, st));
+                HIP_OK(hipEventRecord(b.ev[t], st));
+                HIP_OK(hipEventRecord(b.stream_ev[si], st));
+                b.used[t] = true;
+                b.launches.fetch_add(1, std::memory_order_relaxed);
+                b.rounds.fetch_add(n, std::memory_order_relaxed);
+                pipe_launches.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+    }
+
+    void wait_idle_batch_stream() {
+        FilterBatcher& b = batcher;
+        DeviceStreams& ds = device_streams(device);
+        for (uint32_t spins = 0; spins < 2000000u; ++spins) {
+            for (int c = 0; c < ds.count; ++c)
+                if (!b.stream_ev[c] || hipEventQuery(b.stream_ev[c]) == hipSuccess) return;
+            if (spins > 50) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            else __builtin_ia32_pause();
+        }
+    }
+
+    // queue one round; on return it has been launched (by this thread or the one that was launching) or failed (its flag says redo)
+    void submit_round(const PipeQuery& pq, bool explore, uint32_t ef, size_t n_slots) {
+        FilterBatcher& b = batcher;
+        std::unique_lock<std::mutex> lk(b.mu);
+        b.pending.push_back({pq, explore ? 1 : 0, ef});
+        if (b.launching) return;  // the thread that is launching takes it along
+        b.launching = true;
+        for (;;) {
+            if (b.pending.empty()) {
+                b.launching = false;
+                return;
+            }
+            // (everything queued until a stream is free goes into one launch)
+            lk.unlock();
+            wait_idle_batch_stream();
+            lk.lock();
+            std::vector<FilterBatcher::Req> take;
+            take.swap(b.pending);
+            lk.unlock();
+            try {
+                use_device();
+                launch_rounds(take, n_slots);
+            } catch (...) {
+                // whatever could not be launched is handed back as "not answered": its caller falls back to rounds of its own
+                for (auto& r : take) {
+                    if (__atomic_load_n(r.pq.done, __ATOMIC_ACQUIRE) != r.pq.round_id) {
+                        r.pq.cnt[0] = r.pq.cnt[1] = 0;
+                        r.pq.cnt[2] = kPipeRedoFound;
+                        __atomic_store_n(r.pq.done, r.pq.round_id, __ATOMIC_RELEASE);
+                    }
+                }
+            }
+            lk.lock();
+        }
+    }
+
+    // filtered_lazy through the batcher.  (size_t)-1: hand the query to the unbatched rounds (a tie where order matters, or a failure).
+    size_t filtered_batched(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, uint32_t ef) {
+        use_device();
+        size_t n;
+        {
+            std::lock_guard<std::mutex> g(mod_mu);
+            n = slots;
+        }
+        const size_t words = (n + 31) / 32;
+        const uint32_t cap = 1u << 17;
+        // (at most 128 of these queries hold a context -- a workspace of a few MB each -- at a time)
+        static std::mutex gate_mu;
+        static std::condition_variable gate_cv;
+        static int gate_free = 128;
+        {
+            std::unique_lock<std::mutex> gl(gate_mu);
+            gate_cv.wait(gl, [&] { return gate_free > 0; });
+            --gate_free;
+        }
+        struct Permit {
+            ~Permit() {
+                {
+                    std::lock_guard<std::mutex> gl(gate_mu);
+                    ++gate_free;
+                }
+                gate_cv.notify_one();
+            }
+        } permit;
+        Lease w(device);
+        uint32_t* d_bits = (uint32_t*)w->e.ensure(words * 8);
+        const size_t space = batch_space_bytes(n);
+        if (w->ws.bytes < space || w->ws_zeroed != space) {
+            char* p = (char*)w->ws.ensure(space);
+            HIP_OK(hipMemsetAsync(p, 0, w->ws.bytes, w->stream));
+            HIP_OK(hipStreamSynchronize(w->stream));
+            w->ws_zeroed = space;
+        }
+        // pinned, device-mapped: [flag, counters 64 B | list cap x 4 | verdicts cap | keys k x 8 | dist k x 4 | the query]
+        const size_t pin_need = 64 + (size_t)cap * 5 + k * 12 + 64 + (size_t)dim * 4;
+        if (w->pin_bytes < pin_need) {
+            if (w->pin) (void)hipHostFree(w->pin);
+            w->pin = nullptr;
+            w->pin_bytes = 0;
+            HIP_OK(hipHostMalloc((void**)&w->pin, pin_need, hipHostMallocDefault));
+            w->pin_bytes = pin_need;
+        }
+        uint32_t* h_cnt = (uint32_t*)w->pin;         // [0..3] counters
+        uint32_t* h_done = (uint32_t*)w->pin + 8;    // the flag
+        uint32_t* h_list = (uint32_t*)(w->pin + 64);
+        uint8_t* h_verdict = (uint8_t*)(w->pin + 64 + (size_t)cap * 4);
+        uint64_t* h_k = (uint64_t*)(w->pin + 64 + (size_t)cap * 5);
+        float* h_d = (float*)(h_k + k);
+        float* h_q = (float*)(w->pin + ((64 + (size_t)cap * 5 + k * 12 + 63) & ~(size_t)63));
+        std::memcpy(h_q, q, (size_t)dim * 4);
+        const uint32_t hint = lazy_need_hint.load();
+        const uint32_t sel_hint = lazy_sel_hint.load();
+        const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
+        static const int guess_pct = std::getenv("VS_HNSW_FILTER_GUESS") ? std::atoi(std::getenv("VS_HNSW_FILTER_GUESS")) : 50;
+        uint64_t n_known = 0, n_allowed = 0;
+        bool explored = false;
+        int exact_rounds = 0, explore_rounds = 0;
+        uint32_t apply_m = 0;
+        for (int round = 0; round < 24; ++round) {
+            uint32_t guess = 0;  // of 256
+            if (n_known > 0 && guess_pct > 0) guess = std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * n_allowed * (uint64_t)guess_pct / (100 * n_known)));
+            else if (sel_hint > 0 && guess_pct > 0) guess = std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * sel_hint * (uint64_t)guess_pct / (100ull * 65536ull)));
+            const bool explore = !explored && guess_pct > 0;
+            uint32_t budget;
+            if (explore) {
+                budget = (guess ? cap / 2 : first_budget) | (guess << 24);
+                explored = guess != 0 || ++explore_rounds >= 2;
+            } else {
+                budget = (uint32_t)std::min<size_t>(cap, (size_t)first_budget << exact_rounds);
+                if (n_known > 0) budget |= guess << 24;
+                ++exact_rounds;
+            }
+            PipeQuery pq{};
+            pq.query = h_q;
+            pq.allow = d_bits;
+            pq.known = d_bits + words;
+            pq.words = (uint32_t)words;
+            pq.zero_bits = round == 0 ? 1u : 0u;
+            pq.list = h_list;
+            pq.verdict = h_verdict;
+            pq.apply_m = apply_m;
+            pq.slots = (uint32_t)n;
+            pq.cap = cap;
+            pq.budget = budget;
+            pq.k = (uint32_t)k;
+            pq.round_id = ++w->round_seq ? w->round_seq : ++w->round_seq;
+            pq.cnt = h_cnt;
+            pq.keys = h_k;
+            pq.dist = h_d;
+            pq.done = h_done;
+            pq.space = (char*)w->ws.p;
+            __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
+            submit_round(pq, explore, ef, n);
+            // wait for the kernel's flag: spinning while every caller has a core, in short sleeps beyond that
+            static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+            for (uint32_t spins = 0; __atomic_load_n(h_done, __ATOMIC_ACQUIRE) != pq.round_id; ++spins) {
+                if (spins < 2000 && filtered_active_callers.load(std::memory_order_relaxed) <= cores) {
+                    __builtin_ia32_pause();
+                } else {
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                if (spins > 400000) fail(VS_ERR_DEVICE, "a batched filtered round did not finish");  // (20 s)
+            }
+            const uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
+            if (found == kPipeRedoFound) return (size_t)-1;
+            if (count == 0 && !explore) {
+                if (found == kWalkFailed) return (size_t)-1;
+                std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
+                std::memcpy(dist, h_d, (size_t)std::min<size_t>(found, k) * 4);
+                lazy_rounds += (uint64_t)round + 1;
+                lazy_need_hint = hint ? (3 * hint + consulted) / 4 : consulted;
+                if (n_known) {
+                    const uint32_t sel = (uint32_t)std::min<uint64_t>(65536, n_allowed * 65536ull / n_known);
+                    lazy_sel_hint = sel_hint ? (3 * sel_hint + sel) / 4 : sel;
+                }
+                return found;
+            }
+            const uint32_t m = std::min(count, cap);
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint32_t s = h_list[i];
+                uint8_t v = 0;
+                if (s < n) {
+                    const uint64_t key = h_keys[s];
+                    ++lazy_predicate_calls;
+                    v = key != kFreeKey && pred(key, pctx) ? 1 : 0;
+                }
+                h_verdict[i] = v;
+                n_allowed += v;
+            }
+            n_known += m;
+            apply_m = m;
+        }
+        return (size_t)-1;
+    }
+    static inline std::atomic<int> filtered_active_callers{0};
+
     static constexpr size_t kLazyFilterAbove = 1u << 16;
     size_t filtered_lazy(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist) {
+        struct ActiveCaller {
+            ActiveCaller() { filtered_active_callers.fetch_add(1, std::memory_order_relaxed); }
+            ~ActiveCaller() { filtered_active_callers.fetch_sub(1, std::memory_order_relaxed); }
+        } active_caller;
+        {
+            // Rounds through the batcher when the callers outnumber the device's streams by a margin AND this index's filtered walks are
+            // short: a batch holds its stream until its slowest walk ends, so a crowd of 10 %-selective queries (6 ms a round) gains --
+            // 64 callers 1.77k queries/s against 0.93k one stream each -- while 1 %-selective ones (100 ms a round) keep every stream busy
+            // and the next launch waiting (17 callers: 28 against 62), and a handful of callers is served best one stream each (17
+            // callers at 10 %: 945 against 850).  VS_HNSW_FILTER_BATCH = 0 never, 1 whenever the pipelined walk can serve.
+            static const int batch_env = std::getenv("VS_HNSW_FILTER_BATCH") ? std::atoi(std::getenv("VS_HNSW_FILTER_BATCH")) : -1;
+            uint32_t ef_b = 0;
+            check_search(k, ef_b);
+            const bool crowd = filtered_active_callers.load(std::memory_order_relaxed) > device_streams(device).count + 8;
+            const bool short_walks = lazy_need_hint.load() != 0 && lazy_need_hint.load() < 20000u;
+            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || (crowd && short_walks))) {
+                const size_t f = filtered_batched(q, k, pred, pctx, keys, dist, ef_b);
+                if (f != (size_t)-1) return f;
+                // (two equal distances met where their order matters, or the launch failed: the query starts over on rounds of its own,
+                // whose second-chance launch is the usearch-order walk)
+            }
+        }
         use_device();
         size_t n;
         {
@@ -2433,6 +2760,13 @@ int vs_hnsw_filter_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.lazy_rounds.load();
     out[1] = h->e.lazy_predicate_calls.load();
+    return VS_OK;
+}
+
+int vs_hnsw_filter_batch_stats(vs_hnsw* h, uint64_t out[2]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.batcher.launches.load();
+    out[1] = h->e.batcher.rounds.load();
     return VS_OK;
 }
 

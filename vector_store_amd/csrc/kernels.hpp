@@ -56,6 +56,29 @@ struct LinkArgs {
     unsigned long long* stats;
 };
 
+// One round of one lazily filtered query in a batched launch of the pipelined walk (WalkArgs::pipe_qtable).  Lives in pinned host
+// memory (device-mapped), like everything in it that is marked pinned.
+struct PipeQuery {
+    const float* query;        // pinned: dim floats
+    uint32_t* allow;           // device: one bit per slot; `known` follows at +words
+    uint32_t* known;
+    uint32_t words;            // words of each bitmap
+    uint32_t zero_bits;        // 1: both bitmaps are zeroed first (the query's first round)
+    uint32_t* list;            // pinned: the slots whose verdict the LAST round missed (input, apply_m of them) -- and this round's (output)
+    const uint8_t* verdict;    // pinned: the host's verdicts for list[0 .. apply_m)
+    uint32_t apply_m;
+    uint32_t slots;            // slots of the index (bound of a listed slot)
+    uint32_t cap;              // entries `list` holds
+    uint32_t budget;           // WalkArgs::unknown_budget of this round
+    uint32_t k;
+    uint32_t round_id;         // what *done becomes
+    uint32_t* cnt;             // pinned [4]: listed, consulted, found (kPipeRedoFound: not answered), evaluations
+    uint64_t* keys;            // pinned: k
+    float* dist;               // pinned: k
+    uint32_t* done;            // pinned: set to round_id once everything above is visible to the host
+    char* space;               // device: this query's visited bitmap / log / spill slots (all zero between rounds)
+};
+
 // The usearch-order walk (walk_device.hpp / kernels_walk.hip): persistent workgroups, one WalkSpace each.
 enum : uint32_t { WALK_LDS_128 = 0, WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512, WALK_GLOBAL_2048, WALK_GLOBAL_10240,
                   WALK_LDS_128_TINY /* test hook: 256-bucket visited table (1-chunk rows only), forces the retry path */,
@@ -97,6 +120,10 @@ struct WalkArgs {
     uint32_t* out_found;
     unsigned long long* stats;
     uint32_t* debug;         // nullptr, or nq x 12 words: largest `next`, nodes evaluated, hops, admitted, 8 phase clocks (VS_HNSW_WALK_DEBUG)
+    // Batched rounds of lazily filtered queries (engine.hip FilterBatcher): entry blockIdx.x of this table names one query's buffers and
+    // the kernel does the round's whole exchange itself -- the host's verdicts of the last round are applied first, the answer, the
+    // counters and the list of missing verdicts go to the caller's pinned block, a flag there says when.  nullptr: the strided arrays above.
+    const struct PipeQuery* pipe_qtable = nullptr;
     uint32_t pipe_explore = 0;   // pipelined walk, lazy filter: an exploring round (lists missing verdicts, several candidates at a time; its answer is not one)
     uint32_t pipe_fused_order = 0;  // pipelined walk: the answer must be the fused-list kernel's also among EQUAL distances (plain queries of float indexes): any tie in `top` hands the query over
     uint32_t pipe_lds_visited = 0;  // pipelined walk: the visited set is the LDS tag table (unfiltered; slots < 2^25 at beams <= 256, 2^26 beyond) instead of the bitmap in a.space

@@ -29,15 +29,27 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
         if (qi >= *a.qcount) return;
         qi = a.qlist[qi];
     }
-    uint64_t* ok = a.out_keys + (size_t)qi * a.k;
-    float* od = a.out_dist + (size_t)qi * a.k;
+    // this query's buffers: the strided arrays of WalkArgs, or its entry of the batch table
+    const PipeQuery* pq = a.pipe_qtable ? a.pipe_qtable + blockIdx.x : nullptr;
+    const float* query = pq ? pq->query : a.queries + (size_t)qi * a.q_stride;
+    const uint32_t k = pq ? pq->k : a.k;
+    uint64_t* ok = pq ? pq->keys : a.out_keys + (size_t)qi * a.k;
+    float* od = pq ? pq->dist : a.out_dist + (size_t)qi * a.k;
+    uint32_t* found_out = pq ? pq->cnt + 2 : a.out_found + qi;
     if (ix.max_level < 0) {  // empty index
         if (w == 0) {
-            for (uint32_t i = lane; i < a.k; i += kWave) {
+            for (uint32_t i = lane; i < k; i += kWave) {
                 ok[i] = kFreeKey;
                 od[i] = __builtin_inff();
             }
-            if (lane == 0) a.out_found[qi] = 0;
+            if (lane == 0) {
+                *found_out = 0;
+                if (pq) {
+                    pq->cnt[0] = pq->cnt[1] = pq->cnt[3] = 0u;
+                    __threadfence_system();
+                    __hip_atomic_store(pq->done, pq->round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
         }
         return;
     }
@@ -50,8 +62,8 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
     }
     if (threadIdx.x < (uint32_t)kPipeCache) sh.c_ready[threadIdx.x] = 0u;
     WalkSpace ws = {nullptr, nullptr, nullptr, 0u, 0u, 0u};
-    if constexpr (VISG) {
-        char* base = a.space + (size_t)blockIdx.x * a.space_stride;
+    {
+        char* base = pq ? pq->space : a.space + (size_t)blockIdx.x * a.space_stride;
         ws.bitmap = reinterpret_cast<uint32_t*>(base);
         ws.vlog = ws.bitmap + a.bitmap_words;
         ws.heap = reinterpret_cast<uint2*>(ws.vlog + a.vlog_cap);
@@ -60,10 +72,33 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
         ws.heap_cap = a.heap_cap;
     }
     const bool tomb = a.has_removed != 0;
-    const uint32_t* allow = a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
-    const uint32_t* known = a.known ? a.known + (size_t)qi * a.allow_stride : nullptr;
+    const uint32_t* allow = pq ? pq->allow : a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
+    const uint32_t* known = pq ? pq->known : a.known ? a.known + (size_t)qi * a.allow_stride : nullptr;
+    if (pq) {
+        // The round's exchange with the host, first half: the verdicts it gave for the slots the last round listed become bits of the
+        // query's device-resident bitmaps (the first round zeroes them instead).  Every wave takes part; the barriers of the descent
+        // that follows order it before the first verdict is read.
+        uint32_t* allow_w = pq->allow;
+        uint32_t* known_w = pq->known;
+        if (pq->zero_bits) {
+            for (uint32_t i = threadIdx.x; i < pq->words; i += 64u * kPipeTeam) {
+                allow_w[i] = 0u;
+                known_w[i] = 0u;
+            }
+        }
+        const uint32_t m = pq->apply_m;
+        for (uint32_t i = threadIdx.x; i < m; i += 64u * kPipeTeam) {
+            const uint32_t s = pq->list[i];
+            if (s < pq->slots) {
+                atomicOr(&known_w[s >> 5], 1u << (s & 31u));
+                if (pq->verdict[i]) atomicOr(&allow_w[s >> 5], 1u << (s & 31u));
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
     Query<AR, I> q;
-    query_from_f32<AR, I>(ix, a.queries + (size_t)qi * a.q_stride, q, lane);
+    query_from_f32<AR, I>(ix, query, q, lane);
     if (w != 0) {
         team_helper_loop<AR, I>(ix, q, sh, lane, w);  // the descent through the upper levels: the team form, with barriers
 #ifdef VS_PIPE_SOLO
@@ -83,23 +118,29 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
     team_release(sh, lane);  // the last barrier: from here on the waves meet through LDS words only
     PipeTop<EFCAP / 64> top;
     const PipeOut r = pipe_walk<AR, I, MODE>(ix, sh, pipe_pool, a.pipe_pool_cap, ws, start, start_d, a.ef, tomb, allow, known,
-                                       a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
-                                       a.unknown_count ? a.unknown_count + qi : nullptr, a.unknown_cap, a.unknown_budget,
-                                       a.consulted ? a.consulted + qi : nullptr, cnt, lane, top, a.debug ? a.debug + (size_t)qi * 12 : nullptr,
-                                       a.pipe_fused_order != 0u);
+                                       pq ? pq->list : a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
+                                       pq ? pq->cnt : a.unknown_count ? a.unknown_count + qi : nullptr, pq ? pq->cap : a.unknown_cap,
+                                       pq ? pq->budget : a.unknown_budget, pq ? pq->cnt + 1 : a.consulted ? a.consulted + qi : nullptr, cnt, lane, top,
+                                       a.debug ? a.debug + (size_t)qi * 12 : nullptr, a.pipe_fused_order != 0u);
     if (r.status == 1u) {  // the usearch-order walk answers it (and lists the verdicts IT misses: this walk's list is dropped)
         if (lane == 0) {
             if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;
-            a.out_found[qi] = kPipeRedo;
-            if (a.unknown_count) a.unknown_count[qi] = 0u;
-            if (a.consulted) a.consulted[qi] = 0u;
+            *found_out = kPipeRedo;
+            if (pq) {
+                pq->cnt[0] = pq->cnt[1] = 0u;
+                __threadfence_system();
+                __hip_atomic_store(pq->done, pq->round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                if (a.unknown_count) a.unknown_count[qi] = 0u;
+                if (a.consulted) a.consulted[qi] = 0u;
+            }
         }
         return;
     }
     // top.shrink(wanted): `top` holds admitted, live members only (a round that ran out of budget reports what it has; the host
     // looks at the listed slots first and walks again)
     constexpr uint32_t R = EFCAP / 64;
-    const uint32_t found = r.sz < a.k ? r.sz : a.k;
+    const uint32_t found = r.sz < k ? r.sz : k;
 #pragma unroll
     for (uint32_t j = 0; j < R; ++j) {
         const uint32_t pos = (uint32_t)lane * R + j;
@@ -108,15 +149,23 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
             od[pos] = top.d[j];
         }
     }
-    for (uint32_t i = found + (uint32_t)lane; i < a.k; i += kWave) {
+    for (uint32_t i = found + (uint32_t)lane; i < k; i += kWave) {
         ok[i] = kFreeKey;
         od[i] = __builtin_inff();
     }
     if (lane == 0) {
-        a.out_found[qi] = found;
+        *found_out = found;
         atomicAdd(&a.stats[ST_SEARCH_EVALS], cnt.evals);
         atomicAdd(&a.stats[ST_SEARCH_HOPS], cnt.hops);
         atomicAdd(&a.stats[ST_QUERIES], 1ull);
+        if (pq) pq->cnt[3] = (uint32_t)cnt.evals;
+    }
+    if (pq) {
+        // second half of the exchange: the answer, the counters and the list are in the caller's pinned block -- every lane's stores are
+        // out (the list's as well: pipe_walk drained them) before the flag says so
+        __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(pq->done, pq->round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -144,14 +193,14 @@ static hipError_t pipe_ef(const WalkArgs& a, hipStream_t s) {
     // one instance per purpose (pipe_device.hpp `MODE`): plain lone queries, the exact walk of a filtered query, its exploring rounds
     if (a.ef > 512) return hipErrorInvalidValue;
     if (a.pipe_explore) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeExplore>(a, s) : pipe_launch<AR, I, 512, kPipeExplore>(a, s);
-    if (a.allow) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeFiltered>(a, s) : pipe_launch<AR, I, 512, kPipeFiltered>(a, s);
+    if (a.allow || a.pipe_qtable) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeFiltered>(a, s) : pipe_launch<AR, I, 512, kPipeFiltered>(a, s);
     return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipePlain>(a, s) : pipe_launch<AR, I, 512, kPipePlain>(a, s);
 }
 
 template <>
 hipError_t launch_pipe_walk_ar<VS_AR>(const WalkArgs& a, uint32_t iters, hipStream_t s) {
     if (!a.nq) return hipSuccess;
-    if (a.ix.M0 > 64u || (!a.space && !a.pipe_lds_visited) || a.pipe_pool_cap < 256u) return hipErrorInvalidValue;
+    if (a.ix.M0 > 64u || (!a.space && !a.pipe_qtable) || a.pipe_pool_cap < 256u) return hipErrorInvalidValue;
     switch (iters) {
         case 1: return pipe_ef<VS_AR, 1>(a, s);
         case 2: return pipe_ef<VS_AR, 2>(a, s);

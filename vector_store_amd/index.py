@@ -96,6 +96,8 @@ def lib():
     L.vs_hnsw_memory_info.argtypes = [vp, vp]
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
     L.vs_hnsw_pipe_stats.argtypes = [vp, vp]
+    if hasattr(L, "vs_hnsw_filter_batch_stats"):
+        L.vs_hnsw_filter_batch_stats.argtypes = [vp, vp]
     if hasattr(L, "vs_hnsw_streams_created"):  # (VS_HNSW_LIB may name an older build: A/B measurements)
         L.vs_hnsw_streams_created.argtypes = []
         L.vs_hnsw_streams_created.restype = C.c_uint64
@@ -293,6 +295,11 @@ class HipUsearchIndex:
         out = np.zeros(2, dtype=np.uint64)
         _check(self.L.vs_hnsw_filter_stats(self.h, _p(out)))
         return {"lazy_rounds": int(out[0]), "lazy_predicate_calls": int(out[1])}
+
+    def filter_batch_stats(self) -> dict:
+        out = np.zeros(2, dtype=np.uint64)
+        _check(self.L.vs_hnsw_filter_batch_stats(self.h, _p(out)))
+        return {"batched_launches": int(out[0]), "batched_rounds": int(out[1])}
 
     def pipe_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)

@@ -1104,9 +1104,13 @@ struct Engine {
         // Lone queries on float indexes (the reference issues one query per FFI call, usearch.rs:212; the dispatcher hands over what
         // queued since the last launch): the pipelined walk (kernels_pipe.hip) instead of the team form of the fused-list kernel --
         // the walker decides on registers while the other waves measure candidates ahead of it.
+        // (up to 48 queries on the device: beyond that the team form of the fused-list kernel has the better throughput -- measured at
+        // 10M x 768 on one box, blocking callers 17 / 33 / 65: 13.7k / 26.5k / 47.3k QPS pipelined against 12.2k / 24.5k / 48.6k, and 16 x 16
+        // queries in flight 115k against 167k)
+        constexpr size_t kLonePipeMaxLoad = 48;
         static const bool lone_pipe_off = std::getenv("VS_HNSW_PIPE_LONE") && std::getenv("VS_HNSW_PIPE_LONE")[0] == '0';  // A/B measurements
         const bool lone_pipe = !allow && !global && !usearch_order() && !lone_pipe_off && pipe_usable(ef) && team_mode != 2 && team_mode != 3 &&
-                               std::max(nq, load) <= team_max_nq && !stress_small_table && !force_wide_tags;
+                               std::max(nq, load) <= kLonePipeMaxLoad && !stress_small_table && !force_wide_tags;
         if (global || usearch_order() || lone_pipe) {
             WalkArgs a;
             a.ix = view();

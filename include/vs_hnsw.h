@@ -161,7 +161,7 @@ VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
 VS_API int vs_hnsw_filter_batch_stats(vs_hnsw* index, uint64_t out[2]);
 
 /* Lone queries (one vector per call, usearch.rs:212 / :236) on float indexes take the pipelined walk (kernels_pipe.hip):
- * [0] launches of it so far for this index, [1] lone plain queries (process-wide) it handed over to the team kernels because two
+ * [0] walks of it so far for this index (launched, or posted to a pod), [1] lone plain queries (process-wide) it handed over to the team kernels because two
  * equal distances met where their order matters. */
 VS_API int vs_hnsw_pipe_stats(vs_hnsw* index, uint64_t out[2]);
 
@@ -169,6 +169,14 @@ VS_API int vs_hnsw_pipe_stats(vs_hnsw* index, uint64_t out[2]);
  * VS_HNSW_STREAMS says otherwise) shared by every index handle -- thousands of per-partition handles (usearch.rs:704-705,
  * 766-778) own none. */
 VS_API uint64_t vs_hnsw_streams_created(void);
+
+/* Pods (vector_store_amd/csrc/pipe_pod.hpp): blocking callers of vs_hnsw_search / vs_hnsw_filtered_search on float indexes -- one
+ * query per call (usearch.rs:212, :236), every filtered query on a thread of its own (:937-948) -- post their query to a workgroup of
+ * a resident launch of the pipelined walk instead of launching one: as many walks in flight as callers, no launch per query.
+ * [0] pods opened for this index so far, [1] queries / filter rounds its pods have served, [2] pods open on the index's device now,
+ * [3] 1 unless VS_HNSW_PODS=0; where the time of the plain queries posted on the device went: [4] their number, [5] ns inside the
+ * library, [6] of them waiting for the answer, [7] ns the workgroups spent on them by the device's clock. */
+VS_API int vs_hnsw_pod_stats(vs_hnsw* index, uint64_t out[8]);
 
 /* Exact search on float storage (cos / ip, k <= 64, >= 65,536 slots) nominates with split-bf16 MFMA tiles, re-scores the nominees
  * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's

@@ -42,6 +42,14 @@ print(f"n {n} ef {ef} slots {os.environ.get('VS_HNSW_SERVICE_SLOTS', 'default')}
 legs = [tuple(int(x) for x in leg.split("x")) for leg in sys.argv[5].split(",")] if len(sys.argv) > 5 else ((1, 1), (4, 1), (17, 1), (33, 1), (65, 1), (16, 16), (16, 256))
 for threads, inflight in legs:
     r = Res()
+    ps0 = ix.pod_stats() if hasattr(ix, "pod_stats") else None
     rc = L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], dim, k, truth.ctypes.data, threads, inflight, seconds, C.byref(r))
     print(f"  threads {threads:3d} x {inflight:3d} in flight: {r.qps:10.0f} QPS  min {r.latency_min_ns / 1e6:.3f} ms  agreement {r.recall_avg:.4f}  "
-          f"launches {r.launches} (team {r.team_launches})  queries/launch {r.queries / max(r.launches, 1):.1f}  rc {rc} errors {r.errors}", flush=True)
+          f"launches {r.launches} (team {r.team_launches})  queries/launch {r.queries / max(r.launches, 1):.1f}  rc {rc} errors {r.errors}  p50 {r.p50_ns / 1e6:.3f} p99 {r.p99_ns / 1e6:.3f} ms", flush=True)
+    if ps0 is not None:
+        ps1 = ix.pod_stats()
+        nq = ps1["plain_queries"] - ps0["plain_queries"]
+        if nq:
+            print(f"      posted to pods: {nq} queries; per query: {(ps1['plain_ns'] - ps0['plain_ns']) / nq / 1e3:.0f} us in the library, "
+                  f"{(ps1['plain_wait_ns'] - ps0['plain_wait_ns']) / nq / 1e3:.0f} us waiting, {(ps1['plain_device_ns'] - ps0['plain_device_ns']) / nq / 1e3:.0f} us on the device; "
+                  f"pods opened {ps1['pods_opened'] - ps0['pods_opened']}", flush=True)

@@ -28,6 +28,7 @@
 
 #include "../../include/vs_hnsw.h"
 #include "kernels.hpp"
+#include "pipe_pod.hpp"
 #include "filter_rounds.hpp"
 
 #define VS_VERSION "0.1.0"
@@ -371,6 +372,199 @@ struct Lease {
     WorkCtx* operator->() { return ctx.get(); }
 };
 
+// Cores this process may keep busy: the hardware's, or the cgroup's CPU quota when that is less (a container's quota is enforced per
+// 100 ms period: a crowd of callers that polls its way through the quota is stopped -- every thread at once -- until the period ends).
+static int usable_cores() {
+    static const int n = [] {
+        int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32] = {0};
+            long period = 0;
+            if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && quota[0] != 'm') hw = std::min<int>(hw, std::max<long>(1, std::atol(quota) / period));
+            std::fclose(f);
+        } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            long quota = -1, period = 100000;
+            if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
+            std::fclose(g);
+            if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(h, "%ld", &period) != 1) period = 100000;
+                std::fclose(h);
+            }
+            if (quota > 0 && period > 0) hw = std::min<int>(hw, std::max<long>(1, quota / period));
+        }
+        return hw;
+    }();
+    return n;
+}
+// A caller waiting for a flag the device sets (pinned memory): spinning while the waiting callers are few against the cores, otherwise
+// asleep for most of what such a wait took lately (`typical_us`, a moving average the caller keeps), then in short steps -- a handful
+// of wake-ups per wait instead of one every 20 us.  false: `limit_s` seconds have passed.
+template <class Ready>
+static bool wait_for_device_flag(Ready ready, std::atomic<int>& waiting, std::atomic<uint32_t>& typical_us, double limit_s) {
+    struct Count {
+        std::atomic<int>& w;
+        explicit Count(std::atomic<int>& x) : w(x) { w.fetch_add(1, std::memory_order_relaxed); }
+        ~Count() { w.fetch_sub(1, std::memory_order_relaxed); }
+    } count(waiting);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int spin_below = std::max(1, usable_cores() / 2);
+    bool slept = false;
+    for (uint32_t it = 0;; ++it) {
+        if (ready()) break;
+        if (waiting.load(std::memory_order_relaxed) <= spin_below) {
+            for (int p = 0; p < 8; ++p) __builtin_ia32_pause();
+        } else {
+            const uint32_t typ = typical_us.load(std::memory_order_relaxed);
+            uint32_t us = std::max<uint32_t>(20u, typ / 12u);
+            if (!slept && typ > 200u) {
+                const double gone = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                if (gone < 0.8 * typ) us = (uint32_t)(0.8 * typ - gone);
+            }
+            slept = true;
+            std::this_thread::sleep_for(std::chrono::microseconds(us));
+        }
+        if ((it & 63u) == 63u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) return false;
+    }
+    const uint32_t took = (uint32_t)std::min<double>(1e7, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    const uint32_t typ = typical_us.load(std::memory_order_relaxed);
+    typical_us.store(typ ? (typ * 7u + took) / 8u : took, std::memory_order_relaxed);
+    return true;
+}
+
+// ---- pods (pipe_pod.hpp): resident launches of the pipelined walk that blocking callers post their queries to ---------------------------
+// Up to kPods per device, each on a stream of its own (a pod never ends while it has callers: nothing else may queue behind it) and
+// kSlots workgroups wide -- 3 x 64 leaves a quarter of the chip to everything else, and every workgroup of an open pod is resident (a
+// workgroup that is not cannot poll its slot).  With the engine's 16 streams and the process's default stream that is the 20 hardware
+// queues the library asks for (HwQueuesDefault).  A keeper thread advances the pods' heartbeat, closes a pod that has been idle for
+// VS_HNSW_POD_IDLE_US (20 ms: the two kinds of round of a filtered query alternate) or open for VS_HNSW_POD_AGE_MS (250 ms: a
+// device-wide synchronisation anywhere in the process -- hipFree, hipDeviceSynchronize -- waits for every kernel, pods included), and
+// hands a closed pod back once every workgroup has said it left.  It makes no HIP call: it cannot be held up by one.
+struct Pod {
+    enum State { kFree, kOpen, kClosing };
+    static constexpr uint32_t kSlots = 64;
+    State state = kFree;
+    const void* owner = nullptr;  // the index whose view the launch carries
+    int mode = 0;                 // 0 = plain lone queries, 1 = the exact walk of a filtered query, 2 = its exploring rounds
+    uint32_t efcap = 0;           // 256 / 512: the kernel instance
+    size_t index_slots = 0;       // slots of the index when the pod was opened (its visited bitmaps are laid out for them)
+    hipStream_t st = nullptr;
+    PodCtl* ctl = nullptr;        // pinned
+    PodSlot* slots = nullptr;     // pinned
+    PipeQuery* stage = nullptr;   // device: workgroup b's copy of the query it is answering (what a batch launch reads from its table)
+    uint32_t n = 0, n_busy = 0;
+    uint64_t gen = 0;
+    bool busy[kSlots] = {};
+    uint32_t seq[kSlots] = {};
+    std::chrono::steady_clock::time_point opened, last_used;
+};
+struct PodTicket {
+    int pod = -1;
+    uint32_t slot = 0;
+    uint64_t gen = 0;  // which opening of the pod
+    explicit operator bool() const { return pod >= 0; }
+};
+struct PodPool {
+    static constexpr int kPods = 3;
+    std::mutex mu;
+    std::condition_variable keeper_cv;
+    Pod pods[kPods];
+    bool keeper_started = false;
+    bool enabled = true;
+    uint32_t n_slots = Pod::kSlots;
+    int idle_us = 20000, max_age_ms = 250;
+    std::atomic<uint64_t> n_opened{0}, n_served{0}, n_closed{0};
+    std::atomic<uint64_t> plain_queries{0}, plain_ns{0}, plain_wait_ns{0}, plain_gpu_ticks{0};  // where a posted plain query's time goes (probes)
+    PodPool() {
+        if (const char* v = std::getenv("VS_HNSW_PODS")) enabled = v[0] != '0';
+        if (const char* v = std::getenv("VS_HNSW_POD_SLOTS")) n_slots = (uint32_t)std::min<int>(Pod::kSlots, std::max(1, std::atoi(v)));
+        if (const char* v = std::getenv("VS_HNSW_POD_IDLE_US")) idle_us = std::max(100, std::atoi(v));
+        if (const char* v = std::getenv("VS_HNSW_POD_AGE_MS")) max_age_ms = std::max(10, std::atoi(v));
+    }
+    void close_locked(Pod& p) {
+        p.state = Pod::kClosing;
+        __atomic_store_n(&p.ctl->closed, 1u, __ATOMIC_SEQ_CST);
+        n_closed.fetch_add(1, std::memory_order_relaxed);
+    }
+    static bool all_left(const Pod& p) {
+        for (uint32_t i = 0; i < p.n; ++i)
+            if (!__atomic_load_n(&p.slots[i].left, __ATOMIC_ACQUIRE)) return false;
+        return true;
+    }
+    void keep() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            bool any = false;
+            const auto now = std::chrono::steady_clock::now();
+            for (Pod& p : pods) {
+                if (p.state != Pod::kFree) __atomic_fetch_add(&p.ctl->heartbeat, 1u, __ATOMIC_RELAXED);
+                if (p.state == Pod::kOpen && ((p.n_busy == 0 && now - p.last_used > std::chrono::microseconds(idle_us)) ||
+                                              now - p.opened > std::chrono::milliseconds(max_age_ms)))
+                    close_locked(p);
+                if (p.state == Pod::kClosing && p.n_busy == 0 && all_left(p)) p.state = Pod::kFree;
+                any |= p.state != Pod::kFree;
+            }
+            if (!any) {
+                keeper_cv.wait(lk);
+                continue;
+            }
+            lk.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+            lk.lock();
+        }
+    }
+    // Close the pods of one index (nullptr: all of them) and wait until their workgroups have left: before anything that changes the
+    // index's view, and before a device-wide synchronisation.
+    void quiesce(const void* owner) {
+        std::unique_lock<std::mutex> lk(mu);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            bool pending = false;
+            for (Pod& p : pods) {
+                if (p.state == Pod::kFree || (owner && p.owner != owner)) continue;
+                if (p.state == Pod::kOpen) close_locked(p);
+                if (p.n_busy == 0 && all_left(p)) p.state = Pod::kFree;
+                else pending = true;
+            }
+            if (!pending) return;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) fail(VS_ERR_DEVICE, "a pod of resident walks did not close");
+            lk.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            lk.lock();
+        }
+    }
+    void release(PodTicket t) {
+        std::lock_guard<std::mutex> g(mu);
+        Pod& p = pods[t.pod];
+        if (p.gen != t.gen) return;
+        p.busy[t.slot] = false;
+        --p.n_busy;
+        p.last_used = std::chrono::steady_clock::now();
+    }
+};
+static PodPool& pod_pool(int dev) {
+    static std::mutex mu;
+    static std::unordered_map<int, PodPool*> all;  // leaked with the process (the keeper thread outlives static teardown)
+    std::lock_guard<std::mutex> g(mu);
+    PodPool*& p = all[dev];
+    if (!p) {
+        p = new PodPool();
+        static std::once_flag at_exit;
+        std::call_once(at_exit, [] {
+            std::atexit([] {  // the runtime's teardown waits for every kernel: tell the pods to go first
+                std::lock_guard<std::mutex> g2(mu);
+                for (auto& kv : all) {
+                    try {
+                        kv.second->enabled = false;
+                        kv.second->quiesce(nullptr);
+                    } catch (...) {
+                    }
+                }
+            });
+        });
+    }
+    return *p;
+}
+
 // Workspace of the usearch-order walk kernels (kernels_walk.hip), one per (device, stream): launches on one stream
 // run one after the other and may share it; hipFree synchronises the device, so growing it is safe.
 struct WalkRes {
@@ -539,6 +733,10 @@ struct Engine {
 
     ~Engine() {
         (void)hipSetDevice(device);
+        try {
+            pod_pool(device).quiesce(nullptr);
+        } catch (...) {
+        }
         (void)hipDeviceSynchronize();
         for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) a->release();
         if (d_rho) (void)hipFree(d_rho);
@@ -660,6 +858,7 @@ struct Engine {
             fail(VS_ERR_UNSUPPORTED, "capacity above 2^29 slots needs expansion_add <= 128 (or several shards, include/vs_shards.h)");
         if (cap == capacity) return;
         std::unique_lock<std::shared_mutex> vg(view_mu);
+        pod_pool(device).quiesce(nullptr);
         HIP_OK(hipDeviceSynchronize());
         // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
         // coexist with the old ones while rows are copied across.
@@ -688,6 +887,7 @@ struct Engine {
 
     void ensure_upper_locked(size_t blocks) {  // view_mu held exclusively
         if (blocks <= upper_cap) return;
+        pod_pool(device).quiesce(nullptr);
         HIP_OK(hipDeviceSynchronize());
         size_t ncap = std::max(blocks, upper_cap * 2);
         regrow(ar_upper, d_upper, upper_cap * M, ncap * M, 0xFF);
@@ -713,6 +913,7 @@ struct Engine {
         if (!n) return;
         std::lock_guard<std::mutex> g(mod_mu);
         use_device();
+        pods_quiesce();  // (searches do not overlap adds: usearch.rs:590-612 -- a pod carries the view it was opened with)
         Lease w(device);
         hipStream_t st = w->stream;
         for (size_t c0 = 0; c0 < n; c0 += chunk_rows) {
@@ -1037,6 +1238,7 @@ struct Engine {
     bool remove(uint64_t key) {
         std::lock_guard<std::mutex> g(mod_mu);
         use_device();
+        pods_quiesce();
         uint32_t slot;
         {
             std::lock_guard<std::mutex> kg(key_mu);
@@ -1523,6 +1725,7 @@ struct Engine {
 
     // One query per FFI call (reference usearch.rs:212): handled by the per-device SearchService below.
     int search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found);
+    bool search_one_pod(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found);
     void search_async(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found,
                       void (*cb)(void*, int), void* ctx);
 
@@ -1650,6 +1853,109 @@ struct Engine {
     FilterBatcher batcher;
     static constexpr uint32_t kBatchVlogCap = 1u << 16, kBatchHeapCap = 1u << 18;
     size_t batch_space_bytes(size_t n_slots) const { return walk_space_stride((uint32_t)((n_slots + 31) / 32), kBatchVlogCap, kBatchHeapCap); }
+
+    // ---- pods (pipe_pod.hpp): the round is posted to a resident workgroup instead of being launched ---------------------------------
+    std::atomic<uint64_t> pod_rounds{0}, pod_opens{0};
+    std::atomic<uint32_t> wait_typical_us[3] = {};  // how long this index's callers lately waited for a plain query / an exact filtered walk / an exploring round
+    // Post one query / round (mode: 0 plain, 1 exact filtered walk, 2 exploring round) to a pod of this index; no ticket: no pod can
+    // take it now (the caller launches as before).  `n`: the index's slots, as the caller's workspace is laid out for.
+    PodTicket pod_submit(int mode, uint32_t ef, size_t n, const PipeQuery& pq) {
+        PodPool& pp = pod_pool(device);
+        if (!pp.enabled || ef > 512) return {};
+        const uint32_t efcap = ef <= 256 ? 256u : 512u;
+        std::lock_guard<std::mutex> g(pp.mu);
+        int use = -1, free_pod = -1;
+        for (int i = 0; i < PodPool::kPods && use < 0; ++i) {
+            Pod& p = pp.pods[i];
+            if (p.state == Pod::kOpen && p.owner == this && p.mode == mode && p.efcap == efcap && p.index_slots == n && p.n_busy < p.n) use = i;
+            if (p.state == Pod::kFree && free_pod < 0) free_pod = i;
+        }
+        if (use < 0) {
+            if (free_pod < 0) return {};
+            Pod& p = pp.pods[free_pod];
+            use_device();
+            if (!p.st) {
+                HIP_OK(hipStreamCreateWithFlags(&p.st, hipStreamNonBlocking));
+                g_streams_created.fetch_add(1, std::memory_order_relaxed);
+                HIP_OK(hipHostMalloc((void**)&p.ctl, sizeof(PodCtl), hipHostMallocDefault));
+                HIP_OK(hipHostMalloc((void**)&p.slots, sizeof(PodSlot) * Pod::kSlots, hipHostMallocDefault));
+                HIP_OK(hipMalloc((void**)&p.stage, sizeof(PipeQuery) * Pod::kSlots));
+            }
+            std::memset(p.ctl, 0, sizeof(PodCtl));
+            std::memset(p.slots, 0, sizeof(PodSlot) * Pod::kSlots);
+            std::memset(p.busy, 0, sizeof(p.busy));
+            std::memset(p.seq, 0, sizeof(p.seq));
+            p.n = pp.n_slots;
+            p.n_busy = 0;
+            ++p.gen;
+            WalkArgs a{};
+            {
+                std::shared_lock<std::shared_mutex> vg(view_mu);
+                a.ix = view();
+            }
+            a.nq = p.n;
+            a.ef = efcap;  // (the instance; a query's own beam travels in its slot)
+            a.k = 0;
+            a.has_removed = removed.load() ? 1u : 0u;
+            a.bitmap_words = (uint32_t)((n + 31) / 32);
+            a.vlog_cap = kBatchVlogCap;
+            a.heap_cap = kBatchHeapCap;
+            a.stats = d_stats;
+            a.pipe_qtable = p.stage;
+            a.pipe_explore = mode == 2 ? 1u : 0u;
+            a.pipe_fused_order = mode == 0 ? 1u : 0u;
+            a.pipe_pool_cap = 12288u;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            HIP_OK(launch_pipe_pod(a, iters, p.st, p.slots, p.ctl));
+            p.state = Pod::kOpen;
+            p.owner = this;
+            p.mode = mode;
+            p.efcap = efcap;
+            p.index_slots = n;
+            p.opened = p.last_used = std::chrono::steady_clock::now();
+            pp.n_opened.fetch_add(1, std::memory_order_relaxed);
+            pod_opens.fetch_add(1, std::memory_order_relaxed);
+            if (!pp.keeper_started) {
+                pp.keeper_started = true;
+                std::thread([&pp] { pp.keep(); }).detach();
+            }
+            pp.keeper_cv.notify_all();
+            use = free_pod;
+        }
+        Pod& p = pp.pods[use];
+        uint32_t slot = 0;
+        while (slot < p.n && p.busy[slot]) ++slot;
+        if (slot >= p.n) return {};
+        if (__atomic_load_n(&p.slots[slot].left, __ATOMIC_ACQUIRE)) {  // its workgroup has gone (the host stood still for seconds): no more posts
+            pp.close_locked(p);
+            return {};
+        }
+        PodSlot& sl = p.slots[slot];
+        sl.q = pq;
+        sl.ef = ef;
+        __atomic_store_n(&sl.posted, ++p.seq[slot], __ATOMIC_RELEASE);
+        p.busy[slot] = true;
+        ++p.n_busy;
+        p.last_used = std::chrono::steady_clock::now();
+        pp.n_served.fetch_add(1, std::memory_order_relaxed);
+        pod_rounds.fetch_add(1, std::memory_order_relaxed);
+        pipe_launches.fetch_add(1, std::memory_order_relaxed);  // (walks of the pipelined kernel: launched or posted)
+        PodTicket t;
+        t.pod = use;
+        t.slot = slot;
+        t.gen = p.gen;
+        return t;
+    }
+    struct PodRelease {  // the slot is free for the next caller once this one has its answer (or has given up on it)
+        int device;
+        PodTicket t;
+        void done() {
+            if (t) pod_pool(device).release(t);
+            t = PodTicket{};
+        }
+        ~PodRelease() { done(); }
+    };
+    void pods_quiesce() { pod_pool(device).quiesce(this); }  // before anything that changes the view (entry point, arenas, removed flag)
 
     void launch_rounds(std::vector<FilterBatcher::Req>& take, size_t n_slots) {
         FilterBatcher& b = batcher;
@@ -1863,17 +2169,13 @@ struct Engine {
             pq.done = h_done;
             pq.space = (char*)w->ws.p;
             __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
-            submit_round(pq, explore, ef, n);
-            // wait for the kernel's flag: spinning while every caller has a core, in short sleeps beyond that
-            static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
-            for (uint32_t spins = 0; __atomic_load_n(h_done, __ATOMIC_ACQUIRE) != pq.round_id; ++spins) {
-                if (spins < 2000 && filtered_active_callers.load(std::memory_order_relaxed) <= cores) {
-                    __builtin_ia32_pause();
-                } else {
-                    std::this_thread::sleep_for(std::chrono::microseconds(50));
-                }
-                if (spins > 400000) fail(VS_ERR_DEVICE, "a batched filtered round did not finish");  // (20 s)
-            }
+            PodRelease pod{device, pod_submit(explore ? 2 : 1, ef, n, pq)};
+            if (!pod.t) submit_round(pq, explore, ef, n);
+            // wait for the kernel's flag (the two kinds of round take different times: one moving average each)
+            static std::atomic<int> waiting{0};
+            if (!wait_for_device_flag([&] { return __atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id; }, waiting, wait_typical_us[explore ? 2 : 1], 20.0))
+                fail(VS_ERR_DEVICE, "a batched filtered round did not finish");
+            pod.done();
             const uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
             if (found == kPipeRedoFound) return (size_t)-1;
             if (count == 0 && !explore) {
@@ -1924,7 +2226,9 @@ struct Engine {
             check_search(k, ef_b);
             const bool crowd = filtered_active_callers.load(std::memory_order_relaxed) > device_streams(device).count + 8;
             const bool short_walks = lazy_need_hint.load() != 0 && lazy_need_hint.load() < 20000u;
-            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || (crowd && short_walks))) {
+            // With pods (pipe_pod.hpp) a round is posted to a resident workgroup -- no launch, no stream to wait for -- whatever the crowd.
+            const bool pods = pod_pool(device).enabled;
+            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || pods || (crowd && short_walks))) {
                 const size_t f = filtered_batched(q, k, pred, pctx, keys, dist, ef_b);
                 if (f != (size_t)-1) return f;
                 // (two equal distances met where their order matters, or the launch failed: the query starts over on rounds of its own,
@@ -2476,7 +2780,106 @@ void Engine::search_async(const float* q, size_t k, uint64_t* keys, float* dist,
     SearchService::get(device).submit(std::move(r));
 }
 
+// A lone plain query through a pod (pipe_pod.hpp): posted to a resident workgroup from the caller's own thread -- no dispatcher hop, no
+// launch, no event -- and answered into the caller's pinned block.  false: not served here (no pod free, or not a query the pipelined
+// walk takes): the dispatcher serves it.
+bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
+    uint32_t ef;
+    check_search(k, ef);
+    if (!pod_pool(device).enabled || needs_global_walk(ef) || usearch_order() || !pipe_usable(ef) || team_mode == 2 || team_mode == 3 ||
+        stress_small_table || force_wide_tags)
+        return false;
+    use_device();
+    size_t n;
+    {
+        std::lock_guard<std::mutex> g(mod_mu);
+        n = slots;
+    }
+    if (!n) return false;
+    Lease w(device);
+    const size_t space = batch_space_bytes(n);
+    if (w->ws.bytes < space || w->ws_zeroed != space) {
+        char* p = (char*)w->ws.ensure(space);
+        HIP_OK(hipMemsetAsync(p, 0, w->ws.bytes, w->stream));
+        HIP_OK(hipStreamSynchronize(w->stream));
+        w->ws_zeroed = space;
+    }
+    // pinned, device-mapped: [counters, flag 64 B | keys k x 8 | dist k x 4 | the query]
+    const size_t q_off = (64 + k * 12 + 63) & ~(size_t)63;
+    const size_t pin_need = q_off + (size_t)dim * 4;
+    if (w->pin_bytes < pin_need) {
+        if (w->pin) (void)hipHostFree(w->pin);
+        w->pin = nullptr;
+        w->pin_bytes = 0;
+        HIP_OK(hipHostMalloc((void**)&w->pin, pin_need, hipHostMallocDefault));
+        w->pin_bytes = pin_need;
+    }
+    uint32_t* h_cnt = (uint32_t*)w->pin;
+    uint32_t* h_done = (uint32_t*)w->pin + 8;
+    uint64_t* h_k = (uint64_t*)(w->pin + 64);
+    float* h_d = (float*)(h_k + k);
+    float* h_q = (float*)(w->pin + q_off);
+    std::memcpy(h_q, q, (size_t)dim * 4);
+    PipeQuery pq{};
+    pq.query = h_q;
+    pq.slots = (uint32_t)n;
+    pq.k = (uint32_t)k;
+    pq.round_id = ++w->round_seq ? w->round_seq : ++w->round_seq;
+    pq.cnt = h_cnt;
+    pq.keys = h_k;
+    pq.dist = h_d;
+    pq.done = h_done;
+    pq.space = (char*)w->ws.p;
+    __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
+    const auto t_in = std::chrono::steady_clock::now();
+    PodRelease pod{device, pod_submit(0, ef, n, pq)};
+    if (!pod.t) return false;
+    const int dbg_pod = pod.t.pod;
+    const uint32_t dbg_slot = pod.t.slot;
+    const uint64_t dbg_gen = pod.t.gen;
+    const double dbg_age_ms = std::chrono::duration<double, std::milli>(t_in - pod_pool(device).pods[dbg_pod].opened).count();
+    // (a walk is the better part of a millisecond)
+    static std::atomic<int> waiting{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!wait_for_device_flag([&] { return __atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id; }, waiting, wait_typical_us[0], 20.0))
+        fail(VS_ERR_DEVICE, "a posted query was not answered");
+    pod.done();
+    {
+        PodPool& pp = pod_pool(device);
+        const auto t_out = std::chrono::steady_clock::now();
+        pp.plain_queries.fetch_add(1, std::memory_order_relaxed);
+        pp.plain_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_out - t_in).count(), std::memory_order_relaxed);
+        pp.plain_wait_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_out - t0).count(), std::memory_order_relaxed);
+        pp.plain_gpu_ticks.fetch_add(h_cnt[4], std::memory_order_relaxed);
+        static const bool pod_debug = std::getenv("VS_HNSW_POD_DEBUG") != nullptr;
+        const double wait_us = std::chrono::duration<double, std::micro>(t_out - t0).count();
+        if (pod_debug && wait_us - h_cnt[4] * 0.01 > 3000.0)
+            fprintf(stderr, "[pod] slow answer: waited %.0f us, device %.0f us, pod %d slot %u gen %llu, %.1f ms after the pod was opened\n", wait_us, h_cnt[4] * 0.01,
+                    dbg_pod, dbg_slot, (unsigned long long)dbg_gen, dbg_age_ms);
+    }
+    const uint32_t f = h_cnt[2];
+    if (f == kPipeRedoFound || f == kWalkFailed) {
+        // two equal distances met where their order matters: the team form of the fused-list kernel answers, as for a batch
+        struct NoPipe {
+            NoPipe() { tl_no_pipe = true; }
+            ~NoPipe() { tl_no_pipe = false; }
+        } no_pipe_here;
+        size_t ff = 0;
+        search_host(q, 1, k, keys, dist, &ff, false);
+        if (ff == (size_t)-1) ff = rank_all(q, k, keys, dist);
+        *found = ff;
+        if (f == kPipeRedoFound) SearchService::n_pipe_redone += 1;
+        return true;
+    }
+    const size_t ff = std::min<size_t>(f, k);
+    std::memcpy(keys, h_k, ff * 8);
+    std::memcpy(dist, h_d, ff * 4);
+    *found = ff;
+    return true;
+}
+
 int Engine::search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
+    if (search_one_pod(q, k, keys, dist, found)) return VS_OK;
     struct Waiter {
         std::mutex m;
         std::condition_variable c;
@@ -2728,6 +3131,7 @@ int vs_hnsw_stats(vs_hnsw* h, uint64_t out[8], int reset) {
         need(h && out, "null argument");
         h->e.flush_pending();
         h->e.use_device();
+        vs::pod_pool(h->e.device).quiesce(nullptr);
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemcpy(out, h->e.d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         if (reset) HIP_OK(hipMemset(h->e.d_stats, 0, 8 * sizeof(uint64_t)));
@@ -2775,6 +3179,20 @@ int vs_hnsw_filter_batch_stats(vs_hnsw* h, uint64_t out[2]) {
 }
 
 uint64_t vs_hnsw_streams_created(void) { return vs::g_streams_created.load(); }
+
+int vs_hnsw_pod_stats(vs_hnsw* h, uint64_t out[8]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    vs::PodPool& pp = vs::pod_pool(h->e.device);
+    out[0] = h->e.pod_opens.load();
+    out[1] = h->e.pod_rounds.load();
+    out[2] = pp.n_opened.load() - pp.n_closed.load();
+    out[3] = pp.enabled ? 1 : 0;
+    out[4] = pp.plain_queries.load();
+    out[5] = pp.plain_ns.load();
+    out[6] = pp.plain_wait_ns.load();
+    out[7] = pp.plain_gpu_ticks.load() * 10;
+    return VS_OK;
+}
 
 int vs_hnsw_pipe_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
@@ -2829,6 +3247,7 @@ int vs_hnsw_export_graph(vs_hnsw* h, void* vectors, int32_t* levels, uint64_t* k
         e.flush_pending();
         std::lock_guard<std::mutex> g(e.mod_mu);
         e.use_device();
+        vs::pod_pool(e.device).quiesce(nullptr);
         HIP_OK(hipDeviceSynchronize());
         const size_t n = e.slots;
         if (!n) return;
@@ -2855,6 +3274,7 @@ int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const void* vectors, const int32_
         need(h && (n == 0 || (vectors && levels && keys && adj0 && upper_off)), "null argument");
         Engine& e = h->e;
         need(e.slots == 0, "import needs an empty index");
+        e.pods_quiesce();
         if (n > e.capacity) e.reserve(n);
         std::lock_guard<std::mutex> g(e.mod_mu);
         e.use_device();

@@ -5,6 +5,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "kernels.hpp"
+#include "pipe_pod.hpp"
 
 namespace vs {
 
@@ -82,6 +83,19 @@ hipError_t launch_pipe_walk(const WalkArgs& a, uint32_t iters, hipStream_t s) {
         case AR_F16_L2: return launch_pipe_walk_ar<AR_F16_L2>(a, iters, s);
         case AR_BF16_DOT: return launch_pipe_walk_ar<AR_BF16_DOT>(a, iters, s);
         case AR_BF16_L2: return launch_pipe_walk_ar<AR_BF16_L2>(a, iters, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_pipe_pod(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl) {
+    if (!pipe_walk_supported(a.ix, iters, a.ef)) return hipErrorInvalidValue;
+    switch (arith_of(a.ix.scalar, a.ix.metric)) {
+        case AR_F32_DOT: return launch_pipe_pod_ar<AR_F32_DOT>(a, iters, s, slots, ctl);
+        case AR_F32_L2: return launch_pipe_pod_ar<AR_F32_L2>(a, iters, s, slots, ctl);
+        case AR_F16_DOT: return launch_pipe_pod_ar<AR_F16_DOT>(a, iters, s, slots, ctl);
+        case AR_F16_L2: return launch_pipe_pod_ar<AR_F16_L2>(a, iters, s, slots, ctl);
+        case AR_BF16_DOT: return launch_pipe_pod_ar<AR_BF16_DOT>(a, iters, s, slots, ctl);
+        case AR_BF16_L2: return launch_pipe_pod_ar<AR_BF16_L2>(a, iters, s, slots, ctl);
         default: return hipErrorInvalidValue;
     }
 }

@@ -8,6 +8,7 @@
 
 #include "kernels.hpp"
 #include "pipe_device.hpp"
+#include "pipe_pod.hpp"
 
 #ifndef VS_AR
 #error "compile with -DVS_AR=<arithmetic>"
@@ -15,27 +16,43 @@
 
 namespace vs {
 
-template <int AR, int I, int EFCAP, int MODE>
-__global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs a) {
-    constexpr bool VISG = true;
-    using Sh = PipeShared<EFCAP, kPipeTeam, false, VISG>;
-    __shared__ Sh sh;
-    extern __shared__ uint2 pipe_pool[];
-    const IndexView& ix = a.ix;
-    const int lane = lane_id();
-    const uint32_t w = threadIdx.x >> 6;
-    uint32_t qi = blockIdx.x;
-    if (a.qlist) {  // second-chance launches name their queries
-        if (qi >= *a.qcount) return;
-        qi = a.qlist[qi];
+// A value every lane of the wave holds alike, moved to scalar registers (a pod's staging entry is written by the kernel itself, so its
+// fields come through vector loads: left in vector registers, a dozen uniform pointers push the walker's working set into scratch).
+template <class T>
+__device__ __forceinline__ T uni(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two registers");
+    if constexpr (sizeof(T) == 4) {
+        union {
+            T v;
+            int w;
+        } u;
+        u.v = v;
+        u.w = __builtin_amdgcn_readfirstlane(u.w);
+        return u.v;
+    } else {
+        union {
+            T v;
+            int w[2];
+        } u;
+        u.v = v;
+        u.w[0] = __builtin_amdgcn_readfirstlane(u.w[0]);
+        u.w[1] = __builtin_amdgcn_readfirstlane(u.w[1]);
+        return u.v;
     }
-    // this query's buffers: the strided arrays of WalkArgs, or its entry of the batch table
-    const PipeQuery* pq = a.pipe_qtable ? a.pipe_qtable + blockIdx.x : nullptr;
-    const float* query = pq ? pq->query : a.queries + (size_t)qi * a.q_stride;
-    const uint32_t k = pq ? pq->k : a.k;
-    uint64_t* ok = pq ? pq->keys : a.out_keys + (size_t)qi * a.k;
-    float* od = pq ? pq->dist : a.out_dist + (size_t)qi * a.k;
-    uint32_t* found_out = pq ? pq->cnt + 2 : a.out_found + qi;
+}
+
+// One query, one workgroup.  Its buffers: the strided arrays of WalkArgs (query `qi`), or -- `pq` -- its entry of the batch table.
+template <int AR, int I, int EFCAP, int MODE, class Sh>
+__device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* pq, uint32_t qi, uint32_t ef, Sh& sh, uint2* pipe_pool, const uint32_t tid,
+                                           const uint32_t bid, const uint64_t t_begin) {
+    const IndexView& ix = a.ix;
+    const int lane = (int)(tid & 63u);
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const float* query = pq ? uni(pq->query) : a.queries + (size_t)qi * a.q_stride;
+    const uint32_t k = pq ? uni(pq->k) : a.k;
+    uint64_t* ok = pq ? uni(pq->keys) : a.out_keys + (size_t)qi * a.k;
+    float* od = pq ? uni(pq->dist) : a.out_dist + (size_t)qi * a.k;
+    uint32_t* found_out = pq ? uni(pq->cnt) + 2 : a.out_found + qi;
     if (ix.max_level < 0) {  // empty index
         if (w == 0) {
             for (uint32_t i = lane; i < k; i += kWave) {
@@ -45,25 +62,25 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
             if (lane == 0) {
                 *found_out = 0;
                 if (pq) {
-                    pq->cnt[0] = pq->cnt[1] = pq->cnt[3] = 0u;
+                    uni(pq->cnt)[0] = uni(pq->cnt)[1] = uni(pq->cnt)[3] = 0u;
                     __threadfence_system();
-                    __hip_atomic_store(pq->done, pq->round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(uni(pq->done), uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }
         return;
     }
-    if (threadIdx.x < (uint32_t)kPipeTeam) {
-        sh.job_state[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) {
+    if (tid < (uint32_t)kPipeTeam) {
+        sh.job_state[tid] = 0u;
+        if (tid == 0) {
             sh.stop = 0u;
             sh.prof_jobs[0] = sh.prof_jobs[1] = 0u;
         }
     }
-    if (threadIdx.x < (uint32_t)kPipeCache) sh.c_ready[threadIdx.x] = 0u;
+    if (tid < (uint32_t)kPipeCache) sh.c_ready[tid] = 0u;
     WalkSpace ws = {nullptr, nullptr, nullptr, 0u, 0u, 0u};
     {
-        char* base = pq ? pq->space : a.space + (size_t)blockIdx.x * a.space_stride;
+        char* base = pq ? uni(pq->space) : a.space + (size_t)bid * a.space_stride;
         ws.bitmap = reinterpret_cast<uint32_t*>(base);
         ws.vlog = ws.bitmap + a.bitmap_words;
         ws.heap = reinterpret_cast<uint2*>(ws.vlog + a.vlog_cap);
@@ -72,26 +89,26 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
         ws.heap_cap = a.heap_cap;
     }
     const bool tomb = a.has_removed != 0;
-    const uint32_t* allow = pq ? pq->allow : a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
-    const uint32_t* known = pq ? pq->known : a.known ? a.known + (size_t)qi * a.allow_stride : nullptr;
+    const uint32_t* allow = pq ? uni(pq->allow) : a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
+    const uint32_t* known = pq ? uni(pq->known) : a.known ? a.known + (size_t)qi * a.allow_stride : nullptr;
     if (pq) {
         // The round's exchange with the host, first half: the verdicts it gave for the slots the last round listed become bits of the
         // query's device-resident bitmaps (the first round zeroes them instead).  Every wave takes part; the barriers of the descent
         // that follows order it before the first verdict is read.
-        uint32_t* allow_w = pq->allow;
-        uint32_t* known_w = pq->known;
-        if (pq->zero_bits) {
-            for (uint32_t i = threadIdx.x; i < pq->words; i += 64u * kPipeTeam) {
+        uint32_t* allow_w = uni(pq->allow);
+        uint32_t* known_w = uni(pq->known);
+        if (uni(pq->zero_bits)) {
+            for (uint32_t i = tid; i < uni(pq->words); i += 64u * kPipeTeam) {
                 allow_w[i] = 0u;
                 known_w[i] = 0u;
             }
         }
-        const uint32_t m = pq->apply_m;
-        for (uint32_t i = threadIdx.x; i < m; i += 64u * kPipeTeam) {
-            const uint32_t s = pq->list[i];
-            if (s < pq->slots) {
+        const uint32_t m = uni(pq->apply_m);
+        for (uint32_t i = tid; i < m; i += 64u * kPipeTeam) {
+            const uint32_t s = uni(pq->list)[i];
+            if (s < uni(pq->slots)) {
                 atomicOr(&known_w[s >> 5], 1u << (s & 31u));
-                if (pq->verdict[i]) atomicOr(&allow_w[s >> 5], 1u << (s & 31u));
+                if (uni(pq->verdict)[i]) atomicOr(&allow_w[s >> 5], 1u << (s & 31u));
             }
         }
         __threadfence();
@@ -117,19 +134,19 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
     [[clang::always_inline]] start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane, &start_d);
     team_release(sh, lane);  // the last barrier: from here on the waves meet through LDS words only
     PipeTop<EFCAP / 64> top;
-    const PipeOut r = pipe_walk<AR, I, MODE>(ix, sh, pipe_pool, a.pipe_pool_cap, ws, start, start_d, a.ef, tomb, allow, known,
-                                       pq ? pq->list : a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
-                                       pq ? pq->cnt : a.unknown_count ? a.unknown_count + qi : nullptr, pq ? pq->cap : a.unknown_cap,
-                                       pq ? pq->budget : a.unknown_budget, pq ? pq->cnt + 1 : a.consulted ? a.consulted + qi : nullptr, cnt, lane, top,
+    const PipeOut r = pipe_walk<AR, I, MODE>(ix, sh, pipe_pool, a.pipe_pool_cap, ws, start, start_d, ef, tomb, allow, known,
+                                       pq ? uni(pq->list) : a.unknown_list ? a.unknown_list + (size_t)qi * a.unknown_cap : nullptr,
+                                       pq ? uni(pq->cnt) : a.unknown_count ? a.unknown_count + qi : nullptr, pq ? uni(pq->cap) : a.unknown_cap,
+                                       pq ? uni(pq->budget) : a.unknown_budget, pq ? uni(pq->cnt) + 1 : a.consulted ? a.consulted + qi : nullptr, cnt, lane, top,
                                        a.debug ? a.debug + (size_t)qi * 12 : nullptr, a.pipe_fused_order != 0u);
     if (r.status == 1u) {  // the usearch-order walk answers it (and lists the verdicts IT misses: this walk's list is dropped)
         if (lane == 0) {
             if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;
             *found_out = kPipeRedo;
             if (pq) {
-                pq->cnt[0] = pq->cnt[1] = 0u;
+                uni(pq->cnt)[0] = uni(pq->cnt)[1] = 0u;
                 __threadfence_system();
-                __hip_atomic_store(pq->done, pq->round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(uni(pq->done), uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
                 if (a.unknown_count) a.unknown_count[qi] = 0u;
                 if (a.consulted) a.consulted[qi] = 0u;
@@ -158,19 +175,124 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(WalkArgs
         atomicAdd(&a.stats[ST_SEARCH_EVALS], cnt.evals);
         atomicAdd(&a.stats[ST_SEARCH_HOPS], cnt.hops);
         atomicAdd(&a.stats[ST_QUERIES], 1ull);
-        if (pq) pq->cnt[3] = (uint32_t)cnt.evals;
+        if (pq) {
+            uni(pq->cnt)[3] = (uint32_t)cnt.evals;
+            uni(pq->cnt)[4] = (uint32_t)(wall_clock64() - t_begin);  // 100 MHz ticks from the moment the query was seen (a launch: from its start)
+        }
     }
     if (pq) {
         // second half of the exchange: the answer, the counters and the list are in the caller's pinned block -- every lane's stores are
         // out (the list's as well: pipe_walk drained them) before the flag says so
         __threadfence_system();
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) __hip_atomic_store(pq->done, pq->round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) __hip_atomic_store(uni(pq->done), uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// `slots` == nullptr: one query per workgroup, then done.  Else a POD (pipe_pod.hpp): workgroup b serves slot b -- a line of pinned host
+// memory a caller posts its query to -- until the host closes the pod; a.pipe_qtable is then the pod's staging table in device memory
+// (entry b: this workgroup's copy of the posted PipeQuery, which the walk reads exactly as it reads a batch table's entry).
+struct PipeKernArgs {
+    WalkArgs a;
+    PodSlot* slots;
+    PodCtl* ctl;
+};
+
+template <int AR, int I, int EFCAP, int MODE>
+__global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKernArgs ka_unused) {
+    constexpr bool VISG = true;
+    using Sh = PipeShared<EFCAP, kPipeTeam, false, VISG>;
+    __shared__ Sh sh;
+    extern __shared__ uint2 pipe_pool[];
+    __shared__ uint32_t pod_cmd[2];
+    uint32_t seen = 0;
+    for (;;) {
+        // The kernel's arguments, read from the argument segment INSIDE the loop (the offset is opaque to the compiler): hoisted out of
+        // it, every argument and every address derived from one stays live through the whole walk -- 150 more scalar registers than
+        // there are, spilled through vector registers into scratch memory, and a walk twice as slow.
+        uint32_t zero;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        const PipeKernArgs& ka = *reinterpret_cast<const PipeKernArgs*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + zero);
+        const WalkArgs& a = ka.a;
+        PodSlot* const slots = ka.slots;
+        PodCtl* const ctl = ka.ctl;
+        // (the same for everything derived from the thread's and the workgroup's number: lane masks, offsets, predicates)
+        uint32_t tid = threadIdx.x, bid = blockIdx.x;
+        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+s"(bid));
+        const PipeQuery* pq = a.pipe_qtable ? a.pipe_qtable + bid : nullptr;
+        uint32_t qi = bid, ef = a.ef;
+        uint64_t t_begin = wall_clock64();
+        if (!slots) {
+            if (a.qlist) {  // second-chance launches name their queries
+                if (qi >= *a.qcount) return;
+                qi = a.qlist[qi];
+            }
+        } else {
+            PodSlot* slot = slots + bid;
+            if (tid == 0) {  // one thread polls the slot; the other waves sleep at the barrier
+                uint32_t p = 0, polls = 0, beat = 0;
+                uint64_t beat_at = 0;
+                for (;;) {
+                    // (relaxed: an acquire at system scope invalidates the caches, and every idle workgroup looks every few microseconds)
+                    p = __hip_atomic_load(&slot->posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (p != seen) break;
+                    bool leave = (polls & 7u) == 0u && __hip_atomic_load(&ctl->closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+                    if (!leave && (polls & 255u) == 0u) {  // the host's heartbeat: a pod nobody looks after any more (2 s at 100 MHz) ends by itself
+                        const uint32_t b = __hip_atomic_load(&ctl->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const uint64_t now = wall_clock64();
+                        if (b != beat || beat_at == 0) {
+                            beat = b;
+                            beat_at = now;
+                        } else if (now - beat_at > 200000000ull) {
+                            leave = true;
+                        }
+                    }
+                    if (leave) {
+                        // (a query posted before the pod was closed is still answered: the host posts and closes under one lock)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                        p = __hip_atomic_load(&slot->posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (p == seen) {
+                            p = 0u;
+                            __hip_atomic_store(&slot->left, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        break;
+                    }
+                    ++polls;
+                    // ~1.5 us between looks while a caller is between two rounds, ~8 us once the slot has been idle for a while
+                    __builtin_amdgcn_s_sleep(60);
+                    if (polls > 256u) {
+                        __builtin_amdgcn_s_sleep(127);
+                        __builtin_amdgcn_s_sleep(127);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the query's line, and whatever the caller wrote for it, after its number
+                pod_cmd[0] = p;
+                pod_cmd[1] = __hip_atomic_load(&slot->ef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            // the posted query: read once, past the caches (the host rewrites the line between queries), into this workgroup's entry of
+            // the staging table
+            __syncthreads();
+            const uint32_t p = pod_cmd[0];
+            if (p == 0u) return;  // (every thread reads the same word: the workgroup leaves together)
+            seen = p;
+            t_begin = wall_clock64();
+            ef = (uint32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[1]);
+            if (tid < sizeof(PipeQuery) / 4) {
+                const uint32_t v = __hip_atomic_load(reinterpret_cast<uint32_t*>(&slot->q) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                reinterpret_cast<uint32_t*>(const_cast<PipeQuery*>(pq))[tid] = v;
+            }
+            __threadfence();
+            __syncthreads();
+        }
+        pipe_query<AR, I, EFCAP, MODE>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin);
+        if (!slots) return;
+        __syncthreads();  // every wave is done with this query's LDS before the next one's is laid out
     }
 }
 
 template <int AR, int I, int EFCAP, int MODE>
-static hipError_t pipe_launch(const WalkArgs& a, hipStream_t s) {
+static hipError_t pipe_launch(const WalkArgs& a, hipStream_t s, PodSlot* slots, PodCtl* ctl) {
     auto kernel = hnsw_pipe_walk_kernel<AR, I, EFCAP, MODE>;
     const size_t dyn = (size_t)a.pipe_pool_cap * sizeof(uint2);
     static std::once_flag once[16];  // the attribute is per device
@@ -181,35 +303,44 @@ static hipError_t pipe_launch(const WalkArgs& a, hipStream_t s) {
         attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     });
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(kernel, dim3(a.nq), dim3(64 * kPipeTeam), dyn, s, a);
+    PipeKernArgs ka{a, slots, ctl};
+    hipLaunchKernelGGL(kernel, dim3(a.nq), dim3(64 * kPipeTeam), dyn, s, ka);
     return hipGetLastError();
 }
 
 template <int AR, int I>
-static hipError_t pipe_ef(const WalkArgs& a, hipStream_t s) {
+static hipError_t pipe_ef(const WalkArgs& a, hipStream_t s, PodSlot* slots, PodCtl* ctl) {
     // (the LDS tag table as the visited set -- PipeShared<..., VISG = false> -- was measured for unfiltered lone walks and dropped: its
     // test-and-set costs the walker as much as the returning global atomic, which runs under the early post: 0.80 against 0.74 ms)
     if (a.pipe_lds_visited) return hipErrorInvalidValue;
     // one instance per purpose (pipe_device.hpp `MODE`): plain lone queries, the exact walk of a filtered query, its exploring rounds
     if (a.ef > 512) return hipErrorInvalidValue;
-    if (a.pipe_explore) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeExplore>(a, s) : pipe_launch<AR, I, 512, kPipeExplore>(a, s);
-    if (a.allow || a.pipe_qtable) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeFiltered>(a, s) : pipe_launch<AR, I, 512, kPipeFiltered>(a, s);
-    return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipePlain>(a, s) : pipe_launch<AR, I, 512, kPipePlain>(a, s);
+    if (a.pipe_explore) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeExplore>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipeExplore>(a, s, slots, ctl);
+    // (a pod of plain queries has a staging table too: pipe_fused_order tells it from a pod of filtered ones)
+    if (a.allow || (a.pipe_qtable && !(slots && a.pipe_fused_order))) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeFiltered>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipeFiltered>(a, s, slots, ctl);
+    return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipePlain>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipePlain>(a, s, slots, ctl);
+}
+
+template <>
+hipError_t launch_pipe_pod_ar<VS_AR>(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl) {
+    if (!a.nq) return hipSuccess;
+    if (a.ix.M0 > 64u || (!a.space && !a.pipe_qtable) || a.pipe_pool_cap < 256u || (slots && (!ctl || !a.pipe_qtable))) return hipErrorInvalidValue;
+    switch (iters) {
+#ifndef VS_PIPE_DEV
+        case 1: return pipe_ef<VS_AR, 1>(a, s, slots, ctl);
+        case 2: return pipe_ef<VS_AR, 2>(a, s, slots, ctl);
+        case 3: return pipe_ef<VS_AR, 3>(a, s, slots, ctl);
+        case 4: return pipe_ef<VS_AR, 4>(a, s, slots, ctl);
+        case 8: return pipe_ef<VS_AR, 8>(a, s, slots, ctl);
+#endif
+        case 6: return pipe_ef<VS_AR, 6>(a, s, slots, ctl);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <>
 hipError_t launch_pipe_walk_ar<VS_AR>(const WalkArgs& a, uint32_t iters, hipStream_t s) {
-    if (!a.nq) return hipSuccess;
-    if (a.ix.M0 > 64u || (!a.space && !a.pipe_qtable) || a.pipe_pool_cap < 256u) return hipErrorInvalidValue;
-    switch (iters) {
-        case 1: return pipe_ef<VS_AR, 1>(a, s);
-        case 2: return pipe_ef<VS_AR, 2>(a, s);
-        case 3: return pipe_ef<VS_AR, 3>(a, s);
-        case 4: return pipe_ef<VS_AR, 4>(a, s);
-        case 6: return pipe_ef<VS_AR, 6>(a, s);
-        case 8: return pipe_ef<VS_AR, 8>(a, s);
-        default: return hipErrorInvalidValue;
-    }
+    return launch_pipe_pod_ar<VS_AR>(a, iters, s, nullptr, nullptr);
 }
 
 }  // namespace vs

@@ -1,0 +1,40 @@
+// pipe_pod.hpp -- PODS: the pipelined walk (pipe_device.hpp / kernels_pipe.hip) as a resident kernel that callers hand queries to.
+//
+// The reference issues one query per FFI call (crates/vector-store/src/vs_index/usearch.rs:212, :236) and puts every filtered query
+// on a blocking thread of its own (:937-948): a crowd of callers, each with ONE walk in flight, each walk a workgroup on one CU.  One
+// launch per caller and round caps the crowd at the process's hardware queues (16 walks); batched launches hold their stream until the
+// slowest walk of the batch ends.  A pod is one launch of `n` workgroups that stay: workgroup b polls slot b of a table in pinned host
+// memory, answers the query the host posts there (the same PipeQuery a batched launch reads from its table: the kernel writes the
+// answer and the flag into the caller's pinned block) and polls again -- until the host closes the pod.  The callers are then served
+// by as many walks at a time as there are callers, and a query costs no launch at all.
+//
+// A pod is launched with the index's view as kernel arguments, like every other launch: whatever changes the view (adds, removes,
+// reserve) closes the index's pods first (searches do not overlap those: usearch.rs:590-612).  An idle pod closes after a few
+// milliseconds: its workgroups hold their CUs while they poll.
+#pragma once
+#include <cstddef>
+
+#include "kernels.hpp"
+
+namespace vs {
+
+struct alignas(128) PodSlot {  // pinned host memory: one per workgroup of a pod
+    uint32_t posted;           // host: 1, 2, 3, ...: the number of the query in `q`, stored last (release)
+    uint32_t ef;               // its beam
+    uint32_t left;             // device: 1 = this slot's workgroup has left (the pod was closed, or its host went quiet)
+    uint32_t pad;
+    PipeQuery q;
+};
+static_assert(sizeof(PodSlot) == 128, "one slot, one 128-byte line");
+
+struct alignas(64) PodCtl {    // pinned host memory: one per pod
+    uint32_t closed;           // host: 1 = workgroups leave as soon as they are idle
+    uint32_t heartbeat;        // host: advances while the pod is open; workgroups of a pod whose host has gone quiet for seconds leave by themselves
+    uint32_t pad[14];
+};
+
+// `slots` == nullptr: a plain launch (a.nq queries, one workgroup each).  Else a.nq workgroups that serve slots[blockIdx.x] until ctl->closed.
+template <int AR> hipError_t launch_pipe_pod_ar(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl);
+hipError_t launch_pipe_pod(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl);
+
+}  // namespace vs

@@ -98,6 +98,8 @@ def lib():
     L.vs_hnsw_pipe_stats.argtypes = [vp, vp]
     if hasattr(L, "vs_hnsw_filter_batch_stats"):
         L.vs_hnsw_filter_batch_stats.argtypes = [vp, vp]
+    if hasattr(L, "vs_hnsw_pod_stats"):
+        L.vs_hnsw_pod_stats.argtypes = [vp, vp]
     if hasattr(L, "vs_hnsw_streams_created"):  # (VS_HNSW_LIB may name an older build: A/B measurements)
         L.vs_hnsw_streams_created.argtypes = []
         L.vs_hnsw_streams_created.restype = C.c_uint64
@@ -300,6 +302,14 @@ class HipUsearchIndex:
         out = np.zeros(2, dtype=np.uint64)
         _check(self.L.vs_hnsw_filter_batch_stats(self.h, _p(out)))
         return {"batched_launches": int(out[0]), "batched_rounds": int(out[1])}
+
+    def pod_stats(self) -> dict:
+        """Resident launches of the pipelined walk (csrc/pipe_pod.hpp) that blocking callers post their queries to."""
+        out = np.zeros(8, dtype=np.uint64)
+        if hasattr(self.L, "vs_hnsw_pod_stats"):
+            _check(self.L.vs_hnsw_pod_stats(self.h, _p(out)))
+        return {"pods_opened": int(out[0]), "pod_rounds": int(out[1]), "pods_open_on_device": int(out[2]), "pods_enabled": bool(out[3]),
+                "plain_queries": int(out[4]), "plain_ns": int(out[5]), "plain_wait_ns": int(out[6]), "plain_device_ns": int(out[7])}
 
     def pipe_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)

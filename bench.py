@@ -484,10 +484,22 @@ def boundary_record(ix, queries_host, truth, k, seconds):
                 "p99_ms": ms(r.p99_ns), "recall_at_10": round(r.recall_avg, 4), "errors": int(r.errors), "status": rc,
                 "kernel_launches": int(r.launches), "team_kernel_launches": int(r.team_launches)}
 
-    for name, threads, inflight in (("blocking_callers", cores + 1, 1), ("async_in_flight", 16, 256)):
+    pods = ix.pod_stats() if hasattr(ix, "pod_stats") else {}
+    out["pods_enabled"] = bool(pods.get("pods_enabled", False))
+
+    def pod_delta(before):
+        now = ix.pod_stats() if hasattr(ix, "pod_stats") else {}
+        return {"queries_or_rounds_posted_to_pods": now.get("pod_rounds", 0) - before.get("pod_rounds", 0),
+                "pods_opened": now.get("pods_opened", 0) - before.get("pods_opened", 0)}, now
+
+    # (blocking_callers_64: the reference's callers are as many as there are requests in flight -- usearch.rs:212 is reached from one
+    # tokio task per request --, num_workers() + 1 is only the benchmark's default)
+    for name, threads, inflight in (("blocking_callers", cores + 1, 1), ("blocking_callers_64", 64, 1), ("async_in_flight", 16, 256)):
         r = Res()
-        rc = L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, t.ctypes.data, threads, inflight, seconds, C.byref(r))
+        rc = L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, t.ctypes.data, threads, inflight, seconds if name != "blocking_callers_64" else max(seconds / 2, 1.0), C.byref(r))
         out[name] = rec_of(r, rc, threads, inflight)
+        d, pods = pod_delta(pods)
+        out[name].update(d)
     if hasattr(L, "vs_callers_run_filtered"):
         L.vs_callers_run_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double,
                                               C.POINTER(Res), C.POINTER(C.c_uint64)]
@@ -495,7 +507,7 @@ def boundary_record(ix, queries_host, truth, k, seconds):
         # the third record: the reference puts EVERY filtered query on a blocking thread (spawn_blocking), so under load there are
         # far more of them than cores
         for name, modulus, callers in (("selectivity_10pct", 10, cores + 1), ("selectivity_1pct", 100, cores + 1),
-                                       ("selectivity_10pct_64_callers", 10, 64)):
+                                       ("selectivity_10pct_64_callers", 10, 64), ("selectivity_10pct_128_callers", 10, 128)):
             r = Res()
             extra = (C.c_uint64 * 4)()
             # untimed warm-up, as the main path has: every caller's stream, pinned block and walk workspace exist, and the index has
@@ -509,6 +521,8 @@ def boundary_record(ix, queries_host, truth, k, seconds):
             nqd = max(int(r.queries), 1)
             fr.update({"predicate": f"key % {modulus} == 0", "predicate_calls_per_query": extra[0] / nqd, "results_per_query": extra[1] / nqd,
                        "walk_launches_per_query": (f1["lazy_rounds"] - f0["lazy_rounds"]) / nqd})
+            d, pods = pod_delta(pods)
+            fr.update(d)
             out["filtered"][name] = fr
     out["note"] = ("one query per C-ABI call; percentiles on the reference's histogram (10,000 buckets over 1..100 ms: anything "
                    "faster reads 1.0 ms); latency_min_ms is the raw minimum")

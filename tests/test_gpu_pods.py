@@ -120,3 +120,33 @@ def test_more_indexes_than_pods_and_idle_pods_close():
     while handles[0][0].pod_stats()["pods_open_on_device"] and time.time() < deadline:
         time.sleep(0.01)
     assert handles[0][0].pod_stats()["pods_open_on_device"] == 0
+
+
+def test_a_growing_tiny_index_keeps_every_member_reachable():
+    """The workspace a caller brings is a visited bitmap with the visited log behind it; when the index grows by a few slots the bitmap
+    grows by a word OVER what was the log (slot numbers): the layout, not the byte size, decides when it is zeroed again."""
+    import vector_store_amd as vs
+    rng = np.random.default_rng(1)
+    dim = 20
+    ix = vs.HipUsearchIndex(dim, vs.L2SQ, expansion_search=64)
+    ix.reserve(700)
+    nxt = 0
+    for phase in range(24):
+        n = int(rng.integers(1, 30))
+        keys = np.arange(nxt, nxt + n, dtype=np.uint64)
+        vecs = rng.standard_normal((n, dim)).astype(np.float32)
+        nxt += n
+        if phase % 2:
+            ix.add_batch(keys, vecs)
+        else:
+            for i in range(n):
+                ix.add(int(keys[i]), vecs[i])
+        if phase % 5 == 4:
+            assert ix.remove(nxt - 3)
+        k = min(ix.size() + 3, 250)
+        for r in range(3):
+            q = rng.standard_normal(dim).astype(np.float32)
+            gk, gd = ix.search(q, k)
+            bk, bd, bf = ix.search_batch(q[None, :], k)
+            assert gk.tolist() == bk[0][: bf[0]].tolist(), (phase, r, len(gk), int(bf[0]))
+            assert gd.view(np.uint32).tolist() == bd[0][: bf[0]].view(np.uint32).tolist()

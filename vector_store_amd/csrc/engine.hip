@@ -283,7 +283,8 @@ struct WorkCtx {
     // batched rounds (Engine::filtered_batched): this context's visited bitmap / log / spill slots -- all zero between rounds --, and
     // what it was laid out for
     DeviceBuf ws;
-    size_t ws_zeroed = 0;
+    size_t ws_zeroed = 0;  // bitmap words the workspace is laid out (and all zero) for: the visited log behind the bitmap holds slot numbers, and a
+                           // bitmap that grows by a word over them would read those as visited members
     uint32_t round_seq = 0;
 };
 
@@ -436,7 +437,7 @@ static bool wait_for_device_flag(Ready ready, std::atomic<int>& waiting, std::at
 // kSlots workgroups wide -- 3 x 64 leaves a quarter of the chip to everything else, and every workgroup of an open pod is resident (a
 // workgroup that is not cannot poll its slot).  With the engine's 16 streams and the process's default stream that is the 20 hardware
 // queues the library asks for (HwQueuesDefault).  A keeper thread advances the pods' heartbeat, closes a pod that has been idle for
-// VS_HNSW_POD_IDLE_US (20 ms: the two kinds of round of a filtered query alternate) or open for VS_HNSW_POD_AGE_MS (250 ms: a
+// VS_HNSW_POD_IDLE_US (20 ms) or open for VS_HNSW_POD_AGE_MS (1 s, 2 s when no other pod is free to take its callers over: a
 // device-wide synchronisation anywhere in the process -- hipFree, hipDeviceSynchronize -- waits for every kernel, pods included), and
 // hands a closed pod back once every workgroup has said it left.  It makes no HIP call: it cannot be held up by one.
 struct Pod {
@@ -444,7 +445,7 @@ struct Pod {
     static constexpr uint32_t kSlots = 64;
     State state = kFree;
     const void* owner = nullptr;  // the index whose view the launch carries
-    int mode = 0;                 // 0 = plain lone queries, 1 = the exact walk of a filtered query, 2 = its exploring rounds
+    int mode = 0;                 // 0 = plain lone queries, 1 = filtered queries (exact walks and exploring rounds: the slot says which)
     uint32_t efcap = 0;           // 256 / 512: the kernel instance
     size_t index_slots = 0;       // slots of the index when the pod was opened (its visited bitmaps are laid out for them)
     hipStream_t st = nullptr;
@@ -471,7 +472,7 @@ struct PodPool {
     bool keeper_started = false;
     bool enabled = true;
     uint32_t n_slots = Pod::kSlots;
-    int idle_us = 20000, max_age_ms = 250;
+    int idle_us = 20000, max_age_ms = 1000;
     std::atomic<uint64_t> n_opened{0}, n_served{0}, n_closed{0};
     std::atomic<uint64_t> plain_queries{0}, plain_ns{0}, plain_wait_ns{0}, plain_gpu_ticks{0};  // where a posted plain query's time goes (probes)
     PodPool() {
@@ -495,11 +496,17 @@ struct PodPool {
         for (;;) {
             bool any = false;
             const auto now = std::chrono::steady_clock::now();
+            int free_pods = 0;
+            for (Pod& p : pods) free_pods += p.state == Pod::kFree ? 1 : 0;
             for (Pod& p : pods) {
                 if (p.state != Pod::kFree) __atomic_fetch_add(&p.ctl->heartbeat, 1u, __ATOMIC_RELAXED);
-                if (p.state == Pod::kOpen && ((p.n_busy == 0 && now - p.last_used > std::chrono::microseconds(idle_us)) ||
-                                              now - p.opened > std::chrono::milliseconds(max_age_ms)))
+                // (a busy pod that has reached its age goes once a free pod can take its callers over -- or at twice the age)
+                const auto age = now - p.opened;
+                const bool aged = age > std::chrono::milliseconds(max_age_ms) && (p.n_busy == 0 || free_pods > 0 || age > std::chrono::milliseconds(2 * max_age_ms));
+                if (p.state == Pod::kOpen && ((p.n_busy == 0 && now - p.last_used > std::chrono::microseconds(idle_us)) || aged)) {
                     close_locked(p);
+                    if (p.n_busy) --free_pods;  // (its callers will open one)
+                }
                 if (p.state == Pod::kClosing && p.n_busy == 0 && all_left(p)) p.state = Pod::kFree;
                 any |= p.state != Pod::kFree;
             }
@@ -1863,6 +1870,8 @@ struct Engine {
         PodPool& pp = pod_pool(device);
         if (!pp.enabled || ef > 512) return {};
         const uint32_t efcap = ef <= 256 ? 256u : 512u;
+        const bool explore = mode == 2;
+        if (mode == 2) mode = 1;  // (one kind of pod serves both kinds of round of a filtered query: its callers alternate between them)
         std::lock_guard<std::mutex> g(pp.mu);
         int use = -1, free_pod = -1;
         for (int i = 0; i < PodPool::kPods && use < 0; ++i) {
@@ -1902,7 +1911,7 @@ struct Engine {
             a.heap_cap = kBatchHeapCap;
             a.stats = d_stats;
             a.pipe_qtable = p.stage;
-            a.pipe_explore = mode == 2 ? 1u : 0u;
+            a.pipe_explore = 0u;
             a.pipe_fused_order = mode == 0 ? 1u : 0u;
             a.pipe_pool_cap = 12288u;
             std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -1933,6 +1942,7 @@ struct Engine {
         PodSlot& sl = p.slots[slot];
         sl.q = pq;
         sl.ef = ef;
+        sl.explore = explore ? 1u : 0u;
         __atomic_store_n(&sl.posted, ++p.seq[slot], __ATOMIC_RELEASE);
         p.busy[slot] = true;
         ++p.n_busy;
@@ -2104,11 +2114,11 @@ struct Engine {
         Lease w(device);
         uint32_t* d_bits = (uint32_t*)w->e.ensure(words * 8);
         const size_t space = batch_space_bytes(n);
-        if (w->ws.bytes < space || w->ws_zeroed != space) {
+        if (w->ws.bytes < space || w->ws_zeroed != words) {
             char* p = (char*)w->ws.ensure(space);
             HIP_OK(hipMemsetAsync(p, 0, w->ws.bytes, w->stream));
             HIP_OK(hipStreamSynchronize(w->stream));
-            w->ws_zeroed = space;
+            w->ws_zeroed = words;
         }
         // pinned, device-mapped: [flag, counters 64 B | list cap x 4 | verdicts cap | keys k x 8 | dist k x 4 | the query]
         const size_t pin_need = 64 + (size_t)cap * 5 + k * 12 + 64 + (size_t)dim * 4;
@@ -2798,11 +2808,11 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
     if (!n) return false;
     Lease w(device);
     const size_t space = batch_space_bytes(n);
-    if (w->ws.bytes < space || w->ws_zeroed != space) {
+    if (w->ws.bytes < space || w->ws_zeroed != (n + 31) / 32) {
         char* p = (char*)w->ws.ensure(space);
         HIP_OK(hipMemsetAsync(p, 0, w->ws.bytes, w->stream));
         HIP_OK(hipStreamSynchronize(w->stream));
-        w->ws_zeroed = space;
+        w->ws_zeroed = (n + 31) / 32;
     }
     // pinned, device-mapped: [counters, flag 64 B | keys k x 8 | dist k x 4 | the query]
     const size_t q_off = (64 + k * 12 + 63) & ~(size_t)63;

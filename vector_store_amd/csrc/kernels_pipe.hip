@@ -192,6 +192,8 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
 // `slots` == nullptr: one query per workgroup, then done.  Else a POD (pipe_pod.hpp): workgroup b serves slot b -- a line of pinned host
 // memory a caller posts its query to -- until the host closes the pod; a.pipe_qtable is then the pod's staging table in device memory
 // (entry b: this workgroup's copy of the posted PipeQuery, which the walk reads exactly as it reads a batch table's entry).
+constexpr int kPipeBoth = 3;  // (kernel instances only: a pod whose workgroups serve exact filtered walks and exploring rounds alike)
+
 struct PipeKernArgs {
     WalkArgs a;
     PodSlot* slots;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
     using Sh = PipeShared<EFCAP, kPipeTeam, false, VISG>;
     __shared__ Sh sh;
     extern __shared__ uint2 pipe_pool[];
-    __shared__ uint32_t pod_cmd[2];
+    __shared__ uint32_t pod_cmd[3];
     uint32_t seen = 0;
     for (;;) {
         // The kernel's arguments, read from the argument segment INSIDE the loop (the offset is opaque to the compiler): hoisted out of
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
         const PipeQuery* pq = a.pipe_qtable ? a.pipe_qtable + bid : nullptr;
         uint32_t qi = bid, ef = a.ef;
         uint64_t t_begin = wall_clock64();
+        [[maybe_unused]] bool explore = false;
         if (!slots) {
             if (a.qlist) {  // second-chance launches name their queries
                 if (qi >= *a.qcount) return;
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the query's line, and whatever the caller wrote for it, after its number
                 pod_cmd[0] = p;
                 pod_cmd[1] = __hip_atomic_load(&slot->ef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pod_cmd[2] = __hip_atomic_load(&slot->explore, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             // the posted query: read once, past the caches (the host rewrites the line between queries), into this workgroup's entry of
             // the staging table
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
             seen = p;
             t_begin = wall_clock64();
             ef = (uint32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[1]);
+            explore = __builtin_amdgcn_readfirstlane((int)pod_cmd[2]) != 0;
             if (tid < sizeof(PipeQuery) / 4) {
                 const uint32_t v = __hip_atomic_load(reinterpret_cast<uint32_t*>(&slot->q) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 reinterpret_cast<uint32_t*>(const_cast<PipeQuery*>(pq))[tid] = v;
@@ -285,7 +290,13 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
             __threadfence();
             __syncthreads();
         }
-        pipe_query<AR, I, EFCAP, MODE>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin);
+        if constexpr (MODE == kPipeBoth) {
+            // a pod of filtered queries: the two kinds of round alternate for every caller, so one workgroup serves either
+            if (explore) pipe_query<AR, I, EFCAP, kPipeExplore>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin);
+            else pipe_query<AR, I, EFCAP, kPipeFiltered>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin);
+        } else {
+            pipe_query<AR, I, EFCAP, MODE>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin);
+        }
         if (!slots) return;
         __syncthreads();  // every wave is done with this query's LDS before the next one's is laid out
     }
@@ -315,6 +326,7 @@ static hipError_t pipe_ef(const WalkArgs& a, hipStream_t s, PodSlot* slots, PodC
     if (a.pipe_lds_visited) return hipErrorInvalidValue;
     // one instance per purpose (pipe_device.hpp `MODE`): plain lone queries, the exact walk of a filtered query, its exploring rounds
     if (a.ef > 512) return hipErrorInvalidValue;
+    if (slots && !a.pipe_fused_order) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeBoth>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipeBoth>(a, s, slots, ctl);
     if (a.pipe_explore) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeExplore>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipeExplore>(a, s, slots, ctl);
     // (a pod of plain queries has a staging table too: pipe_fused_order tells it from a pod of filtered ones)
     if (a.allow || (a.pipe_qtable && !(slots && a.pipe_fused_order))) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeFiltered>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipeFiltered>(a, s, slots, ctl);

@@ -175,8 +175,11 @@ VS_API uint64_t vs_hnsw_streams_created(void);
  * a resident launch of the pipelined walk instead of launching one: as many walks in flight as callers, no launch per query.
  * [0] pods opened for this index so far, [1] queries / filter rounds its pods have served, [2] pods open on the index's device now,
  * [3] 1 unless VS_HNSW_PODS=0; where the time of the plain queries posted on the device went: [4] their number, [5] ns inside the
- * library, [6] of them waiting for the answer, [7] ns the workgroups spent on them by the device's clock. */
-VS_API int vs_hnsw_pod_stats(vs_hnsw* index, uint64_t out[8]);
+ * library, [6] of them waiting for the answer, [7] ns the workgroups spent on them by the device's clock; filtered queries of this
+ * index: [8] answered through posted (or batched) rounds, [9] handed over to rounds of their own after such a round met two equal
+ * distances where their order matters, [10] rounds no pod could take (launched in a batch instead), [11] rounds walked again in usearch's order on the caller's own stream
+ * for the same reason. */
+VS_API int vs_hnsw_pod_stats(vs_hnsw* index, uint64_t out[12]);
 
 /* Exact search on float storage (cos / ip, k <= 64, >= 65,536 slots) nominates with split-bf16 MFMA tiles, re-scores the nominees
  * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's

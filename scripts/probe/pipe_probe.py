@@ -57,7 +57,9 @@ for name, index in ((("pipe" if os.environ.get("VS_HNSW_PIPE", "1") != "0" else 
             f0 = index.filter_stats()
             rc = L.vs_callers_run_filtered(index.h, q.ctypes.data, q.shape[0], dim, k, mod, threads, seconds, C.byref(r), extra)
             f1, st = index.filter_stats(), index.stats(reset=True)
+            ps = index.pod_stats() if hasattr(index, "pod_stats") else {}
             nq = max(int(r.queries), 1)
             print(f"{name}: n {n} ef {ef} threads {threads} 1/{mod}: {r.qps:.1f} QPS, min {r.latency_min_ns/1e6:.2f} p50 {r.p50_ns/1e6:.2f} p99 {r.p99_ns/1e6:.2f} ms, "
                   f"pred calls/q {extra[0]/nq:.0f}, launches/q {(f1['lazy_rounds']-f0['lazy_rounds'])/nq:.1f}, "
-                  f"evals/q {st['search_evals']/nq:.0f}, hops/q {st['search_hops']/nq:.0f}, errors {r.errors} rc {rc}", flush=True)
+                  f"evals/q {st['search_evals']/nq:.0f}, hops/q {st['search_hops']/nq:.0f}, errors {r.errors} rc {rc}; p90 {r.p90_ns/1e6:.1f} max {r.latency_max_ns/1e6:.0f} ms; "
+                  f"so far: answered {ps.get('filtered_answered')} handed over {ps.get('filtered_handed_over')} rounds without a pod {ps.get('rounds_without_a_pod')} walked again {ps.get('rounds_walked_again')}", flush=True)

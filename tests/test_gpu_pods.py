@@ -51,7 +51,7 @@ def test_adds_and_removes_between_searches_close_the_pods_and_the_answers_follow
         assert st["pods_opened"] > opened, st  # every step's searches ran in pods opened after the step's adds
         opened = st["pods_opened"]
         assert old.pod_stats()["pods_opened"] == 0
-    assert ix.pod_stats()["pod_rounds"] >= 3 * len(q) * 3
+    assert ix.pod_stats()["pod_rounds"] >= 3 * len(q) * 2  # (a plain query and at least one posted round per filtered one: the very first has no history and takes rounds of its own)
 
 
 def test_a_crowd_of_plain_callers_gets_the_batch_paths_answers():

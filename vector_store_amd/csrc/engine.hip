@@ -1863,7 +1863,8 @@ struct Engine {
 
     // ---- pods (pipe_pod.hpp): the round is posted to a resident workgroup instead of being launched ---------------------------------
     std::atomic<uint64_t> pod_rounds{0}, pod_opens{0};
-    std::atomic<uint32_t> wait_typical_us[3] = {};  // how long this index's callers lately waited for a plain query / an exact filtered walk / an exploring round
+    std::atomic<uint64_t> batched_done{0}, batched_handed_over{0}, batched_no_pod{0}, batched_second_chances{0};  // filtered queries answered by posted / batched rounds; handed over to rounds of their own; rounds no pod could take
+    std::atomic<uint32_t> wait_typical_us[4] = {};  // how long this index's callers lately waited for a plain query / an exact filtered walk / an exploring round
     // Post one query / round (mode: 0 plain, 1 exact filtered walk, 2 exploring round) to a pod of this index; no ticket: no pod can
     // take it now (the caller launches as before).  `n`: the index's slots, as the caller's workspace is laid out for.
     PodTicket pod_submit(int mode, uint32_t ef, size_t n, const PipeQuery& pq) {
@@ -2180,14 +2181,64 @@ struct Engine {
             pq.space = (char*)w->ws.p;
             __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
             PodRelease pod{device, pod_submit(explore ? 2 : 1, ef, n, pq)};
-            if (!pod.t) submit_round(pq, explore, ef, n);
+            if (!pod.t) {
+                batched_no_pod.fetch_add(1, std::memory_order_relaxed);
+                submit_round(pq, explore, ef, n);
+            }
             // wait for the kernel's flag (the two kinds of round take different times: one moving average each)
             static std::atomic<int> waiting{0};
             if (!wait_for_device_flag([&] { return __atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id; }, waiting, wait_typical_us[explore ? 2 : 1], 20.0))
                 fail(VS_ERR_DEVICE, "a batched filtered round did not finish");
             pod.done();
-            const uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
-            if (found == kPipeRedoFound) return (size_t)-1;
+            uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
+            if (found == kPipeRedoFound && explore) {
+                // (an exploring round keeps no order, so nothing it meets hands it over -- but if one ever is: the exact walk lists what it needs)
+                explored = true;
+                apply_m = 0;
+                continue;
+            }
+            if (found == kPipeRedoFound) {
+                // Two equal distances met where their order matters (one filtered walk in 15 at 10M x 768: thousands of candidates wait in
+                // `next` together): THIS round is walked again in usearch's order -- the team form of the usearch-order walk, on the caller's
+                // own stream, with the same device-resident verdicts --, and the query goes on from its outcome.
+                batched_second_chances.fetch_add(1, std::memory_order_relaxed);
+                hipStream_t st = w->stream;
+                uint64_t* d_k = (uint64_t*)w->b.ensure(k * 8);
+                float* d_d = (float*)w->c.ensure(k * 4);
+                uint32_t* d_f = (uint32_t*)w->d.ensure(64);
+                uint32_t* d_unknown = (uint32_t*)w->f.ensure(((size_t)cap + 64) * 4);  // [count, consulted, 62 pad | list]
+                HIP_OK(hipMemsetAsync(d_unknown, 0, 8, st));
+                LazyFilter lf;
+                lf.known = d_bits + words;
+                lf.unknown_list = d_unknown + 64;
+                lf.unknown_count = d_unknown;
+                lf.cap = cap;
+                lf.budget = budget;
+                lf.consulted = d_unknown + 1;
+                {
+                    struct NoPipe {
+                        NoPipe() { tl_no_pipe = true; }
+                        ~NoPipe() { tl_no_pipe = false; }
+                    } no_pipe_here;
+                    search_device(h_q, 1, k, d_k, d_d, d_f, st, 0, d_bits, 0, &lf);
+                }
+                HIP_OK(launch_export_round(d_unknown, cap, d_k, d_d, d_f, (uint32_t)k, h_cnt, h_list, h_k, h_d, st));
+                if (!w->ev) HIP_OK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
+                HIP_OK(hipEventRecord(w->ev, st));
+                static std::atomic<int> waiting_sc{0};
+                if (!wait_for_device_flag(
+                        [&] {
+                            const hipError_t e = hipEventQuery(w->ev);
+                            if (e != hipSuccess && e != hipErrorNotReady) HIP_OK(e);
+                            return e == hipSuccess;
+                        },
+                        waiting_sc, wait_typical_us[3], 60.0))
+                    fail(VS_ERR_DEVICE, "a filtered round's second walk did not finish");
+                count = h_cnt[0];
+                consulted = h_cnt[1];
+                found = h_cnt[2];
+                if (found == kPipeRedoFound) return (size_t)-1;  // (cannot happen: the usearch-order walk answers or fails)
+            }
             if (count == 0 && !explore) {
                 if (found == kWalkFailed) return (size_t)-1;
                 std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
@@ -2201,17 +2252,20 @@ struct Engine {
                 return found;
             }
             const uint32_t m = std::min(count, cap);
+            uint64_t asked = 0;  // (counted here, added once: every caller's every call on one shared counter is a cache line passed round 50M times a second)
             for (uint32_t i = 0; i < m; ++i) {
+                if (i + 8 < m && h_list[i + 8] < n) __builtin_prefetch(&h_keys[h_list[i + 8]]);
                 const uint32_t s = h_list[i];
                 uint8_t v = 0;
                 if (s < n) {
                     const uint64_t key = h_keys[s];
-                    ++lazy_predicate_calls;
+                    ++asked;
                     v = key != kFreeKey && pred(key, pctx) ? 1 : 0;
                 }
                 h_verdict[i] = v;
                 n_allowed += v;
             }
+            lazy_predicate_calls += asked;
             n_known += m;
             apply_m = m;
         }
@@ -2237,9 +2291,12 @@ struct Engine {
             const bool crowd = filtered_active_callers.load(std::memory_order_relaxed) > device_streams(device).count + 8;
             const bool short_walks = lazy_need_hint.load() != 0 && lazy_need_hint.load() < 20000u;
             // With pods (pipe_pod.hpp) a round is posted to a resident workgroup -- no launch, no stream to wait for -- whatever the crowd.
+            // (Filters whose walks are long -- 1 % selective: 100 ms a round, `next` spilling to global memory -- stay on rounds of their own:
+            // measured at 10M x 768, 17 / 64 callers: 58 / 50 queries/s through pods against 62 / 66.)
             const bool pods = pod_pool(device).enabled;
-            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || pods || (crowd && short_walks))) {
+            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || (short_walks && (pods || crowd)))) {
                 const size_t f = filtered_batched(q, k, pred, pctx, keys, dist, ef_b);
+                (f != (size_t)-1 ? batched_done : batched_handed_over).fetch_add(1, std::memory_order_relaxed);
                 if (f != (size_t)-1) return f;
                 // (two equal distances met where their order matters, or the launch failed: the query starts over on rounds of its own,
                 // whose second-chance launch is the usearch-order walk)
@@ -2401,17 +2458,20 @@ struct Engine {
             if (count == 0) continue;  // (an exploring round that found every verdict it wanted)
             const uint32_t m = std::min(count, cap);
             // a walk evaluates a node once, so a list names a slot once, and slots with a verdict are never listed again
+            uint64_t asked = 0;  // (counted here, added once: every caller's every call on one shared counter is a cache line passed round 50M times a second)
             for (uint32_t i = 0; i < m; ++i) {
+                if (i + 8 < m && h_list[i + 8] < n) __builtin_prefetch(&h_keys[h_list[i + 8]]);
                 const uint32_t s = h_list[i];
                 uint8_t v = 0;
                 if (s < n) {
                     const uint64_t key = h_keys[s];
-                    ++lazy_predicate_calls;
+                    ++asked;
                     v = key != kFreeKey && pred(key, pctx) ? 1 : 0;
                 }
                 h_verdict[i] = v;
                 n_allowed += v;
             }
+            lazy_predicate_calls += asked;
             n_known += m;
             HIP_OK(launch_apply_verdicts(d_unknown, h_verdict, m, (uint32_t)n, d_bits, d_bits + words, st));
         }
@@ -3190,7 +3250,7 @@ int vs_hnsw_filter_batch_stats(vs_hnsw* h, uint64_t out[2]) {
 
 uint64_t vs_hnsw_streams_created(void) { return vs::g_streams_created.load(); }
 
-int vs_hnsw_pod_stats(vs_hnsw* h, uint64_t out[8]) {
+int vs_hnsw_pod_stats(vs_hnsw* h, uint64_t out[12]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     vs::PodPool& pp = vs::pod_pool(h->e.device);
     out[0] = h->e.pod_opens.load();
@@ -3201,6 +3261,10 @@ int vs_hnsw_pod_stats(vs_hnsw* h, uint64_t out[8]) {
     out[5] = pp.plain_ns.load();
     out[6] = pp.plain_wait_ns.load();
     out[7] = pp.plain_gpu_ticks.load() * 10;
+    out[8] = h->e.batched_done.load();
+    out[9] = h->e.batched_handed_over.load();
+    out[10] = h->e.batched_no_pod.load();
+    out[11] = h->e.batched_second_chances.load();
     return VS_OK;
 }
 

@@ -305,11 +305,12 @@ class HipUsearchIndex:
 
     def pod_stats(self) -> dict:
         """Resident launches of the pipelined walk (csrc/pipe_pod.hpp) that blocking callers post their queries to."""
-        out = np.zeros(8, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
         if hasattr(self.L, "vs_hnsw_pod_stats"):
             _check(self.L.vs_hnsw_pod_stats(self.h, _p(out)))
         return {"pods_opened": int(out[0]), "pod_rounds": int(out[1]), "pods_open_on_device": int(out[2]), "pods_enabled": bool(out[3]),
-                "plain_queries": int(out[4]), "plain_ns": int(out[5]), "plain_wait_ns": int(out[6]), "plain_device_ns": int(out[7])}
+                "plain_queries": int(out[4]), "plain_ns": int(out[5]), "plain_wait_ns": int(out[6]), "plain_device_ns": int(out[7]),
+                "filtered_answered": int(out[8]), "filtered_handed_over": int(out[9]), "rounds_without_a_pod": int(out[10]), "rounds_walked_again": int(out[11])}
 
     def pipe_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)

@@ -506,15 +506,16 @@ def boundary_record(ix, queries_host, truth, k, seconds):
         out["filtered"] = {}
         # the third record: the reference puts EVERY filtered query on a blocking thread (spawn_blocking), so under load there are
         # far more of them than cores
-        for name, modulus, callers in (("selectivity_10pct", 10, cores + 1), ("selectivity_1pct", 100, cores + 1),
-                                       ("selectivity_10pct_64_callers", 10, 64), ("selectivity_10pct_128_callers", 10, 128)):
+        # (the legs of one filter together: the index sizes a query's first round by what its recent filtered queries needed)
+        for name, modulus, callers in (("selectivity_10pct", 10, cores + 1), ("selectivity_10pct_64_callers", 10, 64),
+                                       ("selectivity_10pct_128_callers", 10, 128), ("selectivity_1pct", 100, cores + 1)):
             r = Res()
             extra = (C.c_uint64 * 4)()
             # untimed warm-up, as the main path has: every caller's stream, pinned block and walk workspace exist, and the index has
             # seen this predicate's appetite (the first round's budget follows recent filtered queries)
             L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, 0.4, C.byref(Res()), (C.c_uint64 * 4)())
             f0 = ix.filter_stats()
-            rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, max(seconds / 2, 1.0), C.byref(r), extra)
+            rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, max(seconds / 2, 1.0) if modulus < 100 else max(seconds, 2.0), C.byref(r), extra)
             f1 = ix.filter_stats()
             fr = rec_of(r, rc, callers, 1)
             fr.pop("recall_at_10", None)

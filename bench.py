@@ -513,7 +513,7 @@ def boundary_record(ix, queries_host, truth, k, seconds):
             extra = (C.c_uint64 * 4)()
             # untimed warm-up, as the main path has: every caller's stream, pinned block and walk workspace exist, and the index has
             # seen this predicate's appetite (the first round's budget follows recent filtered queries)
-            L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, 0.4, C.byref(Res()), (C.c_uint64 * 4)())
+            L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, 0.4 if modulus < 100 else 1.5, C.byref(Res()), (C.c_uint64 * 4)())
             f0 = ix.filter_stats()
             rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, max(seconds / 2, 1.0) if modulus < 100 else max(seconds, 2.0), C.byref(r), extra)
             f1 = ix.filter_stats()

@@ -1884,13 +1884,14 @@ struct Engine {
             if (free_pod < 0) return {};
             Pod& p = pp.pods[free_pod];
             use_device();
+            try {  // (a pod that cannot be opened is no error: the caller launches as before)
             if (!p.st) {
                 HIP_OK(hipStreamCreateWithFlags(&p.st, hipStreamNonBlocking));
                 g_streams_created.fetch_add(1, std::memory_order_relaxed);
-                HIP_OK(hipHostMalloc((void**)&p.ctl, sizeof(PodCtl), hipHostMallocDefault));
-                HIP_OK(hipHostMalloc((void**)&p.slots, sizeof(PodSlot) * Pod::kSlots, hipHostMallocDefault));
-                HIP_OK(hipMalloc((void**)&p.stage, sizeof(PipeQuery) * Pod::kSlots));
             }
+            if (!p.ctl) HIP_OK(hipHostMalloc((void**)&p.ctl, sizeof(PodCtl), hipHostMallocDefault));
+            if (!p.slots) HIP_OK(hipHostMalloc((void**)&p.slots, sizeof(PodSlot) * Pod::kSlots, hipHostMallocDefault));
+            if (!p.stage) HIP_OK(hipMalloc((void**)&p.stage, sizeof(PipeQuery) * Pod::kSlots));
             std::memset(p.ctl, 0, sizeof(PodCtl));
             std::memset(p.slots, 0, sizeof(PodSlot) * Pod::kSlots);
             std::memset(p.busy, 0, sizeof(p.busy));
@@ -1917,6 +1918,10 @@ struct Engine {
             a.pipe_pool_cap = 12288u;
             std::atomic_thread_fence(std::memory_order_seq_cst);
             HIP_OK(launch_pipe_pod(a, iters, p.st, p.slots, p.ctl));
+            } catch (...) {
+                (void)hipGetLastError();
+                return {};
+            }
             p.state = Pod::kOpen;
             p.owner = this;
             p.mode = mode;
@@ -2289,7 +2294,10 @@ struct Engine {
             uint32_t ef_b = 0;
             check_search(k, ef_b);
             const bool crowd = filtered_active_callers.load(std::memory_order_relaxed) > device_streams(device).count + 8;
-            const bool short_walks = lazy_need_hint.load() != 0 && lazy_need_hint.load() < 20000u;
+            // (what the recent filtered queries of this index needed: few verdicts -- or, once the share their filters admit is known, a share
+            // of 3 % or more: the count of verdicts of a 1 % filter hovers around the threshold, its selectivity does not)
+            const uint32_t sel_now = lazy_sel_hint.load();
+            const bool short_walks = lazy_need_hint.load() != 0 && (sel_now ? sel_now >= 1966u : lazy_need_hint.load() < 20000u);
             // With pods (pipe_pod.hpp) a round is posted to a resident workgroup -- no launch, no stream to wait for -- whatever the crowd.
             // (Filters whose walks are long -- 1 % selective: 100 ms a round, `next` spilling to global memory, and seven walks in ten end
             // in a tie that matters, i.e. in a second walk in usearch's order on the caller's stream -- take pods only as a crowd: measured

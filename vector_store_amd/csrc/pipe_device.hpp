@@ -297,10 +297,17 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     // Order among EQUAL distances: the one thing these structures do not reproduce.  While two candidates with one distance v wait in
     // `next` together ("window": from the pop of the first of them until the head of `next` lies beyond v) usearch's heap decides who goes
     // first.  The sets the walk works on -- visited, `next`, `top` -- come out the same either way as long as no comparison against the
-    // radius can tell the orders apart and no two equal distances are inserted into `top` in an order-dependent sequence: i.e. while,
-    // inside the window, `top` is not full, does not fill up, and no insertion meets an equal distance there.  Anything else inside a
-    // window hands the query to the usearch-order walk (status redo).
-    bool tie_active = false;
+    // radius can tell the orders apart and no two equal distances are inserted into `top` in an order-dependent sequence.  Precisely
+    // (filtered walks; plain ones keep the stricter round-4 rule: inside a window `top` is not full and does not fill up):
+    //   * every candidate of the window is expanded whichever goes first iff the radius never falls below v while the window lasts (the
+    //     walk ends at the first candidate BEYOND the radius): then the same nodes are evaluated, and `top` -- the ef best admitted
+    //     members of what was evaluated -- is the same set;
+    //   * `next` may differ by entries at or beyond the radius of their evaluation, which are never expanded -- unless one EQUALS the
+    //     radius: a neighbour rejected at `d == radius` inside a window, a candidate popped at `d == radius` after one, an insertion
+    //     into `top` that meets an equal distance there inside one.
+    // Any of these hands the round to the usearch-order walk (status redo).  One exact walk in 13 did under the stricter rule at 10 %
+    // selectivity (10M x 768), seven in ten at 1 %.
+    bool tie_active = false, any_window = false;
     float tie_v = 0.f;
 
     // distance at position p of `top` (wave-uniform p): one readlane per register row, chosen on the scalar side (a select chain over
@@ -335,7 +342,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 rank += (uint32_t)__popcll(__ballot(in && top.d[j] == d && top.s[j] < s));
             }
         }
-        if (tie_active && (sz + 1u >= ef || eq_any)) redo = true;
+        if (tie_active && (eq_any || (fused_order && sz + 1u >= ef))) redo = true;
         const float cd = __uint_as_float(wave_shr1(__float_as_uint(top.d[R - 1]), 0u));
         const uint32_t cs = wave_shr1(top.s[R - 1], 0u);
 #pragma unroll
@@ -348,6 +355,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         }
         sz = sz < ef ? sz + 1u : ef;
         if (sz == ef) radius = top_at(ef - 1u);
+        if (tie_active && sz == ef && radius < tie_v) redo = true;  // (the window's other candidates would end the walk, not be expanded)
     };
     auto pool_append = [&](bool mine, float d, uint32_t s) {  // every lane with `mine` appends its entry
         const uint64_t mk = __ballot(mine);
@@ -869,6 +877,21 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         const float cd = rl_f(f_d, 0);
         const uint32_t cs = rl_u(f_s, 0);
         if (sz == ef && cd > radius) break;  // `candidate.distance > radius && top.size() == top_limit`
+        if (any_window && !fused_order && sz == ef && cd == radius) {
+            // at the radius: the last member of `top` itself, as a rule (every admitted member waits in `next` too) -- or another node at
+            // the same distance, which usearch's `next` may not hold: the one distance where that matters
+            const uint32_t lp = (ef - 1u) / (uint32_t)R, lr = (ef - 1u) % (uint32_t)R;
+            uint32_t last_s = rl_u(top.s[0], lp);
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                const uint32_t x = rl_u(top.s[j], lp);
+                last_s = lr == (uint32_t)j ? x : last_s;
+            }
+            if (last_s != cs) {
+                redo = true;
+                break;
+            }
+        }
         // pop
         f_d = __uint_as_float(wave_shl1(__float_as_uint(f_d), __float_as_uint(INF)));
         f_s = wave_shl1(f_s, kInvalid);
@@ -879,6 +902,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (tie_active && cd > tie_v) tie_active = false;
         if (!tie_active && next_d == cd) {
             tie_active = true;
+            any_window = true;
             tie_v = cd;
             ++dbg_windows;
         }
@@ -971,6 +995,10 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             // verdicts are needed only for neighbours that can still be admitted: once `top` is full, those below the hop's first radius
             const float radius0 = sz == ef ? radius : INF;
             const uint64_t cand = __ballot(fresh && (sz < ef || nd < radius0));
+            if (tie_active && sz == ef && __ballot(fresh && nd == radius0)) {  // rejected AT the radius inside a window
+                redo = true;
+                break;
+            }
             const uint64_t okmask = verdicts(cand, n, fl);
             if (over_budget) break;  // enough unknown slots listed for one round: the host evaluates them and launches again
             WALK_STAMP(4);  // verdicts
@@ -997,7 +1025,10 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             for (uint64_t r = done ? 0ull : cand; r; r &= r - 1ull) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(r);
                 const float dj = rl_f(nd, j);
-                if (sz == ef && !(dj < radius)) continue;  // `top.size() < top_limit || d < radius`
+                if (sz == ef && !(dj < radius)) {  // `top.size() < top_limit || d < radius`
+                    if (tie_active && dj == radius) redo = true;
+                    continue;
+                }
                 const uint32_t sj = rl_u(n, j);
                 push_one(dj, sj);
                 if ((okmask >> j) & 1ull) top_insert(dj, sj);

@@ -2299,11 +2299,12 @@ struct Engine {
             const uint32_t sel_now = lazy_sel_hint.load();
             const bool short_walks = lazy_need_hint.load() != 0 && (sel_now ? sel_now >= 1966u : lazy_need_hint.load() < 20000u);
             // With pods (pipe_pod.hpp) a round is posted to a resident workgroup -- no launch, no stream to wait for -- whatever the crowd.
-            // (Filters whose walks are long -- 1 % selective: 100 ms a round, `next` spilling to global memory, and seven walks in ten end
-            // in a tie that matters, i.e. in a second walk in usearch's order on the caller's stream -- take pods only as a crowd: measured
-            // at 10M x 768, 17 / 64 / 128 callers: 56 / 125 / 122 queries/s through pods against 62 / 63 / 66 on rounds of their own.)
+            // (Filters whose walks are long -- 1 % selective: 100 ms a round, `next` spilling to global memory -- take pods when several
+            // callers are at it: measured at 10M x 768, 1 / 17 / 64 / 128 callers: 6.3 / 90 / 310 / 597 queries/s through pods against
+            // 9 / 77 / 66 / 66 on rounds of their own, whose workspace holds more of `next`.)
+            const bool several = filtered_active_callers.load(std::memory_order_relaxed) > 8;
             const bool pods = pod_pool(device).enabled;
-            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || (short_walks && (pods || crowd)) || (pods && crowd))) {
+            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || (short_walks && (pods || crowd)) || (pods && several))) {
                 const size_t f = filtered_batched(q, k, pred, pctx, keys, dist, ef_b);
                 (f != (size_t)-1 ? batched_done : batched_handed_over).fetch_add(1, std::memory_order_relaxed);
                 if (f != (size_t)-1) return f;

@@ -187,3 +187,30 @@ def test_a_crowd_of_filtered_callers_shares_launches_and_gets_the_same_answers()
     st, pods = ix.filter_batch_stats(), ix.pod_stats()
     assert pods["pod_rounds"] + st["batched_rounds"] > 0 and st["batched_launches"] <= st["batched_rounds"], (st, pods)
     assert pods["pods_opened"] >= 1 or not pods["pods_enabled"], pods
+
+
+@pytest.mark.parametrize("dim,span,ef,k,modulo", [(12, 6, 64, 10, 3), (8, 4, 128, 20, 10), (16, 10, 200, 10, 7), (6, 3, 48, 48, 2)])
+def test_ties_everywhere_and_the_pipelined_walk_still_answers_most_rounds_itself(dim, span, ef, k, modulo):
+    """Coarse lattices: a handful of distinct distances, so two equal ones wait in `next` at EVERY hop, with `top` full for most of the
+    walk.  The window rule (pipe_device.hpp) lets the pipelined walk go on while the two orders cannot differ -- the radius stays at or
+    above the window's distance, nothing meets the radius or an equal distance in `top` -- and hands over otherwise; either way ids,
+    their order and the distance bits are the oracle's."""
+    import vector_store_amd as vs
+    n, nq = 80_000, 10
+    data = lattice(n + nq, dim, 100 + dim, span=span)
+    base, q = data[:n], data[n:] + 0.5  # (queries off the lattice: fewer exact ties with the radius, ties among candidates stay)
+    ix = vs.HipUsearchIndex(dim, vs.L2SQ, expansion_search=ef)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    o = OracleIndex(dim, oracle.L2SQ)
+    o.import_graph(ix.export_graph())
+    o.set_expansion_search(ef)
+    pred = lambda key: key % modulo == 1
+    for rep in range(2):  # (the second pass runs with the index's filter history: exploring rounds that guess)
+        for i in range(nq):
+            fk, fd = ix.filtered_search(q[i], k, pred)
+            ek, ed = o.filtered_search(q[i], k, pred)
+            assert_same_results(fk, fd, ek, ed, exact=True, what=(dim, span, ef, modulo, rep, i))
+    st = ix.pod_stats()
+    assert ix.pipe_stats()["pipe_launches"] > 0
+    print("rounds posted", st["pod_rounds"], "walked again", st["rounds_walked_again"], "handed over", st["filtered_handed_over"])

@@ -2301,7 +2301,7 @@ struct Engine {
             // With pods (pipe_pod.hpp) a round is posted to a resident workgroup -- no launch, no stream to wait for -- whatever the crowd.
             // (Filters whose walks are long -- 1 % selective: 100 ms a round, `next` spilling to global memory -- take pods when several
             // callers are at it: measured at 10M x 768, 1 / 17 / 64 / 128 callers: 6.3 / 90 / 310 / 597 queries/s through pods against
-            // 9 / 77 / 66 / 66 on rounds of their own, whose workspace holds more of `next`.)
+            // 9 / 77 / 66 / 66 on rounds of their own.)
             const bool several = filtered_active_callers.load(std::memory_order_relaxed) > 8;
             const bool pods = pod_pool(device).enabled;
             if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || (short_walks && (pods || crowd)) || (pods && several))) {

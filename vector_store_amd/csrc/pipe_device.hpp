@@ -342,7 +342,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 rank += (uint32_t)__popcll(__ballot(in && top.d[j] == d && top.s[j] < s));
             }
         }
-        if (tie_active && (eq_any || (fused_order && sz + 1u >= ef))) redo = true;
+        if (tie_active && (eq_any || ((!kFilter || fused_order) && sz + 1u >= ef))) redo = true;
         const float cd = __uint_as_float(wave_shr1(__float_as_uint(top.d[R - 1]), 0u));
         const uint32_t cs = wave_shr1(top.s[R - 1], 0u);
 #pragma unroll
@@ -355,7 +355,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         }
         sz = sz < ef ? sz + 1u : ef;
         if (sz == ef) radius = top_at(ef - 1u);
-        if (tie_active && sz == ef && radius < tie_v) redo = true;  // (the window's other candidates would end the walk, not be expanded)
+        if constexpr (kFilter) {
+            if (tie_active && !fused_order && sz == ef && radius < tie_v) redo = true;  // (the window's other candidates would end the walk, not be expanded)
+        }
     };
     auto pool_append = [&](bool mine, float d, uint32_t s) {  // every lane with `mine` appends its entry
         const uint64_t mk = __ballot(mine);
@@ -877,7 +879,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         const float cd = rl_f(f_d, 0);
         const uint32_t cs = rl_u(f_s, 0);
         if (sz == ef && cd > radius) break;  // `candidate.distance > radius && top.size() == top_limit`
-        if (any_window && !fused_order && sz == ef && cd == radius) {
+        if (kFilter && any_window && !fused_order && sz == ef && cd == radius) {
             // at the radius: the last member of `top` itself, as a rule (every admitted member waits in `next` too) -- or another node at
             // the same distance, which usearch's `next` may not hold: the one distance where that matters
             const uint32_t lp = (ef - 1u) / (uint32_t)R, lr = (ef - 1u) % (uint32_t)R;
@@ -902,7 +904,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (tie_active && cd > tie_v) tie_active = false;
         if (!tie_active && next_d == cd) {
             tie_active = true;
-            any_window = true;
+            if constexpr (kFilter) any_window = true;
             tie_v = cd;
             ++dbg_windows;
         }
@@ -995,7 +997,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             // verdicts are needed only for neighbours that can still be admitted: once `top` is full, those below the hop's first radius
             const float radius0 = sz == ef ? radius : INF;
             const uint64_t cand = __ballot(fresh && (sz < ef || nd < radius0));
-            if (tie_active && sz == ef && __ballot(fresh && nd == radius0)) {  // rejected AT the radius inside a window
+            if (kFilter && tie_active && sz == ef && __ballot(fresh && nd == radius0)) {  // rejected AT the radius inside a window
                 redo = true;
                 break;
             }
@@ -1026,7 +1028,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 const uint32_t j = (uint32_t)__builtin_ctzll(r);
                 const float dj = rl_f(nd, j);
                 if (sz == ef && !(dj < radius)) {  // `top.size() < top_limit || d < radius`
-                    if (tie_active && dj == radius) redo = true;
+                    if (kFilter && tie_active && dj == radius) redo = true;
                     continue;
                 }
                 const uint32_t sj = rl_u(n, j);

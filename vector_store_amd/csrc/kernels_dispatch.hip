@@ -1,5 +1,6 @@
 // kernels_dispatch.hip -- picks the arithmetic (storage type x metric family) and forwards to the per-arithmetic
 // translation units (kernels_arith.hip, one object per -DVS_AR); also hosts the request sort of the build path.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -70,7 +71,10 @@ hipError_t launch_walk(const WalkArgs& a, uint32_t iters, uint32_t instance, uin
 }
 
 bool pipe_walk_supported(const IndexView& ix, uint32_t iters, uint32_t ef) {
-    return ix.scalar != SC_I8 && ix.scalar != SC_B1 && ix.M0 <= 64u && ef >= 1 && ef <= 512 &&
+    // Integer storage (i8, b1): ties are the rule there, and most rounds of a filtered walk still pass the window rule (pipe_device.hpp);
+    // the others are walked again in usearch's order, as on float storage.  VS_HNSW_PIPE_INT=0: never (the state before the end of round 4).
+    static const bool int_too = !(std::getenv("VS_HNSW_PIPE_INT") && std::getenv("VS_HNSW_PIPE_INT")[0] == '0');
+    return (int_too || (ix.scalar != SC_I8 && ix.scalar != SC_B1)) && ix.M0 <= 64u && ef >= 1 && ef <= 512 &&
            (iters == 1 || iters == 2 || iters == 3 || iters == 4 || iters == 6 || iters == 8);
 }
 
@@ -83,6 +87,8 @@ hipError_t launch_pipe_walk(const WalkArgs& a, uint32_t iters, hipStream_t s) {
         case AR_F16_L2: return launch_pipe_walk_ar<AR_F16_L2>(a, iters, s);
         case AR_BF16_DOT: return launch_pipe_walk_ar<AR_BF16_DOT>(a, iters, s);
         case AR_BF16_L2: return launch_pipe_walk_ar<AR_BF16_L2>(a, iters, s);
+        case AR_I8: return launch_pipe_walk_ar<AR_I8>(a, iters, s);
+        case AR_B1: return launch_pipe_walk_ar<AR_B1>(a, iters, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -96,6 +102,8 @@ hipError_t launch_pipe_pod(const WalkArgs& a, uint32_t iters, hipStream_t s, Pod
         case AR_F16_L2: return launch_pipe_pod_ar<AR_F16_L2>(a, iters, s, slots, ctl);
         case AR_BF16_DOT: return launch_pipe_pod_ar<AR_BF16_DOT>(a, iters, s, slots, ctl);
         case AR_BF16_L2: return launch_pipe_pod_ar<AR_BF16_L2>(a, iters, s, slots, ctl);
+        case AR_I8: return launch_pipe_pod_ar<AR_I8>(a, iters, s, slots, ctl);
+        case AR_B1: return launch_pipe_pod_ar<AR_B1>(a, iters, s, slots, ctl);
         default: return hipErrorInvalidValue;
     }
 }

@@ -428,7 +428,8 @@ static bool wait_for_device_flag(Ready ready, std::atomic<int>& waiting, std::at
     }
     const uint32_t took = (uint32_t)std::min<double>(1e7, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     const uint32_t typ = typical_us.load(std::memory_order_relaxed);
-    typical_us.store(typ ? (typ * 7u + took) / 8u : took, std::memory_order_relaxed);
+    // (down fast, up slowly: on an index whose filters differ in selectivity a short round must not sleep through most of a long one's time)
+    typical_us.store(!typ ? took : took < typ ? (typ + took) / 2u : (typ * 7u + took) / 8u, std::memory_order_relaxed);
     return true;
 }
 

@@ -34,6 +34,31 @@ typedef struct vs_actor_options {
 } vs_actor_options;
 
 VS_API int vs_actor_create(const vs_actor_options* options, vs_actor** out);
+
+/* The reference's actor is generic over the index behind it -- `new<I: UsearchIndex + Send + Sync + 'static>`
+ * (usearch.rs:688-696); its own benches and tests run it over a Simulator through that parameter.  The same here: the seven
+ * methods of `trait UsearchIndex` (usearch.rs:142-160: reserve, capacity, add, remove, search, filtered_search, stop) plus
+ * construction (`index_fn`, usearch.rs:689) as a table of C functions.  NULL entries are not allowed.  vs_actor_create binds
+ * the HIP engine (vs_hnsw_*); bench.py's cpu_baseline leg and the tests bind the CPU oracle to time / check the SAME actor
+ * over it. */
+typedef struct vs_actor_index_vtable {
+    int (*create)(const vs_hnsw_options* options, void** out);                      /* index_fn */
+    void (*stop)(void* index);                                                      /* stop + drop */
+    int (*reserve)(void* index, size_t capacity, size_t threads);
+    size_t (*capacity)(void* index);
+    int (*add)(void* index, uint64_t key, const float* vector, size_t dim);
+    int (*remove)(void* index, uint64_t key, int* removed);
+    int (*search)(void* index, const float* query, size_t dim, size_t k, uint64_t* keys, float* distances, size_t* found);
+    int (*filtered_search)(void* index, const float* query, size_t dim, size_t k, vs_hnsw_predicate predicate, void* ctx,
+                           uint64_t* keys, float* distances, size_t* found);
+    const char* (*last_error)(void);
+} vs_actor_index_vtable;
+VS_API int vs_actor_create_with(const vs_actor_options* options, const vs_actor_index_vtable* index, vs_actor** out);
+
+/* Hands an index that already exists (bulk-built, imported) to the actor as partition `partition`: `size` members, capacity as
+ * the index reports it.  The actor does not own it (it is never stopped / freed by the actor).  Before any message for that
+ * partition. */
+VS_API int vs_actor_adopt_partition(vs_actor* actor, uint64_t partition, void* index, size_t size);
 /* Closes both channels, drains what is queued, stops every partition, joins the threads. */
 VS_API void vs_actor_stop(vs_actor* actor);
 
@@ -41,6 +66,11 @@ VS_API void vs_actor_stop(vs_actor* actor);
 VS_API int vs_actor_add_vector(vs_actor* actor, uint64_t partition, uint64_t primary_id, const float* vector, size_t dim);
 VS_API int vs_actor_remove_vector(vs_actor* actor, uint64_t partition, uint64_t primary_id);
 VS_API int vs_actor_remove_partition(vs_actor* actor, uint64_t partition);
+/* The same two messages with the reference's in-progress marker (`AsyncInProgress`, dropped when the worker has processed the
+ * message: what benches/pipeline.rs:685-712 waits for per item): return once the index call has run.  *applied: 1 = the vector
+ * was indexed / a member was removed, 0 = dropped (memory guard, unknown partition, swallowed error). */
+VS_API int vs_actor_add_vector_wait(vs_actor* actor, uint64_t partition, uint64_t primary_id, const float* vector, size_t dim, int* applied);
+VS_API int vs_actor_remove_vector_wait(vs_actor* actor, uint64_t partition, uint64_t primary_id, int* applied);
 
 /* VsIndexSearch (vs_index/actor.rs:46-61): blocking round trip.  Unknown / empty partition => found = 0. */
 VS_API int vs_actor_ann(vs_actor* actor, uint64_t partition, const float* query, size_t dim, size_t k, uint64_t* keys,

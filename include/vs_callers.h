@@ -13,6 +13,7 @@
 #ifndef VS_CALLERS_H
 #define VS_CALLERS_H
 
+#include "vs_actor.h"
 #include "vs_hnsw.h"
 
 #ifdef __cplusplus
@@ -41,6 +42,32 @@ VS_API int vs_callers_run(vs_hnsw* index, const float* queries, size_t nq, size_
  * `errors` also counts results the predicate rejects (must stay 0). */
 VS_API int vs_callers_run_filtered(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus,
                                    unsigned threads, double seconds, vs_callers_result* out, uint64_t extra[4]);
+
+/* The reference's MIXED workloads (crates/vector-store/benches/pipeline.rs:508-1292: cdc_insert, cdc_update, cdc_delete and
+ * search_while_{inserting,updating,deleting}) through a dispatch actor (include/vs_actor.h -- over the HIP engine, or over any
+ * other index bound with vs_actor_create_with): `producers` CDC producers (BENCHES_CONCURRENCY, pipeline.rs:158-163; default
+ * 1), each sending one item at a time and waiting for its in-progress marker (pipeline.rs:685-712), beside `plain_callers`
+ * blocking callers of Ann and `filtered_callers` of FilteredAnn (predicate key % modulus == 0) on the same partition.
+ *   insert: AddVector(first_new_key + i, vectors[i % nv])                                   monitor_items.rs:263-284
+ *   update: RemoveBeforeAddValue(key) then AddVector(key, vectors[i % nv]), key random in [0, existing_keys)   :301-313
+ *   delete: RemoveValue(delete_from + i)                                                     :314-327
+ * Runs for `seconds` (or until max_items), then waits until every producer's last item is applied. */
+typedef enum vs_mixed_modify { VS_MIXED_NONE = 0, VS_MIXED_INSERT = 1, VS_MIXED_UPDATE = 2, VS_MIXED_DELETE = 3 } vs_mixed_modify;
+typedef struct vs_mixed_options {
+    unsigned plain_callers, filtered_callers, producers;
+    int modify; /* vs_mixed_modify */
+    uint64_t modulus, partition, first_new_key, existing_keys, delete_from, max_items;
+    size_t k;
+    double seconds;
+} vs_mixed_options;
+typedef struct vs_mixed_result {
+    double seconds;
+    uint64_t items, adds_applied, removes_applied; /* CDC items completed; index calls that took effect */
+    uint64_t predicate_calls, filtered_results, errors;
+    vs_callers_result item, plain, filtered; /* latency of an item (send .. marker dropped), of a plain / filtered query */
+} vs_mixed_result;
+VS_API int vs_mixed_run(vs_actor* actor, const vs_mixed_options* options, const float* queries, size_t nq, const float* vectors,
+                        size_t nv, size_t dim, vs_mixed_result* out);
 
 #ifdef __cplusplus
 }

@@ -181,6 +181,12 @@ VS_API uint64_t vs_hnsw_streams_created(void);
  * for the same reason. */
 VS_API int vs_hnsw_pod_stats(vs_hnsw* index, uint64_t out[12]);
 
+/* Where modifications spend their time (the reference's mixed add / search workloads, benches/pipeline.rs:508-1292):
+ * [0] flushes of staged single-vector adds (vs_hnsw_add defers the insertion to the next call that observes the index),
+ * [1] vectors they inserted, [2] ns they took; [3] times this index's pods were closed for a modification, [4] ns spent waiting
+ * for their workgroups to leave; [5] vs_hnsw_remove calls, [6] ns inside them; [7] pods opened for this index. */
+VS_API int vs_hnsw_modify_stats(vs_hnsw* index, uint64_t out[8]);
+
 /* Exact search on float storage (cos / ip, k <= 64, >= 65,536 slots) nominates with split-bf16 MFMA tiles, re-scores the nominees
  * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's
  * certificate failed. */

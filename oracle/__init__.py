@@ -89,8 +89,17 @@ def lib():
         L.orc_distance_valid.argtypes = [C.c_float, C.c_int, sz]
         L.orc_similarity.restype = C.c_float
         L.orc_similarity.argtypes = [C.c_float, C.c_int, sz]
+        L.orc_trait_vtable.argtypes = [vp]
         _lib = L
     return _lib
+
+
+def trait_vtable():
+    """The oracle as an implementation of `trait UsearchIndex` for libvs_actor (include/vs_actor.h: vs_actor_index_vtable):
+    nine function pointers.  Only tests and bench.py's cpu_baseline leg pass it to vs_actor_create_with."""
+    t = (C.c_void_p * 9)()
+    lib().orc_trait_vtable(t)
+    return t
 
 
 class OracleError(RuntimeError):
@@ -186,10 +195,11 @@ class OracleIndex:
     def set_expansion_search(self, ef: int):
         self.L.orc_set_expansion_search(self.h, ef)
 
-    def add(self, key: int, vector, level: int | None = None):
+    def add(self, key: int, vector, level: int | None = None, thread: int = 0):
+        """thread: the usearch thread slot (context) the call runs on -- every context has its own level generator."""
         v = self._vec(vector)
         if level is None:
-            self._check(self.L.orc_add(self.h, key, _ptr(v), 0))
+            self._check(self.L.orc_add(self.h, key, _ptr(v), thread))
         else:
             self._check(self.L.orc_add_with_level(self.h, key, _ptr(v), level))
 

@@ -947,6 +947,66 @@ int orc_filtered_search_timed(void* h, const void* Q, size_t nq, size_t k, uint6
     return 0;
 }
 
+// ---- `trait UsearchIndex` (reference usearch.rs:142-160) over the oracle, with the C signatures of include/vs_actor.h's
+// vs_actor_index_vtable: lets bench.py's cpu_baseline leg and the tests run the SAME dispatch actor (libvs_actor) and the same
+// mixed add / search driver over the CPU restatement.  Every calling thread gets a context of its own, as usearch's
+// thread-slot contexts (usearch.rs:184: reserve_capacity_and_threads(capacity, num_workers())).
+struct orc_trait_options {  // = vs_hnsw_options (include/vs_hnsw.h)
+    size_t dimensions, connectivity, expansion_add, expansion_search;
+    int metric, quantization, device, reserved;
+};
+static size_t trait_thread() {
+    static std::atomic<size_t> next{0};
+    thread_local size_t mine = next.fetch_add(1) % 1024;
+    return mine;
+}
+int orc_trait_create(const orc_trait_options* o, void** out) {
+    if (!o || !out) return -1;
+    void* h = orc_create_ex(o->dimensions, o->metric, o->quantization, o->connectivity, o->expansion_add, o->expansion_search);
+    if (!h) return -1;
+    *out = h;
+    return 0;
+}
+void orc_trait_stop(void* h) { orc_free(h); }
+int orc_trait_reserve(void* h, size_t cap, size_t /*threads*/) { return orc_reserve(h, cap) ? -5 : 0; }
+size_t orc_trait_capacity(void* h) { return orc_capacity(h); }
+int orc_trait_add(void* h, uint64_t key, const float* v, size_t dim) {
+    Index* ix = (Index*)h;
+    if (dim != ix->dim) return -2;
+    return ix->add(key, v, trait_thread(), -1) ? -3 : 0;
+}
+int orc_trait_remove(void* h, uint64_t key, int* removed) {
+    const int r = ((Index*)h)->remove(key);
+    if (removed) *removed = r;
+    return 0;
+}
+int orc_trait_search(void* h, const float* q, size_t dim, size_t k, uint64_t* keys, float* d, size_t* found) {
+    Index* ix = (Index*)h;
+    if (dim != ix->dim) return -2;
+    thread_local Context c;
+    *found = ix->search(q, k, nullptr, nullptr, keys, d, c, nullptr);
+    return 0;
+}
+int orc_trait_filtered_search(void* h, const float* q, size_t dim, size_t k, pred_fn pred, void* pctx, uint64_t* keys, float* d, size_t* found) {
+    Index* ix = (Index*)h;
+    if (dim != ix->dim) return -2;
+    thread_local Context c;
+    *found = ix->search(q, k, pred, pctx, keys, d, c, nullptr);
+    return 0;
+}
+// the table itself (nine function pointers, the layout of vs_actor_index_vtable)
+void orc_trait_vtable(void** out9) {
+    out9[0] = (void*)orc_trait_create;
+    out9[1] = (void*)orc_trait_stop;
+    out9[2] = (void*)orc_trait_reserve;
+    out9[3] = (void*)orc_trait_capacity;
+    out9[4] = (void*)orc_trait_add;
+    out9[5] = (void*)orc_trait_remove;
+    out9[6] = (void*)orc_trait_search;
+    out9[7] = (void*)orc_trait_filtered_search;
+    out9[8] = (void*)orc_last_error;
+}
+
 // stats summed over all thread contexts: [0] computed distances, [1] node expansions
 void orc_stats(void* h, uint64_t* out2, int reset) {
     Index* ix = (Index*)h;

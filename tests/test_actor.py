@@ -17,7 +17,73 @@ def test_actor_library_exports_its_header():
     declared = set(re.findall(r"^VS_API [^;(]*?\b(vs_actor_[a-z0-9_]+)\(", header, flags=re.M))
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "vector_store_amd", "libvs_actor.so")], text=True)
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
-    assert declared == {s for s in exported if s.startswith("vs_actor_")} and len(declared) == 13
+    assert declared == {s for s in exported if s.startswith("vs_actor_")} and len(declared) == 17
+
+
+def _oracle_actor(dim, metric, n, seed=0, workers=4, ef=64):
+    """The SAME actor library over the CPU oracle (vs_actor_create_with + oracle.trait_vtable()): what bench.py's cpu_baseline.mixed
+    times, and what makes the actor's own logic testable without a GPU."""
+    import oracle
+    from vector_store_amd.actor import IndexActor
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    o = oracle.OracleIndex(dim, metric, 16, 128, ef)
+    o.reserve(n + 4096)
+    o.add_batch(np.arange(n, dtype=np.uint64), base, threads=4)
+    a = IndexActor(dim, metric, 16, 128, ef, workers=workers, index_vtable=oracle.trait_vtable())
+    a.adopt_partition(0, o.h, n)
+    return a, o, base, rng
+
+
+def test_actor_over_the_cpu_oracle_adopts_an_index_and_keeps_the_markers():
+    """vs_actor_create_with / vs_actor_adopt_partition / the in-progress markers (benches/pipeline.rs:685-712) on CPU."""
+    import oracle
+    a, o, base, rng = _oracle_actor(32, oracle.L2SQ, 2000)
+    try:
+        assert a.count() == 2000 and a.partition_capacity(0) == 2000 + 4096
+        q = base[17] + 0.001
+        keys, d = a.ann(0, q, 5)
+        ok, od = o.search(q, 5)
+        assert keys.tolist() == ok.tolist() and np.array_equal(d, od)
+        # update = RemoveBeforeAddValue + AddVector (monitor_items.rs:301-313); the marker drops once the index call has run
+        a.remove_vector(0, 17)
+        assert a.add_vector_wait(0, 17, base[18] * 2) is True
+        assert a.count() == 2000 and o.size() == 2000
+        assert a.add_vector_wait(0, 17, base[18]) is False        # duplicate key: the add is swallowed (usearch.rs:1028-1030)
+        assert a.remove_vector_wait(0, 17) is True and a.remove_vector_wait(0, 17) is False
+        assert a.count() == 1999
+        assert a.remove_vector_wait(5, 1) is False                 # unknown partition
+        keys, _ = a.filtered_ann(0, q, 5, lambda k: k % 2 == 0)
+        assert len(keys) == 5 and all(k % 2 == 0 for k in keys.tolist())
+        c = a.counters()
+        assert c["adds"] == 1 and c["removes"] == 2 and c["errors"] == 1
+    finally:
+        a.stop()
+
+
+def test_mixed_driver_runs_the_references_pipeline_scenarios_over_the_oracle():
+    """libvs_callers' vs_mixed_run (cdc_insert / cdc_update / cdc_delete / search_while_updating, benches/pipeline.rs:508-1292)
+    through the actor over the CPU oracle: item accounting, predicate-respecting answers, no errors."""
+    import oracle
+    from vector_store_amd import callers
+    n = 3000
+    a, o, base, rng = _oracle_actor(24, oracle.COS, n)
+    try:
+        q = rng.standard_normal((64, 24)).astype(np.float32)
+        fresh = rng.standard_normal((256, 24)).astype(np.float32)
+        r = callers.mixed_run(a, q, fresh, modify=callers.INSERT, first_new_key=1 << 40, max_items=300, seconds=30)
+        assert r["items"] == 300 and r["adds_applied"] == 300 and r["errors"] == 0 and o.size() == n + 300
+        r = callers.mixed_run(a, q, fresh, modify=callers.UPDATE, existing_keys=n, max_items=200, producers=4, seconds=30)
+        assert r["items"] == 200 and r["adds_applied"] == 200 and r["errors"] == 0 and o.size() == n + 300
+        r = callers.mixed_run(a, q, fresh, modify=callers.DELETE, delete_from=0, max_items=100, seconds=30)
+        assert r["removes_applied"] == 100 and o.size() == n + 200
+        r = callers.mixed_run(a, q, fresh, modify=callers.UPDATE, existing_keys=n, plain_callers=3, filtered_callers=2, modulus=3, seconds=0.5)
+        assert r["errors"] == 0 and r["items"] > 0 and r["plain"]["count"] > 0 and r["filtered"]["count"] > 0
+        assert r["filtered"]["predicate_calls_per_query"] > 0
+        c = a.counters()
+        assert c["mode_switches"] > 2 * r["items"] - 4  # every modification is a family of its own between families of searches (usearch.rs:590-612)
+    finally:
+        a.stop()
 
 
 def wait_for_count(actor, expected, timeout=120.0):  # generous: the first GPU call of a fresh box loads 30 MB of code objects

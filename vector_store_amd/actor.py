@@ -28,6 +28,10 @@ def lib():
         L = C.CDLL(os.path.join(_HERE, "libvs_actor.so"))
         vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
         L.vs_actor_create.argtypes = [C.POINTER(_ActorOptions), C.POINTER(vp)]
+        L.vs_actor_create_with.argtypes = [C.POINTER(_ActorOptions), vp, C.POINTER(vp)]
+        L.vs_actor_adopt_partition.argtypes = [vp, u64, vp, sz]
+        L.vs_actor_add_vector_wait.argtypes = [vp, u64, u64, vp, sz, C.POINTER(C.c_int)]
+        L.vs_actor_remove_vector_wait.argtypes = [vp, u64, u64, C.POINTER(C.c_int)]
         L.vs_actor_stop.argtypes = [vp]
         L.vs_actor_add_vector.argtypes = [vp, u64, u64, vp, sz]
         L.vs_actor_remove_vector.argtypes = [vp, u64, u64]
@@ -48,17 +52,43 @@ def lib():
 
 
 class IndexActor:
+    """index_vtable: nine function pointers in the order of include/vs_actor.h's vs_actor_index_vtable (a ctypes array of
+    c_void_p) -- the actor over another implementation of `trait UsearchIndex` (tests and bench.py's cpu_baseline bind the CPU
+    oracle: oracle.trait_vtable()); None: the HIP engine."""
+
     def __init__(self, dimensions: int, metric: int = _ix.COS, connectivity: int = 16, expansion_add: int = 128,
-                 expansion_search: int = 64, workers: int = 0, local: bool = False, reserve_increment: int = 0):
+                 expansion_search: int = 64, workers: int = 0, local: bool = False, reserve_increment: int = 0,
+                 quantization: int = 0, reserved: int = 0, index_vtable=None):
         self.L = lib()
         self.dim = dimensions
-        o = _ActorOptions(_ix._Options(dimensions, connectivity, expansion_add, expansion_search, metric, 0, -1, 0),
+        o = _ActorOptions(_ix._Options(dimensions, connectivity, expansion_add, expansion_search, metric, quantization, -1, reserved),
                           workers, int(local), reserve_increment)
         h = C.c_void_p()
-        rc = self.L.vs_actor_create(C.byref(o), C.byref(h))
+        self._vtable = index_vtable  # (kept alive: the actor copies it, the functions must stay loaded)
+        if index_vtable is None:
+            rc = self.L.vs_actor_create(C.byref(o), C.byref(h))
+        else:
+            rc = self.L.vs_actor_create_with(C.byref(o), C.cast(index_vtable, C.c_void_p), C.byref(h))
         if rc != 0:
             raise _ix.VsError(rc, self.L.vs_actor_last_error().decode())
         self.h = h
+
+    def adopt_partition(self, partition: int, index_handle, size: int):
+        """An index that exists already (bulk-built) becomes partition `partition`; the actor does not own it."""
+        rc = self.L.vs_actor_adopt_partition(self.h, partition, index_handle, size)
+        if rc != 0:
+            raise _ix.VsError(rc, self.L.vs_actor_last_error().decode())
+
+    def add_vector_wait(self, partition: int, primary_id: int, vector) -> bool:
+        v = np.ascontiguousarray(vector, dtype=np.float32)
+        applied = C.c_int(0)
+        self.L.vs_actor_add_vector_wait(self.h, partition, primary_id, v.ctypes.data, v.size, C.byref(applied))
+        return bool(applied.value)
+
+    def remove_vector_wait(self, partition: int, primary_id: int) -> bool:
+        applied = C.c_int(0)
+        self.L.vs_actor_remove_vector_wait(self.h, partition, primary_id, C.byref(applied))
+        return bool(applied.value)
 
     def stop(self):
         if getattr(self, "h", None):

@@ -93,11 +93,13 @@ struct Operation {
 
 struct Partition {  // usearch.rs:626-670
     uint64_t id;
-    vs_hnsw* idx = nullptr;
+    void* idx = nullptr;
+    const vs_actor_index_vtable* vt = nullptr;
+    bool owned = true;  // false: adopted (vs_actor_adopt_partition), the caller stops it
     std::atomic<size_t> size{0}, capacity{0};
     size_t increment, free_threshold;
     ~Partition() {
-        if (idx) vs_hnsw_free(idx);
+        if (idx && owned) vt->stop(idx);  // PartitionState::stop (usearch.rs:667-669) + drop
     }
     bool needs_more_capacity(size_t& want) const {
         size_t cap = capacity.load(), sz = size.load();
@@ -119,13 +121,30 @@ struct Msg {
     uint64_t* keys = nullptr;
     float* dist = nullptr;
     size_t* found = nullptr;
-    std::shared_ptr<std::promise<int>> tx;  // oneshot
+    std::shared_ptr<std::promise<int>> tx;  // oneshot (searches; modify messages: the in-progress marker, value = applied)
 };
+
+// `impl UsearchIndex for ThreadedUsearchIndex` (usearch.rs:162-251) = the HIP engine's C ABI
+int hip_create(const vs_hnsw_options* o, void** out) { return vs_hnsw_create(o, (vs_hnsw**)out); }
+void hip_stop(void* h) { vs_hnsw_free((vs_hnsw*)h); }
+int hip_reserve(void* h, size_t cap, size_t threads) { return vs_hnsw_reserve((vs_hnsw*)h, cap, threads); }
+size_t hip_capacity(void* h) { return vs_hnsw_capacity((vs_hnsw*)h); }
+int hip_add(void* h, uint64_t key, const float* v, size_t dim) { return vs_hnsw_add((vs_hnsw*)h, key, v, dim); }
+int hip_remove(void* h, uint64_t key, int* removed) { return vs_hnsw_remove((vs_hnsw*)h, key, removed); }
+int hip_search(void* h, const float* q, size_t dim, size_t k, uint64_t* keys, float* d, size_t* found) {
+    return vs_hnsw_search((vs_hnsw*)h, q, dim, k, keys, d, found);
+}
+int hip_filtered(void* h, const float* q, size_t dim, size_t k, vs_hnsw_predicate p, void* ctx, uint64_t* keys, float* d, size_t* found) {
+    return vs_hnsw_filtered_search((vs_hnsw*)h, q, dim, k, p, ctx, keys, d, found);
+}
+const vs_actor_index_vtable kHipIndex = {hip_create, hip_stop,   hip_reserve,  hip_capacity,      hip_add,
+                                         hip_remove, hip_search, hip_filtered, vs_hnsw_last_error};
 
 }  // namespace
 
 struct vs_actor {
     vs_actor_options opt;
+    vs_actor_index_vtable vt;
     size_t workers, channel;
     std::unique_ptr<WorkerPool> pool;
     Operation op;
@@ -140,6 +159,8 @@ struct vs_actor {
     std::atomic<int> allocate_can{1};
     int allocate_prev = 1;
     std::atomic<uint64_t> c_adds{0}, c_dropped{0}, c_reserves{0}, c_searches{0}, c_removes{0}, c_errors{0};
+    std::mutex err_mu;
+    std::string last_index_error;
 
     void send(Msg&& m, bool search) {
         std::unique_lock<std::mutex> lk(mu);
@@ -172,6 +193,7 @@ struct vs_actor {
     }
 
     std::shared_ptr<Partition> find(uint64_t id) {
+        std::lock_guard<std::mutex> g(part_mu);  // (vs_actor_adopt_partition inserts from a caller's thread)
         auto it = partitions.find(id);
         return it == partitions.end() ? nullptr : it->second;
     }
@@ -186,6 +208,7 @@ struct vs_actor {
                 allocate_prev = can;
                 if (drop) {
                     ++c_dropped;
+                    if (msg.tx) msg.tx->set_value(0);
                     continue;
                 }
             }
@@ -195,27 +218,23 @@ struct vs_actor {
                 case Msg::Add:
                     part = find(msg.partition);
                     if (!part) {  // lazily created on the first AddVector of the partition
-                        vs_hnsw* h = nullptr;
-                        if (vs_hnsw_create(&opt.index, &h) != VS_OK) {
+                        void* h = nullptr;
+                        if (vt.create(&opt.index, &h) != VS_OK) {
                             ++c_errors;
+                            if (msg.tx) msg.tx->set_value(0);
                             continue;
                         }
-                        part = std::make_shared<Partition>();
-                        part->id = msg.partition;
-                        part->idx = h;
-                        part->increment = opt.reserve_increment ? opt.reserve_increment
-                                                                : (opt.local ? kReserveIncrementLocal : kReserveIncrementGlobal);
-                        // The reference uses perf::channel_size() (3 x workers, usearch.rs:650), although up to
-                        // channel + workers adds can be in flight; the margin here covers all of them so that
-                        // no add can meet "Reserve capacity ahead of insertions!".
-                        part->free_threshold = channel + workers + 1;
+                        part = new_partition(msg.partition, h, true);
                         std::lock_guard<std::mutex> g(part_mu);
                         partitions[msg.partition] = part;
                     }
                     break;
                 case Msg::Remove:
                     part = find(msg.partition);
-                    if (!part) continue;
+                    if (!part) {
+                        if (msg.tx) msg.tx->set_value(0);
+                        continue;
+                    }
                     break;
                 case Msg::RemovePartition: {
                     part = find(msg.partition);
@@ -250,8 +269,8 @@ struct vs_actor {
                 op.permit(Mode::Reserve);
                 if (part->needs_more_capacity(want)) {
                     pool->spawn([this, part, want] {
-                        if (vs_hnsw_reserve(part->idx, want, workers) == VS_OK)
-                            part->capacity = vs_hnsw_capacity(part->idx);
+                        if (vt.reserve(part->idx, want, workers) == VS_OK)
+                            part->capacity = vt.capacity(part->idx);
                         else
                             ++c_errors;  // error!("unable to reserve index capacity ...")
                         ++c_reserves;
@@ -274,27 +293,46 @@ struct vs_actor {
         partitions.clear();
     }
 
+    std::shared_ptr<Partition> new_partition(uint64_t id, void* h, bool owned) {
+        auto part = std::make_shared<Partition>();
+        part->id = id;
+        part->idx = h;
+        part->vt = &vt;
+        part->owned = owned;
+        part->increment = opt.reserve_increment ? opt.reserve_increment : (opt.local ? kReserveIncrementLocal : kReserveIncrementGlobal);
+        // The reference uses perf::channel_size() (3 x workers, usearch.rs:650), although up to
+        // channel + workers adds can be in flight; the margin here covers all of them so that
+        // no add can meet "Reserve capacity ahead of insertions!".
+        part->free_threshold = channel + workers + 1;
+        return part;
+    }
+
     void process(Partition& p, Msg& m) {  // usearch.rs:950-1002
         const size_t dim = opt.index.dimensions;
         switch (m.kind) {
-            case Msg::Add:
-                if (vs_hnsw_add(p.idx, m.primary_id, m.v.data(), m.v.size()) == VS_OK) {
+            case Msg::Add: {
+                const bool ok = vt.add(p.idx, m.primary_id, m.v.data(), m.v.size()) == VS_OK;
+                if (ok) {
                     ++p.size;
                     ++index_size;
                     ++c_adds;
                 } else {
                     ++c_errors;  // warn!("add: unable to add embedding"), the vector is not indexed
                 }
+                if (m.tx) m.tx->set_value(ok ? 1 : 0);  // (the in-progress marker drops with the message)
                 break;
+            }
             case Msg::Remove: {
                 int removed = 0;
-                if (vs_hnsw_remove(p.idx, m.primary_id, &removed) != VS_OK) {
+                if (vt.remove(p.idx, m.primary_id, &removed) != VS_OK) {
                     ++c_errors;
+                    removed = 0;
                 } else if (removed) {
                     --p.size;
                     --index_size;
                     ++c_removes;
                 }
+                if (m.tx) m.tx->set_value(removed ? 1 : 0);
                 break;
             }
             case Msg::Ann:
@@ -305,9 +343,13 @@ struct vs_actor {
                     g_err = "wrong embedding dimension";
                     *m.found = 0;
                 } else if (m.kind == Msg::Ann) {
-                    rc = vs_hnsw_search(p.idx, m.v.data(), dim, m.k, m.keys, m.dist, m.found);
+                    rc = vt.search(p.idx, m.v.data(), dim, m.k, m.keys, m.dist, m.found);
                 } else {
-                    rc = vs_hnsw_filtered_search(p.idx, m.v.data(), dim, m.k, m.pred, m.pctx, m.keys, m.dist, m.found);
+                    rc = vt.filtered_search(p.idx, m.v.data(), dim, m.k, m.pred, m.pctx, m.keys, m.dist, m.found);
+                }
+                if (rc != VS_OK && rc != VS_ERR_DIMENSION) {
+                    std::lock_guard<std::mutex> g(err_mu);
+                    last_index_error = vt.last_error();  // (thread-local in the index: read on the thread that made the call)
                 }
                 ++c_searches;
                 m.tx->set_value(rc);
@@ -322,14 +364,18 @@ extern "C" {
 
 const char* vs_actor_last_error(void) { return g_err.c_str(); }
 
-int vs_actor_create(const vs_actor_options* o, vs_actor** out) {
-    if (!o || !out || !o->index.dimensions) {
+int vs_actor_create(const vs_actor_options* o, vs_actor** out) { return vs_actor_create_with(o, &kHipIndex, out); }
+
+int vs_actor_create_with(const vs_actor_options* o, const vs_actor_index_vtable* vt, vs_actor** out) {
+    if (!o || !out || !o->index.dimensions || !vt || !vt->create || !vt->stop || !vt->reserve || !vt->capacity || !vt->add || !vt->remove ||
+        !vt->search || !vt->filtered_search || !vt->last_error) {
         g_err = "invalid options";
         return VS_ERR_INVALID_ARGUMENT;
     }
     try {
         std::unique_ptr<vs_actor> a(new vs_actor());
         a->opt = *o;
+        a->vt = *vt;
         a->workers = o->workers ? o->workers : std::max(1u, std::thread::hardware_concurrency());
         a->channel = a->workers * 3;  // perf.rs:20-25
         a->pool.reset(new WorkerPool(a->workers, a->channel));
@@ -377,6 +423,49 @@ int vs_actor_remove_vector(vs_actor* a, uint64_t partition, uint64_t primary_id)
     return VS_OK;
 }
 
+int vs_actor_adopt_partition(vs_actor* a, uint64_t partition, void* index, size_t size) {
+    if (!a || !index) return VS_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(a->part_mu);
+    if (a->partitions.count(partition)) {
+        g_err = "the partition exists";
+        return VS_ERR_INVALID_ARGUMENT;
+    }
+    auto part = a->new_partition(partition, index, false);
+    part->size = size;
+    part->capacity = a->vt.capacity(index);
+    a->partitions[partition] = part;
+    a->index_size += size;
+    return VS_OK;
+}
+
+static int modify_wait(vs_actor* a, Msg&& m, int* applied) {
+    m.tx = std::make_shared<std::promise<int>>();
+    auto fut = m.tx->get_future();
+    a->send(std::move(m), false);
+    const int v = fut.get();
+    if (applied) *applied = v > 0 ? 1 : 0;
+    return v < 0 ? v : VS_OK;
+}
+
+int vs_actor_add_vector_wait(vs_actor* a, uint64_t partition, uint64_t primary_id, const float* v, size_t dim, int* applied) {
+    if (!a || !v) return VS_ERR_INVALID_ARGUMENT;
+    Msg m;
+    m.kind = Msg::Add;
+    m.partition = partition;
+    m.primary_id = primary_id;
+    m.v.assign(v, v + dim);
+    return modify_wait(a, std::move(m), applied);
+}
+
+int vs_actor_remove_vector_wait(vs_actor* a, uint64_t partition, uint64_t primary_id, int* applied) {
+    if (!a) return VS_ERR_INVALID_ARGUMENT;
+    Msg m;
+    m.kind = Msg::Remove;
+    m.partition = partition;
+    m.primary_id = primary_id;
+    return modify_wait(a, std::move(m), applied);
+}
+
 int vs_actor_remove_partition(vs_actor* a, uint64_t partition) {
     if (!a) return VS_ERR_INVALID_ARGUMENT;
     Msg m;
@@ -391,7 +480,10 @@ static int round_trip(vs_actor* a, Msg&& m) {
     auto fut = m.tx->get_future();
     a->send(std::move(m), true);
     int rc = fut.get();
-    if (rc != VS_OK && rc != VS_ERR_DIMENSION) g_err = vs_hnsw_last_error();
+    if (rc != VS_OK && rc != VS_ERR_DIMENSION) {
+        std::lock_guard<std::mutex> g(a->err_mu);
+        g_err = a->last_index_error;
+    }
     return rc;
 }
 

@@ -230,3 +230,154 @@ extern "C" int vs_callers_run_filtered(vs_hnsw* h, const float* queries, size_t 
     extra[2] = extra[3] = 0;
     return VS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The reference's mixed workloads through a dispatch actor (include/vs_callers.h).
+namespace {
+void fill_result(vs_callers_result* out, SearchMeasure& all, double wall) {
+    out->seconds = wall;
+    out->queries = all.count;
+    out->qps = wall > 0 ? all.count / wall : 0.0;
+    out->latency_min_ns = all.count ? all.latency_min : 0;
+    out->latency_max_ns = all.latency_max;
+    out->p01_ns = all.histogram.percentile(1);
+    out->p10_ns = all.histogram.percentile(10);
+    out->p25_ns = all.histogram.percentile(25);
+    out->p50_ns = all.histogram.percentile(50);
+    out->p75_ns = all.histogram.percentile(75);
+    out->p90_ns = all.histogram.percentile(90);
+    out->p99_ns = all.histogram.percentile(99);
+    out->recall_avg = -1.0;
+    out->errors = 0;
+    out->launches = out->team_launches = 0;
+}
+}  // namespace
+
+extern "C" int vs_mixed_run(vs_actor* actor, const vs_mixed_options* o, const float* queries, size_t nq, const float* vectors, size_t nv,
+                            size_t dim, vs_mixed_result* out) {
+    if (!actor || !o || !out || !dim || !o->k) return VS_ERR_INVALID_ARGUMENT;
+    const unsigned searchers = o->plain_callers + o->filtered_callers;
+    if (searchers && (!queries || !nq)) return VS_ERR_INVALID_ARGUMENT;
+    if ((o->modify == VS_MIXED_INSERT || o->modify == VS_MIXED_UPDATE) && (!vectors || !nv)) return VS_ERR_INVALID_ARGUMENT;
+    if (o->filtered_callers && !o->modulus) return VS_ERR_INVALID_ARGUMENT;
+    const unsigned producers = o->modify == VS_MIXED_NONE ? 0u : (o->producers ? o->producers : 1u);
+    const size_t k = o->k;
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> next_item{0}, adds_applied{0}, removes_applied{0}, calls{0}, results{0}, errors{0};
+    std::vector<SearchMeasure> per_plain(o->plain_callers), per_filtered(o->filtered_callers), per_item(producers);
+    const auto t0 = Clock::now();
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < o->plain_callers; ++t)
+        th.emplace_back([&, t] {
+            std::mt19937_64 g(t * 7919 + 13);
+            std::vector<uint64_t> keys(k);
+            std::vector<float> dist(k);
+            while (!stop.load(std::memory_order_relaxed)) {
+                const size_t qi = g() % nq;
+                size_t found = 0;
+                const auto s = Clock::now();
+                const int rc = vs_actor_ann(actor, o->partition, queries + qi * dim, dim, k, keys.data(), dist.data(), &found);
+                const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
+                if (rc != VS_OK) {
+                    ++errors;
+                    break;
+                }
+                per_plain[t].record(ns, 0.0);
+            }
+        });
+    for (unsigned t = 0; t < o->filtered_callers; ++t)
+        th.emplace_back([&, t] {
+            std::mt19937_64 g(t * 104729 + 7);
+            std::vector<uint64_t> keys(k);
+            std::vector<float> dist(k);
+            struct Local {
+                uint64_t modulus, calls;
+            } ctx{o->modulus, 0};
+            auto pred = [](uint64_t key, void* c) -> int {
+                Local* l = (Local*)c;
+                ++l->calls;
+                return key % l->modulus == 0 ? 1 : 0;
+            };
+            while (!stop.load(std::memory_order_relaxed)) {
+                const size_t qi = g() % nq;
+                size_t found = 0;
+                const auto s = Clock::now();
+                const int rc = vs_actor_filtered_ann(actor, o->partition, queries + qi * dim, dim, k, pred, &ctx, keys.data(), dist.data(), &found);
+                const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
+                if (rc != VS_OK) {
+                    ++errors;
+                    break;
+                }
+                for (size_t i = 0; i < found; ++i)
+                    if (keys[i] % o->modulus != 0) ++errors;  // a result the predicate rejects
+                results += found;
+                per_filtered[t].record(ns, 0.0);
+            }
+            calls += ctx.calls;
+        });
+    for (unsigned t = 0; t < producers; ++t)
+        th.emplace_back([&, t] {
+            std::mt19937_64 g(t * 15485863 + 29);
+            while (!stop.load(std::memory_order_relaxed)) {
+                const uint64_t it = next_item.fetch_add(1, std::memory_order_relaxed);
+                if (o->max_items && it >= o->max_items) break;
+                int applied = 0, rc = VS_OK;
+                const auto s = Clock::now();
+                switch (o->modify) {
+                    case VS_MIXED_INSERT:
+                        rc = vs_actor_add_vector_wait(actor, o->partition, o->first_new_key + it, vectors + (it % nv) * dim, dim, &applied);
+                        adds_applied += (uint64_t)applied;
+                        break;
+                    case VS_MIXED_UPDATE: {
+                        const uint64_t key = o->existing_keys ? g() % o->existing_keys : 0;
+                        rc = vs_actor_remove_vector(actor, o->partition, key);  // RemoveBeforeAddValue: no marker
+                        if (rc == VS_OK) rc = vs_actor_add_vector_wait(actor, o->partition, key, vectors + (it % nv) * dim, dim, &applied);
+                        adds_applied += (uint64_t)applied;
+                        break;
+                    }
+                    default:
+                        rc = vs_actor_remove_vector_wait(actor, o->partition, o->delete_from + it, &applied);
+                        removes_applied += (uint64_t)applied;
+                        break;
+                }
+                const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
+                if (rc != VS_OK) {
+                    ++errors;
+                    break;
+                }
+                per_item[t].record(ns, 0.0);
+            }
+        });
+    // the run ends after `seconds`, or -- a modify-only run with max_items -- when the producers are through
+    const bool until_items = o->max_items && !searchers && producers;
+    if (until_items) {
+        for (auto& x : th) x.join();
+    } else {
+        std::this_thread::sleep_for(std::chrono::duration<double>(o->seconds));
+        stop = true;
+        for (auto& x : th) x.join();
+    }
+    // whatever is staged inside the index is indexed before the clock stops (Count is answered by the actor; a search reaches the index)
+    if (producers && queries && nq) {
+        std::vector<uint64_t> keys(k);
+        std::vector<float> dist(k);
+        size_t found = 0;
+        (void)vs_actor_ann(actor, o->partition, queries, dim, k, keys.data(), dist.data(), &found);
+    }
+    const double wall = std::chrono::duration<double>(Clock::now() - t0).count();
+    SearchMeasure plain, filtered, item;
+    for (auto& m : per_plain) plain.append(m);
+    for (auto& m : per_filtered) filtered.append(m);
+    for (auto& m : per_item) item.append(m);
+    out->seconds = wall;
+    out->items = item.count;
+    out->adds_applied = adds_applied.load();
+    out->removes_applied = removes_applied.load();
+    out->predicate_calls = calls.load();
+    out->filtered_results = results.load();
+    out->errors = errors.load();
+    fill_result(&out->item, item, wall);
+    fill_result(&out->plain, plain, wall);
+    fill_result(&out->filtered, filtered, wall);
+    return VS_OK;
+}

@@ -64,12 +64,52 @@ struct Fail {
         if (e__ != hipSuccess) ::vs::fail(VS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// hipFree / hipHostFree synchronise the whole device: with resident pods (below) they block until every open pod's kernel ends -- up to a
+// pod's age limit, a second or two -- and the buffers that regrow sit on search paths (a larger batch, a larger k, another index's
+// first query).  A buffer that is replaced while the process runs is therefore PARKED here and freed when no pod is open on any device
+// (drain_graveyard, called where a stall costs nothing: under a pod hold, and by leases taken while every pod is free).
+static std::atomic<size_t> g_buried{0};  // blocks parked on any device (a cheap "anything to do?" for the search paths)
+struct Graveyard {
+    std::mutex mu;
+    std::vector<void*> dev, host;
+    std::atomic<size_t> n{0};
+    void bury(void* device_ptr, void* host_ptr) {
+        std::lock_guard<std::mutex> g(mu);
+        if (device_ptr) dev.push_back(device_ptr);
+        if (host_ptr) host.push_back(host_ptr);
+        g_buried.fetch_add((device_ptr ? 1 : 0) + (host_ptr ? 1 : 0), std::memory_order_relaxed);
+        n.store(dev.size() + host.size(), std::memory_order_relaxed);
+    }
+    void drain() {  // the caller knows that no pod is open (or accepts the wait)
+        std::vector<void*> d, h;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            d.swap(dev);
+            h.swap(host);
+            n.store(0, std::memory_order_relaxed);
+            g_buried.fetch_sub(d.size() + h.size(), std::memory_order_relaxed);
+        }
+        for (void* p : d) (void)hipFree(p);
+        for (void* p : h) (void)hipHostFree(p);
+    }
+};
+static Graveyard& graveyard() {  // of the calling thread's current device (a free synchronises the device the block lives on)
+    static std::mutex mu;
+    static std::unordered_map<int, Graveyard*> all;  // leaked with the process
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    Graveyard*& p = all[dev];
+    if (!p) p = new Graveyard();
+    return *p;
+}
+
 struct DeviceBuf {  // grow-only device scratch
     void* p = nullptr;
     size_t bytes = 0;
     void* ensure(size_t n) {
         if (n > bytes) {
-            if (p) (void)hipFree(p);
+            if (p) graveyard().bury(p, nullptr);
             p = nullptr;
             bytes = 0;
             size_t want = n + n / 4 + 256;
@@ -190,7 +230,7 @@ struct Arena {
                 HIP_OK(hipMemcpy(np, base, keep, hipMemcpyDeviceToDevice));
                 copied_bytes += keep;
             }
-            if (base) HIP_OK(hipFree(base));
+            if (base) graveyard().bury(base, nullptr);  // (freed when no pod is open: a free synchronises the device)
             base = np;
             bytes = want;
             return base;
@@ -222,7 +262,7 @@ struct Arena {
                 HIP_OK(hipMemcpy(base, old, keep, hipMemcpyDeviceToDevice));
                 copied_bytes += keep;
             }
-            if (old) HIP_OK(hipFree(old));
+            if (old) graveyard().bury(old, nullptr);
             return base;
         }
         if (need < bytes) {  // give whole chunks beyond the new end back
@@ -448,7 +488,8 @@ struct Pod {
     const void* owner = nullptr;  // the index whose view the launch carries
     int mode = 0;                 // 0 = plain lone queries, 1 = filtered queries (exact walks and exploring rounds: the slot says which)
     uint32_t efcap = 0;           // 256 / 512: the kernel instance
-    size_t index_slots = 0;       // slots of the index when the pod was opened (its visited bitmaps are laid out for them)
+    size_t index_slots = 0;       // what the callers' visited bitmaps are laid out for: the index's CAPACITY when the pod was opened
+    bool frozen = false;          // its index is being modified: no posts (the caller launches instead); the view in `ctl` is rewritten before it thaws
     hipStream_t st = nullptr;
     PodCtl* ctl = nullptr;        // pinned
     PodSlot* slots = nullptr;     // pinned
@@ -472,6 +513,7 @@ struct PodPool {
     Pod pods[kPods];
     bool keeper_started = false;
     bool enabled = true;
+    int holds = 0;  // > 0: somebody is about to synchronise the device (reserve, stats, export, a drop): no pod may open until it is through
     uint32_t n_slots = Pod::kSlots;
     int idle_us = 20000, max_age_ms = 1000;
     std::atomic<uint64_t> n_opened{0}, n_served{0}, n_closed{0};
@@ -520,8 +562,10 @@ struct PodPool {
             lk.lock();
         }
     }
-    // Close the pods of one index (nullptr: all of them) and wait until their workgroups have left: before anything that changes the
-    // index's view, and before a device-wide synchronisation.
+    // Close the pods of one index (nullptr: all of them) and wait until their workgroups have left: before anything that moves the
+    // index's arenas, and before a device-wide synchronisation.  quiesce(nullptr) is called under a Hold: with callers posting to
+    // any index of the device, a pod freed here would be reopened by the next caller before the others have gone, and the three would
+    // never be free together (advisor finding, round 4).
     void quiesce(const void* owner) {
         std::unique_lock<std::mutex> lk(mu);
         const auto t0 = std::chrono::steady_clock::now();
@@ -548,6 +592,69 @@ struct PodPool {
         --p.n_busy;
         p.last_used = std::chrono::steady_clock::now();
     }
+    bool all_free() {
+        std::lock_guard<std::mutex> g(mu);
+        for (const Pod& p : pods)
+            if (p.state != Pod::kFree) return false;
+        return true;
+    }
+    // An index is being modified (adds, removes: they never overlap its searches, usearch.rs:590-612): its pods take no posts and have
+    // no query in flight while it lasts; thaw() hands them the new entry point / top level / removed flag (PodCtl) -- or closes them,
+    // when what they were launched with no longer holds (`layout`: the capacity their callers' workspaces are laid out for).
+    void freeze(const void* owner) {
+        std::unique_lock<std::mutex> lk(mu);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            bool pending = false;
+            for (Pod& p : pods) {
+                if (p.state == Pod::kFree || p.owner != owner) continue;
+                p.frozen = true;
+                if (p.n_busy) pending = true;
+            }
+            if (!pending) return;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) fail(VS_ERR_DEVICE, "queries posted to a pod did not finish");
+            lk.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
+            lk.lock();
+        }
+    }
+    void thaw(const void* owner, size_t layout, uint32_t entry_slot, int32_t max_level, uint32_t has_removed) {
+        std::lock_guard<std::mutex> g(mu);
+        for (Pod& p : pods) {
+            if (p.owner != owner || !p.frozen) continue;
+            if (p.state == Pod::kOpen && p.index_slots != layout) close_locked(p);
+            if (p.state == Pod::kOpen) {
+                __atomic_store_n(&p.ctl->entry_slot, entry_slot, __ATOMIC_RELAXED);
+                __atomic_store_n(&p.ctl->max_level, max_level, __ATOMIC_RELAXED);
+                __atomic_store_n(&p.ctl->has_removed, has_removed, __ATOMIC_RELEASE);  // (a post's release store follows before any workgroup looks)
+                p.last_used = std::chrono::steady_clock::now();
+            }
+            p.frozen = false;
+        }
+    }
+};
+// Taken around a device-wide synchronisation (and whatever it protects: an arena move, frees): closes every pod of the device, keeps
+// them closed -- pod_submit answers "no pod" meanwhile and its caller launches as before pods existed -- and frees what was parked.
+struct PodHold {
+    PodPool& pp;
+    explicit PodHold(PodPool& pool) : pp(pool) {
+        {
+            std::lock_guard<std::mutex> g(pp.mu);
+            ++pp.holds;
+        }
+        try {
+            pp.quiesce(nullptr);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(pp.mu);
+            --pp.holds;
+            throw;
+        }
+    }
+    ~PodHold() {
+        graveyard().drain();  // (no pod is open: these frees wait for ordinary kernels only)
+        std::lock_guard<std::mutex> g(pp.mu);
+        --pp.holds;
+    }
 };
 static PodPool& pod_pool(int dev) {
     static std::mutex mu;
@@ -571,6 +678,21 @@ static PodPool& pod_pool(int dev) {
         });
     }
     return *p;
+}
+
+// Parked blocks are freed when no pod is open on the device and none can open meanwhile (a free then waits for ordinary kernels only).
+static void drain_graveyard_if_idle(int dev) {
+    if (g_buried.load(std::memory_order_relaxed) == 0 || graveyard().n.load(std::memory_order_relaxed) == 0) return;
+    PodPool& pp = pod_pool(dev);
+    {
+        std::lock_guard<std::mutex> g(pp.mu);
+        for (const Pod& p : pp.pods)
+            if (p.state != Pod::kFree) return;
+        ++pp.holds;
+    }
+    graveyard().drain();
+    std::lock_guard<std::mutex> g(pp.mu);
+    --pp.holds;
 }
 
 // Workspace of the usearch-order walk kernels (kernels_walk.hip), one per (device, stream): launches on one stream
@@ -673,6 +795,10 @@ struct Engine {
     unsigned long long* d_stats = nullptr;
     size_t capacity = 0, upper_cap = 0;
     std::atomic<size_t> capacity_atomic{0};  // mirror of `capacity` for lock-free reads in add_one
+    std::atomic<size_t> slots_atomic{0};     // mirror of `slots` for the search paths (they read it per query: no mod_mu there)
+    // What the workspaces of posted / batched walks (visited bitmap | log | spill slots) are laid out for: the CAPACITY, not the slots in
+    // use -- so the layout, and with it an open pod, survives adds (round 5); it changes with reserve, which closes the pods.
+    size_t layout_slots() const { return capacity_atomic.load(std::memory_order_acquire); }
 
     // host bookkeeping (guarded by mod_mu)
     std::mutex mod_mu;
@@ -693,29 +819,34 @@ struct Engine {
     std::atomic<uint32_t> entry_slot{0};
     std::atomic<int32_t> max_level{-1};
 
-    // batching of concurrent single-vector callers
-    // Deferred single-vector adds (vs_hnsw_add): validated and queued under pend_mu, inserted in bulk by
-    // flush_pending() -- see add_one().
+    // Staged single-vector modifications (vs_hnsw_add / vs_hnsw_remove): validated and logged under pend_mu, applied in order and in
+    // bulk by flush_pending() -- see add_one() / remove_one().
     struct Pending {
-        std::vector<uint64_t> keys;
+        static constexpr uint32_t kRemove = 0xFFFFFFFFu;
+        struct Op {
+            uint64_t key;
+            uint32_t vec;  // index of the add's vector in `vecs`; kRemove: a remove
+        };
+        std::vector<Op> ops;
         std::vector<float> vecs;
-        std::unordered_set<uint64_t> keyset;
-        void clear() {
-            keys.clear();
-            vecs.clear();
-            keyset.clear();
-        }
+        std::unordered_map<uint64_t, uint8_t> last;  // per key: 1 = its last staged operation is an add, 2 = a remove
+        size_t adds = 0;
     };
     std::mutex pend_mu;
+    std::condition_variable flush_cv;
     Pending pend;
-    std::unordered_set<uint64_t> flushing_keys;  // taken out of `pend`, not yet in `lookup`
-    std::atomic<size_t> queued{0};               // pending + being flushed
-    std::atomic<size_t> committed{0};            // live members + staged adds: what capacity is checked against
+    bool flushing = false;                                  // one flush at a time: logs are applied in the order they were taken
+    std::unordered_map<uint64_t, uint8_t> flushing_last;   // the log being applied (host state not yet updated): final state per key
+    std::atomic<size_t> queued{0};               // operations staged + being applied
+    std::atomic<size_t> committed{0};            // live members + staged adds - staged removes: what capacity is checked against
     std::mutex key_mu;                           // guards `lookup` membership (adds validate against it concurrently)
     std::mutex poison_mu;
     std::string poison;                          // set when a deferred insertion failed: every later call reports it
 
-    void use_device() const { HIP_OK(hipSetDevice(device)); }
+    void use_device() const {
+        HIP_OK(hipSetDevice(device));
+        drain_graveyard_if_idle(device);
+    }
 
     IndexView view() const {
         IndexView v;
@@ -741,15 +872,34 @@ struct Engine {
 
     ~Engine() {
         (void)hipSetDevice(device);
+        // Dropping an index frees its arenas, and a free synchronises the device: with pods open -- this index's or another's -- each
+        // free would wait out a pod's life.  Small indexes (the reference keeps thousands of per-partition handles and drops them with
+        // their partitions, usearch.rs:766-778, :881-887) only close their own pods and PARK their blocks; large ones (VMM arenas are
+        // unmapped, not freed) take the hold.
         try {
-            pod_pool(device).quiesce(nullptr);
+            pod_pool(device).quiesce(this);
         } catch (...) {
         }
-        (void)hipDeviceSynchronize();
-        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) a->release();
-        if (d_rho) (void)hipFree(d_rho);
-        if (d_stats) (void)hipFree(d_stats);
-        if (d_max_norm) (void)hipFree(d_max_norm);
+        bool any_vmm = false;
+        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) any_vmm |= a->vmm;
+        if (any_vmm) {
+            try {
+                PodHold hold(pod_pool(device));
+                (void)hipDeviceSynchronize();
+                for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) a->release();
+            } catch (...) {
+            }
+        }
+        // (plain blocks: nothing of this index runs any more -- its calls have returned, its pods are gone -- so they can wait)
+        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) {
+            if (!a->vmm && a->base) graveyard().bury(a->base, nullptr);
+            a->base = nullptr;
+            a->bytes = 0;
+        }
+        graveyard().bury(d_rho, nullptr);
+        graveyard().bury(d_stats, nullptr);
+        graveyard().bury(d_max_norm, nullptr);
+        drain_graveyard_if_idle(device);
     }
 
     void init(const vs_hnsw_options& o) {
@@ -866,7 +1016,7 @@ struct Engine {
             fail(VS_ERR_UNSUPPORTED, "capacity above 2^29 slots needs expansion_add <= 128 (or several shards, include/vs_shards.h)");
         if (cap == capacity) return;
         std::unique_lock<std::shared_mutex> vg(view_mu);
-        pod_pool(device).quiesce(nullptr);
+        PodHold hold(pod_pool(device));  // (arenas may move: no pod of the device is open, and none opens, until this returns)
         HIP_OK(hipDeviceSynchronize());
         // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
         // coexist with the old ones while rows are copied across.
@@ -895,7 +1045,7 @@ struct Engine {
 
     void ensure_upper_locked(size_t blocks) {  // view_mu held exclusively
         if (blocks <= upper_cap) return;
-        pod_pool(device).quiesce(nullptr);
+        PodHold hold(pod_pool(device));
         HIP_OK(hipDeviceSynchronize());
         size_t ncap = std::max(blocks, upper_cap * 2);
         regrow(ar_upper, d_upper, upper_cap * M, ncap * M, 0xFF);
@@ -915,13 +1065,32 @@ struct Engine {
 
     // ------------------------------------------------------------------ add
     // Returns per-item status (VS_OK / VS_ERR_*), all items attempted.
+    // While an index is modified its pods take no posts; afterwards they get the new entry point / top level / removed flag (PodCtl)
+    // and go on -- searches do not overlap modifications (usearch.rs:590-612).  mod_mu is held.
+    struct PodFreeze {
+        Engine& e;
+        explicit PodFreeze(Engine& eng) : e(eng) {
+            Stopwatch sw(e.m_quiesce_ns);
+            e.m_quiesces.fetch_add(1, std::memory_order_relaxed);
+            pod_pool(e.device).freeze(&e);
+        }
+        ~PodFreeze() { pod_pool(e.device).thaw(&e, e.capacity, e.entry_slot.load(), e.max_level.load(), e.removed.load() ? 1u : 0u); }
+    };
+
     void add_batch(const uint64_t* keys, const float* vecs, bool on_device, size_t n, std::vector<int>& status,
                    std::string& first_err, bool staged = false) {
         status.assign(n, VS_OK);
         if (!n) return;
         std::lock_guard<std::mutex> g(mod_mu);
         use_device();
-        pods_quiesce();  // (searches do not overlap adds: usearch.rs:590-612 -- a pod carries the view it was opened with)
+        PodFreeze freeze(*this);
+        add_batch_locked(keys, vecs, on_device, n, status, first_err, staged);
+    }
+
+    void add_batch_locked(const uint64_t* keys, const float* vecs, bool on_device, size_t n, std::vector<int>& status,
+                          std::string& first_err, bool staged) {  // mod_mu held, this index's pods frozen
+        status.assign(n, VS_OK);
+        if (!n) return;
         Lease w(device);
         hipStream_t st = w->stream;
         for (size_t c0 = 0; c0 < n; c0 += chunk_rows) {
@@ -1130,37 +1299,46 @@ struct Engine {
             for (uint32_t i = 0; i < m; ++i) h_keys[slot_v[i]] = key_v[i];
             live += m;
             if (!staged) committed += m;  // staged vectors were counted when add_one accepted them
+            slots_atomic.store(slots, std::memory_order_release);
         }
     }
 
-    // Single-vector callers (one add per FFI call from <= num_workers()+1 threads, reference worker.rs:44-118).
-    // An insert is one graph walk (~1.4 ms of latency for a lone wave), so inserting per call would cap the build
-    // at the walk latency.  The reference treats adds as fire-and-forget messages (usearch.rs:1028-1034), which
-    // allows the same "as-if" here: add_one validates synchronously (reserved / duplicate key, capacity), stages
-    // the vector and returns; staged vectors are inserted in bulk when kFlushThreshold of them are waiting and,
-    // at the latest, before any other operation observes the index (search, remove, reserve, size, stats,
-    // export), so every call still sees the effect of all adds that returned before it.
+    // Single-vector callers (one add / remove per FFI call from <= num_workers()+1 threads, reference worker.rs:44-118).
+    // An insert is one graph walk (~1 ms of latency for a lone team of waves), so inserting per call would cap the build
+    // at the walk latency.  The reference treats adds and removes as fire-and-forget messages (usearch.rs:1028-1049), which
+    // allows the same "as-if" here: add_one / remove_one validate synchronously against the state every EARLIER call left
+    // (reserved / duplicate / unknown key, capacity), log the operation and return; the log is applied IN ORDER and in bulk
+    // when kFlushThreshold operations are waiting and, at the latest, before any other call observes the index (search,
+    // reserve, size, stats, export), so every call still sees the effect of everything that returned before it.
+    // Round 5: removes are logged too.  Until then each remove flushed the adds before it, so the reference's update --
+    // RemoveBeforeAddValue then AddVector, monitor_items.rs:301-313 -- paid one lone insert walk per item (1.1k updates/s
+    // through the actor at 10M x 768, scripts/mixed_probe.py; the bulk insert path does hundreds of thousands).
     static constexpr size_t kFlushThreshold = 4096;
 
+    // pend_mu held.  Is `key` a member once everything logged so far has been applied?
+    bool key_present_locked(uint64_t key) {
+        auto it = pend.last.find(key);
+        if (it != pend.last.end()) return it->second == 1;
+        auto jt = flushing_last.find(key);
+        if (jt != flushing_last.end()) return jt->second == 1;
+        std::lock_guard<std::mutex> kg(key_mu);
+        return lookup.count(key) != 0;
+    }
+    bool poisoned() {
+        std::lock_guard<std::mutex> pg(poison_mu);
+        if (poison.empty()) return false;
+        g_err = poison;
+        return true;
+    }
+
     int add_one(uint64_t key, const float* v) {
-        {
-            std::lock_guard<std::mutex> pg(poison_mu);
-            if (!poison.empty()) {
-                g_err = poison;
-                return VS_ERR_DEVICE;
-            }
-        }
+        if (poisoned()) return VS_ERR_DEVICE;
         std::unique_lock<std::mutex> lk(pend_mu);
         if (key == kFreeKey) {
             g_err = error_text(VS_ERR_INVALID_ARGUMENT);
             return VS_ERR_INVALID_ARGUMENT;
         }
-        bool dup = pend.keyset.count(key) || flushing_keys.count(key);
-        if (!dup) {
-            std::lock_guard<std::mutex> kg(key_mu);
-            dup = lookup.count(key) != 0;
-        }
-        if (dup) {
+        if (key_present_locked(key)) {
             g_err = error_text(VS_ERR_DUPLICATE_KEY);
             return VS_ERR_DUPLICATE_KEY;
         }
@@ -1168,30 +1346,54 @@ struct Engine {
             g_err = error_text(VS_ERR_CAPACITY);
             return VS_ERR_CAPACITY;
         }
-        pend.keys.push_back(key);
+        pend.ops.push_back({key, (uint32_t)pend.adds});
         pend.vecs.insert(pend.vecs.end(), v, v + dim);
-        pend.keyset.insert(key);
+        ++pend.adds;
+        pend.last[key] = 1;
         ++queued;
         ++committed;
-        if (pend.keys.size() < kFlushThreshold) return VS_OK;
-        return flush_locked(lk);
+        if (pend.ops.size() < kFlushThreshold) return VS_OK;
+        return flush_locked(lk, false);
     }
 
-    // Inserts everything staged so far.  Called with pend_mu held; releases it while the GPU works so that
-    // other callers keep staging into the fresh buffer.
-    int flush_locked(std::unique_lock<std::mutex>& lk) {
-        if (pend.keys.empty()) return VS_OK;
+    // usearch index_dense::remove: true when the key was a member.
+    int remove_one(uint64_t key, bool* was_member) {
+        Stopwatch sw(m_remove_ns);
+        m_removes.fetch_add(1, std::memory_order_relaxed);
+        *was_member = false;
+        if (poisoned()) return VS_ERR_DEVICE;
+        std::unique_lock<std::mutex> lk(pend_mu);
+        if (key == kFreeKey || !key_present_locked(key)) return VS_OK;
+        pend.ops.push_back({key, Pending::kRemove});
+        pend.last[key] = 2;
+        ++queued;
+        --committed;
+        *was_member = true;
+        if (pend.ops.size() < kFlushThreshold) return VS_OK;
+        return flush_locked(lk, false);
+    }
+
+    // Applies everything logged so far, in order.  Called with pend_mu held; releases it while the GPU works so that
+    // other callers keep logging.  One flush at a time (logs are applied in the order they were taken): a caller that
+    // finds one running waits for it when it needs the barrier (`barrier`), and otherwise leaves its operations staged.
+    int flush_locked(std::unique_lock<std::mutex>& lk, bool barrier) {
+        while (flushing) {
+            if (!barrier) return VS_OK;
+            flush_cv.wait(lk);
+        }
+        if (pend.ops.empty()) return VS_OK;
+        Stopwatch sw(m_flush_ns);
+        m_flushes.fetch_add(1, std::memory_order_relaxed);
+        m_flushed.fetch_add(pend.adds, std::memory_order_relaxed);
         Pending take;
         std::swap(take, pend);
-        for (uint64_t k : take.keys) flushing_keys.insert(k);
+        flushing_last.swap(take.last);
+        flushing = true;
         lk.unlock();
-        std::vector<int> status;
-        std::string err;
         int rc = VS_OK;
+        size_t lost = 0;
         try {
-            add_batch(take.keys.data(), take.vecs.data(), false, take.keys.size(), status, err, true);
-            for (int st : status)
-                if (st != VS_OK) --committed;  // accepted at staging time, rejected at insertion (cannot normally happen)
+            apply_log(take, lost);
         } catch (const Fail& f) {
             rc = f.code;
             g_err = f.msg;
@@ -1200,37 +1402,99 @@ struct Engine {
             g_err = e.what();
         }
         if (rc != VS_OK) {
-            // The staged vectors are lost although their vs_hnsw_add calls returned VS_OK, and add_batch may have stopped
-            // between the host bookkeeping and the GPU work: the index is not trustworthy any more.  It says so to every
-            // later call (a device failure is not recoverable in this process anyway) instead of reporting a false
-            // "Reserve capacity" to an unrelated caller (advisor finding, round 1).
-            size_t lost = 0;
-            {
-                std::lock_guard<std::mutex> kg(key_mu);
-                for (uint64_t k : take.keys) lost += lookup.count(k) ? 0 : 1;
-            }
-            committed -= std::min(lost, committed.load());
+            // Staged vectors are lost although their vs_hnsw_add calls returned VS_OK, and the log may have stopped between the
+            // host bookkeeping and the GPU work: the index is not trustworthy any more.  It says so to every later call (a
+            // device failure is not recoverable in this process anyway) instead of reporting a false "Reserve capacity" to an
+            // unrelated caller (advisor finding, round 1).
             std::lock_guard<std::mutex> pg(poison_mu);
-            if (poison.empty()) poison = "index unusable after a failed insertion of " + std::to_string(lost) + " staged vectors: " + g_err;
+            if (poison.empty()) poison = "index unusable after a failed flush of " + std::to_string(take.ops.size()) + " staged operations: " + g_err;
         }
         lk.lock();
-        for (uint64_t k : take.keys) flushing_keys.erase(k);
-        queued -= take.keys.size();
+        flushing = false;
+        flushing_last.clear();
+        queued -= take.ops.size();
+        flush_cv.notify_all();
         return rc;
+    }
+
+    // The staged log, in order: runs of consecutive adds go through the bulk insert (slots are assigned as the run is reached, so an
+    // add re-uses the slot a remove EARLIER in the log freed, exactly as the calls would have one by one: usearch's free ring is FIFO),
+    // removes update the host maps and are tombstoned on the device in one launch at the end (a slot that was removed and re-added in
+    // this log carries its new key by then).
+    void apply_log(Pending& log, size_t& lost) {
+        std::lock_guard<std::mutex> g(mod_mu);
+        use_device();
+        PodFreeze freeze(*this);
+        std::vector<uint32_t> tomb;
+        std::vector<uint64_t> run_keys;
+        const size_t n = log.ops.size();
+        for (size_t i = 0; i < n;) {
+            if (log.ops[i].vec == Pending::kRemove) {
+                uint32_t slot = kInvalid;
+                {
+                    std::lock_guard<std::mutex> kg(key_mu);
+                    auto it = lookup.find(log.ops[i].key);
+                    if (it != lookup.end()) {
+                        slot = it->second;
+                        lookup.erase(it);
+                    }
+                }
+                if (slot != kInvalid) {  // (always: the call was validated against the state this log produces)
+                    h_keys[slot] = kFreeKey;
+                    free_slots.push_back(slot);
+                    ++removed;
+                    --live;
+                    tomb.push_back(slot);
+                } else {
+                    ++committed;  // the remove was counted when it was staged
+                }
+                ++i;
+                continue;
+            }
+            size_t j = i;
+            run_keys.clear();
+            while (j < n && log.ops[j].vec != Pending::kRemove) run_keys.push_back(log.ops[j++].key);
+            std::vector<int> status;
+            std::string err;
+            add_batch_locked(run_keys.data(), log.vecs.data() + (size_t)log.ops[i].vec * dim, false, j - i, status, err, true);
+            for (int st : status)
+                if (st != VS_OK) {  // accepted at staging time, rejected at insertion (cannot normally happen)
+                    --committed;
+                    ++lost;
+                }
+            i = j;
+        }
+        if (!tomb.empty()) {
+            size_t m = 0;
+            for (uint32_t s : tomb)
+                if (h_keys[s] == kFreeKey) tomb[m++] = s;  // not re-added later in this log
+            if (m) {
+                Lease w(device);
+                uint32_t* d_t = (uint32_t*)w->d.ensure(m * 4 + 64);
+                HIP_OK(hipMemcpyAsync(d_t, tomb.data(), m * 4, hipMemcpyHostToDevice, w->stream));
+                HIP_OK(launch_fill_rows_u32((uint32_t*)d_keys, 2, d_t, (uint32_t)m, kInvalid, w->stream));  // key := ~0 (usearch free_key)
+                HIP_OK(hipStreamSynchronize(w->stream));
+            }
+        }
     }
 
     // Barrier used by every operation that observes the index.
     void flush_pending() {
+        if (queued.load(std::memory_order_acquire) == 0) {  // nothing staged, nothing being applied
+            std::lock_guard<std::mutex> pg(poison_mu);
+            if (!poison.empty()) fail(VS_ERR_DEVICE, poison);
+            return;
+        }
         {
             std::lock_guard<std::mutex> pg(poison_mu);
             if (!poison.empty()) fail(VS_ERR_DEVICE, poison);
         }
         {
             std::unique_lock<std::mutex> lk(pend_mu);
-            int rc = flush_locked(lk);
+            int rc = flush_locked(lk, true);
             if (rc != VS_OK) fail(rc, g_err);
         }
-        std::lock_guard<std::mutex> g(mod_mu);  // a flush started by another caller has finished too
+        std::lock_guard<std::mutex> g(mod_mu);  // a bulk add started by another caller has finished too
     }
 
     static const char* error_text(int code) {
@@ -1240,29 +1504,6 @@ struct Engine {
             case VS_ERR_INVALID_ARGUMENT: return "Key is reserved for internal use";
             default: return "add failed";
         }
-    }
-
-    // ------------------------------------------------------------------ remove (usearch index_dense::remove)
-    bool remove(uint64_t key) {
-        std::lock_guard<std::mutex> g(mod_mu);
-        use_device();
-        pods_quiesce();
-        uint32_t slot;
-        {
-            std::lock_guard<std::mutex> kg(key_mu);
-            auto it = lookup.find(key);
-            if (it == lookup.end()) return false;
-            slot = it->second;
-            lookup.erase(it);
-        }
-        const uint64_t free_key = kFreeKey;
-        HIP_OK(hipMemcpy(d_keys + slot, &free_key, 8, hipMemcpyHostToDevice));
-        h_keys[slot] = kFreeKey;
-        free_slots.push_back(slot);
-        ++removed;
-        --live;
-        --committed;
-        return true;
     }
 
     // ------------------------------------------------------------------ search
@@ -1851,7 +2092,7 @@ struct Engine {
         std::atomic<uint64_t> launches{0}, rounds{0};
         ~FilterBatcher() {
             for (int i = 0; i < kTables; ++i) {
-                if (table[i]) (void)hipHostFree(table[i]);
+                if (table[i]) graveyard().bury(nullptr, table[i]);
                 if (ev[i]) (void)hipEventDestroy(ev[i]);
             }
             for (auto& e : stream_ev)
@@ -1868,6 +2109,7 @@ struct Engine {
     std::atomic<uint32_t> wait_typical_us[4] = {};  // how long this index's callers lately waited for a plain query / an exact filtered walk / an exploring round
     // Post one query / round (mode: 0 plain, 1 exact filtered walk, 2 exploring round) to a pod of this index; no ticket: no pod can
     // take it now (the caller launches as before).  `n`: the index's slots, as the caller's workspace is laid out for.
+    // `n`: what the caller's workspace is laid out for (layout_slots(): the index's capacity).
     PodTicket pod_submit(int mode, uint32_t ef, size_t n, const PipeQuery& pq) {
         PodPool& pp = pod_pool(device);
         if (!pp.enabled || ef > 512) return {};
@@ -1875,9 +2117,11 @@ struct Engine {
         const bool explore = mode == 2;
         if (mode == 2) mode = 1;  // (one kind of pod serves both kinds of round of a filtered query: its callers alternate between them)
         std::lock_guard<std::mutex> g(pp.mu);
+        if (pp.holds > 0) return {};  // somebody is about to synchronise the device: no pod opens, none takes a post
         int use = -1, free_pod = -1;
         for (int i = 0; i < PodPool::kPods && use < 0; ++i) {
             Pod& p = pp.pods[i];
+            if (p.state != Pod::kFree && p.owner == this && p.frozen) return {};  // (the index is being modified: the caller breaks the reference's contract, and is served by a launch)
             if (p.state == Pod::kOpen && p.owner == this && p.mode == mode && p.efcap == efcap && p.index_slots == n && p.n_busy < p.n) use = i;
             if (p.state == Pod::kFree && free_pod < 0) free_pod = i;
         }
@@ -1894,6 +2138,7 @@ struct Engine {
             if (!p.slots) HIP_OK(hipHostMalloc((void**)&p.slots, sizeof(PodSlot) * Pod::kSlots, hipHostMallocDefault));
             if (!p.stage) HIP_OK(hipMalloc((void**)&p.stage, sizeof(PipeQuery) * Pod::kSlots));
             std::memset(p.ctl, 0, sizeof(PodCtl));
+            p.frozen = false;
             std::memset(p.slots, 0, sizeof(PodSlot) * Pod::kSlots);
             std::memset(p.busy, 0, sizeof(p.busy));
             std::memset(p.seq, 0, sizeof(p.seq));
@@ -1909,6 +2154,10 @@ struct Engine {
             a.ef = efcap;  // (the instance; a query's own beam travels in its slot)
             a.k = 0;
             a.has_removed = removed.load() ? 1u : 0u;
+            // (what adds and removes change is read per query from the pod's control block: PodFreeze rewrites it after every modification)
+            p.ctl->entry_slot = a.ix.entry_slot;
+            p.ctl->max_level = a.ix.max_level;
+            p.ctl->has_removed = a.has_removed;
             a.bitmap_words = (uint32_t)((n + 31) / 32);
             a.vlog_cap = kBatchVlogCap;
             a.heap_cap = kBatchHeapCap;
@@ -1972,7 +2221,19 @@ struct Engine {
         }
         ~PodRelease() { done(); }
     };
-    void pods_quiesce() { pod_pool(device).quiesce(this); }  // before anything that changes the view (entry point, arenas, removed flag)
+    // where a modification's time goes (vs_hnsw_modify_stats): flushes of staged adds, closing of this index's pods, removes
+    std::atomic<uint64_t> m_flushes{0}, m_flushed{0}, m_flush_ns{0}, m_quiesces{0}, m_quiesce_ns{0}, m_removes{0}, m_remove_ns{0};
+    struct Stopwatch {
+        std::atomic<uint64_t>& ns;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        explicit Stopwatch(std::atomic<uint64_t>& total) : ns(total) {}
+        ~Stopwatch() { ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
+    };
+    void pods_quiesce() {  // before anything that changes the view (entry point, arenas, removed flag)
+        Stopwatch sw(m_quiesce_ns);
+        m_quiesces.fetch_add(1, std::memory_order_relaxed);
+        pod_pool(device).quiesce(this);
+    }
 
     void launch_rounds(std::vector<FilterBatcher::Req>& take, size_t n_slots) {
         FilterBatcher& b = batcher;
@@ -2093,12 +2354,8 @@ struct Engine {
     // filtered_lazy through the batcher.  (size_t)-1: hand the query to the unbatched rounds (a tie where order matters, or a failure).
     size_t filtered_batched(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, uint32_t ef) {
         use_device();
-        size_t n;
-        {
-            std::lock_guard<std::mutex> g(mod_mu);
-            n = slots;
-        }
-        const size_t words = (n + 31) / 32;
+        const size_t n = slots_atomic.load(std::memory_order_acquire), lay = layout_slots();
+        const size_t words = (n + 31) / 32, lay_words = (lay + 31) / 32;
         const uint32_t cap = 1u << 17;
         // (at most 128 of these queries hold a context -- a workspace of a few MB each -- at a time)
         static std::mutex gate_mu;
@@ -2120,17 +2377,17 @@ struct Engine {
         } permit;
         Lease w(device);
         uint32_t* d_bits = (uint32_t*)w->e.ensure(words * 8);
-        const size_t space = batch_space_bytes(n);
-        if (w->ws.bytes < space || w->ws_zeroed != words) {
+        const size_t space = batch_space_bytes(lay);
+        if (w->ws.bytes < space || w->ws_zeroed != lay_words) {
             char* p = (char*)w->ws.ensure(space);
             HIP_OK(hipMemsetAsync(p, 0, w->ws.bytes, w->stream));
             HIP_OK(hipStreamSynchronize(w->stream));
-            w->ws_zeroed = words;
+            w->ws_zeroed = lay_words;
         }
         // pinned, device-mapped: [flag, counters 64 B | list cap x 4 | verdicts cap | keys k x 8 | dist k x 4 | the query]
         const size_t pin_need = 64 + (size_t)cap * 5 + k * 12 + 64 + (size_t)dim * 4;
         if (w->pin_bytes < pin_need) {
-            if (w->pin) (void)hipHostFree(w->pin);
+            if (w->pin) graveyard().bury(nullptr, w->pin);
             w->pin = nullptr;
             w->pin_bytes = 0;
             HIP_OK(hipHostMalloc((void**)&w->pin, pin_need, hipHostMallocDefault));
@@ -2186,10 +2443,10 @@ struct Engine {
             pq.done = h_done;
             pq.space = (char*)w->ws.p;
             __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
-            PodRelease pod{device, pod_submit(explore ? 2 : 1, ef, n, pq)};
+            PodRelease pod{device, pod_submit(explore ? 2 : 1, ef, lay, pq)};
             if (!pod.t) {
                 batched_no_pod.fetch_add(1, std::memory_order_relaxed);
-                submit_round(pq, explore, ef, n);
+                submit_round(pq, explore, ef, lay);
             }
             // wait for the kernel's flag (the two kinds of round take different times: one moving average each)
             static std::atomic<int> waiting{0};
@@ -2362,7 +2619,7 @@ struct Engine {
         // query and the verdicts from it and writes each round's outcome into it -- no copy engine on this path
         const size_t pin_need = 64 + (size_t)cap * 5 + k * 12 + 64 + (size_t)dim * 4;
         if (w->pin_bytes < pin_need) {
-            if (w->pin) (void)hipHostFree(w->pin);
+            if (w->pin) graveyard().bury(nullptr, w->pin);
             w->pin = nullptr;
             w->pin_bytes = 0;
             HIP_OK(hipHostMalloc((void**)&w->pin, pin_need, hipHostMallocDefault));
@@ -2626,15 +2883,13 @@ class SearchService {
     static void grow(Slot& s, size_t nq, size_t dim, size_t k) {
         const size_t qb = nq * dim * 4, ob = nq * k * 12 + nq * 4;
         if (qb > s.q_bytes) {
-            if (s.h_q) (void)hipHostFree(s.h_q);
-            if (s.d_q) (void)hipFree(s.d_q);
+            graveyard().bury(s.d_q, s.h_q);
             s.q_bytes = qb + qb / 2;
             HIP_OK(hipHostMalloc((void**)&s.h_q, s.q_bytes, hipHostMallocDefault));
             HIP_OK(hipMalloc((void**)&s.d_q, s.q_bytes));
         }
         if (ob > s.out_bytes) {
-            if (s.h_out) (void)hipHostFree(s.h_out);
-            if (s.d_out) (void)hipFree(s.d_out);
+            graveyard().bury(s.d_out, s.h_out);
             s.out_bytes = ob + ob / 2;
             HIP_OK(hipHostMalloc((void**)&s.h_out, s.out_bytes, hipHostMallocDefault));
             HIP_OK(hipMalloc((void**)&s.d_out, s.out_bytes));
@@ -2871,25 +3126,21 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
         stress_small_table || force_wide_tags)
         return false;
     use_device();
-    size_t n;
-    {
-        std::lock_guard<std::mutex> g(mod_mu);
-        n = slots;
-    }
+    const size_t n = slots_atomic.load(std::memory_order_acquire), lay = layout_slots();
     if (!n) return false;
     Lease w(device);
-    const size_t space = batch_space_bytes(n);
-    if (w->ws.bytes < space || w->ws_zeroed != (n + 31) / 32) {
+    const size_t space = batch_space_bytes(lay);
+    if (w->ws.bytes < space || w->ws_zeroed != (lay + 31) / 32) {
         char* p = (char*)w->ws.ensure(space);
         HIP_OK(hipMemsetAsync(p, 0, w->ws.bytes, w->stream));
         HIP_OK(hipStreamSynchronize(w->stream));
-        w->ws_zeroed = (n + 31) / 32;
+        w->ws_zeroed = (lay + 31) / 32;
     }
     // pinned, device-mapped: [counters, flag 64 B | keys k x 8 | dist k x 4 | the query]
     const size_t q_off = (64 + k * 12 + 63) & ~(size_t)63;
     const size_t pin_need = q_off + (size_t)dim * 4;
     if (w->pin_bytes < pin_need) {
-        if (w->pin) (void)hipHostFree(w->pin);
+        if (w->pin) graveyard().bury(nullptr, w->pin);
         w->pin = nullptr;
         w->pin_bytes = 0;
         HIP_OK(hipHostMalloc((void**)&w->pin, pin_need, hipHostMallocDefault));
@@ -2913,7 +3164,7 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
     pq.space = (char*)w->ws.p;
     __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
     const auto t_in = std::chrono::steady_clock::now();
-    PodRelease pod{device, pod_submit(0, ef, n, pq)};
+    PodRelease pod{device, pod_submit(0, ef, lay, pq)};
     if (!pod.t) return false;
     const int dbg_pod = pod.t.pod;
     const uint32_t dbg_slot = pod.t.slot;
@@ -3098,8 +3349,9 @@ int vs_hnsw_add_batch_device(vs_hnsw* h, const uint64_t* keys, const float* d_ve
 int vs_hnsw_remove(vs_hnsw* h, uint64_t key, int* removed) {
     return guarded([&] {
         need(h, "null index");
-        h->e.flush_pending();
-        bool r = h->e.remove(key);
+        bool r = false;
+        const int rc = h->e.remove_one(key, &r);
+        if (rc != VS_OK) vs::fail(rc, vs::g_err);
         if (removed) *removed = r ? 1 : 0;
     });
 }
@@ -3212,7 +3464,7 @@ int vs_hnsw_stats(vs_hnsw* h, uint64_t out[8], int reset) {
         need(h && out, "null argument");
         h->e.flush_pending();
         h->e.use_device();
-        vs::pod_pool(h->e.device).quiesce(nullptr);
+        vs::PodHold hold(vs::pod_pool(h->e.device));
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemcpy(out, h->e.d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         if (reset) HIP_OK(hipMemset(h->e.d_stats, 0, 8 * sizeof(uint64_t)));
@@ -3279,6 +3531,19 @@ int vs_hnsw_pod_stats(vs_hnsw* h, uint64_t out[12]) {
     return VS_OK;
 }
 
+int vs_hnsw_modify_stats(vs_hnsw* h, uint64_t out[8]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.m_flushes.load();
+    out[1] = h->e.m_flushed.load();
+    out[2] = h->e.m_flush_ns.load();
+    out[3] = h->e.m_quiesces.load();
+    out[4] = h->e.m_quiesce_ns.load();
+    out[5] = h->e.m_removes.load();
+    out[6] = h->e.m_remove_ns.load();
+    out[7] = h->e.pod_opens.load();
+    return VS_OK;
+}
+
 int vs_hnsw_pipe_stats(vs_hnsw* h, uint64_t out[2]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.pipe_launches.load();
@@ -3332,7 +3597,7 @@ int vs_hnsw_export_graph(vs_hnsw* h, void* vectors, int32_t* levels, uint64_t* k
         e.flush_pending();
         std::lock_guard<std::mutex> g(e.mod_mu);
         e.use_device();
-        vs::pod_pool(e.device).quiesce(nullptr);
+        vs::PodHold hold(vs::pod_pool(e.device));
         HIP_OK(hipDeviceSynchronize());
         const size_t n = e.slots;
         if (!n) return;
@@ -3379,6 +3644,7 @@ int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const void* vectors, const int32_
         HIP_OK(hipMemcpy(e.d_upper_off, upper_off, n * 4, hipMemcpyHostToDevice));
         if (upper_blocks) HIP_OK(hipMemcpy(e.d_upper, upper, upper_blocks * e.M * 4, hipMemcpyHostToDevice));
         e.slots = n;
+        e.slots_atomic.store(n, std::memory_order_release);
         e.linked = n;
         e.upper_blocks = upper_blocks;
         size_t live = 0;

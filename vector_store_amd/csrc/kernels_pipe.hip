@@ -44,7 +44,7 @@ __device__ __forceinline__ T uni(T v) {
 // One query, one workgroup.  Its buffers: the strided arrays of WalkArgs (query `qi`), or -- `pq` -- its entry of the batch table.
 template <int AR, int I, int EFCAP, int MODE, class Sh>
 __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* pq, uint32_t qi, uint32_t ef, Sh& sh, uint2* pipe_pool, const uint32_t tid,
-                                           const uint32_t bid, const uint64_t t_begin) {
+                                           const uint32_t bid, const uint64_t t_begin, const uint32_t entry_slot, const int32_t max_level, const bool tomb) {
     const IndexView& ix = a.ix;
     const int lane = (int)(tid & 63u);
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -53,7 +53,7 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
     uint64_t* ok = pq ? uni(pq->keys) : a.out_keys + (size_t)qi * a.k;
     float* od = pq ? uni(pq->dist) : a.out_dist + (size_t)qi * a.k;
     uint32_t* found_out = pq ? uni(pq->cnt) + 2 : a.out_found + qi;
-    if (ix.max_level < 0) {  // empty index
+    if (max_level < 0) {  // empty index
         if (w == 0) {
             for (uint32_t i = lane; i < k; i += kWave) {
                 ok[i] = kFreeKey;
@@ -88,7 +88,6 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
         ws.vlog_cap = a.vlog_cap;
         ws.heap_cap = a.heap_cap;
     }
-    const bool tomb = a.has_removed != 0;
     const uint32_t* allow = pq ? uni(pq->allow) : a.allow ? a.allow + (size_t)qi * a.allow_stride : nullptr;
     const uint32_t* known = pq ? uni(pq->known) : a.known ? a.known + (size_t)qi * a.allow_stride : nullptr;
     if (pq) {
@@ -131,7 +130,7 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
     float start_d = 0.f;
     uint32_t start;
     // (inlined whatever the size of the kernel: an out-of-line call passes the query's registers through scratch memory)
-    [[clang::always_inline]] start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane, &start_d);
+    [[clang::always_inline]] start = greedy_descent<AR, I>(ix, sh, q, entry_slot, max_level, 0, cnt, lane, &start_d);
     team_release(sh, lane);  // the last barrier: from here on the waves meet through LDS words only
     PipeTop<EFCAP / 64> top;
     const PipeOut r = pipe_walk<AR, I, MODE>(ix, sh, pipe_pool, a.pipe_pool_cap, ws, start, start_d, ef, tomb, allow, known,
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
     using Sh = PipeShared<EFCAP, kPipeTeam, false, VISG>;
     __shared__ Sh sh;
     extern __shared__ uint2 pipe_pool[];
-    __shared__ uint32_t pod_cmd[3];
+    __shared__ uint32_t pod_cmd[6];
     uint32_t seen = 0;
     for (;;) {
         // The kernel's arguments, read from the argument segment INSIDE the loop (the offset is opaque to the compiler): hoisted out of
@@ -226,6 +225,10 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
         uint32_t qi = bid, ef = a.ef;
         uint64_t t_begin = wall_clock64();
         [[maybe_unused]] bool explore = false;
+        // what adds and removes change: a launch carries it in its arguments, a pod reads it per query (pipe_pod.hpp: PodCtl)
+        uint32_t entry_slot = a.ix.entry_slot;
+        int32_t max_level = a.ix.max_level;
+        bool tomb = a.has_removed != 0;
         if (!slots) {
             if (a.qlist) {  // second-chance launches name their queries
                 if (qi >= *a.qcount) return;
@@ -273,6 +276,9 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
                 pod_cmd[0] = p;
                 pod_cmd[1] = __hip_atomic_load(&slot->ef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 pod_cmd[2] = __hip_atomic_load(&slot->explore, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pod_cmd[3] = __hip_atomic_load(&ctl->entry_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pod_cmd[4] = (uint32_t)__hip_atomic_load(&ctl->max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pod_cmd[5] = __hip_atomic_load(&ctl->has_removed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             // the posted query: read once, past the caches (the host rewrites the line between queries), into this workgroup's entry of
             // the staging table
@@ -283,6 +289,9 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
             t_begin = wall_clock64();
             ef = (uint32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[1]);
             explore = __builtin_amdgcn_readfirstlane((int)pod_cmd[2]) != 0;
+            entry_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[3]);
+            max_level = (int32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[4]);
+            tomb = __builtin_amdgcn_readfirstlane((int)pod_cmd[5]) != 0;
             if (tid < sizeof(PipeQuery) / 4) {
                 const uint32_t v = __hip_atomic_load(reinterpret_cast<uint32_t*>(&slot->q) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 reinterpret_cast<uint32_t*>(const_cast<PipeQuery*>(pq))[tid] = v;
@@ -292,10 +301,10 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
         }
         if constexpr (MODE == kPipeBoth) {
             // a pod of filtered queries: the two kinds of round alternate for every caller, so one workgroup serves either
-            if (explore) pipe_query<AR, I, EFCAP, kPipeExplore>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin);
-            else pipe_query<AR, I, EFCAP, kPipeFiltered>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin);
+            if (explore) pipe_query<AR, I, EFCAP, kPipeExplore>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
+            else pipe_query<AR, I, EFCAP, kPipeFiltered>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
         } else {
-            pipe_query<AR, I, EFCAP, MODE>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin);
+            pipe_query<AR, I, EFCAP, MODE>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
         }
         if (!slots) return;
         __syncthreads();  // every wave is done with this query's LDS before the next one's is laid out

@@ -8,9 +8,10 @@
 // answer and the flag into the caller's pinned block) and polls again -- until the host closes the pod.  The callers are then served
 // by as many walks at a time as there are callers, and a query costs no launch at all.
 //
-// A pod is launched with the index's view as kernel arguments, like every other launch: whatever changes the view (adds, removes,
-// reserve) closes the index's pods first (searches do not overlap those: usearch.rs:590-612).  An idle pod closes after a few
-// milliseconds: its workgroups hold their CUs while they poll.
+// A pod is launched with the index's arenas and layouts as kernel arguments, like every other launch: whatever moves an arena (reserve)
+// closes the index's pods first.  What adds and removes change -- entry point, top level, "has removed members" -- is read per query
+// from PodCtl, so a pod survives them (they never overlap searches: usearch.rs:590-612; the host freezes the pod while it modifies).
+// An idle pod closes after a few milliseconds: its workgroups hold their CUs while they poll.
 #pragma once
 #include <cstddef>
 
@@ -30,7 +31,15 @@ static_assert(sizeof(PodSlot) == 128, "one slot, one 128-byte line");
 struct alignas(64) PodCtl {    // pinned host memory: one per pod
     uint32_t closed;           // host: 1 = workgroups leave as soon as they are idle
     uint32_t heartbeat;        // host: advances while the pod is open; workgroups of a pod whose host has gone quiet for seconds leave by themselves
-    uint32_t pad[14];
+    // The part of the index's view that adds and removes change (round 5): read by a workgroup for every query it takes, behind the
+    // acquire that follows the query's number -- so a pod stays open across modifications (the reference alternates families of adds
+    // and searches, usearch.rs:590-612: closing and re-launching 64 workgroups per family was a tenth of a millisecond each way).  The
+    // arenas' addresses, the row layout and the workspace layout (laid out for the index's CAPACITY) still travel as kernel arguments:
+    // what moves an arena closes the pods.  Written by the host while no query of the pod is in flight.
+    uint32_t entry_slot;
+    int32_t max_level;
+    uint32_t has_removed;
+    uint32_t pad[11];
 };
 
 // `slots` == nullptr: a plain launch (a.nq queries, one workgroup each).  Else a.nq workgroups that serve slots[blockIdx.x] until ctl->closed.

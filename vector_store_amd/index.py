@@ -95,11 +95,11 @@ def lib():
     L.vs_hnsw_stats.argtypes = [vp, vp, C.c_int]
     L.vs_hnsw_memory_info.argtypes = [vp, vp]
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
-    L.vs_hnsw_pipe_stats.argtypes = [vp, vp]
-    if hasattr(L, "vs_hnsw_filter_batch_stats"):
-        L.vs_hnsw_filter_batch_stats.argtypes = [vp, vp]
-    if hasattr(L, "vs_hnsw_pod_stats"):
-        L.vs_hnsw_pod_stats.argtypes = [vp, vp]
+    # (VS_HNSW_LIB may name an older build for A/B measurements: symbols younger than round 3 are bound only where they exist,
+    # and their accessors below return zeros without them)
+    for young in ("vs_hnsw_pipe_stats", "vs_hnsw_filter_batch_stats", "vs_hnsw_pod_stats", "vs_hnsw_modify_stats"):
+        if hasattr(L, young):
+            getattr(L, young).argtypes = [vp, vp]
     if hasattr(L, "vs_hnsw_streams_created"):  # (VS_HNSW_LIB may name an older build: A/B measurements)
         L.vs_hnsw_streams_created.argtypes = []
         L.vs_hnsw_streams_created.restype = C.c_uint64
@@ -121,7 +121,7 @@ def lib():
 
 def streams_created() -> int:
     """HIP streams the engine has created in this process (a fixed set per device, never one per index)."""
-    return int(lib().vs_hnsw_streams_created())
+    return int(lib().vs_hnsw_streams_created()) if hasattr(lib(), "vs_hnsw_streams_created") else 0
 
 
 def version() -> str:
@@ -300,7 +300,8 @@ class HipUsearchIndex:
 
     def filter_batch_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)
-        _check(self.L.vs_hnsw_filter_batch_stats(self.h, _p(out)))
+        if hasattr(self.L, "vs_hnsw_filter_batch_stats"):
+            _check(self.L.vs_hnsw_filter_batch_stats(self.h, _p(out)))
         return {"batched_launches": int(out[0]), "batched_rounds": int(out[1])}
 
     def pod_stats(self) -> dict:
@@ -314,8 +315,17 @@ class HipUsearchIndex:
 
     def pipe_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)
-        _check(self.L.vs_hnsw_pipe_stats(self.h, _p(out)))
+        if hasattr(self.L, "vs_hnsw_pipe_stats"):
+            _check(self.L.vs_hnsw_pipe_stats(self.h, _p(out)))
         return {"pipe_launches": int(out[0]), "lone_queries_handed_over": int(out[1])}
+
+    def modify_stats(self) -> dict:
+        """Where modifications spend their time (include/vs_hnsw.h: vs_hnsw_modify_stats)."""
+        out = np.zeros(8, dtype=np.uint64)
+        if hasattr(self.L, "vs_hnsw_modify_stats"):
+            _check(self.L.vs_hnsw_modify_stats(self.h, _p(out)))
+        return {"flushes": int(out[0]), "vectors_flushed": int(out[1]), "flush_ms": int(out[2]) / 1e6, "pod_closings": int(out[3]),
+                "pod_closing_ms": int(out[4]) / 1e6, "removes": int(out[5]), "remove_ms": int(out[6]) / 1e6, "pods_opened": int(out[7])}
 
     def exact_stats(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)

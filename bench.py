@@ -186,7 +186,8 @@ def hbm_roofline(ix, st, nq, dim, kernel_ms, kernel_name):
             "visited_overflow": st["visited_overflow"]}
 
 
-def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_host=None, filtered_seconds=0.0):
+def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_host=None, filtered_seconds=0.0, boundary_answers=None,
+                 mixed_seconds=0.0, mixed_fresh=None, headroom=0):
     """The CPU restatement of the usearch algorithm (oracle/, kind "port") on the host cores of this box, on the
     SAME graph: searches one query per call from T threads (reference usearch.rs:212), then -- the build half of the
     metric -- inserts `extra_host` further vectors into that full-size index from T threads (usearch.rs:194-196).
@@ -197,7 +198,9 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
     o = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef, quantization=ix.scalar)
     slots = ix.graph_info()["slots"]
     extra = 0 if extra_host is None else len(extra_host)
-    o.reserve(slots + extra)
+    # (headroom: the mixed legs insert through the actor, whose growth step -- capacity + 1,000,000, usearch.rs:442 -- is a realloc of
+    # the whole 30 GB arena in a CPU usearch: it would be the only thing a 2-second leg measures)
+    o.reserve(slots + extra + headroom)
     g = ix.export_graph(vectors_out=o.vector_arena(slots))  # straight into the oracle's arena
     o.import_graph(g)
     slot_of_key = None if np.array_equal(g["keys"], np.arange(slots, dtype=np.uint64)) else {int(kk): i for i, kk in enumerate(g["keys"])}
@@ -223,12 +226,34 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
 
     exact = ix.scalar in (oracle.I8, oracle.B1)
     out["id_parity"] = count_parity(gpu_keys, gpu_dist, keys, dists, found, oracle_distance, exact=exact)
+    brief = ("rows", "identical_rows", "near_tie_positions", "violations")
+
+    def parity_of_answers(rec, want_k, want_d, want_f, answered):
+        """What a crowd of callers RECEIVED through the C ABI (boundary_record's recorded answers) against the oracle's answers for
+        the same queries: every recorded row whose query the oracle answered."""
+        if rec is None or len(rec["query"]) == 0:
+            return None
+        use = rec["query"] < answered
+        qi = rec["query"][use].astype(np.int64)
+        if len(qi) == 0:
+            return None
+        par = count_parity(rec["keys"][use], rec["distances"][use], want_k[qi], want_d[qi], want_f[qi],
+                           lambda row, key: oracle_distance(int(qi[row]), key), exact=exact, got_found=rec["found"][use])
+        return dict({kk: par[kk] for kk in brief}, first_violations=par["first_violations"][:2], distinct_queries=int(len(np.unique(qi))))
+
+    out["boundary_id_parity"] = {}
+    for leg, rec in (boundary_answers or {}).items():
+        if not leg.startswith("filtered."):
+            par = parity_of_answers(rec, keys, dists, found, nq)
+            if par is not None:
+                out["boundary_id_parity"][leg] = par
     # filtered_search on the same graph, same predicate and call pattern as boundary.filtered (one query per call from T threads,
     # reference filtered_ann usearch.rs:1107-1154): the CPU number beside the GPU's, and id parity of the engine's answers
     if filtered_seconds > 0:
         out["filtered"] = {}
-        for name, modulus in (("selectivity_10pct", 10), ("selectivity_1pct", 100)):
-            fk, fd, ff, answered, calls, wall = o.filtered_search_timed(queries_host, k, modulus, threads=threads, seconds=filtered_seconds)
+        for name, modulus, nq_used in (("selectivity_10pct", 10, 2048), ("selectivity_1pct", 100, 256)):
+            # (the first nq_used queries of the batch, to the end if the seconds allow: the set boundary.filtered draws from)
+            fk, fd, ff, answered, calls, wall = o.filtered_search_timed(queries_host[:nq_used], k, modulus, threads=threads, seconds=filtered_seconds)
             rec = {"queries_per_s": answered / wall, "queries": answered, "seconds": wall, "threads": threads,
                    "predicate": f"key % {modulus} == 0", "predicate_calls_per_query": calls / max(answered, 1)}
             # the engine's answers for the first queries of the batch, through the C ABI with the same predicate, against the oracle's
@@ -242,6 +267,11 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
                     gd[i, : len(a_d)] = a_d
                 par = count_parity(gk, gd, fk[:m], fd[:m], ff[:m], oracle_distance, exact=exact)
                 rec["id_parity"] = {kk: par[kk] for kk in ("rows", "identical_rows", "near_tie_positions", "violations")}
+            for leg, brec in (boundary_answers or {}).items():
+                if leg.startswith("filtered." + name):
+                    par = parity_of_answers(brec, fk, fd, ff, answered)
+                    if par is not None:
+                        out["boundary_id_parity"][leg] = par
             out["filtered"][name] = rec
     if extra:
         t0 = time.perf_counter()
@@ -249,6 +279,19 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
         el = time.perf_counter() - t0
         out["build_vectors_per_s"] = extra / el
         out["build_sample"] = f"{extra} further vectors inserted into the {slots}-vector index in {el:.1f}s, {threads} threads"
+    # the reference's mixed workloads through the SAME dispatch actor (libvs_actor bound to the oracle: vs_actor_create_with) and the
+    # same driver as boundary.mixed -- last: they modify the index
+    if mixed_seconds > 0 and mixed_fresh is not None:
+        from vector_store_amd import actor as _actor
+
+        def actor_of():
+            act = _actor.IndexActor(ix.dim, ix.metric, 16, 128, ef, workers=threads, quantization=ix.scalar, index_vtable=oracle.trait_vtable())
+            act.adopt_partition(0, o.h, o.size())
+            return act
+        try:
+            out["mixed"] = mixed_record(actor_of, queries_host, mixed_fresh, slots, mixed_seconds)
+        except Exception as e:  # noqa: BLE001
+            out["mixed"] = {"error": repr(e)}
     return out, keys
 
 
@@ -459,21 +502,16 @@ def boundary_record(ix, queries_host, truth, k, seconds):
     non-blocking entry point with 16 x 256 queries in flight; the reference's loop and histogram
     (crates/benchmark/src/main.rs:435-604) as libvs_callers.so runs them.  `filtered`: the reference dispatches every
     filtered query through spawn_blocking (usearch.rs:937-948), i.e. the same blocking callers over
-    vs_hnsw_filtered_search, here with a predicate that admits 10 % / 1 % of the keys."""
-    import ctypes as C
-
-    class Res(C.Structure):
-        _fields_ = [("seconds", C.c_double), ("queries", C.c_uint64), ("qps", C.c_double), ("latency_min_ns", C.c_int64),
-                    ("latency_max_ns", C.c_int64)] + [(f"p{p:02d}_ns", C.c_int64) for p in (1, 10, 25, 50, 75, 90, 99)] + [
-                    ("recall_avg", C.c_double), ("errors", C.c_uint64), ("launches", C.c_uint64), ("team_launches", C.c_uint64)]
-
-    L = C.CDLL(os.path.join(ROOT, "vector_store_amd", "libvs_callers.so"))
-    L.vs_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint,
-                                 C.c_double, C.POINTER(Res)]
+    vs_hnsw_filtered_search, here with a predicate that admits 10 % / 1 % of the keys.
+    Round 5: every leg also RECORDS what its callers received (the first 100,000 answers); cpu_baseline compares each of them with
+    the oracle's answer for the same query (`id_parity` per leg).  Returns (record for the line, {leg: answers})."""
+    from vector_store_amd import callers
     q = np.ascontiguousarray(queries_host, dtype=np.float32)
     t = np.ascontiguousarray(truth, dtype=np.uint64)
     cores = effective_cores()
     out = {"cores": cores}
+    answers = {}
+    cap = 100_000
 
     def ms(ns):
         return None if ns >= 2 ** 62 else round(ns / 1e6, 3)
@@ -495,38 +533,60 @@ def boundary_record(ix, queries_host, truth, k, seconds):
     # (blocking_callers_64: the reference's callers are as many as there are requests in flight -- usearch.rs:212 is reached from one
     # tokio task per request --, num_workers() + 1 is only the benchmark's default)
     for name, threads, inflight in (("blocking_callers", cores + 1, 1), ("blocking_callers_64", 64, 1), ("async_in_flight", 16, 256)):
-        r = Res()
-        rc = L.vs_callers_run(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, t.ctypes.data, threads, inflight, seconds if name != "blocking_callers_64" else max(seconds / 2, 1.0), C.byref(r))
+        r, rec, rc = callers.run(ix, q, k, t, threads, inflight, seconds if name != "blocking_callers_64" else max(seconds / 2, 1.0), record=cap)
         out[name] = rec_of(r, rc, threads, inflight)
         d, pods = pod_delta(pods)
         out[name].update(d)
-    if hasattr(L, "vs_callers_run_filtered"):
-        L.vs_callers_run_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double,
-                                              C.POINTER(Res), C.POINTER(C.c_uint64)]
-        out["filtered"] = {}
-        # the third record: the reference puts EVERY filtered query on a blocking thread (spawn_blocking), so under load there are
-        # far more of them than cores
-        # (the legs of one filter together: the index sizes a query's first round by what its recent filtered queries needed)
-        for name, modulus, callers in (("selectivity_10pct", 10, cores + 1), ("selectivity_10pct_64_callers", 10, 64),
-                                       ("selectivity_10pct_128_callers", 10, 128), ("selectivity_1pct", 100, cores + 1)):
-            r = Res()
-            extra = (C.c_uint64 * 4)()
-            # untimed warm-up, as the main path has: every caller's stream, pinned block and walk workspace exist, and the index has
-            # seen this predicate's appetite (the first round's budget follows recent filtered queries)
-            L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, 0.4 if modulus < 100 else 1.5, C.byref(Res()), (C.c_uint64 * 4)())
-            f0 = ix.filter_stats()
-            rc = L.vs_callers_run_filtered(ix.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, callers, max(seconds / 2, 1.0) if modulus < 100 else max(seconds, 2.0), C.byref(r), extra)
-            f1 = ix.filter_stats()
-            fr = rec_of(r, rc, callers, 1)
-            fr.pop("recall_at_10", None)
-            nqd = max(int(r.queries), 1)
-            fr.update({"predicate": f"key % {modulus} == 0", "predicate_calls_per_query": extra[0] / nqd, "results_per_query": extra[1] / nqd,
-                       "walk_launches_per_query": (f1["lazy_rounds"] - f0["lazy_rounds"]) / nqd})
-            d, pods = pod_delta(pods)
-            fr.update(d)
-            out["filtered"][name] = fr
+        answers[name] = rec
+    out["filtered"] = {}
+    # the reference puts EVERY filtered query on a blocking thread (spawn_blocking), so under load there are far more of them than cores
+    # (the legs of one filter together: the index sizes a query's first round by what its recent filtered queries needed).  The legs draw
+    # from the first 2,048 (10 %) / 256 (1 %) queries of the batch: the set the CPU leg answers completely within its seconds, so that
+    # every recorded answer has an oracle answer to be compared with.
+    for name, modulus, threads, nq_used in (("selectivity_10pct", 10, cores + 1, 2048), ("selectivity_10pct_64_callers", 10, 64, 2048),
+                                            ("selectivity_10pct_128_callers", 10, 128, 2048), ("selectivity_1pct", 100, cores + 1, 256)):
+        qs = q[:nq_used]
+        # untimed warm-up, as the main path has: every caller's stream, pinned block and walk workspace exist, and the index has
+        # seen this predicate's appetite (the first round's budget follows recent filtered queries)
+        callers.run_filtered(ix, qs, k, modulus, threads, 0.4 if modulus < 100 else 1.5)
+        f0 = ix.filter_stats()
+        r, extra, rec, rc = callers.run_filtered(ix, qs, k, modulus, threads, max(seconds / 2, 1.0) if modulus < 100 else max(seconds, 2.0), record=cap)
+        f1 = ix.filter_stats()
+        fr = rec_of(r, rc, threads, 1)
+        fr.pop("recall_at_10", None)
+        nqd = max(int(r.queries), 1)
+        fr.update({"predicate": f"key % {modulus} == 0", "predicate_calls_per_query": extra[0] / nqd, "results_per_query": extra[1] / nqd,
+                   "walk_launches_per_query": (f1["lazy_rounds"] - f0["lazy_rounds"]) / nqd, "queries_drawn_from": nq_used})
+        d, pods = pod_delta(pods)
+        fr.update(d)
+        out["filtered"][name] = fr
+        answers["filtered." + name] = rec
     out["note"] = ("one query per C-ABI call; percentiles on the reference's histogram (10,000 buckets over 1..100 ms: anything "
-                   "faster reads 1.0 ms); latency_min_ms is the raw minimum")
+                   "faster reads 1.0 ms); latency_min_ms is the raw minimum; id_parity: every recorded answer against the CPU oracle's for the same query")
+    return out, answers
+
+
+MIXED_LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search_while_updating:16+0", "search_while_updating", "search_while_inserting", "search_while_deleting")
+
+
+def mixed_record(actor_of, queries_host, fresh, n, seconds, producers=(1, 16)):
+    """The reference's MIXED workloads (crates/vector-store/benches/pipeline.rs:1407-1418: cdc_insert, cdc_update, cdc_delete,
+    search_while_{updating,inserting,deleting}) through the dispatch actor (libvs_actor: search-first channels, Operation permits,
+    usearch.rs:515-624, :897-948; one vector per add / remove call, :1019-1049) on the full-size index: `producers` CDC producers
+    (BENCHES_CONCURRENCY; the reference's default is 1), each waiting for its item's in-progress marker, beside 16 plain (+ 16
+    filtered, 10 % selective) blocking searchers on the same index.  actor_of() -> an IndexActor that has adopted the index."""
+    from vector_store_amd import callers
+    out = {}
+    for p in producers:
+        act = actor_of()
+        try:
+            legs = MIXED_LEGS if p == producers[0] else ("cdc_insert", "cdc_update", "search_while_updating:16+0", "search_while_updating")
+            rec = callers.pipeline_legs(act, queries_host[:4096], fresh, n, legs, seconds=seconds, producers=p,
+                                        state={"next_key": (1 << 40) + (p << 32) + (1 << 30), "delete_from": n // 2 + (p % 7) * 100_000})
+            rec["actor_counters"] = act.counters()
+        finally:
+            act.stop()
+        out[f"producers_{p}"] = rec
     return out
 
 
@@ -587,6 +647,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall seconds of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-build-vectors", type=int, default=20_000, help="vectors the cpu_baseline leg inserts into the full-size index (0 = skip)")
     ap.add_argument("--boundary-seconds", type=float, default=3.0, help="seconds per leg of the through-the-C-ABI record (0 = skip)")
+    ap.add_argument("--mixed-seconds", type=float, default=1.5, help="seconds per leg of boundary.mixed / cpu_baseline.mixed: the reference's pipeline benches through the dispatch actor (0 = skip)")
     ap.add_argument("--no-side-records", action="store_true", help="skip the generator side records (gaussian / clustered / rank sweep at 1M) and the configs side records")
     ap.add_argument("--configs", default="auto", help="BASELINE configs timed as side records at N=1: comma list of c2,c5,c3, 'none', or 'auto' (c2, c5, and c3 when >= 180 GiB of HBM is free)")
     ap.add_argument("--no-sharded-leg", action="store_true")
@@ -836,9 +897,10 @@ def main():
         out["same_device"] = True  # testing aid: every rank on GPU 0 -- exercises the N > 1 code, is NOT a scaling measurement
 
     # ---- through the boundary: what a drop-in caller of the trait gets on this index (N=1 only)
+    boundary_answers = None
     if world == 1 and a.boundary_seconds > 0:
         try:
-            out["boundary"] = boundary_record(ix, queries.cpu().numpy(), truth, k, a.boundary_seconds)
+            out["boundary"], boundary_answers = boundary_record(ix, queries.cpu().numpy(), truth, k, a.boundary_seconds)
         except Exception as e:
             out["boundary"] = {"error": repr(e)}
 
@@ -852,11 +914,20 @@ def main():
             gk, gd = result_keys().view(np.uint64).copy(), result_dist().copy()
             extra = make_data(a.cpu_build_vectors, dim, a.dist, 97531, dev, a.rank).cpu().numpy() if a.cpu_build_vectors else None
             want_filtered = a.quantization == "f32" and isinstance(out.get("boundary"), dict) and "filtered" in out["boundary"]
+            mixed_fresh = make_data(8192, dim, a.dist, 24680, dev, a.rank).cpu().numpy() if a.mixed_seconds > 0 else None
             cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds, gk, gd, extra,
-                                     filtered_seconds=min(4.0, a.cpu_seconds / 2) if want_filtered else 0.0)
+                                     filtered_seconds=min(6.0, a.cpu_seconds) if want_filtered else 0.0, boundary_answers=boundary_answers,
+                                     mixed_seconds=a.mixed_seconds if a.quantization == "f32" else 0.0, mixed_fresh=mixed_fresh, headroom=300_000)
+            boundary_answers = None
             cb["recall_at_10"] = round(recall_at_k(truth, ckeys), 4)
             out["cpu_baseline"] = cb
             violations = cb["id_parity"]["violations"]
+            # what the crowds of the boundary legs received, against the oracle: the parity record moves next to each leg
+            for leg, par in cb.pop("boundary_id_parity", {}).items():
+                violations += par["violations"]
+                where = out["boundary"]["filtered"] if leg.startswith("filtered.") else out["boundary"]
+                if isinstance(where.get(leg.replace("filtered.", "")), dict):
+                    where[leg.replace("filtered.", "")]["id_parity"] = par
             # the CPU's filtered rate beside each GPU record of the same predicate (same graph, same call pattern, `cores` threads)
             for name, crec in cb.get("filtered", {}).items():
                 violations += crec.get("id_parity", {}).get("violations", 0)
@@ -866,6 +937,38 @@ def main():
                         grec["vs_cpu"] = grec["queries_per_s"] / crec["queries_per_s"]
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
+
+    # ---- the reference's mixed add / search workloads through the dispatch actor on this index (N=1 only; last: they modify it)
+    if world == 1 and a.mixed_seconds > 0 and a.quantization == "f32":
+        try:
+            from vector_store_amd import actor as _actor
+            mixed_fresh = make_data(8192, dim, a.dist, 24680, dev, a.rank).cpu().numpy()
+
+            def actor_of():
+                act = _actor.IndexActor(dim, vs.METRICS[a.metric], 16, 128, ef, workers=effective_cores())
+                act.adopt_partition(0, ix.h, ix.size())
+                return act
+            m0 = ix.modify_stats()
+            mixed = mixed_record(actor_of, queries.cpu().numpy(), mixed_fresh, n, a.mixed_seconds)
+            m1 = ix.modify_stats()
+            mixed["engine"] = {kk: m1[kk] - m0[kk] for kk in m1}
+            cm = out.get("cpu_baseline", {}).get("mixed", {}) if isinstance(out.get("cpu_baseline"), dict) else {}
+            for pk, legs in mixed.items():  # the CPU's rate beside each leg (same actor, same driver, the oracle behind it)
+                if not pk.startswith("producers_") or not isinstance(cm.get(pk), dict):
+                    continue
+                for leg, rec in legs.items():
+                    crec = cm[pk].get(leg)
+                    if isinstance(rec, dict) and isinstance(crec, dict) and "items_per_s" in rec:
+                        rec["vs_cpu"] = {"items": rec["items_per_s"] / crec["items_per_s"] if crec.get("items_per_s") else None}
+                        for kind in ("plain", "filtered"):
+                            if kind in rec and kind in crec and crec[kind]["per_s"] > 0:
+                                rec["vs_cpu"][kind] = rec[kind]["per_s"] / crec[kind]["per_s"]
+            if isinstance(out.get("boundary"), dict):
+                out["boundary"]["mixed"] = mixed
+            else:
+                out["boundary"] = {"mixed": mixed}
+        except Exception as e:
+            out.setdefault("boundary", {})["mixed"] = {"error": repr(e)}
 
     # ---- the other BASELINE configs and the survey's own generators as side records (N=1 only); the headline index is released first
     if world == 1 and not a.no_side_records and a.quantization == "f32":

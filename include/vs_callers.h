@@ -36,6 +36,22 @@ typedef struct vs_callers_result {
 VS_API int vs_callers_run(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, const uint64_t* truth,
                           unsigned threads, unsigned inflight, double seconds, vs_callers_result* out);
 
+/* What the callers RECEIVED (round 5: the boundary legs of bench.py compare every answer with the CPU oracle's, not only recall):
+ * the first `cap` completed calls of a run, in completion order -- query index, result count, k keys, k distances each.  `n` = calls
+ * recorded. */
+typedef struct vs_callers_record {
+    uint32_t* query;  /* cap */
+    uint32_t* found;  /* cap */
+    uint64_t* keys;   /* cap x k */
+    float* distances; /* cap x k */
+    size_t cap, n;
+} vs_callers_record;
+VS_API int vs_callers_run_recorded(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, const uint64_t* truth,
+                                   unsigned threads, unsigned inflight, double seconds, vs_callers_result* out, vs_callers_record* record);
+VS_API int vs_callers_run_filtered_recorded(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus,
+                                            unsigned threads, double seconds, vs_callers_result* out, uint64_t extra[4],
+                                            vs_callers_record* record);
+
 /* The same loop over vs_hnsw_filtered_search: the reference runs every filtered query on a blocking thread (spawn_blocking,
  * usearch.rs:937-948) with a predicate that takes a table read-lock per call (usearch.rs:1118-1124).  Predicate here:
  * key % modulus == 0 (selectivity 1 / modulus), counted.  extra: [0] predicate calls, [1] results returned, [2..3] 0.

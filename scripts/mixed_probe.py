@@ -21,31 +21,12 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402  (make_data, build_index, effective_cores)
 
-LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search", "search_while_inserting", "search_while_updating", "search_while_deleting")
+LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search", "search:16+0", "search_while_inserting", "search_while_updating", "search_while_updating:16+0", "search_while_deleting")
 
 
 def run_legs(actor, callers, queries, vectors, n, legs, seconds, producers, plain, filtered, modulus, state, tag):
-    """state: {"next_key", "delete_from"}: new keys never repeat, deleted keys are never deleted twice."""
-    out = {}
-    for leg in legs:
-        kw = dict(k=10, seconds=seconds, producers=producers, modulus=modulus)
-        if leg.startswith("search"):
-            kw.update(plain_callers=plain, filtered_callers=filtered)
-        what = leg.replace("search_while_", "cdc_")
-        if what in ("cdc_insert", "cdc_inserting"):
-            kw.update(modify=callers.INSERT, first_new_key=state["next_key"])
-        elif what in ("cdc_update", "cdc_updating"):
-            kw.update(modify=callers.UPDATE, existing_keys=n // 2)  # (the upper half is what cdc_delete eats)
-        elif what in ("cdc_delete", "cdc_deleting"):
-            kw.update(modify=callers.DELETE, delete_from=state["delete_from"])
-        r = callers.mixed_run(actor, queries, vectors, **kw)
-        if kw.get("modify") == callers.INSERT:
-            state["next_key"] += r["items"] + producers + 1
-        if kw.get("modify") == callers.DELETE:
-            state["delete_from"] += r["items"] + producers + 1
-        out[leg] = r
-        print(f"[{tag}] {leg}: " + json.dumps(r), file=sys.stderr, flush=True)
-    return out
+    return callers.pipeline_legs(actor, queries, vectors, n, legs, seconds=seconds, producers=producers, plain_callers=plain, filtered_callers=filtered,
+                                 modulus=modulus, state=state, log=lambda leg, r: print(f"[{tag}] {leg}: " + json.dumps(r), file=sys.stderr, flush=True))
 
 
 def main():

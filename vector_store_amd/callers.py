@@ -36,6 +36,10 @@ class MixedResult(C.Structure):
                 ("item", CallersResult), ("plain", CallersResult), ("filtered", CallersResult)]
 
 
+class CallersRecord(C.Structure):
+    _fields_ = [("query", C.c_void_p), ("found", C.c_void_p), ("keys", C.c_void_p), ("distances", C.c_void_p), ("cap", C.c_size_t), ("n", C.c_size_t)]
+
+
 NONE, INSERT, UPDATE, DELETE = 0, 1, 2, 3
 _lib = None
 
@@ -47,8 +51,49 @@ def lib():
         L = C.CDLL(os.path.join(_HERE, "libvs_callers.so"))
         L.vs_mixed_run.argtypes = [C.c_void_p, C.POINTER(MixedOptions), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                    C.POINTER(MixedResult)]
+        L.vs_callers_run_recorded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint,
+                                              C.c_double, C.POINTER(CallersResult), C.POINTER(CallersRecord)]
+        L.vs_callers_run_filtered_recorded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double,
+                                                       C.POINTER(CallersResult), C.POINTER(C.c_uint64), C.POINTER(CallersRecord)]
         _lib = L
     return _lib
+
+
+def _record(cap: int, k: int):
+    arrays = {"query": np.zeros(cap, dtype=np.uint32), "found": np.zeros(cap, dtype=np.uint32),
+              "keys": np.zeros((cap, k), dtype=np.uint64), "distances": np.zeros((cap, k), dtype=np.float32)}
+    rec = CallersRecord(arrays["query"].ctypes.data, arrays["found"].ctypes.data, arrays["keys"].ctypes.data, arrays["distances"].ctypes.data, cap, 0)
+    return rec, arrays
+
+
+def _cut(rec, arrays):
+    n = int(rec.n)
+    return {name: a[:n] for name, a in arrays.items()}
+
+
+def run(index, queries, k, truth=None, threads=17, inflight=1, seconds=3.0, record=0):
+    """The reference's search loop (crates/benchmark/src/main.rs:435-525) over vs_hnsw_search / vs_hnsw_search_async on `index`
+    (vector_store_amd.HipUsearchIndex).  record > 0: also what the first `record` completed calls RECEIVED ({"query", "found",
+    "keys", "distances"}), for id parity against the oracle.  Returns (CallersResult, record or None, status)."""
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    t = None if truth is None else np.ascontiguousarray(truth, dtype=np.uint64)
+    r = CallersResult()
+    rec, arrays = _record(record, k) if record else (None, None)
+    rc = lib().vs_callers_run_recorded(index.h, q.ctypes.data, q.shape[0], q.shape[1], k, None if t is None else t.ctypes.data, threads, inflight,
+                                       seconds, C.byref(r), None if rec is None else C.byref(rec))
+    return r, (None if rec is None else _cut(rec, arrays)), rc
+
+
+def run_filtered(index, queries, k, modulus, threads=17, seconds=3.0, record=0):
+    """The same loop over vs_hnsw_filtered_search with the predicate key % modulus == 0 (usearch.rs:937-948: every filtered query on a
+    blocking thread of its own).  Returns (CallersResult, [predicate calls, results returned], record or None, status)."""
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    r = CallersResult()
+    extra = (C.c_uint64 * 4)()
+    rec, arrays = _record(record, k) if record else (None, None)
+    rc = lib().vs_callers_run_filtered_recorded(index.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, threads, seconds, C.byref(r), extra,
+                                                None if rec is None else C.byref(rec))
+    return r, [int(extra[0]), int(extra[1])], (None if rec is None else _cut(rec, arrays)), rc
 
 
 def mixed_run(actor, queries, vectors, *, modify=NONE, plain_callers=0, filtered_callers=0, producers=1, modulus=10, partition=0,
@@ -73,4 +118,42 @@ def mixed_run(actor, queries, vectors, *, modify=NONE, plain_callers=0, filtered
     if filtered_callers:
         out["filtered"] = dict(r.filtered.as_dict(), callers=filtered_callers, predicate=f"key % {modulus} == 0",
                                predicate_calls_per_query=r.predicate_calls / max(int(r.filtered.queries), 1))
+    return out
+
+
+PIPELINE_LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search_while_inserting", "search_while_updating", "search_while_deleting")
+
+
+def pipeline_legs(actor, queries, vectors, existing_keys, legs=PIPELINE_LEGS, *, seconds=2.0, producers=1, plain_callers=16, filtered_callers=16,
+                  modulus=10, state=None, log=None) -> dict:
+    """The reference's pipeline benches (crates/vector-store/benches/pipeline.rs:1407-1418) as legs of vs_mixed_run through `actor`:
+    cdc_insert / cdc_update / cdc_delete alone, and search_while_{inserting,updating,deleting} with `plain_callers` + `filtered_callers`
+    blocking searchers on the same partition.  Keys 0 .. existing_keys - 1 exist: updates draw from the lower half, deletes eat the upper
+    half upwards from state["delete_from"]; inserts use fresh keys from state["next_key"].  A leg name may carry a caller mix:
+    "search_while_updating:16+0" = 16 plain, no filtered callers."""
+    state = state if state is not None else {}
+    state.setdefault("next_key", 1 << 40)
+    state.setdefault("delete_from", existing_keys // 2)
+    out = {}
+    for leg in legs:
+        name, _, mix = leg.partition(":")
+        plain, filtered = (int(x) for x in mix.split("+")) if mix else (plain_callers, filtered_callers)
+        kw = dict(k=10, seconds=seconds, producers=producers, modulus=modulus)
+        if name.startswith("search"):
+            kw.update(plain_callers=plain, filtered_callers=filtered)
+        what = name.replace("search_while_", "cdc_")
+        if what in ("cdc_insert", "cdc_inserting"):
+            kw.update(modify=INSERT, first_new_key=state["next_key"])
+        elif what in ("cdc_update", "cdc_updating"):
+            kw.update(modify=UPDATE, existing_keys=existing_keys // 2)
+        elif what in ("cdc_delete", "cdc_deleting"):
+            kw.update(modify=DELETE, delete_from=state["delete_from"])
+        r = mixed_run(actor, queries, vectors, **kw)
+        if kw.get("modify") == INSERT:
+            state["next_key"] += r["items"] + producers + 1
+        if kw.get("modify") == DELETE:
+            state["delete_from"] += r["items"] + producers + 1
+        out[leg] = r
+        if log:
+            log(leg, r)
     return out

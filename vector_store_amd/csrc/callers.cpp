@@ -2,6 +2,7 @@
 // (crates/benchmark/src/main.rs:435-525) over the C ABI of the engine, blocking or with queries in flight.
 #include "../../include/vs_callers.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -27,12 +28,30 @@ double recall_of(const uint64_t* truth, size_t k, const uint64_t* found, size_t 
             }
     return k ? (double)hit / (double)k : 0.0;
 }
+// one answer into the record (the first `cap` completed calls; slots are handed out by an atomic counter)
+void keep(vs_callers_record* rec, std::atomic<size_t>& next, size_t qi, size_t k, const uint64_t* keys, const float* dist, size_t found) {
+    if (!rec || !rec->cap) return;
+    const size_t at = next.fetch_add(1, std::memory_order_relaxed);
+    if (at >= rec->cap) return;
+    rec->query[at] = (uint32_t)qi;
+    rec->found[at] = (uint32_t)found;
+    for (size_t i = 0; i < k; ++i) {
+        rec->keys[at * k + i] = i < found ? keys[i] : ~0ull;
+        rec->distances[at * k + i] = i < found ? dist[i] : __builtin_inff();
+    }
+}
 }  // namespace
 
 extern "C" int vs_callers_run(vs_hnsw* h, const float* queries, size_t nq, size_t dim, size_t k, const uint64_t* truth,
                               unsigned threads, unsigned inflight, double seconds, vs_callers_result* out) {
+    return vs_callers_run_recorded(h, queries, nq, dim, k, truth, threads, inflight, seconds, out, nullptr);
+}
+
+extern "C" int vs_callers_run_recorded(vs_hnsw* h, const float* queries, size_t nq, size_t dim, size_t k, const uint64_t* truth,
+                                       unsigned threads, unsigned inflight, double seconds, vs_callers_result* out, vs_callers_record* rec) {
     if (!h || !queries || !nq || !k || !threads || !out) return VS_ERR_INVALID_ARGUMENT;
     if (!inflight) inflight = 1;
+    std::atomic<size_t> rec_next{0};
     std::atomic<bool> stop{false};
     std::vector<SearchMeasure> per(threads);
     std::vector<uint64_t> errors(threads, 0);
@@ -58,6 +77,7 @@ extern "C" int vs_callers_run(vs_hnsw* h, const float* queries, size_t nq, size_
                         break;
                     }
                     per[t].record(ns, truth ? recall_of(truth + qi * k, k, keys.data(), found) : 0.0);
+                    keep(rec, rec_next, qi, k, keys.data(), dist.data(), found);
                 }
                 return;
             }
@@ -96,7 +116,10 @@ extern "C" int vs_callers_run(vs_hnsw* h, const float* queries, size_t nq, size_
                     if (sl.busy) {  // a completed query
                         int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - sl.start).count();
                         if (sl.status != VS_OK) ++errors[t];
-                        else per[t].record(ns, truth ? recall_of(truth + sl.qi * k, k, sl.keys.data(), sl.found) : 0.0);
+                        else {
+                            per[t].record(ns, truth ? recall_of(truth + sl.qi * k, k, sl.keys.data(), sl.found) : 0.0);
+                            keep(rec, rec_next, sl.qi, k, sl.keys.data(), sl.dist.data(), sl.found);
+                        }
                         sl.busy = false;
                         --outstanding;
                     }
@@ -151,6 +174,7 @@ extern "C" int vs_callers_run(vs_hnsw* h, const float* queries, size_t nq, size_
     for (uint64_t e : errors) out->errors += e;
     out->launches = sv1[0] - sv0[0];
     out->team_launches = sv1[2] - sv0[2];
+    if (rec) rec->n = std::min(rec->cap, rec_next.load());
     return VS_OK;
 }
 
@@ -160,7 +184,13 @@ extern "C" int vs_callers_run(vs_hnsw* h, const float* queries, size_t nq, size_
 // extra[1] = results returned, over the whole run.
 extern "C" int vs_callers_run_filtered(vs_hnsw* h, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus, unsigned threads,
                                        double seconds, vs_callers_result* out, uint64_t extra[4]) {
+    return vs_callers_run_filtered_recorded(h, queries, nq, dim, k, modulus, threads, seconds, out, extra, nullptr);
+}
+
+extern "C" int vs_callers_run_filtered_recorded(vs_hnsw* h, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus, unsigned threads,
+                                                double seconds, vs_callers_result* out, uint64_t extra[4], vs_callers_record* rec) {
     if (!h || !queries || !nq || !k || !threads || !out || !modulus || !extra) return VS_ERR_INVALID_ARGUMENT;
+    std::atomic<size_t> rec_next{0};
     struct Ctx {
         uint64_t modulus;
         std::atomic<uint64_t>* calls;
@@ -200,12 +230,14 @@ extern "C" int vs_callers_run_filtered(vs_hnsw* h, const float* queries, size_t 
                     if (keys[i] % modulus != 0) ++errors[t];  // a result the predicate rejects
                 results += found;
                 per[t].record(ns, 0.0);
+                keep(rec, rec_next, qi, k, keys.data(), dist.data(), found);
             }
             calls += local_calls;
         });
     std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
     stop = true;
     for (auto& x : th) x.join();
+    if (rec) rec->n = std::min(rec->cap, rec_next.load());
     const double wall = std::chrono::duration<double>(Clock::now() - t0).count();
     SearchMeasure all;
     for (auto& m : per) all.append(m);

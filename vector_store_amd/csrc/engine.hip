@@ -407,9 +407,13 @@ struct Lease {
         }
     }
     ~Lease() {
+        if (!ctx) return;
         std::lock_guard<std::mutex> g(pl.mu);
         pl.idle.push_back(std::move(ctx));
     }
+    // A wait on the device timed out: whatever was launched or posted may still write into this context's buffers, so it never goes
+    // back to the pool (leaked, with its buffers: the caller is about to report a device failure anyway).
+    void retire() { (void)ctx.release(); }
     WorkCtx* operator->() { return ctx.get(); }
 };
 
@@ -591,6 +595,18 @@ struct PodPool {
         p.busy[t.slot] = false;
         --p.n_busy;
         p.last_used = std::chrono::steady_clock::now();
+    }
+    // A query was posted to a slot whose workgroup had decided to leave just before (a pod whose host stood still for seconds ends
+    // by itself: kernels_pipe.hip): the workgroup stores `left` as its last act and touches nothing afterwards, so "left, and no
+    // answer" means the post was never seen -- the caller serves the query by a launch (advisor finding, round 4: it used to wait out
+    // 20 s and fail).  The pod is closed.
+    bool lost_post(PodTicket t) {
+        std::lock_guard<std::mutex> g(mu);
+        Pod& p = pods[t.pod];
+        if (p.gen != t.gen || !p.slots) return false;
+        if (!__atomic_load_n(&p.slots[t.slot].left, __ATOMIC_ACQUIRE)) return false;
+        if (p.state == Pod::kOpen) close_locked(p);
+        return true;
     }
     bool all_free() {
         std::lock_guard<std::mutex> g(mu);
@@ -843,10 +859,10 @@ struct Engine {
     std::mutex poison_mu;
     std::string poison;                          // set when a deferred insertion failed: every later call reports it
 
-    void use_device() const {
-        HIP_OK(hipSetDevice(device));
-        drain_graveyard_if_idle(device);
-    }
+    void use_device() const { HIP_OK(hipSetDevice(device)); }
+    // Blocks that were replaced while pods were open are freed once none is (a free synchronises the device).  Called at the top of
+    // the host entry points -- never with the pod pool's lock held (pod_submit calls use_device() under it).
+    void housekeeping() const { drain_graveyard_if_idle(device); }
 
     IndexView view() const {
         IndexView v;
@@ -899,7 +915,7 @@ struct Engine {
         graveyard().bury(d_rho, nullptr);
         graveyard().bury(d_stats, nullptr);
         graveyard().bury(d_max_norm, nullptr);
-        drain_graveyard_if_idle(device);
+        housekeeping();
     }
 
     void init(const vs_hnsw_options& o) {
@@ -1015,8 +1031,9 @@ struct Engine {
         if (cap > (1ull << visited_domain_bits(ef_add, true)))
             fail(VS_ERR_UNSUPPORTED, "capacity above 2^29 slots needs expansion_add <= 128 (or several shards, include/vs_shards.h)");
         if (cap == capacity) return;
+        // (the hold BEFORE the view lock: a caller opening a pod holds the pool's lock while it reads the view)
+        PodHold hold(pod_pool(device));  // arenas may move: no pod of the device is open, and none opens, until this returns
         std::unique_lock<std::shared_mutex> vg(view_mu);
-        PodHold hold(pod_pool(device));  // (arenas may move: no pod of the device is open, and none opens, until this returns)
         HIP_OK(hipDeviceSynchronize());
         // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
         // coexist with the old ones while rows are copied across.
@@ -1053,6 +1070,7 @@ struct Engine {
     }
     void ensure_upper(size_t blocks) {
         if (blocks <= upper_cap) return;
+        PodHold hold(pod_pool(device));                   // (before the view lock, as in reserve)
         std::unique_lock<std::shared_mutex> vg(view_mu);  // no search may hold the old pointer (advisor finding, round 1)
         ensure_upper_locked(blocks);
     }
@@ -1083,6 +1101,7 @@ struct Engine {
         if (!n) return;
         std::lock_guard<std::mutex> g(mod_mu);
         use_device();
+        housekeeping();
         PodFreeze freeze(*this);
         add_batch_locked(keys, vecs, on_device, n, status, first_err, staged);
     }
@@ -1171,39 +1190,78 @@ struct Engine {
                     req_off[i + 1] = req_off[i] + cnt;
                 }
             }
-            uint32_t* d_slots = (uint32_t*)w->a.ensure((size_t)m * 4 * 4 + 64);
-            int32_t* d_lv = (int32_t*)(d_slots + m);
-            uint32_t* d_uoff = (uint32_t*)(d_lv + m);
-            uint32_t* d_reqoff = d_uoff + m;
-            uint64_t* d_keyv = (uint64_t*)w->b.ensure((size_t)m * 8);
-            HIP_OK(hipMemcpyAsync(d_slots, slot_v.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(d_lv, level_v.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(d_uoff, uoff.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(d_reqoff, req_off.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(d_keyv, key_v.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
+            // A handful of vectors from the host (a flush between two families of searches: the reference alternates them,
+            // usearch.rs:590-612, so a mixed workload flushes ONE add at a time): everything the kernels need goes through one
+            // pinned block and ONE copy -- eight small copies from pageable memory were a tenth of such a flush.
+            const bool small = !on_device && m <= 256;
+            uint32_t *d_slots, *d_uoff, *d_reqoff, *d_rr = nullptr, *d_ru = nullptr;
+            int32_t* d_lv;
+            uint64_t* d_keyv;
             const float* src = nullptr;
-            const uint32_t* d_src_slots = d_slots;
-            if (on_device) {
-                if (m == cn) {
-                    src = vecs + c0 * dim;
-                } else {  // some rows were rejected: compact on the host side list of source rows
+            if (small) {
+                const size_t o_keys = ((size_t)m * 16 + 7) & ~(size_t)7, o_vec = (o_keys + (size_t)m * 8 + 15) & ~(size_t)15;
+                const size_t o_rr = o_vec + (size_t)m * dim * 4, o_ru = o_rr + reuse_rows.size() * 4;
+                const size_t total = o_ru + reuse_upper.size() * 4 + 64;
+                if (w->pin_bytes < total) {
+                    if (w->pin) graveyard().bury(nullptr, w->pin);
+                    w->pin = nullptr;
+                    w->pin_bytes = 0;
+                    HIP_OK(hipHostMalloc((void**)&w->pin, total + total / 2, hipHostMallocDefault));
+                    w->pin_bytes = total + total / 2;
+                }
+                char* hp = w->pin;
+                std::memcpy(hp, slot_v.data(), (size_t)m * 4);
+                std::memcpy(hp + (size_t)m * 4, level_v.data(), (size_t)m * 4);
+                std::memcpy(hp + (size_t)m * 8, uoff.data(), (size_t)m * 4);
+                std::memcpy(hp + (size_t)m * 12, req_off.data(), (size_t)m * 4);
+                std::memcpy(hp + o_keys, key_v.data(), (size_t)m * 8);
+                for (uint32_t i = 0; i < m; ++i) std::memcpy(hp + o_vec + (size_t)i * dim * 4, vecs + (c0 + src_row[i]) * dim, (size_t)dim * 4);
+                if (!reuse_rows.empty()) std::memcpy(hp + o_rr, reuse_rows.data(), reuse_rows.size() * 4);
+                if (!reuse_upper.empty()) std::memcpy(hp + o_ru, reuse_upper.data(), reuse_upper.size() * 4);
+                char* dp = (char*)w->a.ensure(total);
+                HIP_OK(hipMemcpyAsync(dp, hp, total - 64, hipMemcpyHostToDevice, st));
+                d_slots = (uint32_t*)dp;
+                d_lv = (int32_t*)(dp + (size_t)m * 4);
+                d_uoff = (uint32_t*)(dp + (size_t)m * 8);
+                d_reqoff = (uint32_t*)(dp + (size_t)m * 12);
+                d_keyv = (uint64_t*)(dp + o_keys);
+                src = (const float*)(dp + o_vec);
+                d_rr = (uint32_t*)(dp + o_rr);
+                d_ru = (uint32_t*)(dp + o_ru);
+            } else {
+                d_slots = (uint32_t*)w->a.ensure((size_t)m * 4 * 4 + 64);
+                d_lv = (int32_t*)(d_slots + m);
+                d_uoff = (uint32_t*)(d_lv + m);
+                d_reqoff = d_uoff + m;
+                d_keyv = (uint64_t*)w->b.ensure((size_t)m * 8);
+                HIP_OK(hipMemcpyAsync(d_slots, slot_v.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemcpyAsync(d_lv, level_v.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemcpyAsync(d_uoff, uoff.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemcpyAsync(d_reqoff, req_off.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemcpyAsync(d_keyv, key_v.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
+                if (on_device) {
+                    if (m == cn) {
+                        src = vecs + c0 * dim;
+                    } else {  // some rows were rejected: compact on the host side list of source rows
+                        float* stg = (float*)w->c.ensure((size_t)m * dim * 4);
+                        for (uint32_t i = 0; i < m; ++i)
+                            HIP_OK(hipMemcpyAsync(stg + (size_t)i * dim, vecs + (c0 + src_row[i]) * dim, (size_t)dim * 4,
+                                                  hipMemcpyDeviceToDevice, st));
+                        src = stg;
+                    }
+                } else {
                     float* stg = (float*)w->c.ensure((size_t)m * dim * 4);
-                    for (uint32_t i = 0; i < m; ++i)
-                        HIP_OK(hipMemcpyAsync(stg + (size_t)i * dim, vecs + (c0 + src_row[i]) * dim, (size_t)dim * 4,
-                                              hipMemcpyDeviceToDevice, st));
+                    if (m == cn) {
+                        HIP_OK(hipMemcpyAsync(stg, vecs + c0 * dim, (size_t)m * dim * 4, hipMemcpyHostToDevice, st));
+                    } else {
+                        for (uint32_t i = 0; i < m; ++i)
+                            HIP_OK(hipMemcpyAsync(stg + (size_t)i * dim, vecs + (c0 + src_row[i]) * dim, (size_t)dim * 4,
+                                                  hipMemcpyHostToDevice, st));
+                    }
                     src = stg;
                 }
-            } else {
-                float* stg = (float*)w->c.ensure((size_t)m * dim * 4);
-                if (m == cn) {
-                    HIP_OK(hipMemcpyAsync(stg, vecs + c0 * dim, (size_t)m * dim * 4, hipMemcpyHostToDevice, st));
-                } else {
-                    for (uint32_t i = 0; i < m; ++i)
-                        HIP_OK(hipMemcpyAsync(stg + (size_t)i * dim, vecs + (c0 + src_row[i]) * dim, (size_t)dim * 4,
-                                              hipMemcpyHostToDevice, st));
-                }
-                src = stg;
             }
+            const uint32_t* d_src_slots = d_slots;
             HIP_OK(launch_quantise_rows(ix, d_vectors, d_aux, src, dim, d_src_slots, 0, m, st));
             HIP_OK(launch_scatter_u64(d_keys, d_slots, d_keyv, m, st));
             HIP_OK(launch_scatter_u32((uint32_t*)d_levels, d_slots, (const uint32_t*)d_lv, m, st));
@@ -1217,14 +1275,14 @@ struct Engine {
                 plane_done = 0;
             }
             if (!reuse_rows.empty()) {  // usearch update(): the reused node's links are zeroed first
-                uint32_t* d_rr = (uint32_t*)w->d.ensure((reuse_rows.size() + reuse_upper.size()) * 4 + 64);
-                HIP_OK(hipMemcpyAsync(d_rr, reuse_rows.data(), reuse_rows.size() * 4, hipMemcpyHostToDevice, st));
-                HIP_OK(launch_fill_rows_u32(d_adj0, M0, d_rr, (uint32_t)reuse_rows.size(), kInvalid, st));
-                if (!reuse_upper.empty()) {
-                    uint32_t* d_ru = d_rr + reuse_rows.size();
-                    HIP_OK(hipMemcpyAsync(d_ru, reuse_upper.data(), reuse_upper.size() * 4, hipMemcpyHostToDevice, st));
-                    HIP_OK(launch_fill_rows_u32(d_upper, M, d_ru, (uint32_t)reuse_upper.size(), kInvalid, st));
+                if (!small) {
+                    d_rr = (uint32_t*)w->d.ensure((reuse_rows.size() + reuse_upper.size()) * 4 + 64);
+                    HIP_OK(hipMemcpyAsync(d_rr, reuse_rows.data(), reuse_rows.size() * 4, hipMemcpyHostToDevice, st));
+                    d_ru = d_rr + reuse_rows.size();
+                    if (!reuse_upper.empty()) HIP_OK(hipMemcpyAsync(d_ru, reuse_upper.data(), reuse_upper.size() * 4, hipMemcpyHostToDevice, st));
                 }
+                HIP_OK(launch_fill_rows_u32(d_adj0, M0, d_rr, (uint32_t)reuse_rows.size(), kInvalid, st));
+                if (!reuse_upper.empty()) HIP_OK(launch_fill_rows_u32(d_upper, M, d_ru, (uint32_t)reuse_upper.size(), kInvalid, st));
             }
 
             // 3. sub-batches against the frozen graph
@@ -1424,6 +1482,7 @@ struct Engine {
     void apply_log(Pending& log, size_t& lost) {
         std::lock_guard<std::mutex> g(mod_mu);
         use_device();
+        housekeeping();
         PodFreeze freeze(*this);
         std::vector<uint32_t> tomb;
         std::vector<uint64_t> run_keys;
@@ -1948,6 +2007,7 @@ struct Engine {
                      const std::vector<uint32_t>* allow = nullptr) {
         if (!nq) return;
         use_device();
+        housekeeping();
         Lease w(device);
         hipStream_t st = w->stream;
         float* d_q = (float*)w->a.ensure(nq * dim * 4);
@@ -2354,6 +2414,7 @@ struct Engine {
     // filtered_lazy through the batcher.  (size_t)-1: hand the query to the unbatched rounds (a tie where order matters, or a failure).
     size_t filtered_batched(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, uint32_t ef) {
         use_device();
+        housekeeping();
         const size_t n = slots_atomic.load(std::memory_order_acquire), lay = layout_slots();
         const size_t words = (n + 31) / 32, lay_words = (lay + 31) / 32;
         const uint32_t cap = 1u << 17;
@@ -2450,9 +2511,23 @@ struct Engine {
             }
             // wait for the kernel's flag (the two kinds of round take different times: one moving average each)
             static std::atomic<int> waiting{0};
-            if (!wait_for_device_flag([&] { return __atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id; }, waiting, wait_typical_us[explore ? 2 : 1], 20.0))
-                fail(VS_ERR_DEVICE, "a batched filtered round did not finish");
-            pod.done();
+            for (int attempt = 0;; ++attempt) {
+                bool lost = false;
+                uint32_t looks = 0;
+                if (!wait_for_device_flag(
+                        [&] {
+                            if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id) return true;
+                            if (pod.t && (++looks & 1023u) == 0u && pod_pool(device).lost_post(pod.t)) lost = __atomic_load_n(h_done, __ATOMIC_ACQUIRE) != pq.round_id;
+                            return lost;
+                        },
+                        waiting, wait_typical_us[explore ? 2 : 1], 20.0)) {
+                    w.retire();
+                    fail(VS_ERR_DEVICE, "a batched filtered round did not finish");
+                }
+                pod.done();
+                if (!lost || attempt) break;
+                submit_round(pq, explore, ef, lay);  // the workgroup had left before it saw the post: the round goes into a batched launch
+            }
             uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
             if (found == kPipeRedoFound && explore) {
                 // (an exploring round keeps no order, so nothing it meets hands it over -- but if one ever is: the exact walk lists what it needs)
@@ -3126,6 +3201,7 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
         stress_small_table || force_wide_tags)
         return false;
     use_device();
+    housekeeping();
     const size_t n = slots_atomic.load(std::memory_order_acquire), lay = layout_slots();
     if (!n) return false;
     Lease w(device);
@@ -3173,9 +3249,20 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
     // (a walk is the better part of a millisecond)
     static std::atomic<int> waiting{0};
     const auto t0 = std::chrono::steady_clock::now();
-    if (!wait_for_device_flag([&] { return __atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id; }, waiting, wait_typical_us[0], 20.0))
+    bool lost = false;
+    uint32_t looks = 0;
+    if (!wait_for_device_flag(
+            [&] {
+                if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id) return true;
+                if ((++looks & 1023u) == 0u && pod_pool(device).lost_post(pod.t)) lost = __atomic_load_n(h_done, __ATOMIC_ACQUIRE) != pq.round_id;
+                return lost;
+            },
+            waiting, wait_typical_us[0], 20.0)) {
+        w.retire();
         fail(VS_ERR_DEVICE, "a posted query was not answered");
+    }
     pod.done();
+    if (lost) return false;  // (the dispatcher serves it)
     {
         PodPool& pp = pod_pool(device);
         const auto t_out = std::chrono::steady_clock::now();

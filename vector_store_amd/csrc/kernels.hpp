@@ -72,7 +72,7 @@ struct PipeQuery {
     uint32_t budget;           // WalkArgs::unknown_budget of this round
     uint32_t k;
     uint32_t round_id;         // what *done becomes
-    uint32_t* cnt;             // pinned [4]: listed, consulted, found (kPipeRedoFound: not answered), evaluations
+    uint32_t* cnt;             // pinned [5]: listed, consulted, found (kPipeRedoFound: not answered), evaluations, 100 MHz ticks the workgroup spent on it
     uint64_t* keys;            // pinned: k
     float* dist;               // pinned: k
     uint32_t* done;            // pinned: set to round_id once everything above is visible to the host

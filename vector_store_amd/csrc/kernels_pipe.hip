@@ -4,6 +4,7 @@
 // One workgroup of kPipeTeam waves per query: wave 0 walks, the others evaluate candidates ahead of it.  A query this kernel
 // cannot answer exactly as usearch orders it (two equal distances met, or `next` outgrew the pool) is flagged kPipeRedo and
 // served by the usearch-order walk (kernels_walk.hip).
+#include <atomic>
 #include <mutex>
 
 #include "kernels.hpp"
@@ -315,14 +316,16 @@ template <int AR, int I, int EFCAP, int MODE>
 static hipError_t pipe_launch(const WalkArgs& a, hipStream_t s, PodSlot* slots, PodCtl* ctl) {
     auto kernel = hnsw_pipe_walk_kernel<AR, I, EFCAP, MODE>;
     const size_t dyn = (size_t)a.pipe_pool_cap * sizeof(uint2);
-    static std::once_flag once[16];  // the attribute is per device
+    // the attribute is per device; a failed attempt is tried again by the next launch (a once_flag would be spent on it, and every later
+    // launch would fail at the launch itself with an unrelated error: advisor finding, round 4)
+    static std::atomic<int> attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    hipError_t attr = hipSuccess;
-    std::call_once(once[dev & 15], [&] {
-        attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    });
-    if (attr != hipSuccess) return attr;
+    if (!attr_set[dev & 15].load(std::memory_order_acquire)) {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (attr != hipSuccess) return attr;
+        attr_set[dev & 15].store(1, std::memory_order_release);
+    }
     PipeKernArgs ka{a, slots, ctl};
     hipLaunchKernelGGL(kernel, dim3(a.nq), dim3(64 * kPipeTeam), dyn, s, ka);
     return hipGetLastError();

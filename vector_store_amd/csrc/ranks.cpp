@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -288,10 +289,23 @@ int vs_ranks_create_ex(vs_hnsw* shard, int rank, int world, const uint8_t id[VS_
             if (world > 1 && exchange == VS_RANKS_HOSTSHM) {
                 r->host.open(id, rank, world);
             } else if (exchange == VS_RANKS_RCCL) {
-                ncclUniqueId u;
-                if (id) std::memcpy(&u, id, sizeof u);
-                else NCCL_OK(ncclGetUniqueId(&u));  // (world == 1: nobody to share it with)
-                NCCL_OK(ncclCommInitRank(&r->comm, world, u, rank));
+                if (world > 1) {
+                    ncclUniqueId u;
+                    std::memcpy(&u, id, sizeof u);
+                    NCCL_OK(ncclCommInitRank(&r->comm, world, u, rank));
+                } else {
+                    // A world of one runs the collective too -- but it does not NEED it (the block is gathered in place): where RCCL
+                    // cannot initialise (a container without shared memory or a network interface) the handle serves without a
+                    // communicator, says so once, and reports rccl_ranks = 0 (advisor finding, round 4: it used to fail there).
+                    ncclUniqueId u;
+                    ncclResult_t e = id ? ncclSuccess : ncclGetUniqueId(&u);
+                    if (id) std::memcpy(&u, id, sizeof u);
+                    if (e == ncclSuccess) e = ncclCommInitRank(&r->comm, 1, u, 0);
+                    if (e != ncclSuccess) {
+                        r->comm = nullptr;
+                        std::fprintf(stderr, "[vs_ranks] a world of one could not initialise RCCL (%s): serving without a communicator\n", ncclGetErrorString(e));
+                    }
+                }
             }
         } catch (...) {
             vs_ranks_free(r);

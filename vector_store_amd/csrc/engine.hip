@@ -1106,69 +1106,115 @@ struct Engine {
         add_batch_locked(keys, vecs, on_device, n, status, first_err, staged);
     }
 
+    // Nodes whose slot and level are assigned (the host maps already know them) and whose device pass is still to come.  A slot
+    // appears once per run: the device pass stages every node's vector and zeroes the links of re-used slots before the first insert
+    // walk, so the same slot twice (removed, re-added, removed and re-added again within one log) needs two passes.
+    struct Run {
+        std::vector<uint32_t> slot_v, src_row, reuse_rows, reuse_upper;
+        std::vector<int32_t> level_v;
+        std::vector<uint64_t> key_v;
+        std::unordered_set<uint32_t> slots;
+        size_t size() const { return slot_v.size(); }
+        void clear() {
+            slot_v.clear();
+            src_row.clear();
+            reuse_rows.clear();
+            reuse_upper.clear();
+            level_v.clear();
+            key_v.clear();
+            slots.clear();
+        }
+    };
+    static constexpr int kRunFull = 1;  // assign_one: the slot this add would re-use is already in the run -- insert the run first
+    // usearch add(): validate the key, take a slot (a removed node's, FIFO, else the next unused one) and a level; the host maps are
+    // updated at once (a later remove in the same log finds the key).  VS_OK / VS_ERR_* / kRunFull.  mod_mu held.
+    int assign_one(uint64_t key, uint32_t src_index, Run& run, const char** why) {
+        if (key == kFreeKey) {
+            *why = "Key is reserved for internal use";
+            return VS_ERR_INVALID_ARGUMENT;
+        }
+        {
+            std::lock_guard<std::mutex> kg(key_mu);
+            if (lookup.count(key)) {
+                *why = "Duplicate keys not allowed in high-level wrappers";
+                return VS_ERR_DUPLICATE_KEY;
+            }
+        }
+        uint32_t slot;
+        int32_t level;
+        if (!free_slots.empty()) {  // usearch index_dense: reuse a removed node in place (update path)
+            if (run.slots.count(free_slots.front())) return kRunFull;
+            slot = free_slots.front();
+            free_slots.pop_front();
+            --removed;
+            level = h_levels[slot];
+            run.reuse_rows.push_back(slot);
+            for (int l = 0; l < level; ++l) run.reuse_upper.push_back(h_upper_off[slot] + l);
+        } else {
+            if (slots >= capacity) {
+                *why = "Reserve capacity ahead of insertions!";
+                return VS_ERR_CAPACITY;
+            }
+            slot = (uint32_t)slots++;
+            level = draw_level();
+            h_levels[slot] = (uint8_t)std::min(level, 255);
+            if (level > 0) {
+                h_upper_off[slot] = (uint32_t)upper_blocks;
+                upper_blocks += (size_t)level;
+            }
+        }
+        run.slot_v.push_back(slot);
+        run.level_v.push_back(level);
+        run.key_v.push_back(key);
+        run.src_row.push_back(src_index);
+        run.slots.insert(slot);
+        {
+            std::lock_guard<std::mutex> kg(key_mu);
+            lookup.emplace(key, slot);
+        }
+        h_keys[slot] = key;
+        ++live;
+        return VS_OK;
+    }
+
     void add_batch_locked(const uint64_t* keys, const float* vecs, bool on_device, size_t n, std::vector<int>& status,
                           std::string& first_err, bool staged) {  // mod_mu held, this index's pods frozen
         status.assign(n, VS_OK);
         if (!n) return;
         Lease w(device);
-        hipStream_t st = w->stream;
+        Run run;
         for (size_t c0 = 0; c0 < n; c0 += chunk_rows) {
             const size_t cn = std::min<size_t>(chunk_rows, n - c0);
-            // 1. validate, assign slots and levels
-            std::vector<uint32_t> slot_v, src_row, reuse_rows, reuse_upper;
-            std::vector<int32_t> level_v;
-            std::vector<uint64_t> key_v;
-            std::unordered_set<uint64_t> in_chunk;
-            slot_v.reserve(cn);
+            run.clear();
             for (size_t i = 0; i < cn; ++i) {
-                const uint64_t key = keys[c0 + i];
-                auto bad = [&](int code, const char* m) {
-                    status[c0 + i] = code;
-                    if (first_err.empty()) first_err = m;
-                };
-                if (key == kFreeKey) {
-                    bad(VS_ERR_INVALID_ARGUMENT, "Key is reserved for internal use");
-                    continue;
+                const char* why = "";
+                const int rc = assign_one(keys[c0 + i], (uint32_t)i, run, &why);  // (never kRunFull: nothing is removed in between)
+                if (rc != VS_OK) {
+                    status[c0 + i] = rc == kRunFull ? VS_ERR_DEVICE : rc;
+                    if (first_err.empty()) first_err = why;
                 }
-                bool known;
-                {
-                    std::lock_guard<std::mutex> kg(key_mu);
-                    known = lookup.count(key) != 0;
-                }
-                if (known || !in_chunk.insert(key).second) {
-                    bad(VS_ERR_DUPLICATE_KEY, "Duplicate keys not allowed in high-level wrappers");
-                    continue;
-                }
-                uint32_t slot;
-                int32_t level;
-                if (!free_slots.empty()) {  // usearch index_dense: reuse a removed node in place (update path)
-                    slot = free_slots.front();
-                    free_slots.pop_front();
-                    --removed;
-                    level = h_levels[slot];
-                    reuse_rows.push_back(slot);
-                    for (int l = 0; l < level; ++l) reuse_upper.push_back(h_upper_off[slot] + l);
-                } else {
-                    if (slots >= capacity) {
-                        in_chunk.erase(key);
-                        bad(VS_ERR_CAPACITY, "Reserve capacity ahead of insertions!");
-                        continue;
-                    }
-                    slot = (uint32_t)slots++;
-                    level = draw_level();
-                    h_levels[slot] = (uint8_t)std::min(level, 255);
-                    if (level > 0) {
-                        h_upper_off[slot] = (uint32_t)upper_blocks;
-                        upper_blocks += (size_t)level;
-                    }
-                }
-                slot_v.push_back(slot);
-                level_v.push_back(level);
-                key_v.push_back(key);
-                src_row.push_back((uint32_t)i);
             }
+            insert_run(run, vecs + c0 * dim, on_device, *w.ctx);
+            if (!staged) committed += run.size();  // staged vectors were counted when add_one accepted them
+        }
+    }
+
+    // The device pass of a run: vectors into their (padded, cast) rows, keys / levels / upper offsets, links of re-used slots zeroed,
+    // then sub-batches of insert walks against the frozen graph and their links.  `vecs`: rows indexed by the run's src_row.
+    void insert_run(Run& run, const float* vecs, bool on_device, WorkCtx& wc) {
+        {
+            WorkCtx* w = &wc;
+            hipStream_t st = w->stream;
+            std::vector<uint32_t>&slot_v = run.slot_v, &src_row = run.src_row, &reuse_rows = run.reuse_rows, &reuse_upper = run.reuse_upper;
+            std::vector<int32_t>& level_v = run.level_v;
+            std::vector<uint64_t>& key_v = run.key_v;
+            const size_t c0 = 0;
+            bool contiguous = true;  // the run's vectors are consecutive rows of `vecs`: one copy
+            for (size_t i = 1; i < src_row.size() && contiguous; ++i) contiguous = src_row[i] == src_row[0] + i;
+            const size_t cn = contiguous ? slot_v.size() : (size_t)-1;
+            const float* vecs0 = vecs + (src_row.empty() ? 0 : (size_t)src_row[0] * dim);
             const uint32_t m = (uint32_t)slot_v.size();
-            if (!m) continue;
+            if (!m) return;
             ensure_upper(upper_blocks);
             IndexView ix = view();
 
@@ -1241,7 +1287,7 @@ struct Engine {
                 HIP_OK(hipMemcpyAsync(d_keyv, key_v.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
                 if (on_device) {
                     if (m == cn) {
-                        src = vecs + c0 * dim;
+                        src = vecs0;
                     } else {  // some rows were rejected: compact on the host side list of source rows
                         float* stg = (float*)w->c.ensure((size_t)m * dim * 4);
                         for (uint32_t i = 0; i < m; ++i)
@@ -1252,7 +1298,7 @@ struct Engine {
                 } else {
                     float* stg = (float*)w->c.ensure((size_t)m * dim * 4);
                     if (m == cn) {
-                        HIP_OK(hipMemcpyAsync(stg, vecs + c0 * dim, (size_t)m * dim * 4, hipMemcpyHostToDevice, st));
+                        HIP_OK(hipMemcpyAsync(stg, vecs0, (size_t)m * dim * 4, hipMemcpyHostToDevice, st));
                     } else {
                         for (uint32_t i = 0; i < m; ++i)
                             HIP_OK(hipMemcpyAsync(stg + (size_t)i * dim, vecs + (c0 + src_row[i]) * dim, (size_t)dim * 4,
@@ -1350,13 +1396,7 @@ struct Engine {
                 linked += take;
             }
             HIP_OK(hipStreamSynchronize(st));
-            {
-                std::lock_guard<std::mutex> kg(key_mu);
-                for (uint32_t i = 0; i < m; ++i) lookup.emplace(key_v[i], slot_v[i]);
-            }
-            for (uint32_t i = 0; i < m; ++i) h_keys[slot_v[i]] = key_v[i];
-            live += m;
-            if (!staged) committed += m;  // staged vectors were counted when add_one accepted them
+            (void)key_v;
             slots_atomic.store(slots, std::memory_order_release);
         }
     }
@@ -1475,24 +1515,27 @@ struct Engine {
         return rc;
     }
 
-    // The staged log, in order: runs of consecutive adds go through the bulk insert (slots are assigned as the run is reached, so an
-    // add re-uses the slot a remove EARLIER in the log freed, exactly as the calls would have one by one: usearch's free ring is FIFO),
-    // removes update the host maps and are tombstoned on the device in one launch at the end (a slot that was removed and re-added in
-    // this log carries its new key by then).
+    // The staged log, in order.  HOST state follows the calls one by one: an add takes the slot a remove EARLIER in the log freed
+    // (usearch's free ring is FIFO), a remove finds the key an earlier add of the same log brought.  The DEVICE work is batched across
+    // the removes: assigned adds collect in a run that goes through the bulk insert in one pass (interleaved with removes, as the
+    // reference's update is -- RemoveBeforeAddValue + AddVector per item -- runs of one add each made a log of 2,048 updates 2,048
+    // lone insert walks: 1.3k updates/s), cut only where an add would re-use a slot that is already in the run; removes are
+    // tombstoned on the device in one launch at the end (a slot that was removed and re-added in this log carries its new key by then).
     void apply_log(Pending& log, size_t& lost) {
         std::lock_guard<std::mutex> g(mod_mu);
         use_device();
         housekeeping();
         PodFreeze freeze(*this);
+        Lease w(device);
         std::vector<uint32_t> tomb;
-        std::vector<uint64_t> run_keys;
-        const size_t n = log.ops.size();
-        for (size_t i = 0; i < n;) {
-            if (log.ops[i].vec == Pending::kRemove) {
+        Run run;
+        const float* vecs = log.vecs.data();
+        for (const Pending::Op& op : log.ops) {
+            if (op.vec == Pending::kRemove) {
                 uint32_t slot = kInvalid;
                 {
                     std::lock_guard<std::mutex> kg(key_mu);
-                    auto it = lookup.find(log.ops[i].key);
+                    auto it = lookup.find(op.key);
                     if (it != lookup.end()) {
                         slot = it->second;
                         lookup.erase(it);
@@ -1507,28 +1550,30 @@ struct Engine {
                 } else {
                     ++committed;  // the remove was counted when it was staged
                 }
-                ++i;
                 continue;
             }
-            size_t j = i;
-            run_keys.clear();
-            while (j < n && log.ops[j].vec != Pending::kRemove) run_keys.push_back(log.ops[j++].key);
-            std::vector<int> status;
-            std::string err;
-            add_batch_locked(run_keys.data(), log.vecs.data() + (size_t)log.ops[i].vec * dim, false, j - i, status, err, true);
-            for (int st : status)
-                if (st != VS_OK) {  // accepted at staging time, rejected at insertion (cannot normally happen)
-                    --committed;
-                    ++lost;
-                }
-            i = j;
+            const char* why = "";
+            int rc = assign_one(op.key, op.vec, run, &why);
+            if (rc == kRunFull) {
+                insert_run(run, vecs, false, *w.ctx);
+                run.clear();
+                rc = assign_one(op.key, op.vec, run, &why);
+            }
+            if (rc != VS_OK) {  // accepted at staging time, rejected at insertion (cannot normally happen)
+                --committed;
+                ++lost;
+            }
+            if (run.size() >= chunk_rows) {
+                insert_run(run, vecs, false, *w.ctx);
+                run.clear();
+            }
         }
+        insert_run(run, vecs, false, *w.ctx);
         if (!tomb.empty()) {
             size_t m = 0;
             for (uint32_t s : tomb)
                 if (h_keys[s] == kFreeKey) tomb[m++] = s;  // not re-added later in this log
             if (m) {
-                Lease w(device);
                 uint32_t* d_t = (uint32_t*)w->d.ensure(m * 4 + 64);
                 HIP_OK(hipMemcpyAsync(d_t, tomb.data(), m * 4, hipMemcpyHostToDevice, w->stream));
                 HIP_OK(launch_fill_rows_u32((uint32_t*)d_keys, 2, d_t, (uint32_t)m, kInvalid, w->stream));  // key := ~0 (usearch free_key)

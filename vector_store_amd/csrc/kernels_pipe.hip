@@ -274,6 +274,11 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the query's line, and whatever the caller wrote for it, after its number
+                // ... and the SCALAR cache: the compiler turns wave-uniform loads of the index (upper_off[cur], a level's block) into
+                // scalar loads, whose cache no fence invalidates -- a launch starts with it clean, a pod that survives an add (round 5)
+                // must clean it itself or it walks with a stale upper_off of a slot that has been filled since
+                __builtin_amdgcn_s_dcache_inv();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 pod_cmd[0] = p;
                 pod_cmd[1] = __hip_atomic_load(&slot->ef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 pod_cmd[2] = __hip_atomic_load(&slot->explore, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

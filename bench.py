@@ -538,6 +538,31 @@ def boundary_record(ix, queries_host, truth, k, seconds):
         d, pods = pod_delta(pods)
         out[name].update(d)
         answers[name] = rec
+    # Pods BESIDE a stream of batches (round 5): the reference runs plain Ann inline on its async workers and every filtered query on a
+    # blocking thread AT THE SAME TIME (usearch.rs:928-948) -- blocking callers (served by pods: up to 3 x 64 resident workgroups) and
+    # the non-blocking entry point (batches from the dispatcher) on the same index, each against its solo rate above.
+    try:
+        import threading
+        side = {}
+
+        def blocking():
+            side["b"] = callers.run(ix, q, k, t, cores + 1, 1, max(seconds / 2, 1.0))
+
+        def in_flight():
+            side["a"] = callers.run(ix, q, k, t, 16, 256, max(seconds / 2, 1.0))
+        th = [threading.Thread(target=blocking), threading.Thread(target=in_flight)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        rb, ra = side["b"][0], side["a"][0]
+        out["pods_beside_async"] = {
+            "blocking_callers": {"threads": cores + 1, "queries_per_s": rb.qps, "p50_ms": ms(rb.p50_ns), "p99_ms": ms(rb.p99_ns), "errors": int(rb.errors),
+                                 "vs_solo": rb.qps / out["blocking_callers"]["queries_per_s"] if out["blocking_callers"]["queries_per_s"] else None},
+            "async_in_flight": {"threads": 16, "in_flight_per_thread": 256, "queries_per_s": ra.qps, "p50_ms": ms(ra.p50_ns), "p99_ms": ms(ra.p99_ns),
+                                "errors": int(ra.errors), "vs_solo": ra.qps / out["async_in_flight"]["queries_per_s"] if out["async_in_flight"]["queries_per_s"] else None}}
+        d, pods = pod_delta(pods)
+        out["pods_beside_async"].update(d)
+    except Exception as e:  # noqa: BLE001
+        out["pods_beside_async"] = {"error": repr(e)}
     out["filtered"] = {}
     # the reference puts EVERY filtered query on a blocking thread (spawn_blocking), so under load there are far more of them than cores
     # (the legs of one filter together: the index sizes a query's first round by what its recent filtered queries needed).  The legs draw

@@ -136,7 +136,7 @@ def test_another_index_reserves_adds_and_drops_while_one_serves_a_crowd_through_
             b.reserve(60_000)
             steps.append(("grow", time.perf_counter() - t0))
             t0 = time.perf_counter()
-            assert b.stats()["added"] >= 20_000
+            assert b.stats()["added"] >= 19_999  # (the first member becomes the entry point without a walk)
             steps.append(("stats", time.perf_counter() - t0))
             t0 = time.perf_counter()
             assert len(b.export_graph()["levels"]) == 20_000
@@ -222,3 +222,59 @@ def test_row_layouts_without_a_pipelined_instance_fall_back_and_equal_the_oracle
         assert_same_results(gk, gd, wk, wd, lambda key, i=i: o.distance_to_slot(q[i], int(key)), what=("filtered", i))
     assert ix.pipe_stats()["pipe_launches"] == before
     assert ix.pod_stats()["pods_opened"] == 0
+
+
+def test_pods_beside_a_stream_of_batches_and_more_kinds_of_caller_than_pods():
+    """The reference serves plain queries inline on its async workers and every filtered query on a blocking thread at the same time
+    (usearch.rs:928-948), on every index it holds.  Here: two indexes x {plain, filtered} blocking callers -- four (index, kind)
+    combinations for three pods, so one of them is served by launches -- WHILE the non-blocking entry point keeps 8 x 64 queries of
+    index A in flight.  Every answer is the one the same call gives on a quiet device; nothing fails, nothing starves."""
+    import vector_store_amd as vs
+    from vector_store_amd import callers
+    n, dim, k = 110_000, 64, 10
+    data = _dataset(2 * n + 512, dim, 53)
+    a = vs.HipUsearchIndex(dim, vs.COS, expansion_search=96)
+    b = vs.HipUsearchIndex(dim, vs.COS, expansion_search=96)
+    for h, lo in ((a, 0), (b, n)):
+        h.reserve(n)
+        h.add_batch(np.arange(n, dtype=np.uint64), data[lo:lo + n])
+    if not a.pod_stats()["pods_enabled"]:
+        pytest.skip("VS_HNSW_PODS=0")
+    q = data[2 * n:]
+    pred = lambda key: key % 4 == 3
+    want = {}
+    for name, h in (("a", a), ("b", b)):
+        want[name, "plain"] = [h.search(q[i], k)[0].tolist() for i in range(64)]
+        want[name, "filtered"] = [h.filtered_search(q[i], k, pred)[0].tolist() for i in range(64)]
+    tk, _, _ = a.search_batch(q, k)
+    stop = threading.Event()
+    errors, done = [], {}
+
+    def caller(name, h, kind, t):
+        i = t
+        try:
+            while not stop.is_set():
+                keys = (h.search(q[i % 64], k) if kind == "plain" else h.filtered_search(q[i % 64], k, pred))[0]
+                assert keys.tolist() == want[name, kind][i % 64], (name, kind, i % 64)
+                done[name, kind, t] = done.get((name, kind, t), 0) + 1
+                i += 7
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=caller, args=(name, h, kind, t)) for name, h in (("a", a), ("b", b)) for kind in ("plain", "filtered")
+          for t in range(6)]
+    [x.start() for x in th]
+    try:
+        r, rec, rc = callers.run(a, q, k, tk, threads=8, inflight=64, seconds=3.0, record=4000)
+    finally:
+        stop.set()
+        [x.join() for x in th]
+    assert not errors, errors[:3]
+    assert rc == 0 and r.errors == 0 and r.queries > 1000
+    # the stream of batches got the batch path's answers (recall against the batch answers themselves = 1)
+    assert r.recall_avg > 0.999, r.recall_avg
+    for name in ("a", "b"):
+        for kind in ("plain", "filtered"):
+            assert sum(v for (nm, kd, _), v in done.items() if nm == name and kd == kind) > 20, (name, kind, done)
+    st = a.pod_stats()
+    assert st["pod_rounds"] > 100 and st["pods_open_on_device"] <= 3

@@ -243,7 +243,7 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
 
     out["boundary_id_parity"] = {}
     for leg, rec in (boundary_answers or {}).items():
-        if not leg.startswith("filtered."):
+        if not leg.startswith("filtered"):
             par = parity_of_answers(rec, keys, dists, found, nq)
             if par is not None:
                 out["boundary_id_parity"][leg] = par
@@ -268,7 +268,7 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
                 par = count_parity(gk, gd, fk[:m], fd[:m], ff[:m], oracle_distance, exact=exact)
                 rec["id_parity"] = {kk: par[kk] for kk in ("rows", "identical_rows", "near_tie_positions", "violations")}
             for leg, brec in (boundary_answers or {}).items():
-                if leg.startswith("filtered." + name):
+                if leg.startswith("filtered." + name) or leg.startswith("filtered_named." + name):
                     par = parity_of_answers(brec, fk, fd, ff, answered)
                     if par is not None:
                         out["boundary_id_parity"][leg] = par
@@ -289,7 +289,7 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
             act.adopt_partition(0, o.h, o.size())
             return act
         try:
-            out["mixed"] = mixed_record(actor_of, queries_host, mixed_fresh, slots, mixed_seconds)
+            out["mixed"] = mixed_record(actor_of, queries_host, mixed_fresh, slots, mixed_seconds, named=False)  # (a CPU usearch has no verdict memory)
         except Exception as e:  # noqa: BLE001
             out["mixed"] = {"error": repr(e)}
     return out, keys
@@ -586,15 +586,41 @@ def boundary_record(ix, queries_host, truth, k, seconds):
         fr.update(d)
         out["filtered"][name] = fr
         answers["filtered." + name] = rec
+    # The same callers with a NAMED filter (vs_hnsw_filtered_search_keyed, round 5: a fingerprint of the restrictions lets the engine
+    # remember the predicate's verdicts across queries -- usearch asks about every candidate of every query): each leg after a warm-up
+    # of the same callers, so the figures are the warm state of a filter whose queries revisit their neighbourhoods; verdicts_asked_per_query
+    # says how warm.  The opaque-predicate legs above are what a caller that does not name its filter gets.
+    out["filtered_named"] = {}
+    for name, modulus, threads, nq_used, fkey in (("selectivity_10pct", 10, cores + 1, 2048, 0xA10), ("selectivity_10pct_64_callers", 10, 64, 2048, 0xA10),
+                                                  ("selectivity_10pct_128_callers", 10, 128, 2048, 0xA10), ("selectivity_1pct", 100, cores + 1, 256, 0xA100)):
+        try:
+            qs = q[:nq_used]
+            callers.run_filtered(ix, qs, k, modulus, threads, 1.0 if modulus < 100 else 2.0, filter_key=fkey)
+            f0, m0 = ix.filter_stats(), ix.filter_memo_stats()
+            r, extra, rec, rc = callers.run_filtered(ix, qs, k, modulus, threads, max(seconds / 2, 1.0) if modulus < 100 else max(seconds, 2.0), record=cap, filter_key=fkey)
+            f1, m1 = ix.filter_stats(), ix.filter_memo_stats()
+            fr = rec_of(r, rc, threads, 1)
+            fr.pop("recall_at_10", None)
+            nqd = max(int(r.queries), 1)
+            fr.update({"predicate": f"key % {modulus} == 0", "filter_key": fkey, "predicate_calls_per_query": extra[0] / nqd, "results_per_query": extra[1] / nqd,
+                       "walk_launches_per_query": (f1["lazy_rounds"] - f0["lazy_rounds"]) / nqd, "queries_drawn_from": nq_used,
+                       "verdicts_asked_per_query": (m1["verdicts_asked"] - m0["verdicts_asked"]) / max(m1["queries"] - m0["queries"], 1)})
+            d, pods = pod_delta(pods)
+            fr.update(d)
+            out["filtered_named"][name] = fr
+            answers["filtered_named." + name] = rec
+        except Exception as e:  # noqa: BLE001
+            out["filtered_named"][name] = {"error": repr(e)}
     out["note"] = ("one query per C-ABI call; percentiles on the reference's histogram (10,000 buckets over 1..100 ms: anything "
                    "faster reads 1.0 ms); latency_min_ms is the raw minimum; id_parity: every recorded answer against the CPU oracle's for the same query")
     return out, answers
 
 
-MIXED_LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search_while_updating:16+0", "search_while_updating", "search_while_inserting", "search_while_deleting")
+MIXED_LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search_while_updating:16+0", "search_while_updating", "search_while_updating@named",
+              "search_while_inserting", "search_while_deleting")
 
 
-def mixed_record(actor_of, queries_host, fresh, n, seconds, producers=(1, 16)):
+def mixed_record(actor_of, queries_host, fresh, n, seconds, producers=(1, 16), named=True):
     """The reference's MIXED workloads (crates/vector-store/benches/pipeline.rs:1407-1418: cdc_insert, cdc_update, cdc_delete,
     search_while_{updating,inserting,deleting}) through the dispatch actor (libvs_actor: search-first channels, Operation permits,
     usearch.rs:515-624, :897-948; one vector per add / remove call, :1019-1049) on the full-size index: `producers` CDC producers
@@ -605,7 +631,9 @@ def mixed_record(actor_of, queries_host, fresh, n, seconds, producers=(1, 16)):
     for p in producers:
         act = actor_of()
         try:
-            legs = MIXED_LEGS if p == producers[0] else ("cdc_insert", "cdc_update", "search_while_updating:16+0", "search_while_updating")
+            legs = MIXED_LEGS if p == producers[0] else ("cdc_insert", "cdc_update", "search_while_updating:16+0", "search_while_updating", "search_while_updating@named")
+            if not named:
+                legs = tuple(x for x in legs if "@named" not in x)
             rec = callers.pipeline_legs(act, queries_host[:4096], fresh, n, legs, seconds=seconds, producers=p,
                                         state={"next_key": (1 << 40) + (p << 32) + (1 << 30), "delete_from": n // 2 + (p % 7) * 100_000})
             rec["actor_counters"] = act.counters()
@@ -950,16 +978,18 @@ def main():
             # what the crowds of the boundary legs received, against the oracle: the parity record moves next to each leg
             for leg, par in cb.pop("boundary_id_parity", {}).items():
                 violations += par["violations"]
-                where = out["boundary"]["filtered"] if leg.startswith("filtered.") else out["boundary"]
-                if isinstance(where.get(leg.replace("filtered.", "")), dict):
-                    where[leg.replace("filtered.", "")]["id_parity"] = par
+                group, _, short = leg.partition(".")
+                where = out["boundary"].get(group, {}) if short else out["boundary"]
+                if isinstance(where.get(short or leg), dict):
+                    where[short or leg]["id_parity"] = par
             # the CPU's filtered rate beside each GPU record of the same predicate (same graph, same call pattern, `cores` threads)
             for name, crec in cb.get("filtered", {}).items():
                 violations += crec.get("id_parity", {}).get("violations", 0)
-                for gname, grec in out["boundary"]["filtered"].items():
-                    if gname.startswith(name) and isinstance(grec, dict) and crec["queries_per_s"] > 0:
-                        grec["cpu_queries_per_s"] = crec["queries_per_s"]
-                        grec["vs_cpu"] = grec["queries_per_s"] / crec["queries_per_s"]
+                for group in ("filtered", "filtered_named"):
+                    for gname, grec in out["boundary"].get(group, {}).items():
+                        if gname.startswith(name) and isinstance(grec, dict) and "queries_per_s" in grec and crec["queries_per_s"] > 0:
+                            grec["cpu_queries_per_s"] = crec["queries_per_s"]
+                            grec["vs_cpu"] = grec["queries_per_s"] / crec["queries_per_s"]
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
 
@@ -982,7 +1012,7 @@ def main():
                 if not pk.startswith("producers_") or not isinstance(cm.get(pk), dict):
                     continue
                 for leg, rec in legs.items():
-                    crec = cm[pk].get(leg)
+                    crec = cm[pk].get(leg.replace("@named", ""))
                     if isinstance(rec, dict) and isinstance(crec, dict) and "items_per_s" in rec:
                         rec["vs_cpu"] = {"items": rec["items_per_s"] / crec["items_per_s"] if crec.get("items_per_s") else None}
                         for kind in ("plain", "filtered"):

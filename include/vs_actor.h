@@ -52,6 +52,9 @@ typedef struct vs_actor_index_vtable {
     int (*filtered_search)(void* index, const float* query, size_t dim, size_t k, vs_hnsw_predicate predicate, void* ctx,
                            uint64_t* keys, float* distances, size_t* found);
     const char* (*last_error)(void);
+    /* optional (NULL: filtered_search serves): the filtered search of a NAMED filter, vs_hnsw_filtered_search_keyed */
+    int (*filtered_search_keyed)(void* index, const float* query, size_t dim, size_t k, vs_hnsw_predicate predicate, void* ctx,
+                                 uint64_t filter_key, uint64_t* keys, float* distances, size_t* found);
 } vs_actor_index_vtable;
 VS_API int vs_actor_create_with(const vs_actor_options* options, const vs_actor_index_vtable* index, vs_actor** out);
 
@@ -77,6 +80,10 @@ VS_API int vs_actor_ann(vs_actor* actor, uint64_t partition, const float* query,
                         float* distances, size_t* found);
 VS_API int vs_actor_filtered_ann(vs_actor* actor, uint64_t partition, const float* query, size_t dim, size_t k,
                                  vs_hnsw_predicate predicate, void* ctx, uint64_t* keys, float* distances, size_t* found);
+/* FilteredAnn whose filter has a name: a fingerprint of `Filter::restrictions` (vs_index/actor.rs:53-59), see vs_hnsw_filtered_search_keyed. */
+VS_API int vs_actor_filtered_ann_keyed(vs_actor* actor, uint64_t partition, const float* query, size_t dim, size_t k,
+                                       vs_hnsw_predicate predicate, void* ctx, uint64_t filter_key, uint64_t* keys, float* distances,
+                                       size_t* found);
 VS_API size_t vs_actor_count(vs_actor* actor);
 
 /* Memory guard (memory.rs Allocate::{Can, Cannot}): can = 0 makes the actor drop AddVector messages. */

@@ -52,6 +52,12 @@ VS_API int vs_callers_run_filtered_recorded(vs_hnsw* index, const float* queries
                                             unsigned threads, double seconds, vs_callers_result* out, uint64_t extra[4],
                                             vs_callers_record* record);
 
+/* ... and with a NAMED filter (vs_hnsw_filtered_search_keyed: the engine remembers the predicate's verdicts across the queries that carry
+ * filter_key; 0 = the plain call). */
+VS_API int vs_callers_run_filtered_keyed(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus,
+                                         uint64_t filter_key, unsigned threads, double seconds, vs_callers_result* out, uint64_t extra[4],
+                                         vs_callers_record* record);
+
 /* The same loop over vs_hnsw_filtered_search: the reference runs every filtered query on a blocking thread (spawn_blocking,
  * usearch.rs:937-948) with a predicate that takes a table read-lock per call (usearch.rs:1118-1124).  Predicate here:
  * key % modulus == 0 (selectivity 1 / modulus), counted.  extra: [0] predicate calls, [1] results returned, [2..3] 0.
@@ -75,6 +81,7 @@ typedef struct vs_mixed_options {
     uint64_t modulus, partition, first_new_key, existing_keys, delete_from, max_items;
     size_t k;
     double seconds;
+    uint64_t filter_key; /* != 0: the filtered callers name their filter (vs_actor_filtered_ann_keyed) */
 } vs_mixed_options;
 typedef struct vs_mixed_result {
     double seconds;

@@ -118,6 +118,17 @@ VS_API int vs_hnsw_search_async(vs_hnsw* index, const float* query, size_t dim, 
 typedef int (*vs_hnsw_predicate)(uint64_t key, void* ctx);
 VS_API int vs_hnsw_filtered_search(vs_hnsw* index, const float* query, size_t dim, size_t k, vs_hnsw_predicate predicate,
                             void* ctx, uint64_t* keys, float* distances, size_t* found);
+/* The same call for a filter that has a NAME: `filter_key` != 0 is a fingerprint of the restrictions the predicate evaluates (the
+ * reference's predicate is a table read-lock + restriction evaluation per candidate, usearch.rs:1118-1124: the same function of the key
+ * for every query with the same `Filter::restrictions`).  The engine then remembers verdicts across the queries of that filter (two
+ * bits per slot in HBM, up to 4 filters per index, least recently used first out): a key is asked about at most once, and once a
+ * filter's neighbourhoods are known a query is one exact walk with no predicate call.  Results are those of vs_hnsw_filtered_search
+ * as long as predicate(key) depends on nothing but (filter_key, key); a member that is removed or re-added is asked about again.
+ * filter_key == 0: no memory (= vs_hnsw_filtered_search). */
+VS_API int vs_hnsw_filtered_search_keyed(vs_hnsw* index, const float* query, size_t dim, size_t k, vs_hnsw_predicate predicate,
+                                         void* ctx, uint64_t filter_key, uint64_t* keys, float* distances, size_t* found);
+/* [0] queries answered with a filter memory, [1] verdicts they still asked the host for, [2] memories created, [3] memories held now */
+VS_API int vs_hnsw_filter_memo_stats(vs_hnsw* index, uint64_t out[4]);
 /* nq queries, row-major nq x dim; keys/distances are nq x k, found is nq. */
 VS_API int vs_hnsw_search_batch(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, uint64_t* keys,
                          float* distances, size_t* found);

@@ -96,8 +96,9 @@ def lib():
 
 def trait_vtable():
     """The oracle as an implementation of `trait UsearchIndex` for libvs_actor (include/vs_actor.h: vs_actor_index_vtable):
-    nine function pointers.  Only tests and bench.py's cpu_baseline leg pass it to vs_actor_create_with."""
-    t = (C.c_void_p * 9)()
+    nine function pointers and the optional tenth (filtered_search_keyed) left NULL -- a CPU usearch has no verdict memory.  Only
+    tests and bench.py's cpu_baseline leg pass it to vs_actor_create_with."""
+    t = (C.c_void_p * 10)()
     lib().orc_trait_vtable(t)
     return t
 

@@ -21,7 +21,8 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402  (make_data, build_index, effective_cores)
 
-LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search", "search:16+0", "search_while_inserting", "search_while_updating", "search_while_updating:16+0", "search_while_deleting")
+LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search", "search@named", "search:16+0", "search_while_inserting", "search_while_updating", "search_while_updating@named",
+        "search_while_updating:16+0", "search_while_deleting")
 
 
 def run_legs(actor, callers, queries, vectors, n, legs, seconds, producers, plain, filtered, modulus, state, tag):

@@ -17,7 +17,7 @@ def test_actor_library_exports_its_header():
     declared = set(re.findall(r"^VS_API [^;(]*?\b(vs_actor_[a-z0-9_]+)\(", header, flags=re.M))
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "vector_store_amd", "libvs_actor.so")], text=True)
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
-    assert declared == {s for s in exported if s.startswith("vs_actor_")} and len(declared) == 17
+    assert declared == {s for s in exported if s.startswith("vs_actor_")} and len(declared) == 18
 
 
 def _oracle_actor(dim, metric, n, seed=0, workers=4, ef=64):

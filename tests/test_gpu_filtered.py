@@ -83,3 +83,75 @@ def test_filtered_search_with_removed_members_and_exact_data():
             ek, ed = o.filtered_search(q[i], k, pred)
             assert_same_results(fk, fd, ek, ed, exact=True, what=(modulo, k, i))
             assert all(int(x) % 5 != 0 for x in fk)
+
+
+def test_a_named_filter_remembers_verdicts_and_answers_like_the_unnamed_one():
+    """vs_hnsw_filtered_search_keyed (round 5): queries that carry the same filter_key share the verdicts the predicate gave (two bits
+    per slot on the device).  Answers are those of the plain call -- the oracle's, ids and distances --; the predicate is asked about a
+    key at most once per filter; once the neighbourhoods are known a query is one walk without a single predicate call; a member that
+    is removed and re-added under the same key is asked about again (its verdict may have changed); another key is another filter."""
+    import threading
+
+    import vector_store_amd as v
+    n, dim, k = 100_000, 64, 10
+    data = _dataset(n + 64, dim, 61)
+    base, q = data[:n], data[n:]
+    ix = v.HipUsearchIndex(dim, v.COS, expansion_search=96)
+    ix.reserve(n + 64)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    o = OracleIndex(dim, oracle.COS, 16, 128, 96)
+    o.import_graph(ix.export_graph())
+    asked = {}
+    flip = set()
+
+    def pred(key):
+        asked[key] = asked.get(key, 0) + 1
+        return (key % 10 == 3) != (key in flip)
+
+    FK = 0xF117E5
+    for rnd in range(3):
+        before = sum(asked.values())
+        for i in range(len(q)):
+            gk, gd = ix.filtered_search(q[i], k, pred, filter_key=FK)
+            wk, wd = o.filtered_search(q[i], k, lambda key: (key % 10 == 3) != (key in flip))
+            assert_same_results(gk, gd, wk, wd, lambda key, i=i: o.distance_to_slot(q[i], int(key)), what=("keyed", rnd, i))
+        calls = sum(asked.values()) - before
+        if rnd == 0:
+            assert calls > 1000 * 8, calls          # the first pass asks
+        else:
+            assert calls == 0, (rnd, calls)         # the same queries again: every verdict is remembered
+    assert max(asked.values()) == 1                 # nothing was asked twice
+    st = ix.filter_memo_stats()
+    assert st["queries"] == 3 * len(q) and st["memories_held"] == 1
+    # the unnamed call still asks (and answers the same)
+    before = sum(asked.values())
+    gk, gd = ix.filtered_search(q[0], k, pred)
+    assert sum(asked.values()) > before
+    wk, wd = o.filtered_search(q[0], k, lambda key: key % 10 == 3)
+    assert_same_results(gk, gd, wk, wd, lambda key: o.distance_to_slot(q[0], int(key)), what="unnamed")
+    # a member that changes is asked about again: remove the best match of q[0], re-add it with a verdict that flipped
+    best = int(ix.filtered_search(q[0], 1, pred, filter_key=FK)[0][0])
+    asked.clear()
+    assert ix.remove(best)
+    ix.add(best, base[best])
+    flip.add(best)                                   # the row's filterable column changed with it: now rejected
+    gk, gd = ix.filtered_search(q[0], k, pred, filter_key=FK)
+    assert best not in gk.tolist() and asked.get(best, 0) == 1, (best, gk, asked.get(best))
+    # another name, another memory: the same key is asked about again
+    asked.clear()
+    ix.filtered_search(q[1], k, pred, filter_key=FK + 1)
+    assert sum(asked.values()) > 100 and ix.filter_memo_stats()["memories_held"] == 2
+    # concurrent callers of one filter: same answers
+    want = [ix.filtered_search(q[i], k, lambda key: key % 7 == 1)[0].tolist() for i in range(16)]
+    errors = []
+
+    def caller(t):
+        try:
+            for i in range(t, 16, 4):
+                assert ix.filtered_search(q[i], k, lambda key: key % 7 == 1, filter_key=77)[0].tolist() == want[i]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(4)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors[:2]

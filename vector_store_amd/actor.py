@@ -38,6 +38,7 @@ def lib():
         L.vs_actor_remove_partition.argtypes = [vp, u64]
         L.vs_actor_ann.argtypes = [vp, u64, vp, sz, sz, vp, vp, C.POINTER(sz)]
         L.vs_actor_filtered_ann.argtypes = [vp, u64, vp, sz, sz, _ix.PRED, vp, vp, vp, C.POINTER(sz)]
+        L.vs_actor_filtered_ann_keyed.argtypes = [vp, u64, vp, sz, sz, _ix.PRED, vp, u64, vp, vp, C.POINTER(sz)]
         L.vs_actor_count.restype = sz
         L.vs_actor_count.argtypes = [vp]
         L.vs_actor_set_allocate.argtypes = [vp, C.c_int]
@@ -121,8 +122,10 @@ class IndexActor:
     def ann(self, partition: int, vector, limit: int):
         return self._search(self.L.vs_actor_ann, partition, vector, limit)
 
-    def filtered_ann(self, partition: int, vector, limit: int, predicate):
+    def filtered_ann(self, partition: int, vector, limit: int, predicate, filter_key: int = 0):
         cb = _ix.PRED(lambda key, _ctx: 1 if predicate(key) else 0)
+        if filter_key:
+            return self._search(self.L.vs_actor_filtered_ann_keyed, partition, vector, limit, cb, None, filter_key)
         return self._search(self.L.vs_actor_filtered_ann, partition, vector, limit, cb, None)
 
     def count(self) -> int:

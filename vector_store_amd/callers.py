@@ -27,7 +27,7 @@ class CallersResult(C.Structure):
 class MixedOptions(C.Structure):
     _fields_ = [("plain_callers", C.c_uint), ("filtered_callers", C.c_uint), ("producers", C.c_uint), ("modify", C.c_int),
                 ("modulus", C.c_uint64), ("partition", C.c_uint64), ("first_new_key", C.c_uint64), ("existing_keys", C.c_uint64),
-                ("delete_from", C.c_uint64), ("max_items", C.c_uint64), ("k", C.c_size_t), ("seconds", C.c_double)]
+                ("delete_from", C.c_uint64), ("max_items", C.c_uint64), ("k", C.c_size_t), ("seconds", C.c_double), ("filter_key", C.c_uint64)]
 
 
 class MixedResult(C.Structure):
@@ -53,8 +53,8 @@ def lib():
                                    C.POINTER(MixedResult)]
         L.vs_callers_run_recorded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint,
                                               C.c_double, C.POINTER(CallersResult), C.POINTER(CallersRecord)]
-        L.vs_callers_run_filtered_recorded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint, C.c_double,
-                                                       C.POINTER(CallersResult), C.POINTER(C.c_uint64), C.POINTER(CallersRecord)]
+        L.vs_callers_run_filtered_keyed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint, C.c_double,
+                                                    C.POINTER(CallersResult), C.POINTER(C.c_uint64), C.POINTER(CallersRecord)]
         _lib = L
     return _lib
 
@@ -84,25 +84,25 @@ def run(index, queries, k, truth=None, threads=17, inflight=1, seconds=3.0, reco
     return r, (None if rec is None else _cut(rec, arrays)), rc
 
 
-def run_filtered(index, queries, k, modulus, threads=17, seconds=3.0, record=0):
+def run_filtered(index, queries, k, modulus, threads=17, seconds=3.0, record=0, filter_key=0):
     """The same loop over vs_hnsw_filtered_search with the predicate key % modulus == 0 (usearch.rs:937-948: every filtered query on a
     blocking thread of its own).  Returns (CallersResult, [predicate calls, results returned], record or None, status)."""
     q = np.ascontiguousarray(queries, dtype=np.float32)
     r = CallersResult()
     extra = (C.c_uint64 * 4)()
     rec, arrays = _record(record, k) if record else (None, None)
-    rc = lib().vs_callers_run_filtered_recorded(index.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, threads, seconds, C.byref(r), extra,
-                                                None if rec is None else C.byref(rec))
+    rc = lib().vs_callers_run_filtered_keyed(index.h, q.ctypes.data, q.shape[0], q.shape[1], k, modulus, filter_key, threads, seconds, C.byref(r), extra,
+                                             None if rec is None else C.byref(rec))
     return r, [int(extra[0]), int(extra[1])], (None if rec is None else _cut(rec, arrays)), rc
 
 
 def mixed_run(actor, queries, vectors, *, modify=NONE, plain_callers=0, filtered_callers=0, producers=1, modulus=10, partition=0,
-              first_new_key=0, existing_keys=0, delete_from=0, max_items=0, k=10, seconds=2.0) -> dict:
+              first_new_key=0, existing_keys=0, delete_from=0, max_items=0, k=10, seconds=2.0, filter_key=0) -> dict:
     """One leg of the reference's pipeline benches (include/vs_callers.h: vs_mixed_run) through `actor` (vector_store_amd.actor.IndexActor)."""
     q = None if queries is None else np.ascontiguousarray(queries, dtype=np.float32)
     v = None if vectors is None else np.ascontiguousarray(vectors, dtype=np.float32)
     o = MixedOptions(plain_callers, filtered_callers, producers, modify, modulus, partition, first_new_key, existing_keys, delete_from,
-                     max_items, k, seconds)
+                     max_items, k, seconds, filter_key)
     r = MixedResult()
     rc = lib().vs_mixed_run(actor.h, C.byref(o), None if q is None else q.ctypes.data, 0 if q is None else q.shape[0],
                             None if v is None else v.ctypes.data, 0 if v is None else v.shape[0], actor.dim, C.byref(r))
@@ -117,7 +117,7 @@ def mixed_run(actor, queries, vectors, *, modify=NONE, plain_callers=0, filtered
         out["plain"] = dict(r.plain.as_dict(), callers=plain_callers)
     if filtered_callers:
         out["filtered"] = dict(r.filtered.as_dict(), callers=filtered_callers, predicate=f"key % {modulus} == 0",
-                               predicate_calls_per_query=r.predicate_calls / max(int(r.filtered.queries), 1))
+                               predicate_calls_per_query=r.predicate_calls / max(int(r.filtered.queries), 1), filter_named=bool(filter_key))
     return out
 
 
@@ -125,20 +125,24 @@ PIPELINE_LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search_while_inserti
 
 
 def pipeline_legs(actor, queries, vectors, existing_keys, legs=PIPELINE_LEGS, *, seconds=2.0, producers=1, plain_callers=16, filtered_callers=16,
-                  modulus=10, state=None, log=None) -> dict:
+                  modulus=10, state=None, log=None, filter_key=0) -> dict:
     """The reference's pipeline benches (crates/vector-store/benches/pipeline.rs:1407-1418) as legs of vs_mixed_run through `actor`:
     cdc_insert / cdc_update / cdc_delete alone, and search_while_{inserting,updating,deleting} with `plain_callers` + `filtered_callers`
     blocking searchers on the same partition.  Keys 0 .. existing_keys - 1 exist: updates draw from the lower half, deletes eat the upper
     half upwards from state["delete_from"]; inserts use fresh keys from state["next_key"].  A leg name may carry a caller mix:
-    "search_while_updating:16+0" = 16 plain, no filtered callers."""
+    "search_while_updating:16+0" = 16 plain, no filtered callers; "...@named": the filtered callers name their filter."""
     state = state if state is not None else {}
     state.setdefault("next_key", 1 << 40)
     state.setdefault("delete_from", existing_keys // 2)
     out = {}
     for leg in legs:
         name, _, mix = leg.partition(":")
+        mix, _, named = mix.partition("@")
+        if "@" in name:
+            name, _, named = name.partition("@")
         plain, filtered = (int(x) for x in mix.split("+")) if mix else (plain_callers, filtered_callers)
-        kw = dict(k=10, seconds=seconds, producers=producers, modulus=modulus)
+        # "...@named": the filtered callers name their filter (vs_actor_filtered_ann_keyed: verdicts remembered across queries)
+        kw = dict(k=10, seconds=seconds, producers=producers, modulus=modulus, filter_key=(filter_key or 0xF117E5) if named else filter_key)
         if name.startswith("search"):
             kw.update(plain_callers=plain, filtered_callers=filtered)
         what = name.replace("search_while_", "cdc_")

@@ -118,6 +118,7 @@ struct Msg {
     size_t k = 0;
     vs_hnsw_predicate pred = nullptr;
     void* pctx = nullptr;
+    uint64_t filter_key = 0;
     uint64_t* keys = nullptr;
     float* dist = nullptr;
     size_t* found = nullptr;
@@ -137,8 +138,12 @@ int hip_search(void* h, const float* q, size_t dim, size_t k, uint64_t* keys, fl
 int hip_filtered(void* h, const float* q, size_t dim, size_t k, vs_hnsw_predicate p, void* ctx, uint64_t* keys, float* d, size_t* found) {
     return vs_hnsw_filtered_search((vs_hnsw*)h, q, dim, k, p, ctx, keys, d, found);
 }
-const vs_actor_index_vtable kHipIndex = {hip_create, hip_stop,   hip_reserve,  hip_capacity,      hip_add,
-                                         hip_remove, hip_search, hip_filtered, vs_hnsw_last_error};
+int hip_filtered_keyed(void* h, const float* q, size_t dim, size_t k, vs_hnsw_predicate p, void* ctx, uint64_t fk, uint64_t* keys, float* d,
+                       size_t* found) {
+    return vs_hnsw_filtered_search_keyed((vs_hnsw*)h, q, dim, k, p, ctx, fk, keys, d, found);
+}
+const vs_actor_index_vtable kHipIndex = {hip_create, hip_stop,   hip_reserve,  hip_capacity,       hip_add,
+                                         hip_remove, hip_search, hip_filtered, vs_hnsw_last_error, hip_filtered_keyed};
 
 }  // namespace
 
@@ -344,6 +349,8 @@ struct vs_actor {
                     *m.found = 0;
                 } else if (m.kind == Msg::Ann) {
                     rc = vt.search(p.idx, m.v.data(), dim, m.k, m.keys, m.dist, m.found);
+                } else if (m.filter_key && vt.filtered_search_keyed) {
+                    rc = vt.filtered_search_keyed(p.idx, m.v.data(), dim, m.k, m.pred, m.pctx, m.filter_key, m.keys, m.dist, m.found);
                 } else {
                     rc = vt.filtered_search(p.idx, m.v.data(), dim, m.k, m.pred, m.pctx, m.keys, m.dist, m.found);
                 }
@@ -511,6 +518,23 @@ int vs_actor_filtered_ann(vs_actor* a, uint64_t partition, const float* q, size_
     m.k = k;
     m.pred = pred;
     m.pctx = ctx;
+    m.keys = keys;
+    m.dist = dist;
+    m.found = found;
+    return round_trip(a, std::move(m));
+}
+
+int vs_actor_filtered_ann_keyed(vs_actor* a, uint64_t partition, const float* q, size_t dim, size_t k, vs_hnsw_predicate pred, void* ctx,
+                                uint64_t filter_key, uint64_t* keys, float* dist, size_t* found) {
+    if (!a || !q || !keys || !dist || !found || !k || !pred) return VS_ERR_INVALID_ARGUMENT;
+    Msg m;
+    m.kind = Msg::FilteredAnn;
+    m.partition = partition;
+    m.v.assign(q, q + dim);
+    m.k = k;
+    m.pred = pred;
+    m.pctx = ctx;
+    m.filter_key = filter_key;
     m.keys = keys;
     m.dist = dist;
     m.found = found;

@@ -189,6 +189,11 @@ extern "C" int vs_callers_run_filtered(vs_hnsw* h, const float* queries, size_t 
 
 extern "C" int vs_callers_run_filtered_recorded(vs_hnsw* h, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus, unsigned threads,
                                                 double seconds, vs_callers_result* out, uint64_t extra[4], vs_callers_record* rec) {
+    return vs_callers_run_filtered_keyed(h, queries, nq, dim, k, modulus, 0, threads, seconds, out, extra, rec);
+}
+
+extern "C" int vs_callers_run_filtered_keyed(vs_hnsw* h, const float* queries, size_t nq, size_t dim, size_t k, uint64_t modulus, uint64_t filter_key,
+                                             unsigned threads, double seconds, vs_callers_result* out, uint64_t extra[4], vs_callers_record* rec) {
     if (!h || !queries || !nq || !k || !threads || !out || !modulus || !extra) return VS_ERR_INVALID_ARGUMENT;
     std::atomic<size_t> rec_next{0};
     struct Ctx {
@@ -220,7 +225,8 @@ extern "C" int vs_callers_run_filtered_recorded(vs_hnsw* h, const float* queries
                 const size_t qi = g() % nq;
                 size_t found = 0;
                 auto s = Clock::now();
-                int rc = vs_hnsw_filtered_search(h, queries + qi * dim, dim, k, pred, &ctx, keys.data(), dist.data(), &found);
+                int rc = filter_key ? vs_hnsw_filtered_search_keyed(h, queries + qi * dim, dim, k, pred, &ctx, filter_key, keys.data(), dist.data(), &found)
+                                    : vs_hnsw_filtered_search(h, queries + qi * dim, dim, k, pred, &ctx, keys.data(), dist.data(), &found);
                 int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
                 if (rc != VS_OK) {
                     ++errors[t];
@@ -334,7 +340,8 @@ extern "C" int vs_mixed_run(vs_actor* actor, const vs_mixed_options* o, const fl
                 const size_t qi = g() % nq;
                 size_t found = 0;
                 const auto s = Clock::now();
-                const int rc = vs_actor_filtered_ann(actor, o->partition, queries + qi * dim, dim, k, pred, &ctx, keys.data(), dist.data(), &found);
+                const int rc = o->filter_key ? vs_actor_filtered_ann_keyed(actor, o->partition, queries + qi * dim, dim, k, pred, &ctx, o->filter_key, keys.data(), dist.data(), &found)
+                                             : vs_actor_filtered_ann(actor, o->partition, queries + qi * dim, dim, k, pred, &ctx, keys.data(), dist.data(), &found);
                 const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - s).count();
                 if (rc != VS_OK) {
                     ++errors;

@@ -1035,6 +1035,7 @@ struct Engine {
         PodHold hold(pod_pool(device));  // arenas may move: no pod of the device is open, and none opens, until this returns
         std::unique_lock<std::shared_mutex> vg(view_mu);
         HIP_OK(hipDeviceSynchronize());
+        memos_drop();  // (remembered verdicts are laid out for the capacity)
         // HBM budget (the GPU analogue of the reference's host-RAM guard, memory.rs): the new arenas
         // coexist with the old ones while rows are copied across.
         size_t free_b = 0, total_b = 0;
@@ -1570,6 +1571,7 @@ struct Engine {
         }
         insert_run(run, vecs, false, *w.ctx);
         if (!tomb.empty()) {
+            memos_forget(tomb, *w.ctx);  // (every removed slot, re-used or not: its member changed)
             size_t m = 0;
             for (uint32_t s : tomb)
                 if (h_keys[s] == kFreeKey) tomb[m++] = s;  // not re-added later in this log
@@ -2445,10 +2447,10 @@ struct Engine {
             } catch (...) {
                 // whatever could not be launched is handed back as "not answered": its caller falls back to rounds of its own
                 for (auto& r : take) {
-                    if (__atomic_load_n(r.pq.done, __ATOMIC_ACQUIRE) != r.pq.round_id) {
+                    if (__atomic_load_n(r.pq.cnt + 8, __ATOMIC_ACQUIRE) != r.pq.round_id) {
                         r.pq.cnt[0] = r.pq.cnt[1] = 0;
                         r.pq.cnt[2] = kPipeRedoFound;
-                        __atomic_store_n(r.pq.done, r.pq.round_id, __ATOMIC_RELEASE);
+                        __atomic_store_n(r.pq.cnt + 8, r.pq.round_id, __ATOMIC_RELEASE);
                     }
                 }
             }
@@ -2456,8 +2458,76 @@ struct Engine {
         }
     }
 
+    // ---- verdicts remembered across the queries of ONE filter (vs_hnsw_filtered_search_keyed, round 5) ----------------------------------
+    // usearch asks the predicate for every candidate of every query; the reference's predicate is a table read-lock + a restriction
+    // evaluation (usearch.rs:1118-1124), the same function of the key for every query that carries the same restrictions.  A caller
+    // that NAMES its filter (a fingerprint of the restrictions) lets the engine remember verdicts: device bitmaps [allow | known] per
+    // filter, shared by its queries -- each seeds its own bitmaps from them and ORs what it learns into them (kernels_pipe.hip).  Once
+    // the filter's neighbourhoods are known a query is ONE exact walk with no predicate call and no exploring round.  A slot whose
+    // member changes (remove, re-use) is forgotten by every filter; reserve (the layout follows the capacity) drops the memories.
+    struct FilterMemo {
+        uint64_t key = 0;
+        uint32_t* bits = nullptr;  // device: [allow: stride words | known: stride words]
+        uint32_t stride = 0;
+        uint64_t last_use = 0;
+        std::atomic<uint32_t> asked_avg{0xFFFFFFFFu};  // verdicts the recent queries of this filter still had to ask the host for (moving average)
+        std::atomic<uint64_t> queries{0}, asked{0};
+        ~FilterMemo() {
+            if (bits) graveyard().bury(bits, nullptr);
+        }
+    };
+    static constexpr size_t kMaxMemos = 4;
+    std::mutex memo_mu;
+    std::vector<std::shared_ptr<FilterMemo>> memos;
+    uint64_t memo_clock = 0;
+    std::atomic<uint64_t> memo_queries{0}, memo_asked{0}, memo_created{0};
+    std::shared_ptr<FilterMemo> memo_for(uint64_t filter_key) {
+        if (!filter_key) return nullptr;
+        std::lock_guard<std::mutex> g(memo_mu);
+        for (auto& m : memos)
+            if (m->key == filter_key) {
+                m->last_use = ++memo_clock;
+                return m;
+            }
+        const uint32_t stride = (uint32_t)((layout_slots() + 31) / 32);
+        if (!stride) return nullptr;
+        auto m = std::make_shared<FilterMemo>();
+        if (hipMalloc((void**)&m->bits, (size_t)stride * 8) != hipSuccess) {  // (no HBM for it: the query runs without a memory)
+            (void)hipGetLastError();
+            m->bits = nullptr;
+            return nullptr;
+        }
+        Lease w(device);
+        HIP_OK(hipMemsetAsync(m->bits, 0, (size_t)stride * 8, w->stream));
+        HIP_OK(hipStreamSynchronize(w->stream));
+        m->key = filter_key;
+        m->stride = stride;
+        m->last_use = ++memo_clock;
+        if (memos.size() >= kMaxMemos) {  // the least recently used one goes (queries that hold it finish with it)
+            size_t lru = 0;
+            for (size_t i = 1; i < memos.size(); ++i)
+                if (memos[i]->last_use < memos[lru]->last_use) lru = i;
+            memos.erase(memos.begin() + (long)lru);
+        }
+        memos.push_back(m);
+        memo_created.fetch_add(1, std::memory_order_relaxed);
+        return m;
+    }
+    void memos_forget(const std::vector<uint32_t>& changed, WorkCtx& w) {  // mod_mu held; no search runs (usearch.rs:590-612)
+        std::lock_guard<std::mutex> g(memo_mu);
+        if (memos.empty() || changed.empty()) return;
+        uint32_t* d = (uint32_t*)w.f.ensure(changed.size() * 4 + 64);
+        HIP_OK(hipMemcpyAsync(d, changed.data(), changed.size() * 4, hipMemcpyHostToDevice, w.stream));
+        for (auto& m : memos) HIP_OK(launch_memo_forget(m->bits, m->stride, d, (uint32_t)changed.size(), w.stream));
+        HIP_OK(hipStreamSynchronize(w.stream));
+    }
+    void memos_drop() {
+        std::lock_guard<std::mutex> g(memo_mu);
+        memos.clear();
+    }
+
     // filtered_lazy through the batcher.  (size_t)-1: hand the query to the unbatched rounds (a tie where order matters, or a failure).
-    size_t filtered_batched(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, uint32_t ef) {
+    size_t filtered_batched(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, uint32_t ef, FilterMemo* memo = nullptr) {
         use_device();
         housekeeping();
         const size_t n = slots_atomic.load(std::memory_order_acquire), lay = layout_slots();
@@ -2512,7 +2582,9 @@ struct Engine {
         const uint32_t first_budget = std::max<uint32_t>(2048u, std::min<uint32_t>(cap / 2, hint + hint / 2));
         static const int guess_pct = std::getenv("VS_HNSW_FILTER_GUESS") ? std::atoi(std::getenv("VS_HNSW_FILTER_GUESS")) : 50;
         uint64_t n_known = 0, n_allowed = 0;
-        bool explored = false;
+        // (a filter whose recent queries found nearly every verdict in its memory starts with the exact walk: no exploring round)
+        if (memo && memo->stride < words) memo = nullptr;
+        bool explored = memo && memo->asked_avg.load(std::memory_order_relaxed) < 512u;
         int exact_rounds = 0, explore_rounds = 0;
         uint32_t apply_m = 0;
         for (int round = 0; round < 24; ++round) {
@@ -2534,7 +2606,7 @@ struct Engine {
             pq.allow = d_bits;
             pq.known = d_bits + words;
             pq.words = (uint32_t)words;
-            pq.zero_bits = round == 0 ? 1u : 0u;
+            pq.zero_bits = round == 0 ? (memo ? 2u : 1u) : 0u;
             pq.list = h_list;
             pq.verdict = h_verdict;
             pq.apply_m = apply_m;
@@ -2545,9 +2617,9 @@ struct Engine {
             pq.round_id = ++w->round_seq ? w->round_seq : ++w->round_seq;
             pq.cnt = h_cnt;
             pq.keys = h_k;
-            pq.dist = h_d;
-            pq.done = h_done;
             pq.space = (char*)w->ws.p;
+            pq.memo = memo ? memo->bits : nullptr;
+            pq.memo_stride = memo ? memo->stride : 0u;
             __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
             PodRelease pod{device, pod_submit(explore ? 2 : 1, ef, lay, pq)};
             if (!pod.t) {
@@ -2627,6 +2699,14 @@ struct Engine {
                 std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
                 std::memcpy(dist, h_d, (size_t)std::min<size_t>(found, k) * 4);
                 lazy_rounds += (uint64_t)round + 1;
+                if (memo) {
+                    const uint32_t asked = (uint32_t)std::min<uint64_t>(n_known, 0x7FFFFFFFu), avg = memo->asked_avg.load(std::memory_order_relaxed);
+                    memo->asked_avg.store(avg == 0xFFFFFFFFu ? asked : (uint32_t)(((uint64_t)avg * 3 + asked) / 4), std::memory_order_relaxed);
+                    memo->queries.fetch_add(1, std::memory_order_relaxed);
+                    memo->asked.fetch_add(n_known, std::memory_order_relaxed);
+                    memo_queries.fetch_add(1, std::memory_order_relaxed);
+                    memo_asked.fetch_add(n_known, std::memory_order_relaxed);
+                }
                 lazy_need_hint = hint ? (3 * hint + consulted) / 4 : consulted;
                 if (n_known) {
                     const uint32_t sel = (uint32_t)std::min<uint64_t>(65536, n_allowed * 65536ull / n_known);
@@ -2657,7 +2737,7 @@ struct Engine {
     static inline std::atomic<int> filtered_active_callers{0};
 
     static constexpr size_t kLazyFilterAbove = 1u << 16;
-    size_t filtered_lazy(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist) {
+    size_t filtered_lazy(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, uint64_t filter_key = 0) {
         struct ActiveCaller {
             ActiveCaller() { filtered_active_callers.fetch_add(1, std::memory_order_relaxed); }
             ~ActiveCaller() { filtered_active_callers.fetch_sub(1, std::memory_order_relaxed); }
@@ -2682,8 +2762,10 @@ struct Engine {
             // 9 / 77 / 66 / 66 on rounds of their own.)
             const bool several = filtered_active_callers.load(std::memory_order_relaxed) > 8;
             const bool pods = pod_pool(device).enabled;
-            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || (short_walks && (pods || crowd)) || (pods && several))) {
-                const size_t f = filtered_batched(q, k, pred, pctx, keys, dist, ef_b);
+            // (a NAMED filter always takes the posted / batched rounds: that is where its remembered verdicts are used)
+            std::shared_ptr<FilterMemo> memo = (filter_key && batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b)) ? memo_for(filter_key) : nullptr;
+            if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || memo || (short_walks && (pods || crowd)) || (pods && several))) {
+                const size_t f = filtered_batched(q, k, pred, pctx, keys, dist, ef_b, memo.get());
                 (f != (size_t)-1 ? batched_done : batched_handed_over).fetch_add(1, std::memory_order_relaxed);
                 if (f != (size_t)-1) return f;
                 // (two equal distances met where their order matters, or the launch failed: the query starts over on rounds of its own,
@@ -2873,12 +2955,12 @@ struct Engine {
         return filtered(q, k, &All::yes, nullptr, keys, dist, true);
     }
 
-    size_t filtered(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, bool exhaustive = false) {
+    size_t filtered(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, bool exhaustive = false, uint64_t filter_key = 0) {
         const size_t n_live = live.load();
         if (!n_live) return 0;
         if (!exhaustive && std::max<size_t>(k, ef_search.load()) <= kMaxWalkBeam) {
             if (slots > kLazyFilterAbove && !eager_filter) {
-                const size_t f = filtered_lazy(q, k, pred, pctx, keys, dist);
+                const size_t f = filtered_lazy(q, k, pred, pctx, keys, dist, filter_key);
                 if (f != (size_t)-1) return f;
             }
             const std::vector<uint32_t> bits = allow_bitmap(pred, pctx);
@@ -3280,8 +3362,6 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
     pq.round_id = ++w->round_seq ? w->round_seq : ++w->round_seq;
     pq.cnt = h_cnt;
     pq.keys = h_k;
-    pq.dist = h_d;
-    pq.done = h_done;
     pq.space = (char*)w->ws.p;
     __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
     const auto t_in = std::chrono::steady_clock::now();
@@ -3535,6 +3615,29 @@ int vs_hnsw_filtered_search(vs_hnsw* h, const float* q, size_t dim, size_t k, vs
         h->e.flush_pending();
         *found = h->e.filtered(q, k, pred, ctx, keys, dist);
     });
+}
+
+int vs_hnsw_filtered_search_keyed(vs_hnsw* h, const float* q, size_t dim, size_t k, vs_hnsw_predicate pred, void* ctx, uint64_t filter_key,
+                                  uint64_t* keys, float* dist, size_t* found) {
+    return guarded([&] {
+        need(h && q && keys && dist && found && pred, "null argument");
+        need(k > 0, "k must be > 0");
+        check_dim(h, dim);
+        h->e.flush_pending();
+        *found = h->e.filtered(q, k, pred, ctx, keys, dist, false, filter_key);
+    });
+}
+
+int vs_hnsw_filter_memo_stats(vs_hnsw* h, uint64_t out[4]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.memo_queries.load();
+    out[1] = h->e.memo_asked.load();
+    out[2] = h->e.memo_created.load();
+    {
+        std::lock_guard<std::mutex> g(h->e.memo_mu);
+        out[3] = h->e.memos.size();
+    }
+    return VS_OK;
 }
 
 int vs_hnsw_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim, size_t k, uint64_t* keys, float* dist,

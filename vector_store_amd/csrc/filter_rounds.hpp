@@ -15,4 +15,7 @@ hipError_t launch_export_round(const uint32_t* unknown, uint32_t cap, const uint
 hipError_t launch_apply_verdicts(uint32_t* unknown, const uint8_t* verdict, uint32_t m, uint32_t slots, uint32_t* allow, uint32_t* known,
                                  hipStream_t s);
 
+// verdicts remembered across the queries of one filter (PipeQuery::memo): the slots whose member changed lose theirs
+hipError_t launch_memo_forget(uint32_t* memo, uint32_t stride, const uint32_t* slots, uint32_t m, hipStream_t s);
+
 }  // namespace vs

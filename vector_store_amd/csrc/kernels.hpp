@@ -63,7 +63,7 @@ struct PipeQuery {
     uint32_t* allow;           // device: one bit per slot; `known` follows at +words
     uint32_t* known;
     uint32_t words;            // words of each bitmap
-    uint32_t zero_bits;        // 1: both bitmaps are zeroed first (the query's first round)
+    uint32_t zero_bits;        // the query's first round: 1 = both bitmaps are zeroed first; 2 = they are SEEDED from `memo` (round 5)
     uint32_t* list;            // pinned: the slots whose verdict the LAST round missed (input, apply_m of them) -- and this round's (output)
     const uint8_t* verdict;    // pinned: the host's verdicts for list[0 .. apply_m)
     uint32_t apply_m;
@@ -71,13 +71,19 @@ struct PipeQuery {
     uint32_t cap;              // entries `list` holds
     uint32_t budget;           // WalkArgs::unknown_budget of this round
     uint32_t k;
-    uint32_t round_id;         // what *done becomes
-    uint32_t* cnt;             // pinned [5]: listed, consulted, found (kPipeRedoFound: not answered), evaluations, 100 MHz ticks the workgroup spent on it
-    uint64_t* keys;            // pinned: k
-    float* dist;               // pinned: k
-    uint32_t* done;            // pinned: set to round_id once everything above is visible to the host
+    uint32_t round_id;         // what the flag (cnt[8]) becomes once everything is visible to the host
+    uint32_t* cnt;             // pinned [16]: listed, consulted, found (kPipeRedoFound: not answered), evaluations, 100 MHz ticks the workgroup spent on it; [8] = the flag
+    uint64_t* keys;            // pinned: k keys, followed by k distances (f32)
     char* space;               // device: this query's visited bitmap / log / spill slots (all zero between rounds)
+    // Verdicts remembered ACROSS queries of one filter (vs_hnsw_filtered_search_keyed, round 5): device bitmaps [allow: memo_stride
+    // words | known: memo_stride words] shared by every query that names the filter.  A query seeds its own bitmaps from them
+    // (zero_bits 2) and ORs every verdict the host gives it into them (allow before known, so a reader that sees `known` sees the
+    // verdict).  nullptr: no memory.
+    uint32_t* memo;
+    uint32_t memo_stride;
+    uint32_t pad_;
 };
+static_assert(sizeof(PipeQuery) == 112, "a PodSlot is one 128-byte line");
 
 // The usearch-order walk (walk_device.hpp / kernels_walk.hip): persistent workgroups, one WalkSpace each.
 enum : uint32_t { WALK_LDS_128 = 0, WALK_LDS_256, WALK_LDS_512, WALK_GLOBAL_512, WALK_GLOBAL_2048, WALK_GLOBAL_10240,

@@ -1069,6 +1069,22 @@ hipError_t launch_apply_verdicts(uint32_t* unknown, const uint8_t* verdict, uint
     return hipGetLastError();
 }
 
+// A filter's remembered verdicts (PipeQuery::memo: [allow | known], `stride` words each) forget the slots whose member changed (removed,
+// or re-used by another key): both bits, so that a later verdict of 0 finds no stale 1.  No search runs meanwhile (usearch.rs:590-612).
+__global__ void memo_forget_kernel(uint32_t* __restrict__ memo, uint32_t stride, const uint32_t* __restrict__ slots, uint32_t m) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t s = slots[i];
+    if ((s >> 5) >= stride) return;
+    atomicAnd(&memo[s >> 5], ~(1u << (s & 31u)));
+    atomicAnd(&memo[stride + (s >> 5)], ~(1u << (s & 31u)));
+}
+hipError_t launch_memo_forget(uint32_t* memo, uint32_t stride, const uint32_t* slots, uint32_t m, hipStream_t s) {
+    if (!m) return hipSuccess;
+    hipLaunchKernelGGL(memo_forget_kernel, dim3((m + 255) / 256), dim3(256), 0, s, memo, stride, slots, m);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_norm_max(const IndexView& ix, uint32_t first, uint32_t n, uint32_t* d_max_bits, hipStream_t s) {
     if (!n) return hipSuccess;
     const uint32_t kpad = (ix.dim + 31u) & ~31u;

@@ -52,7 +52,7 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
     const float* query = pq ? uni(pq->query) : a.queries + (size_t)qi * a.q_stride;
     const uint32_t k = pq ? uni(pq->k) : a.k;
     uint64_t* ok = pq ? uni(pq->keys) : a.out_keys + (size_t)qi * a.k;
-    float* od = pq ? uni(pq->dist) : a.out_dist + (size_t)qi * a.k;
+    float* od = pq ? reinterpret_cast<float*>(ok + k) : a.out_dist + (size_t)qi * a.k;  // (a posted query's distances follow its keys)
     uint32_t* found_out = pq ? uni(pq->cnt) + 2 : a.out_found + qi;
     if (max_level < 0) {  // empty index
         if (w == 0) {
@@ -65,7 +65,7 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
                 if (pq) {
                     uni(pq->cnt)[0] = uni(pq->cnt)[1] = uni(pq->cnt)[3] = 0u;
                     __threadfence_system();
-                    __hip_atomic_store(uni(pq->done), uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(uni(pq->cnt) + 8, uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }
@@ -97,7 +97,16 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
         // that follows order it before the first verdict is read.
         uint32_t* allow_w = uni(pq->allow);
         uint32_t* known_w = uni(pq->known);
-        if (uni(pq->zero_bits)) {
+        uint32_t* memo = uni(pq->memo);  // verdicts remembered across the queries of one filter: [allow | known], memo_stride words each
+        const uint32_t mstride = uni(pq->memo_stride);
+        if (uni(pq->zero_bits) == 2u && memo) {
+            // seeded from the filter's memory.  Other queries of the filter add verdicts meanwhile (allow first, then known): `known`
+            // is read first, and `allow` behind a fence -- a known bit seen here has its verdict in the allow word read after it
+            for (uint32_t i = tid; i < uni(pq->words); i += 64u * kPipeTeam) known_w[i] = __hip_atomic_load(&memo[mstride + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            __syncthreads();
+            for (uint32_t i = tid; i < uni(pq->words); i += 64u * kPipeTeam) allow_w[i] = __hip_atomic_load(&memo[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (uni(pq->zero_bits)) {
             for (uint32_t i = tid; i < uni(pq->words); i += 64u * kPipeTeam) {
                 allow_w[i] = 0u;
                 known_w[i] = 0u;
@@ -108,11 +117,20 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
             const uint32_t s = uni(pq->list)[i];
             if (s < uni(pq->slots)) {
                 atomicOr(&known_w[s >> 5], 1u << (s & 31u));
-                if (uni(pq->verdict)[i]) atomicOr(&allow_w[s >> 5], 1u << (s & 31u));
+                if (uni(pq->verdict)[i]) {
+                    atomicOr(&allow_w[s >> 5], 1u << (s & 31u));
+                    if (memo) atomicOr(&memo[s >> 5], 1u << (s & 31u));
+                }
             }
         }
         __threadfence();
         __syncthreads();
+        if (memo && m) {  // ... and the filter's memory learns them: `known` only once every `allow` bit of the list is out
+            for (uint32_t i = tid; i < m; i += 64u * kPipeTeam) {
+                const uint32_t s = uni(pq->list)[i];
+                if (s < uni(pq->slots)) atomicOr(&memo[mstride + (s >> 5)], 1u << (s & 31u));
+            }
+        }
     }
     Query<AR, I> q;
     query_from_f32<AR, I>(ix, query, q, lane);
@@ -146,7 +164,7 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
             if (pq) {
                 uni(pq->cnt)[0] = uni(pq->cnt)[1] = 0u;
                 __threadfence_system();
-                __hip_atomic_store(uni(pq->done), uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(uni(pq->cnt) + 8, uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
                 if (a.unknown_count) a.unknown_count[qi] = 0u;
                 if (a.consulted) a.consulted[qi] = 0u;
@@ -185,7 +203,7 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
         // out (the list's as well: pipe_walk drained them) before the flag says so
         __threadfence_system();
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) __hip_atomic_store(uni(pq->done), uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) __hip_atomic_store(uni(pq->cnt) + 8, uni(pq->round_id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -97,7 +97,9 @@ def lib():
     L.vs_hnsw_filter_stats.argtypes = [vp, vp]
     # (VS_HNSW_LIB may name an older build for A/B measurements: symbols younger than round 3 are bound only where they exist,
     # and their accessors below return zeros without them)
-    for young in ("vs_hnsw_pipe_stats", "vs_hnsw_filter_batch_stats", "vs_hnsw_pod_stats", "vs_hnsw_modify_stats"):
+    if hasattr(L, "vs_hnsw_filtered_search_keyed"):
+        L.vs_hnsw_filtered_search_keyed.argtypes = [vp, vp, sz, sz, PRED, vp, u64, vp, vp, C.POINTER(sz)]
+    for young in ("vs_hnsw_pipe_stats", "vs_hnsw_filter_batch_stats", "vs_hnsw_pod_stats", "vs_hnsw_modify_stats", "vs_hnsw_filter_memo_stats"):
         if hasattr(L, young):
             getattr(L, young).argtypes = [vp, vp]
     if hasattr(L, "vs_hnsw_streams_created"):  # (VS_HNSW_LIB may name an older build: A/B measurements)
@@ -231,15 +233,26 @@ class HipUsearchIndex:
                                            None))
         return holder
 
-    def filtered_search(self, vector, limit: int, predicate):
+    def filtered_search(self, vector, limit: int, predicate, filter_key: int = 0):
+        """filter_key != 0: the filter has a name (a fingerprint of its restrictions) -- the engine remembers verdicts across the
+        queries that carry it (include/vs_hnsw.h: vs_hnsw_filtered_search_keyed)."""
         v = np.ascontiguousarray(vector, dtype=np.float32)
         keys = np.zeros(limit, dtype=np.uint64)
         d = np.zeros(limit, dtype=np.float32)
         found = C.c_size_t(0)
         cb = PRED(lambda key, _ctx: 1 if predicate(key) else 0)
-        _check(self.L.vs_hnsw_filtered_search(self.h, _p(v), v.size, limit, cb, None, _p(keys), _p(d),
-                                              C.byref(found)))
+        if filter_key:
+            _check(self.L.vs_hnsw_filtered_search_keyed(self.h, _p(v), v.size, limit, cb, None, filter_key, _p(keys), _p(d), C.byref(found)))
+        else:
+            _check(self.L.vs_hnsw_filtered_search(self.h, _p(v), v.size, limit, cb, None, _p(keys), _p(d),
+                                                  C.byref(found)))
         return keys[: found.value], d[: found.value]
+
+    def filter_memo_stats(self) -> dict:
+        out = np.zeros(4, dtype=np.uint64)
+        if hasattr(self.L, "vs_hnsw_filter_memo_stats"):
+            _check(self.L.vs_hnsw_filter_memo_stats(self.h, _p(out)))
+        return {"queries": int(out[0]), "verdicts_asked": int(out[1]), "memories_created": int(out[2]), "memories_held": int(out[3])}
 
     # --- bulk / device paths used by the benchmark driver --------------------------------
     def add_batch(self, keys, vectors):

@@ -33,683 +33,10 @@
 
 #define VS_VERSION "0.1.0"
 
+#include "engine_base.hpp"
+#include "engine_pods.hpp"
+
 namespace vs {
-
-// Filtered searches run one walk launch per caller on the caller's own stream (the predicate is the caller's), and the
-// reference runs every filtered query on a blocking thread (usearch.rs:937-948): dozens of small kernels must be able to run
-// side by side.  ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels that share a
-// queue run one after the other: 17 callers got 2.8 x one caller's rate.  The library therefore asks for 20 queues unless the
-// process has chosen a value -- effective when it is loaded before the HIP runtime initialises (a Rust service linking it; the
-// Python binding and bench.py set the variable themselves before touching the GPU).  Measured at 2M x 768, 10 % selective
-// filter, 17 blocking callers: 35 -> 210 queries/s (scripts/probe/filtered_probe.py).
-// 20, not more: the device has 24 hardware queue slots for user queues; once a process holds more queues than that (24 of
-// its own + the runtime's internal ones) the hardware scheduler time-slices them, and EVERY kernel of the process runs
-// ~20 % slower from then on, busy queue or idle (scripts/probe/aftermath_probe.py: the 10,000-query batch kernel 13.5 -> 16.3 ms
-// after 17 filtered callers had each opened their stream; 12 / 16 / 20 queues: unchanged).
-struct HwQueuesDefault {
-    HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
-};
-static HwQueuesDefault g_hw_queues_default;
-
-thread_local std::string g_err;
-
-struct Fail {
-    int code;
-    std::string msg;
-};
-[[noreturn]] static void fail(int code, std::string msg) { throw Fail{code, std::move(msg)}; }
-#define HIP_OK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e__ = (expr);                                                                       \
-        if (e__ != hipSuccess) ::vs::fail(VS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
-    } while (0)
-
-// hipFree / hipHostFree synchronise the whole device: with resident pods (below) they block until every open pod's kernel ends -- up to a
-// pod's age limit, a second or two -- and the buffers that regrow sit on search paths (a larger batch, a larger k, another index's
-// first query).  A buffer that is replaced while the process runs is therefore PARKED here and freed when no pod is open on any device
-// (drain_graveyard, called where a stall costs nothing: under a pod hold, and by leases taken while every pod is free).
-static std::atomic<size_t> g_buried{0};  // blocks parked on any device (a cheap "anything to do?" for the search paths)
-struct Graveyard {
-    std::mutex mu;
-    std::vector<void*> dev, host;
-    std::atomic<size_t> n{0};
-    void bury(void* device_ptr, void* host_ptr) {
-        std::lock_guard<std::mutex> g(mu);
-        if (device_ptr) dev.push_back(device_ptr);
-        if (host_ptr) host.push_back(host_ptr);
-        g_buried.fetch_add((device_ptr ? 1 : 0) + (host_ptr ? 1 : 0), std::memory_order_relaxed);
-        n.store(dev.size() + host.size(), std::memory_order_relaxed);
-    }
-    void drain() {  // the caller knows that no pod is open (or accepts the wait)
-        std::vector<void*> d, h;
-        {
-            std::lock_guard<std::mutex> g(mu);
-            d.swap(dev);
-            h.swap(host);
-            n.store(0, std::memory_order_relaxed);
-            g_buried.fetch_sub(d.size() + h.size(), std::memory_order_relaxed);
-        }
-        for (void* p : d) (void)hipFree(p);
-        for (void* p : h) (void)hipHostFree(p);
-    }
-};
-static Graveyard& graveyard() {  // of the calling thread's current device (a free synchronises the device the block lives on)
-    static std::mutex mu;
-    static std::unordered_map<int, Graveyard*> all;  // leaked with the process
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> g(mu);
-    Graveyard*& p = all[dev];
-    if (!p) p = new Graveyard();
-    return *p;
-}
-
-struct DeviceBuf {  // grow-only device scratch
-    void* p = nullptr;
-    size_t bytes = 0;
-    void* ensure(size_t n) {
-        if (n > bytes) {
-            if (p) graveyard().bury(p, nullptr);
-            p = nullptr;
-            bytes = 0;
-            size_t want = n + n / 4 + 256;
-            HIP_OK(hipMalloc(&p, want));
-            bytes = want;
-        }
-        return p;
-    }
-    ~DeviceBuf() {
-        if (p) (void)hipFree(p);
-    }
-};
-
-// HBM arena that grows in place.  Above kVmmThreshold the arena is a reserved virtual range with physical chunks
-// mapped behind it on demand (hipMemAddressReserve / hipMemCreate / hipMemMap): growing maps one more chunk --
-// no second copy of the index in HBM while it grows, no D2D copy, stable addresses -- so an index can keep
-// following the reference's "+1,000,000" growth policy (usearch.rs:442, :908-921) up to the whole 288 GB.
-// When the virtual range itself runs out, the SAME physical chunks are remapped into a range twice as large
-// (still no copy).  Small arenas (thousands of per-partition indexes) stay on hipMalloc + copy.
-constexpr size_t kVmmThreshold = 64ull << 20;
-struct Arena {
-    void* base = nullptr;
-    size_t bytes = 0;  // usable bytes behind base
-    bool vmm = false;
-    size_t va_bytes = 0;
-    struct Chunk {
-        hipMemGenericAllocationHandle_t h;
-        size_t off, size;
-    };
-    std::vector<Chunk> chunks;
-    static inline std::atomic<unsigned long long> copied_bytes{0};  // D2D bytes moved by growth (process-wide)
-
-    static bool vmm_supported(int device) {
-        static std::mutex mu;
-        static std::unordered_map<int, int> cache;
-        std::lock_guard<std::mutex> g(mu);
-        auto it = cache.find(device);
-        if (it != cache.end()) return it->second != 0;
-        int v = 0;
-        const char* off = std::getenv("VS_HNSW_NO_VMM");
-        if (!(off && off[0] == '1') &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeVirtualMemoryManagementSupported, device) != hipSuccess)
-            v = 0;
-        if (off && off[0] == '1') v = 0;
-        cache[device] = v;
-        return v != 0;
-    }
-    static hipMemAllocationProp prop(int device) {
-        hipMemAllocationProp p = {};
-        p.type = hipMemAllocationTypePinned;
-        p.location.type = hipMemLocationTypeDevice;
-        p.location.id = device;
-        return p;
-    }
-    static size_t granularity(int device) {  // the runtime reports 4 KiB; chunks are kept 2 MiB-aligned (large-page friendly)
-        hipMemAllocationProp p = prop(device);
-        size_t g = 0;
-        HIP_OK(hipMemGetAllocationGranularity(&g, &p, hipMemAllocationGranularityRecommended));
-        return std::max<size_t>(g, 2ull << 20);
-    }
-    static size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
-
-    // Additional HBM that resize(want) would take.
-    size_t extra_needed(size_t want, int device) const {
-        want = std::max<size_t>(want, 1);
-        if (vmm) return want > bytes ? want - bytes : 0;
-        if (want >= kVmmThreshold && vmm_supported(device)) return want;  // transition: old block freed after the copy
-        return want == bytes ? 0 : want;
-    }
-
-    void set_access(char* p, size_t n, int device) {
-        hipMemAccessDesc acc = {};
-        acc.location.type = hipMemLocationTypeDevice;
-        acc.location.id = device;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        HIP_OK(hipMemSetAccess(p, n, &acc, 1));
-    }
-    void map_chunk(size_t size, int device) {  // at the end of the mapped range
-        hipMemAllocationProp p = prop(device);
-        Chunk c{};
-        c.off = bytes;
-        c.size = size;
-        hipError_t e = hipMemCreate(&c.h, size, &p, 0);
-        if (e == hipErrorOutOfMemory) ::vs::fail(VS_ERR_OUT_OF_MEMORY, "not enough HBM to grow the index");
-        HIP_OK(e);
-        e = hipMemMap((char*)base + c.off, size, 0, c.h, 0);
-        if (e != hipSuccess) {
-            (void)hipMemRelease(c.h);
-            HIP_OK(e);
-        }
-        chunks.push_back(c);
-        bytes += size;
-        // Access is always (re)set over the WHOLE mapped range: on ROCm 7.2 hipMemSetAccess on the sub-range of a
-        // later chunk intermittently returns "invalid argument" (scripts/probe/vmm_probe3.cpp: 20 x 12 growth steps
-        // fail with sub-ranges, pass with the whole range, with and without remapping).
-        try {
-            set_access((char*)base, bytes, device);
-        } catch (...) {  // leave the arena as it was
-            (void)hipMemUnmap((char*)base + c.off, size);
-            (void)hipMemRelease(c.h);
-            chunks.pop_back();
-            bytes -= size;
-            throw;
-        }
-    }
-
-    // Make [0, want) usable; the first `keep` bytes survive.  Returns the (possibly new) base.
-    void* resize(size_t want, size_t keep, int device) {
-        want = std::max<size_t>(want, 1);
-        if (!vmm && !(want >= kVmmThreshold && vmm_supported(device))) {  // plain block + copy
-            if (want == bytes && base) return base;
-            void* np = nullptr;
-            hipError_t e = hipMalloc(&np, want);
-            if (e == hipErrorOutOfMemory) ::vs::fail(VS_ERR_OUT_OF_MEMORY, "not enough HBM to grow the index");
-            HIP_OK(e);
-            keep = std::min(keep, std::min(want, bytes));
-            if (base && keep) {
-                HIP_OK(hipMemcpy(np, base, keep, hipMemcpyDeviceToDevice));
-                copied_bytes += keep;
-            }
-            if (base) graveyard().bury(base, nullptr);  // (freed when no pod is open: a free synchronises the device)
-            base = np;
-            bytes = want;
-            return base;
-        }
-        const size_t g = granularity(device);
-        const size_t need = round_up(want, g);
-        if (!vmm) {  // first time above the threshold: move the plain block behind a virtual range
-            void* old = base;
-            const size_t old_bytes = bytes;
-            void* va = nullptr;
-            const size_t vb = round_up(std::max<size_t>(2 * need, 256ull << 20), g);
-            HIP_OK(hipMemAddressReserve(&va, vb, 0, nullptr, 0));
-            base = va;
-            va_bytes = vb;
-            bytes = 0;
-            vmm = true;
-            try {
-                map_chunk(need, device);
-            } catch (...) {
-                (void)hipMemAddressFree(va, vb);
-                base = old;
-                bytes = old_bytes;
-                va_bytes = 0;
-                vmm = false;
-                throw;
-            }
-            keep = std::min(keep, std::min(want, old_bytes));
-            if (old && keep) {
-                HIP_OK(hipMemcpy(base, old, keep, hipMemcpyDeviceToDevice));
-                copied_bytes += keep;
-            }
-            if (old) graveyard().bury(old, nullptr);
-            return base;
-        }
-        if (need < bytes) {  // give whole chunks beyond the new end back
-            while (!chunks.empty() && chunks.back().off >= need) {
-                Chunk c = chunks.back();
-                HIP_OK(hipMemUnmap((char*)base + c.off, c.size));
-                HIP_OK(hipMemRelease(c.h));
-                bytes = c.off;
-                chunks.pop_back();
-            }
-            return base;
-        }
-        if (need == bytes) return base;
-        if (need > va_bytes) {  // remap the same physical chunks into a larger range: no copy
-            void* va = nullptr;
-            const size_t vb = round_up(2 * need, g);
-            HIP_OK(hipMemAddressReserve(&va, vb, 0, nullptr, 0));
-            for (const Chunk& c : chunks) {
-                HIP_OK(hipMemUnmap((char*)base + c.off, c.size));
-                HIP_OK(hipMemMap((char*)va + c.off, c.size, 0, c.h, 0));
-            }
-            if (bytes) set_access((char*)va, bytes, device);
-            HIP_OK(hipMemAddressFree(base, va_bytes));
-            base = va;
-            va_bytes = vb;
-        }
-        map_chunk(need - bytes, device);
-        return base;
-    }
-
-    void release() {
-        if (vmm) {
-            for (const Chunk& c : chunks) {
-                (void)hipMemUnmap((char*)base + c.off, c.size);
-                (void)hipMemRelease(c.h);
-            }
-            if (base) (void)hipMemAddressFree(base, va_bytes);
-        } else if (base) {
-            (void)hipFree(base);
-        }
-        base = nullptr;
-        bytes = va_bytes = 0;
-        chunks.clear();
-        vmm = false;
-    }
-};
-
-// Stream + scratch leased per host call.  Shared by every index on the device, so thousands
-// of per-partition handles (reference usearch.rs:704-705,766-778) do not each own a stream.
-struct WorkCtx {
-    hipStream_t stream = nullptr;
-    DeviceBuf a, b, c, d, e, f;
-    // filtered search with a lazily evaluated predicate (Engine::filtered_lazy): pinned staging for the lists and verdicts
-    // of a round, and the event a crowd of callers sleeps on
-    char* pin = nullptr;
-    size_t pin_bytes = 0;
-    hipEvent_t ev = nullptr;
-    // batched rounds (Engine::filtered_batched): this context's visited bitmap / log / spill slots -- all zero between rounds --, and
-    // what it was laid out for
-    DeviceBuf ws;
-    size_t ws_zeroed = 0;  // bitmap words the workspace is laid out (and all zero) for: the visited log behind the bitmap holds slot numbers, and a
-                           // bitmap that grows by a word over them would read those as visited members
-    uint32_t round_seq = 0;
-};
-
-// The engine's streams on one device: a fixed set, shared by the leased contexts (from index 0 up) and the single-query
-// dispatcher's pipeline slots (from the top down).  The process has GPU_MAX_HW_QUEUES hardware queues (20, see HwQueuesDefault);
-// streams beyond that share queues, and two walks on one queue take turns even when other queues are idle -- with a stream per
-// context AND per slot, 17 filtered callers after some unfiltered traffic made 26 streams and ran at 329 QPS where a fresh
-// process runs at 430.  Contexts beyond the set share a stream with an earlier one (their launches then run in stream order,
-// each on its own buffers).  VS_HNSW_STREAMS: 4..20 (default 16: room for the caller's own streams).
-// The single-query dispatcher looks at every answer on the host anyway: it asks for no second-chance launch behind the pipelined walk
-// (tl_pipe_no_second) and serves a handed-over query itself, with the pipelined walk off (tl_no_pipe).
-static thread_local bool tl_pipe_no_second = false, tl_no_pipe = false;
-static std::atomic<uint64_t> g_streams_created{0};  // HIP streams the engine has made in this process (every device): a fixed set per device, never one per index
-struct DeviceStreams {
-    static constexpr int kMax = 20;
-    std::mutex mu;
-    hipStream_t st[kMax] = {};
-    int count = 16;
-    unsigned next_ctx = 0;
-    DeviceStreams() {
-        if (const char* v = std::getenv("VS_HNSW_STREAMS")) count = std::min(kMax, std::max(4, std::atoi(v)));
-    }
-    hipStream_t at(int i) {  // mu held
-        i = ((i % count) + count) % count;
-        if (!st[i]) {
-            HIP_OK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
-            g_streams_created.fetch_add(1, std::memory_order_relaxed);
-        }
-        return st[i];
-    }
-    hipStream_t for_new_context() {
-        std::lock_guard<std::mutex> g(mu);
-        return at((int)(next_ctx++));
-    }
-    hipStream_t round_robin() {  // batched filtered rounds: launches take the device's streams in turn
-        std::lock_guard<std::mutex> g(mu);
-        return at((int)(next_rr++));
-    }
-    unsigned next_rr = 0;
-    hipStream_t for_slot(int slot) {
-        std::lock_guard<std::mutex> g(mu);
-        return at(count - 1 - slot);
-    }
-};
-static DeviceStreams& device_streams(int dev) {
-    static std::mutex mu;
-    static std::unordered_map<int, std::unique_ptr<DeviceStreams>> all;  // leaked with the process
-    std::lock_guard<std::mutex> g(mu);
-    auto& p = all[dev];
-    if (!p) p.reset(new DeviceStreams());
-    return *p;
-}
-
-struct DevicePool {
-    std::mutex mu;
-    std::vector<std::unique_ptr<WorkCtx>> idle;
-};
-static DevicePool& pool(int dev) {
-    static std::mutex mu;
-    static std::unordered_map<int, std::unique_ptr<DevicePool>> pools;
-    std::lock_guard<std::mutex> g(mu);
-    auto& p = pools[dev];
-    if (!p) p.reset(new DevicePool());
-    return *p;
-}
-struct Lease {
-    DevicePool& pl;
-    std::unique_ptr<WorkCtx> ctx;
-    explicit Lease(int dev) : pl(pool(dev)) {
-        {
-            std::lock_guard<std::mutex> g(pl.mu);
-            if (!pl.idle.empty()) {
-                ctx = std::move(pl.idle.back());
-                pl.idle.pop_back();
-            }
-        }
-        if (!ctx) {
-            ctx.reset(new WorkCtx());
-            ctx->stream = device_streams(dev).for_new_context();  // the context keeps it: its buffers are only ever used in this stream's order
-        }
-    }
-    ~Lease() {
-        if (!ctx) return;
-        std::lock_guard<std::mutex> g(pl.mu);
-        pl.idle.push_back(std::move(ctx));
-    }
-    // A wait on the device timed out: whatever was launched or posted may still write into this context's buffers, so it never goes
-    // back to the pool (leaked, with its buffers: the caller is about to report a device failure anyway).
-    void retire() { (void)ctx.release(); }
-    WorkCtx* operator->() { return ctx.get(); }
-};
-
-// Cores this process may keep busy: the hardware's, or the cgroup's CPU quota when that is less (a container's quota is enforced per
-// 100 ms period: a crowd of callers that polls its way through the quota is stopped -- every thread at once -- until the period ends).
-static int usable_cores() {
-    static const int n = [] {
-        int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char quota[32] = {0};
-            long period = 0;
-            if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && quota[0] != 'm') hw = std::min<int>(hw, std::max<long>(1, std::atol(quota) / period));
-            std::fclose(f);
-        } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-            long quota = -1, period = 100000;
-            if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
-            std::fclose(g);
-            if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-                if (std::fscanf(h, "%ld", &period) != 1) period = 100000;
-                std::fclose(h);
-            }
-            if (quota > 0 && period > 0) hw = std::min<int>(hw, std::max<long>(1, quota / period));
-        }
-        return hw;
-    }();
-    return n;
-}
-// A caller waiting for a flag the device sets (pinned memory): spinning while the waiting callers are few against the cores, otherwise
-// asleep for most of what such a wait took lately (`typical_us`, a moving average the caller keeps), then in short steps -- a handful
-// of wake-ups per wait instead of one every 20 us.  false: `limit_s` seconds have passed.
-template <class Ready>
-static bool wait_for_device_flag(Ready ready, std::atomic<int>& waiting, std::atomic<uint32_t>& typical_us, double limit_s) {
-    struct Count {
-        std::atomic<int>& w;
-        explicit Count(std::atomic<int>& x) : w(x) { w.fetch_add(1, std::memory_order_relaxed); }
-        ~Count() { w.fetch_sub(1, std::memory_order_relaxed); }
-    } count(waiting);
-    const auto t0 = std::chrono::steady_clock::now();
-    const int spin_below = std::max(1, usable_cores() / 2);
-    bool slept = false;
-    for (uint32_t it = 0;; ++it) {
-        if (ready()) break;
-        if (waiting.load(std::memory_order_relaxed) <= spin_below) {
-            for (int p = 0; p < 8; ++p) __builtin_ia32_pause();
-        } else {
-            const uint32_t typ = typical_us.load(std::memory_order_relaxed);
-            uint32_t us = std::max<uint32_t>(20u, typ / 12u);
-            if (!slept && typ > 200u) {
-                const double gone = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-                if (gone < 0.8 * typ) us = (uint32_t)(0.8 * typ - gone);
-            }
-            slept = true;
-            std::this_thread::sleep_for(std::chrono::microseconds(us));
-        }
-        if ((it & 63u) == 63u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) return false;
-    }
-    const uint32_t took = (uint32_t)std::min<double>(1e7, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
-    const uint32_t typ = typical_us.load(std::memory_order_relaxed);
-    // (down fast, up slowly: on an index whose filters differ in selectivity a short round must not sleep through most of a long one's time)
-    typical_us.store(!typ ? took : took < typ ? (typ + took) / 2u : (typ * 7u + took) / 8u, std::memory_order_relaxed);
-    return true;
-}
-
-// ---- pods (pipe_pod.hpp): resident launches of the pipelined walk that blocking callers post their queries to ---------------------------
-// Up to kPods per device, each on a stream of its own (a pod never ends while it has callers: nothing else may queue behind it) and
-// kSlots workgroups wide -- 3 x 64 leaves a quarter of the chip to everything else, and every workgroup of an open pod is resident (a
-// workgroup that is not cannot poll its slot).  With the engine's 16 streams and the process's default stream that is the 20 hardware
-// queues the library asks for (HwQueuesDefault).  A keeper thread advances the pods' heartbeat, closes a pod that has been idle for
-// VS_HNSW_POD_IDLE_US (20 ms) or open for VS_HNSW_POD_AGE_MS (1 s, 2 s when no other pod is free to take its callers over: a
-// device-wide synchronisation anywhere in the process -- hipFree, hipDeviceSynchronize -- waits for every kernel, pods included), and
-// hands a closed pod back once every workgroup has said it left.  It makes no HIP call: it cannot be held up by one.
-struct Pod {
-    enum State { kFree, kOpen, kClosing };
-    static constexpr uint32_t kSlots = 64;
-    State state = kFree;
-    const void* owner = nullptr;  // the index whose view the launch carries
-    int mode = 0;                 // 0 = plain lone queries, 1 = filtered queries (exact walks and exploring rounds: the slot says which)
-    uint32_t efcap = 0;           // 256 / 512: the kernel instance
-    size_t index_slots = 0;       // what the callers' visited bitmaps are laid out for: the index's CAPACITY when the pod was opened
-    bool frozen = false;          // its index is being modified: no posts (the caller launches instead); the view in `ctl` is rewritten before it thaws
-    hipStream_t st = nullptr;
-    PodCtl* ctl = nullptr;        // pinned
-    PodSlot* slots = nullptr;     // pinned
-    PipeQuery* stage = nullptr;   // device: workgroup b's copy of the query it is answering (what a batch launch reads from its table)
-    uint32_t n = 0, n_busy = 0;
-    uint64_t gen = 0;
-    bool busy[kSlots] = {};
-    uint32_t seq[kSlots] = {};
-    std::chrono::steady_clock::time_point opened, last_used;
-};
-struct PodTicket {
-    int pod = -1;
-    uint32_t slot = 0;
-    uint64_t gen = 0;  // which opening of the pod
-    explicit operator bool() const { return pod >= 0; }
-};
-struct PodPool {
-    static constexpr int kPods = 3;
-    std::mutex mu;
-    std::condition_variable keeper_cv;
-    Pod pods[kPods];
-    bool keeper_started = false;
-    bool enabled = true;
-    int holds = 0;  // > 0: somebody is about to synchronise the device (reserve, stats, export, a drop): no pod may open until it is through
-    uint32_t n_slots = Pod::kSlots;
-    int idle_us = 20000, max_age_ms = 1000;
-    std::atomic<uint64_t> n_opened{0}, n_served{0}, n_closed{0};
-    std::atomic<uint64_t> plain_queries{0}, plain_ns{0}, plain_wait_ns{0}, plain_gpu_ticks{0};  // where a posted plain query's time goes (probes)
-    PodPool() {
-        if (const char* v = std::getenv("VS_HNSW_PODS")) enabled = v[0] != '0';
-        if (const char* v = std::getenv("VS_HNSW_POD_SLOTS")) n_slots = (uint32_t)std::min<int>(Pod::kSlots, std::max(1, std::atoi(v)));
-        if (const char* v = std::getenv("VS_HNSW_POD_IDLE_US")) idle_us = std::max(100, std::atoi(v));
-        if (const char* v = std::getenv("VS_HNSW_POD_AGE_MS")) max_age_ms = std::max(10, std::atoi(v));
-    }
-    void close_locked(Pod& p) {
-        p.state = Pod::kClosing;
-        __atomic_store_n(&p.ctl->closed, 1u, __ATOMIC_SEQ_CST);
-        n_closed.fetch_add(1, std::memory_order_relaxed);
-    }
-    static bool all_left(const Pod& p) {
-        for (uint32_t i = 0; i < p.n; ++i)
-            if (!__atomic_load_n(&p.slots[i].left, __ATOMIC_ACQUIRE)) return false;
-        return true;
-    }
-    void keep() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            bool any = false;
-            const auto now = std::chrono::steady_clock::now();
-            int free_pods = 0;
-            for (Pod& p : pods) free_pods += p.state == Pod::kFree ? 1 : 0;
-            for (Pod& p : pods) {
-                if (p.state != Pod::kFree) __atomic_fetch_add(&p.ctl->heartbeat, 1u, __ATOMIC_RELAXED);
-                // (a busy pod that has reached its age goes once a free pod can take its callers over -- or at twice the age)
-                const auto age = now - p.opened;
-                const bool aged = age > std::chrono::milliseconds(max_age_ms) && (p.n_busy == 0 || free_pods > 0 || age > std::chrono::milliseconds(2 * max_age_ms));
-                if (p.state == Pod::kOpen && ((p.n_busy == 0 && now - p.last_used > std::chrono::microseconds(idle_us)) || aged)) {
-                    close_locked(p);
-                    if (p.n_busy) --free_pods;  // (its callers will open one)
-                }
-                if (p.state == Pod::kClosing && p.n_busy == 0 && all_left(p)) p.state = Pod::kFree;
-                any |= p.state != Pod::kFree;
-            }
-            if (!any) {
-                keeper_cv.wait(lk);
-                continue;
-            }
-            lk.unlock();
-            std::this_thread::sleep_for(std::chrono::microseconds(200));
-            lk.lock();
-        }
-    }
-    // Close the pods of one index (nullptr: all of them) and wait until their workgroups have left: before anything that moves the
-    // index's arenas, and before a device-wide synchronisation.  quiesce(nullptr) is called under a Hold: with callers posting to
-    // any index of the device, a pod freed here would be reopened by the next caller before the others have gone, and the three would
-    // never be free together (advisor finding, round 4).
-    void quiesce(const void* owner) {
-        std::unique_lock<std::mutex> lk(mu);
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            bool pending = false;
-            for (Pod& p : pods) {
-                if (p.state == Pod::kFree || (owner && p.owner != owner)) continue;
-                if (p.state == Pod::kOpen) close_locked(p);
-                if (p.n_busy == 0 && all_left(p)) p.state = Pod::kFree;
-                else pending = true;
-            }
-            if (!pending) return;
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) fail(VS_ERR_DEVICE, "a pod of resident walks did not close");
-            lk.unlock();
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
-            lk.lock();
-        }
-    }
-    void release(PodTicket t) {
-        std::lock_guard<std::mutex> g(mu);
-        Pod& p = pods[t.pod];
-        if (p.gen != t.gen) return;
-        p.busy[t.slot] = false;
-        --p.n_busy;
-        p.last_used = std::chrono::steady_clock::now();
-    }
-    // A query was posted to a slot whose workgroup had decided to leave just before (a pod whose host stood still for seconds ends
-    // by itself: kernels_pipe.hip): the workgroup stores `left` as its last act and touches nothing afterwards, so "left, and no
-    // answer" means the post was never seen -- the caller serves the query by a launch (advisor finding, round 4: it used to wait out
-    // 20 s and fail).  The pod is closed.
-    bool lost_post(PodTicket t) {
-        std::lock_guard<std::mutex> g(mu);
-        Pod& p = pods[t.pod];
-        if (p.gen != t.gen || !p.slots) return false;
-        if (!__atomic_load_n(&p.slots[t.slot].left, __ATOMIC_ACQUIRE)) return false;
-        if (p.state == Pod::kOpen) close_locked(p);
-        return true;
-    }
-    bool all_free() {
-        std::lock_guard<std::mutex> g(mu);
-        for (const Pod& p : pods)
-            if (p.state != Pod::kFree) return false;
-        return true;
-    }
-    // An index is being modified (adds, removes: they never overlap its searches, usearch.rs:590-612): its pods take no posts and have
-    // no query in flight while it lasts; thaw() hands them the new entry point / top level / removed flag (PodCtl) -- or closes them,
-    // when what they were launched with no longer holds (`layout`: the capacity their callers' workspaces are laid out for).
-    void freeze(const void* owner) {
-        std::unique_lock<std::mutex> lk(mu);
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            bool pending = false;
-            for (Pod& p : pods) {
-                if (p.state == Pod::kFree || p.owner != owner) continue;
-                p.frozen = true;
-                if (p.n_busy) pending = true;
-            }
-            if (!pending) return;
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) fail(VS_ERR_DEVICE, "queries posted to a pod did not finish");
-            lk.unlock();
-            std::this_thread::sleep_for(std::chrono::microseconds(10));
-            lk.lock();
-        }
-    }
-    void thaw(const void* owner, size_t layout, uint32_t entry_slot, int32_t max_level, uint32_t has_removed) {
-        std::lock_guard<std::mutex> g(mu);
-        for (Pod& p : pods) {
-            if (p.owner != owner || !p.frozen) continue;
-            if (p.state == Pod::kOpen && p.index_slots != layout) close_locked(p);
-            if (p.state == Pod::kOpen) {
-                __atomic_store_n(&p.ctl->entry_slot, entry_slot, __ATOMIC_RELAXED);
-                __atomic_store_n(&p.ctl->max_level, max_level, __ATOMIC_RELAXED);
-                __atomic_store_n(&p.ctl->has_removed, has_removed, __ATOMIC_RELEASE);  // (a post's release store follows before any workgroup looks)
-                p.last_used = std::chrono::steady_clock::now();
-            }
-            p.frozen = false;
-        }
-    }
-};
-// Taken around a device-wide synchronisation (and whatever it protects: an arena move, frees): closes every pod of the device, keeps
-// them closed -- pod_submit answers "no pod" meanwhile and its caller launches as before pods existed -- and frees what was parked.
-struct PodHold {
-    PodPool& pp;
-    explicit PodHold(PodPool& pool) : pp(pool) {
-        {
-            std::lock_guard<std::mutex> g(pp.mu);
-            ++pp.holds;
-        }
-        try {
-            pp.quiesce(nullptr);
-        } catch (...) {
-            std::lock_guard<std::mutex> g(pp.mu);
-            --pp.holds;
-            throw;
-        }
-    }
-    ~PodHold() {
-        graveyard().drain();  // (no pod is open: these frees wait for ordinary kernels only)
-        std::lock_guard<std::mutex> g(pp.mu);
-        --pp.holds;
-    }
-};
-static PodPool& pod_pool(int dev) {
-    static std::mutex mu;
-    static std::unordered_map<int, PodPool*> all;  // leaked with the process (the keeper thread outlives static teardown)
-    std::lock_guard<std::mutex> g(mu);
-    PodPool*& p = all[dev];
-    if (!p) {
-        p = new PodPool();
-        static std::once_flag at_exit;
-        std::call_once(at_exit, [] {
-            std::atexit([] {  // the runtime's teardown waits for every kernel: tell the pods to go first
-                std::lock_guard<std::mutex> g2(mu);
-                for (auto& kv : all) {
-                    try {
-                        kv.second->enabled = false;
-                        kv.second->quiesce(nullptr);
-                    } catch (...) {
-                    }
-                }
-            });
-        });
-    }
-    return *p;
-}
-
-// Parked blocks are freed when no pod is open on the device and none can open meanwhile (a free then waits for ordinary kernels only).
-static void drain_graveyard_if_idle(int dev) {
-    if (g_buried.load(std::memory_order_relaxed) == 0 || graveyard().n.load(std::memory_order_relaxed) == 0) return;
-    PodPool& pp = pod_pool(dev);
-    {
-        std::lock_guard<std::mutex> g(pp.mu);
-        for (const Pod& p : pp.pods)
-            if (p.state != Pod::kFree) return;
-        ++pp.holds;
-    }
-    graveyard().drain();
-    std::lock_guard<std::mutex> g(pp.mu);
-    --pp.holds;
-}
 
 // Workspace of the usearch-order walk kernels (kernels_walk.hip), one per (device, stream): launches on one stream
 // run one after the other and may share it; hipFree synchronises the device, so growing it is safe.
@@ -3000,966 +2327,8 @@ struct Engine {
 };
 
 
-// ---------------------------------------------------------------------------------------------
-// SearchService: one dispatcher thread per device turns the stream of single-query calls
-// (vs_hnsw_search / vs_hnsw_search_async, one vector per FFI call as the reference issues them,
-// usearch.rs:212) into kernel launches.  Requests queue under a mutex; the dispatcher drains the queue
-// into one of kSlots pipeline slots (pinned staging, own stream), so up to kSlots batches are in flight
-// and a batch is simply "whatever queued since the last launch" -- no timer, no per-caller HIP calls.
-// Lightly loaded the latency is one graph walk; under load batches grow and the GPU saturates.
-// ---------------------------------------------------------------------------------------------
-struct SearchReq {
-    Engine* e;
-    std::vector<float> q;
-    size_t k;
-    uint64_t* keys;
-    float* dist;
-    size_t* found;
-    void (*cb)(void*, int);
-    void* ctx;
-};
-
-class SearchService {
-   public:
-    static SearchService& get(int device) {
-        static std::mutex mu;
-        static std::unordered_map<int, SearchService*> all;  // leaked on purpose: outlives static teardown
-        std::lock_guard<std::mutex> g(mu);
-        SearchService*& s = all[device];
-        if (!s) s = new SearchService(device);
-        return *s;
-    }
-    void submit(SearchReq&& r) {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            pending_.push_back(std::move(r));
-            n_pending_.store(pending_.size(), std::memory_order_release);
-        }
-        cv_.notify_one();
-    }
-
-   private:
-    // Pipeline slots.  Blocking callers (the reference's num_workers() + 1 threads, one query each) come back in ones and
-    // twos as their results are delivered: with two slots most of them found both busy and waited out half a walk on
-    // average (1.5 walks per round trip); with eight a free slot is there when the query is, and the round trip is one
-    // walk (team kernels of different streams run side by side: GPU_MAX_HW_QUEUES).  VS_HNSW_SERVICE_SLOTS: 1..16.
-    static constexpr int kSlots = 16;
-    int n_slots_ = 8;
-    // While a batch is in flight the dispatcher polls its event and the queue instead of sleeping in timer steps (a
-    // 20 us condition-variable wait is 70 us of timer slack and wake-up on Linux): VS_HNSW_SERVICE_SPIN=0 sleeps instead.
-    bool spin_ = true;
-    std::atomic<size_t> n_pending_{0};
-    static constexpr size_t kMaxBatch = 8192;
-    static constexpr size_t kZeroCopyBatch = 256;
-    static constexpr size_t kHeavyLoad = 512;  // queries in flight beyond which only two slots are used
-    struct Slot {
-        hipStream_t st = nullptr;
-        hipEvent_t ev = nullptr;
-        float* h_q = nullptr;
-        float* d_q = nullptr;
-        // results of one batch live in ONE block, device and pinned host alike: [keys nb*k u64 | dist nb*k f32 | found nb u32],
-        // so a batch costs one copy in and one copy out
-        char* d_out = nullptr;
-        char* h_out = nullptr;
-        uint64_t *d_k = nullptr, *h_k = nullptr;
-        float *d_d = nullptr, *h_d = nullptr;
-        uint32_t *d_f = nullptr, *h_f = nullptr;
-        size_t q_bytes = 0, out_bytes = 0;
-        std::vector<SearchReq> reqs;
-        bool busy = false;
-        int status = VS_OK;
-        std::string err;
-    };
-    int device_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::deque<SearchReq> pending_;
-    Slot slots_[kSlots];
-
-    explicit SearchService(int device) : device_(device) {
-        if (const char* v = std::getenv("VS_HNSW_SERVICE_SLOTS")) n_slots_ = std::min(kSlots, std::max(1, std::atoi(v)));
-        if (const char* v = std::getenv("VS_HNSW_SERVICE_SPIN")) spin_ = v[0] != '0';
-        std::thread([this] { run(); }).detach();
-    }
-
-    static void grow(Slot& s, size_t nq, size_t dim, size_t k) {
-        const size_t qb = nq * dim * 4, ob = nq * k * 12 + nq * 4;
-        if (qb > s.q_bytes) {
-            graveyard().bury(s.d_q, s.h_q);
-            s.q_bytes = qb + qb / 2;
-            HIP_OK(hipHostMalloc((void**)&s.h_q, s.q_bytes, hipHostMallocDefault));
-            HIP_OK(hipMalloc((void**)&s.d_q, s.q_bytes));
-        }
-        if (ob > s.out_bytes) {
-            graveyard().bury(s.d_out, s.h_out);
-            s.out_bytes = ob + ob / 2;
-            HIP_OK(hipHostMalloc((void**)&s.h_out, s.out_bytes, hipHostMallocDefault));
-            HIP_OK(hipMalloc((void**)&s.d_out, s.out_bytes));
-        }
-        s.d_k = (uint64_t*)s.d_out;
-        s.h_k = (uint64_t*)s.h_out;
-        s.d_d = (float*)(s.d_out + nq * k * 8);
-        s.h_d = (float*)(s.h_out + nq * k * 8);
-        s.d_f = (uint32_t*)(s.d_out + nq * k * 12);
-        s.h_f = (uint32_t*)(s.h_out + nq * k * 12);
-    }
-
-    void launch(Slot& s) {
-        s.status = VS_OK;
-        s.err.clear();
-        try {
-            Engine* e = s.reqs[0].e;
-            const size_t nb = s.reqs.size(), k = s.reqs[0].k, dim = e->dim;
-            if (!s.st) {
-                s.st = device_streams(device_).for_slot((int)(&s - slots_));
-                HIP_OK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
-            }
-            grow(s, nb, dim, k);
-            for (size_t i = 0; i < nb; ++i) std::memcpy(s.h_q + i * dim, s.reqs[i].q.data(), dim * 4);
-            size_t load = 0;  // this batch + the batches of the other slots still in flight
-            for (int i = 0; i < n_slots_; ++i) load += slots_[i].busy ? slots_[i].reqs.size() : 0;
-            // Small batches skip the copy engine: the kernel reads its queries from, and writes its results to, the
-            // pinned host block directly (device-mapped) -- 3 KB in and 124 B out per query over PCIe, two API calls
-            // and two copy-engine latencies less per launch (the dispatcher thread is what bounds small batches).
-            const bool zero_copy = nb <= kZeroCopyBatch;
-            if (!zero_copy) HIP_OK(hipMemcpyAsync(s.d_q, s.h_q, nb * dim * 4, hipMemcpyHostToDevice, s.st));
-            tl_pipe_no_second = true;  // deliver() serves the rare query the pipelined walk hands over
-            struct Reset {
-                ~Reset() { tl_pipe_no_second = false; }
-            } reset;
-            if (zero_copy)
-                e->search_device(s.h_q, nb, k, s.h_k, s.h_d, s.h_f, s.st, load);
-            else
-                e->search_device(s.d_q, nb, k, s.d_k, s.d_d, s.d_f, s.st, load);
-            const bool team = e->team_mode == 1 || e->team_mode == 3 || (e->team_mode == 0 && std::max(nb, load) <= 3 * e->team_max_nq);  // 8- or 4-wave teams
-            n_batches += 1;
-            n_queries += nb;
-            if (team) {
-                n_team_batches += 1;
-                n_team_queries += nb;
-            }
-            if (!zero_copy) HIP_OK(hipMemcpyAsync(s.h_out, s.d_out, nb * k * 12 + nb * 4, hipMemcpyDeviceToHost, s.st));
-            HIP_OK(hipEventRecord(s.ev, s.st));
-        } catch (const Fail& f) {
-            s.status = f.code;
-            s.err = f.msg;
-        } catch (const std::exception& x) {
-            s.status = VS_ERR_DEVICE;
-            s.err = x.what();
-        }
-    }
-
-    void deliver(Slot& s) {
-        const size_t k = s.reqs.empty() ? 0 : s.reqs[0].k;
-        for (size_t i = 0; i < s.reqs.size(); ++i) {
-            SearchReq& r = s.reqs[i];
-            int status = s.status;
-            if (status == VS_OK && s.h_f[i] == kWalkFailed) {
-                // The walk outgrew its workspace (e.g. fewer live members than the beam after mass removes: `top` never
-                // fills and the walk floods the graph): rank exhaustively, as the header promises for every host entry point.
-                try {
-                    *r.found = r.e->rank_all(r.q.data(), k, r.keys, r.dist);
-                    n_ranked_fallbacks += 1;
-                } catch (const Fail& f) {
-                    status = f.code;
-                    s.err = f.msg;
-                } catch (const std::exception& x) {
-                    status = VS_ERR_DEVICE;
-                    s.err = x.what();
-                }
-            } else if (status == VS_OK && s.h_f[i] == kPipeRedoFound) {
-                // two equal distances met where their order matters: the team form of the fused-list kernel answers, as for a batch
-                try {
-                    tl_no_pipe = true;
-                    size_t f = 0;
-                    r.e->search_host(r.q.data(), 1, k, r.keys, r.dist, &f, false);
-                    tl_no_pipe = false;
-                    if (f == (size_t)-1) f = r.e->rank_all(r.q.data(), k, r.keys, r.dist);
-                    *r.found = f;
-                    n_pipe_redone += 1;
-                } catch (const Fail& f) {
-                    tl_no_pipe = false;
-                    status = f.code;
-                    s.err = f.msg;
-                } catch (const std::exception& x) {
-                    tl_no_pipe = false;
-                    status = VS_ERR_DEVICE;
-                    s.err = x.what();
-                }
-            } else if (status == VS_OK) {
-                const size_t f = std::min<size_t>(s.h_f[i], k);
-                std::memcpy(r.keys, s.h_k + i * k, f * 8);
-                std::memcpy(r.dist, s.h_d + i * k, f * 4);
-                *r.found = f;
-            }
-            if (status != VS_OK) {
-                *r.found = 0;
-                g_async_err = s.err;
-                g_err = s.err;  // vs_hnsw_last_error() inside the completion callback
-            }
-            r.cb(r.ctx, status);
-        }
-        s.reqs.clear();
-    }
-
-    void run() {
-        (void)hipSetDevice(device_);
-        std::unique_lock<std::mutex> lk(mu_);
-        for (;;) {
-            bool progressed = false;
-            // reap
-            for (int si = 0; si < n_slots_; ++si) {
-                Slot& s = slots_[si];
-                if (!s.busy) continue;
-                bool done = s.status != VS_OK || hipEventQuery(s.ev) == hipSuccess;
-                if (done) {
-                    lk.unlock();
-                    deliver(s);
-                    lk.lock();
-                    s.busy = false;
-                    progressed = true;
-                }
-            }
-            // launch
-            if (!pending_.empty()) {
-                // under load (the non-blocking entry point with thousands of queries in flight) two batches in flight keep
-                // the chip full and large batches are the efficient ones: the other slots are for the trickle of lone callers
-                size_t in_flight = 0;
-                int busy_n = 0;
-                for (int si = 0; si < n_slots_; ++si)
-                    if (slots_[si].busy) {
-                        in_flight += slots_[si].reqs.size();
-                        ++busy_n;
-                    }
-                for (int si = 0; si < n_slots_; ++si) {
-                    Slot& s = slots_[si];
-                    if (s.busy || pending_.empty()) continue;
-                    if (busy_n >= 2 && in_flight >= kHeavyLoad) break;
-                    Engine* e = pending_.front().e;
-                    const size_t k = pending_.front().k;
-                    std::deque<SearchReq> rest;
-                    while (!pending_.empty()) {
-                        SearchReq& r = pending_.front();
-                        if (r.e == e && r.k == k && s.reqs.size() < kMaxBatch) s.reqs.push_back(std::move(r));
-                        else rest.push_back(std::move(r));
-                        pending_.pop_front();
-                    }
-                    pending_.swap(rest);
-                    n_pending_.store(pending_.size(), std::memory_order_release);
-                    s.busy = true;
-                    in_flight += s.reqs.size();
-                    ++busy_n;
-                    lk.unlock();
-                    launch(s);
-                    lk.lock();
-                    progressed = true;
-                }
-            }
-            if (progressed) continue;
-            bool any_busy = false, any_free = false;
-            {
-                size_t in_flight = 0;
-                int busy_n = 0;
-                for (int si = 0; si < n_slots_; ++si) {
-                    any_busy |= slots_[si].busy;
-                    any_free |= !slots_[si].busy;
-                    if (slots_[si].busy) {
-                        in_flight += slots_[si].reqs.size();
-                        ++busy_n;
-                    }
-                }
-                if (busy_n >= 2 && in_flight >= kHeavyLoad) any_free = false;  // (no launch before one of them is back)
-            }
-            if (!any_busy) {
-                cv_.wait(lk, [this] { return !pending_.empty(); });
-                continue;
-            }
-            if (!spin_) {
-                cv_.wait_for(lk, std::chrono::microseconds(20));
-                continue;
-            }
-            // poll the events of the batches in flight and the queue (`busy` is written by this thread only); a batch
-            // that takes longer than 2 ms (large batches of the non-blocking entry point) is slept on in timer steps
-            lk.unlock();
-            bool woke = false;
-            const auto t0 = std::chrono::steady_clock::now();
-            for (unsigned it = 1; !woke; ++it) {
-                if (any_free && n_pending_.load(std::memory_order_acquire) > 0) woke = true;
-                for (int si = 0; si < n_slots_ && !woke; ++si)
-                    if (slots_[si].busy && (slots_[si].status != VS_OK || hipEventQuery(slots_[si].ev) == hipSuccess)) woke = true;
-                if (woke || ((it & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))) break;
-                for (int p = 0; p < 16; ++p) __builtin_ia32_pause();
-            }
-            lk.lock();
-            if (!woke) cv_.wait_for(lk, std::chrono::microseconds(50));
-        }
-    }
-
-   public:
-    static thread_local std::string g_async_err;
-    // launches / queries, and how many of them went to the team kernel (process-wide; vs_search_service_stats)
-    static inline std::atomic<unsigned long long> n_batches{0}, n_team_batches{0}, n_queries{0}, n_team_queries{0};
-    static inline std::atomic<unsigned long long> n_pipe_redone{0};  // lone queries the pipelined walk handed over (served by the team kernels)
-    static inline std::atomic<unsigned long long> n_ranked_fallbacks{0};  // queries whose walk reported kWalkFailed and were ranked exhaustively
-};
-thread_local std::string SearchService::g_async_err;
-
-void Engine::search_async(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found,
-                          void (*cb)(void*, int), void* ctx) {
-    SearchReq r;
-    r.e = this;
-    r.q.assign(q, q + dim);  // inputs are borrowed for the duration of the call only
-    r.k = k;
-    r.keys = keys;
-    r.dist = dist;
-    r.found = found;
-    r.cb = cb;
-    r.ctx = ctx;
-    SearchService::get(device).submit(std::move(r));
-}
-
-// A lone plain query through a pod (pipe_pod.hpp): posted to a resident workgroup from the caller's own thread -- no dispatcher hop, no
-// launch, no event -- and answered into the caller's pinned block.  false: not served here (no pod free, or not a query the pipelined
-// walk takes): the dispatcher serves it.
-bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
-    uint32_t ef;
-    check_search(k, ef);
-    if (!pod_pool(device).enabled || needs_global_walk(ef) || usearch_order() || !pipe_usable(ef) || team_mode == 2 || team_mode == 3 ||
-        stress_small_table || force_wide_tags)
-        return false;
-    use_device();
-    housekeeping();
-    const size_t n = slots_atomic.load(std::memory_order_acquire), lay = layout_slots();
-    if (!n) return false;
-    Lease w(device);
-    const size_t space = batch_space_bytes(lay);
-    if (w->ws.bytes < space || w->ws_zeroed != (lay + 31) / 32) {
-        char* p = (char*)w->ws.ensure(space);
-        HIP_OK(hipMemsetAsync(p, 0, w->ws.bytes, w->stream));
-        HIP_OK(hipStreamSynchronize(w->stream));
-        w->ws_zeroed = (lay + 31) / 32;
-    }
-    // pinned, device-mapped: [counters, flag 64 B | keys k x 8 | dist k x 4 | the query]
-    const size_t q_off = (64 + k * 12 + 63) & ~(size_t)63;
-    const size_t pin_need = q_off + (size_t)dim * 4;
-    if (w->pin_bytes < pin_need) {
-        if (w->pin) graveyard().bury(nullptr, w->pin);
-        w->pin = nullptr;
-        w->pin_bytes = 0;
-        HIP_OK(hipHostMalloc((void**)&w->pin, pin_need, hipHostMallocDefault));
-        w->pin_bytes = pin_need;
-    }
-    uint32_t* h_cnt = (uint32_t*)w->pin;
-    uint32_t* h_done = (uint32_t*)w->pin + 8;
-    uint64_t* h_k = (uint64_t*)(w->pin + 64);
-    float* h_d = (float*)(h_k + k);
-    float* h_q = (float*)(w->pin + q_off);
-    std::memcpy(h_q, q, (size_t)dim * 4);
-    PipeQuery pq{};
-    pq.query = h_q;
-    pq.slots = (uint32_t)n;
-    pq.k = (uint32_t)k;
-    pq.round_id = ++w->round_seq ? w->round_seq : ++w->round_seq;
-    pq.cnt = h_cnt;
-    pq.keys = h_k;
-    pq.space = (char*)w->ws.p;
-    __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
-    const auto t_in = std::chrono::steady_clock::now();
-    PodRelease pod{device, pod_submit(0, ef, lay, pq)};
-    if (!pod.t) return false;
-    const int dbg_pod = pod.t.pod;
-    const uint32_t dbg_slot = pod.t.slot;
-    const uint64_t dbg_gen = pod.t.gen;
-    const double dbg_age_ms = std::chrono::duration<double, std::milli>(t_in - pod_pool(device).pods[dbg_pod].opened).count();
-    // (a walk is the better part of a millisecond)
-    static std::atomic<int> waiting{0};
-    const auto t0 = std::chrono::steady_clock::now();
-    bool lost = false;
-    uint32_t looks = 0;
-    if (!wait_for_device_flag(
-            [&] {
-                if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id) return true;
-                if ((++looks & 1023u) == 0u && pod_pool(device).lost_post(pod.t)) lost = __atomic_load_n(h_done, __ATOMIC_ACQUIRE) != pq.round_id;
-                return lost;
-            },
-            waiting, wait_typical_us[0], 20.0)) {
-        w.retire();
-        fail(VS_ERR_DEVICE, "a posted query was not answered");
-    }
-    pod.done();
-    if (lost) return false;  // (the dispatcher serves it)
-    {
-        PodPool& pp = pod_pool(device);
-        const auto t_out = std::chrono::steady_clock::now();
-        pp.plain_queries.fetch_add(1, std::memory_order_relaxed);
-        pp.plain_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_out - t_in).count(), std::memory_order_relaxed);
-        pp.plain_wait_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_out - t0).count(), std::memory_order_relaxed);
-        pp.plain_gpu_ticks.fetch_add(h_cnt[4], std::memory_order_relaxed);
-        static const bool pod_debug = std::getenv("VS_HNSW_POD_DEBUG") != nullptr;
-        const double wait_us = std::chrono::duration<double, std::micro>(t_out - t0).count();
-        if (pod_debug && wait_us - h_cnt[4] * 0.01 > 3000.0)
-            fprintf(stderr, "[pod] slow answer: waited %.0f us, device %.0f us, pod %d slot %u gen %llu, %.1f ms after the pod was opened\n", wait_us, h_cnt[4] * 0.01,
-                    dbg_pod, dbg_slot, (unsigned long long)dbg_gen, dbg_age_ms);
-    }
-    const uint32_t f = h_cnt[2];
-    if (f == kPipeRedoFound || f == kWalkFailed) {
-        // two equal distances met where their order matters: the team form of the fused-list kernel answers, as for a batch
-        struct NoPipe {
-            NoPipe() { tl_no_pipe = true; }
-            ~NoPipe() { tl_no_pipe = false; }
-        } no_pipe_here;
-        size_t ff = 0;
-        search_host(q, 1, k, keys, dist, &ff, false);
-        if (ff == (size_t)-1) ff = rank_all(q, k, keys, dist);
-        *found = ff;
-        if (f == kPipeRedoFound) SearchService::n_pipe_redone += 1;
-        return true;
-    }
-    const size_t ff = std::min<size_t>(f, k);
-    std::memcpy(keys, h_k, ff * 8);
-    std::memcpy(dist, h_d, ff * 4);
-    *found = ff;
-    return true;
-}
-
-int Engine::search_one(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
-    if (search_one_pod(q, k, keys, dist, found)) return VS_OK;
-    struct Waiter {
-        std::mutex m;
-        std::condition_variable c;
-        bool done = false;
-        int status = VS_OK;
-        std::string err;
-    } w;
-    search_async(q, k, keys, dist, found,
-                 [](void* p, int status) {
-                     Waiter* w = (Waiter*)p;
-                     std::lock_guard<std::mutex> g(w->m);
-                     w->status = status;
-                     if (status != VS_OK) w->err = SearchService::g_async_err;
-                     w->done = true;
-                     w->c.notify_one();
-                 },
-                 &w);
-    std::unique_lock<std::mutex> lk(w.m);
-    w.c.wait(lk, [&] { return w.done; });
-    if (w.status != VS_OK) g_err = w.err;
-    return w.status;
-}
 
 }  // namespace vs
 
-// =============================================================================== C ABI
-using vs::Engine;
-using vs::Fail;
-
-struct vs_hnsw {
-    Engine e;
-};
-
-template <class F>
-static int guarded(F&& f) {
-    try {
-        f();
-        return VS_OK;
-    } catch (const Fail& x) {
-        vs::g_err = x.msg;
-        return x.code;
-    } catch (const std::bad_alloc&) {
-        vs::g_err = "host out of memory";
-        return VS_ERR_OUT_OF_MEMORY;
-    } catch (const std::exception& x) {
-        vs::g_err = x.what();
-        return VS_ERR_DEVICE;
-    } catch (...) {
-        vs::g_err = "unknown error";
-        return VS_ERR_DEVICE;
-    }
-}
-
-static void need(bool cond, const char* what) {
-    if (!cond) vs::fail(VS_ERR_INVALID_ARGUMENT, what);
-}
-static void check_dim(const vs_hnsw* h, size_t dim) {
-    if (dim != h->e.dim)
-        vs::fail(VS_ERR_DIMENSION, "wrong embedding dimension: got " + std::to_string(dim) + ", index has " +
-                                       std::to_string(h->e.dim));
-}
-
-extern "C" {
-
-const char* vs_hnsw_version(void) { return VS_VERSION; }
-const char* vs_hnsw_last_error(void) { return vs::g_err.c_str(); }
-
-int vs_hnsw_create(const vs_hnsw_options* o, vs_hnsw** out) {
-    return guarded([&] {
-        need(o && out, "null argument");
-        std::unique_ptr<vs_hnsw> h(new vs_hnsw());
-        h->e.init(*o);
-        *out = h.release();
-    });
-}
-void vs_hnsw_free(vs_hnsw* h) {
-    try {
-        delete h;
-    } catch (...) {
-    }
-}
-int vs_hnsw_reserve(vs_hnsw* h, size_t capacity, size_t /*threads*/) {
-    return guarded([&] {
-        need(h, "null index");
-        h->e.flush_pending();
-        h->e.reserve(capacity);
-    });
-}
-size_t vs_hnsw_capacity(const vs_hnsw* h) { return h ? h->e.capacity : 0; }
-size_t vs_hnsw_size(const vs_hnsw* h) {
-    if (!h) return 0;
-    try {
-        const_cast<vs_hnsw*>(h)->e.flush_pending();  // staged adds count: they are indexed before anyone can look
-    } catch (...) {
-    }
-    return h->e.live.load();
-}
-size_t vs_hnsw_bytes_per_vector(const vs_hnsw* h) { return h ? h->e.row_bytes : 0; }
-
-int vs_hnsw_add(vs_hnsw* h, uint64_t key, const float* v, size_t dim) {
-    int rc = VS_OK;
-    int g = guarded([&] {
-        need(h && v, "null argument");
-        check_dim(h, dim);
-        rc = h->e.add_one(key, v);
-    });
-    return g != VS_OK ? g : rc;
-}
-
-static int add_many(vs_hnsw* h, const uint64_t* keys, const float* vecs, size_t n, size_t dim, bool on_device) {
-    return guarded([&] {
-        need(h && (n == 0 || (keys && vecs)), "null argument");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        std::vector<int> status;
-        std::string err;
-        h->e.add_batch(keys, vecs, on_device, n, status, err);
-        size_t bad = 0;
-        int code = VS_OK;
-        for (int s : status)
-            if (s != VS_OK) {
-                if (!bad) code = s;
-                ++bad;
-            }
-        if (bad) vs::fail(code, err + " (" + std::to_string(bad) + " of " + std::to_string(n) + " vectors rejected)");
-    });
-}
-int vs_hnsw_add_batch(vs_hnsw* h, const uint64_t* keys, const float* vecs, size_t n, size_t dim) {
-    return add_many(h, keys, vecs, n, dim, false);
-}
-int vs_hnsw_add_batch_device(vs_hnsw* h, const uint64_t* keys, const float* d_vecs, size_t n, size_t dim) {
-    return add_many(h, keys, d_vecs, n, dim, true);
-}
-
-int vs_hnsw_remove(vs_hnsw* h, uint64_t key, int* removed) {
-    return guarded([&] {
-        need(h, "null index");
-        bool r = false;
-        const int rc = h->e.remove_one(key, &r);
-        if (rc != VS_OK) vs::fail(rc, vs::g_err);
-        if (removed) *removed = r ? 1 : 0;
-    });
-}
-
-int vs_hnsw_search(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* keys, float* dist, size_t* found) {
-    int rc = VS_OK;
-    int g = guarded([&] {
-        need(h && q && keys && dist && found, "null argument");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        uint32_t ef;
-        *found = 0;
-        need(k > 0, "k must be > 0");
-        const size_t beam = std::max<size_t>(k, h->e.ef_search.load());
-        if (beam > vs::kMaxWalkBeam) {  // beyond the widest walk: exhaustive ranking (exact, a superset of any beam's answer)
-            *found = h->e.rank_all(q, k, keys, dist);
-            return;
-        }
-        h->e.check_search(k, ef);
-        if (h->e.needs_global_walk(ef)) {  // wide beams / huge indexes: the global-bitmap walk, own launch
-            h->e.search_host(q, 1, k, keys, dist, found, false);
-            if (*found == (size_t)-1) *found = h->e.rank_all(q, k, keys, dist);
-            return;
-        }
-        rc = h->e.search_one(q, k, keys, dist, found);
-    });
-    return g != VS_OK ? g : rc;
-}
-
-int vs_hnsw_search_async(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* keys, float* dist, size_t* found,
-                         vs_hnsw_completion done, void* ctx) {
-    return guarded([&] {
-        need(h && q && keys && dist && found && done, "null argument");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        uint32_t ef;
-        h->e.check_search(k, ef);
-        *found = 0;
-        h->e.search_async(q, k, keys, dist, found, done, ctx);
-    });
-}
-
-int vs_hnsw_filtered_search(vs_hnsw* h, const float* q, size_t dim, size_t k, vs_hnsw_predicate pred, void* ctx,
-                            uint64_t* keys, float* dist, size_t* found) {
-    return guarded([&] {
-        need(h && q && keys && dist && found && pred, "null argument");
-        need(k > 0, "k must be > 0");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        *found = h->e.filtered(q, k, pred, ctx, keys, dist);
-    });
-}
-
-int vs_hnsw_filtered_search_keyed(vs_hnsw* h, const float* q, size_t dim, size_t k, vs_hnsw_predicate pred, void* ctx, uint64_t filter_key,
-                                  uint64_t* keys, float* dist, size_t* found) {
-    return guarded([&] {
-        need(h && q && keys && dist && found && pred, "null argument");
-        need(k > 0, "k must be > 0");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        *found = h->e.filtered(q, k, pred, ctx, keys, dist, false, filter_key);
-    });
-}
-
-int vs_hnsw_filter_memo_stats(vs_hnsw* h, uint64_t out[4]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    out[0] = h->e.memo_queries.load();
-    out[1] = h->e.memo_asked.load();
-    out[2] = h->e.memo_created.load();
-    {
-        std::lock_guard<std::mutex> g(h->e.memo_mu);
-        out[3] = h->e.memos.size();
-    }
-    return VS_OK;
-}
-
-int vs_hnsw_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim, size_t k, uint64_t* keys, float* dist,
-                         size_t* found) {
-    return guarded([&] {
-        need(h && (nq == 0 || (q && keys && dist && found)), "null argument");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        if (std::max<size_t>(k, h->e.ef_search.load()) > vs::kMaxWalkBeam) {
-            for (size_t i = 0; i < nq; ++i) found[i] = h->e.rank_all(q + i * dim, k, keys + i * k, dist + i * k);
-            return;
-        }
-        h->e.search_host(q, nq, k, keys, dist, found, false);
-        for (size_t i = 0; i < nq; ++i)
-            if (found[i] == (size_t)-1) found[i] = h->e.rank_all(q + i * dim, k, keys + i * k, dist + i * k);
-    });
-}
-int vs_hnsw_exact_search_batch(vs_hnsw* h, const float* q, size_t nq, size_t dim, size_t k, uint64_t* keys, float* dist,
-                               size_t* found) {
-    return guarded([&] {
-        need(h && (nq == 0 || (q && keys && dist && found)), "null argument");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        h->e.search_host(q, nq, k, keys, dist, found, true);
-    });
-}
-int vs_hnsw_search_batch_device(vs_hnsw* h, const float* d_q, size_t nq, size_t dim, size_t k, uint64_t* d_keys,
-                                float* d_dist, uint32_t* d_found, void* stream) {
-    return guarded([&] {
-        need(h && (nq == 0 || (d_q && d_keys && d_dist && d_found)), "null argument");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        h->e.use_device();
-        h->e.search_device(d_q, nq, k, d_keys, d_dist, d_found, (hipStream_t)stream);
-    });
-}
-int vs_hnsw_exact_search_batch_device(vs_hnsw* h, const float* d_q, size_t nq, size_t dim, size_t k, uint64_t* d_keys,
-                                      float* d_dist, uint32_t* d_found, void* stream) {
-    return guarded([&] {
-        need(h && (nq == 0 || (d_q && d_keys && d_dist && d_found)), "null argument");
-        check_dim(h, dim);
-        h->e.flush_pending();
-        h->e.use_device();
-        vs::Lease w(h->e.device);
-        h->e.exact_device(d_q, nq, k, d_keys, d_dist, d_found, (hipStream_t)stream, *w.ctx);
-        HIP_OK(hipStreamSynchronize((hipStream_t)stream));  // scratch returns to the pool with the lease
-    });
-}
-
-int vs_hnsw_set_expansion_search(vs_hnsw* h, size_t ef) {
-    return guarded([&] {
-        need(h && ef > 0, "invalid argument");
-        h->e.ef_search = (uint32_t)ef;
-    });
-}
-
-int vs_hnsw_stats(vs_hnsw* h, uint64_t out[8], int reset) {
-    return guarded([&] {
-        need(h && out, "null argument");
-        h->e.flush_pending();
-        h->e.use_device();
-        vs::PodHold hold(vs::pod_pool(h->e.device));
-        HIP_OK(hipDeviceSynchronize());
-        HIP_OK(hipMemcpy(out, h->e.d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        if (reset) HIP_OK(hipMemset(h->e.d_stats, 0, 8 * sizeof(uint64_t)));
-    });
-}
-
-int vs_search_service_stats(uint64_t out[4]) {
-    if (!out) return VS_ERR_INVALID_ARGUMENT;
-    out[0] = vs::SearchService::n_batches.load();
-    out[1] = vs::SearchService::n_queries.load();
-    out[2] = vs::SearchService::n_team_batches.load();
-    out[3] = vs::SearchService::n_team_queries.load();
-    return VS_OK;
-}
-
-int vs_hnsw_memory_info(vs_hnsw* h, uint64_t out[4]) {
-    return guarded([&] {
-        need(h && out, "null argument");
-        std::lock_guard<std::mutex> g(h->e.mod_mu);
-        Engine& e = h->e;
-        out[0] = out[1] = out[2] = 0;
-        for (const vs::Arena* a : {&e.ar_vectors, &e.ar_aux, &e.ar_adj0, &e.ar_upper, &e.ar_upper_off, &e.ar_keys, &e.ar_levels, &e.ar_plane}) {
-            out[0] += a->bytes;
-            if (a->vmm) {
-                out[1] += a->bytes;
-                out[2] += a->chunks.size();
-            }
-        }
-        out[3] = vs::Arena::copied_bytes.load();
-    });
-}
-
-int vs_hnsw_filter_stats(vs_hnsw* h, uint64_t out[2]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    out[0] = h->e.lazy_rounds.load();
-    out[1] = h->e.lazy_predicate_calls.load();
-    return VS_OK;
-}
-
-int vs_hnsw_filter_batch_stats(vs_hnsw* h, uint64_t out[2]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    out[0] = h->e.batcher.launches.load();
-    out[1] = h->e.batcher.rounds.load();
-    return VS_OK;
-}
-
-uint64_t vs_hnsw_streams_created(void) { return vs::g_streams_created.load(); }
-
-int vs_hnsw_pod_stats(vs_hnsw* h, uint64_t out[12]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    vs::PodPool& pp = vs::pod_pool(h->e.device);
-    out[0] = h->e.pod_opens.load();
-    out[1] = h->e.pod_rounds.load();
-    out[2] = pp.n_opened.load() - pp.n_closed.load();
-    out[3] = pp.enabled ? 1 : 0;
-    out[4] = pp.plain_queries.load();
-    out[5] = pp.plain_ns.load();
-    out[6] = pp.plain_wait_ns.load();
-    out[7] = pp.plain_gpu_ticks.load() * 10;
-    out[8] = h->e.batched_done.load();
-    out[9] = h->e.batched_handed_over.load();
-    out[10] = h->e.batched_no_pod.load();
-    out[11] = h->e.batched_second_chances.load();
-    return VS_OK;
-}
-
-int vs_hnsw_modify_stats(vs_hnsw* h, uint64_t out[8]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    out[0] = h->e.m_flushes.load();
-    out[1] = h->e.m_flushed.load();
-    out[2] = h->e.m_flush_ns.load();
-    out[3] = h->e.m_quiesces.load();
-    out[4] = h->e.m_quiesce_ns.load();
-    out[5] = h->e.m_removes.load();
-    out[6] = h->e.m_remove_ns.load();
-    out[7] = h->e.pod_opens.load();
-    return VS_OK;
-}
-
-int vs_hnsw_pipe_stats(vs_hnsw* h, uint64_t out[2]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    out[0] = h->e.pipe_launches.load();
-    out[1] = vs::SearchService::n_pipe_redone.load();
-    return VS_OK;
-}
-
-int vs_hnsw_walk_info(vs_hnsw* h, uint64_t out[2]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    const uint32_t inst = h->e.last_walk_instance.load();
-    out[0] = inst == 0xFFFFFFFFu ? ~0ull : inst;
-    out[1] = vs::SearchService::n_ranked_fallbacks.load();
-    return VS_OK;
-}
-
-int vs_hnsw_exact_stats(vs_hnsw* h, uint64_t out[2]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    out[0] = h->e.block_batches.load();
-    out[1] = h->e.block_fallbacks.load();
-    return VS_OK;
-}
-
-int vs_hnsw_exact_stats2(vs_hnsw* h, uint64_t out[4]) {
-    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
-    out[0] = h->e.plane_batches.load();
-    out[1] = h->e.plane_fallbacks.load();
-    out[2] = h->e.block_batches.load();
-    out[3] = h->e.block_fallbacks.load();
-    return VS_OK;
-}
-
-int vs_hnsw_graph_info_get(vs_hnsw* h, vs_hnsw_graph_info* info) {
-    return guarded([&] {
-        need(h && info, "null argument");
-        h->e.flush_pending();
-        std::lock_guard<std::mutex> g(h->e.mod_mu);
-        info->slots = h->e.slots;
-        info->upper_blocks = h->e.upper_blocks;
-        info->max_level = h->e.max_level.load();
-        info->entry_slot = h->e.entry_slot.load();
-        info->connectivity = h->e.M;
-        info->connectivity_base = h->e.M0;
-    });
-}
-
-int vs_hnsw_export_graph(vs_hnsw* h, void* vectors, int32_t* levels, uint64_t* keys, uint32_t* adj0, uint32_t* upper_off,
-                         uint32_t* upper) {
-    return guarded([&] {
-        need(h, "null index");
-        Engine& e = h->e;
-        e.flush_pending();
-        std::lock_guard<std::mutex> g(e.mod_mu);
-        e.use_device();
-        vs::PodHold hold(vs::pod_pool(e.device));
-        HIP_OK(hipDeviceSynchronize());
-        const size_t n = e.slots;
-        if (!n) return;
-        if (vectors) {  // storage format, unpadded: row_bytes per vector (f32 storage: the floats themselves)
-            vs::Lease w(e.device);
-            void* tmp = w->a.ensure(n * (size_t)e.row_bytes);
-            HIP_OK(vs::launch_copy_rows(tmp, e.row_bytes, e.d_vectors, e.stride4 * 16, e.row_bytes, e.row_bytes, (uint32_t)n,
-                                        w->stream));
-            HIP_OK(hipMemcpyAsync(vectors, tmp, n * (size_t)e.row_bytes, hipMemcpyDeviceToHost, w->stream));
-            HIP_OK(hipStreamSynchronize(w->stream));
-        }
-        if (levels) HIP_OK(hipMemcpy(levels, e.d_levels, n * 4, hipMemcpyDeviceToHost));
-        if (keys) HIP_OK(hipMemcpy(keys, e.d_keys, n * 8, hipMemcpyDeviceToHost));
-        if (adj0) HIP_OK(hipMemcpy(adj0, e.d_adj0, n * e.M0 * 4, hipMemcpyDeviceToHost));
-        if (upper_off) HIP_OK(hipMemcpy(upper_off, e.d_upper_off, n * 4, hipMemcpyDeviceToHost));
-        if (upper && e.upper_blocks) HIP_OK(hipMemcpy(upper, e.d_upper, e.upper_blocks * e.M * 4, hipMemcpyDeviceToHost));
-    });
-}
-
-int vs_hnsw_import_graph(vs_hnsw* h, size_t n, const void* vectors, const int32_t* levels, const uint64_t* keys,
-                         const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* upper, size_t upper_blocks,
-                         int32_t max_level, uint32_t entry_slot) {
-    return guarded([&] {
-        need(h && (n == 0 || (vectors && levels && keys && adj0 && upper_off)), "null argument");
-        Engine& e = h->e;
-        need(e.slots == 0, "import needs an empty index");
-        e.pods_quiesce();
-        if (n > e.capacity) e.reserve(n);
-        std::lock_guard<std::mutex> g(e.mod_mu);
-        e.use_device();
-        if (!n) return;
-        e.ensure_upper(upper_blocks);
-        vs::Lease w(e.device);
-        void* tmp = w->a.ensure(n * (size_t)e.row_bytes);
-        HIP_OK(hipMemcpyAsync(tmp, vectors, n * (size_t)e.row_bytes, hipMemcpyHostToDevice, w->stream));
-        HIP_OK(vs::launch_copy_rows(e.d_vectors, e.stride4 * 16, tmp, e.row_bytes, e.row_bytes, e.stride4 * 16, (uint32_t)n,
-                                    w->stream));
-        vs::IndexView ix = e.view();
-        HIP_OK(vs::launch_aux_rows(ix, e.d_aux, (uint32_t)n, w->stream));
-        HIP_OK(hipStreamSynchronize(w->stream));
-        HIP_OK(hipMemcpy(e.d_levels, levels, n * 4, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(e.d_keys, keys, n * 8, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(e.d_adj0, adj0, n * e.M0 * 4, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(e.d_upper_off, upper_off, n * 4, hipMemcpyHostToDevice));
-        if (upper_blocks) HIP_OK(hipMemcpy(e.d_upper, upper, upper_blocks * e.M * 4, hipMemcpyHostToDevice));
-        e.slots = n;
-        e.slots_atomic.store(n, std::memory_order_release);
-        e.linked = n;
-        e.upper_blocks = upper_blocks;
-        size_t live = 0;
-        for (size_t s = 0; s < n; ++s) {
-            e.h_levels[s] = (uint8_t)levels[s];
-            e.h_upper_off[s] = upper_off[s];
-            e.h_keys[s] = keys[s];
-            if (keys[s] != vs::kFreeKey) {
-                e.lookup.emplace(keys[s], (uint32_t)s);
-                ++live;
-            } else {
-                e.free_slots.push_back((uint32_t)s);
-                ++e.removed;
-            }
-        }
-        e.live = live;
-        e.committed = live;
-        {
-            std::lock_guard<std::mutex> ng(e.norm_mu);
-            e.max_norm_slots = 0;  // the contents were replaced
-        }
-        {
-            std::lock_guard<std::mutex> pg(e.plane_mu);
-            e.plane_done = 0;
-        }
-        e.max_level = max_level;
-        e.entry_slot = entry_slot;
-    });
-}
-
-int vs_topk_merge_device(const uint64_t* d_part_keys, const float* d_part_dists, size_t parts, size_t nq, size_t k,
-                         uint64_t* d_keys, float* d_dists, uint32_t* d_found, void* stream) {
-    return guarded([&] {
-        need(d_part_keys && d_part_dists && d_keys && d_dists, "null argument");
-        HIP_OK(vs::launch_topk_merge(d_part_keys, d_part_dists, (uint32_t)parts, (uint32_t)nq, (uint32_t)k, d_keys, d_dists,
-                                     d_found, (hipStream_t)stream));
-    });
-}
-
-int vs_topk_merge_packed_device(const void* d_blocks, size_t parts, size_t block_bytes, size_t nq, size_t k, uint64_t* d_keys,
-                                float* d_dists, uint32_t* d_found, void* stream) {
-    return guarded([&] {
-        need(d_blocks && d_keys && d_dists, "null argument");
-        need(block_bytes % 16 == 0 && block_bytes >= nq * k * 12, "blocks must be 16-byte multiples of at least nq * k * 12 bytes");
-        const char* base = (const char*)d_blocks;
-        HIP_OK(vs::launch_topk_merge((const uint64_t*)base, (const float*)(base + nq * k * 8), (uint32_t)parts, (uint32_t)nq, (uint32_t)k,
-                                     d_keys, d_dists, d_found, (hipStream_t)stream, block_bytes / 8, block_bytes / 4));
-    });
-}
-
-// reference vs_index/usearch.rs:1179-1205
-void vs_f32_to_b1x8(const float* v, size_t n, uint8_t* out) {
-    const size_t nb = (n + 7) / 8;
-    for (size_t j = 0; j < nb; ++j) {
-        uint8_t byte = 0;
-        for (size_t i = 0; i < 8 && j * 8 + i < n; ++i)
-            if (v[j * 8 + i] > 0.0f) byte |= (uint8_t)(1u << i);
-        out[j] = byte;
-    }
-}
-
-// reference distance.rs:58-105
-int vs_distance_valid(float v, int metric, size_t dim) {
-    switch (metric) {
-        case VS_METRIC_COS: return v >= 0.0f && v <= 2.0f;
-        case VS_METRIC_L2SQ: return v >= 0.0f;
-        case VS_METRIC_IP: return !std::isnan(v);
-        case VS_METRIC_HAMMING: return v >= 0.0f && std::isfinite(v) && v == std::trunc(v) && v <= (float)dim;
-        default: return 0;
-    }
-}
-
-// reference similarity.rs:28-35
-float vs_similarity_score(float d, int metric, size_t dim) {
-    switch (metric) {
-        case VS_METRIC_COS:
-        case VS_METRIC_IP: return (2.0f - d) / 2.0f;
-        case VS_METRIC_L2SQ: return 1.0f / (1.0f + d);
-        default: return 1.0f - d / (float)dim;
-    }
-}
-
-}  // extern "C"
+#include "engine_service.hpp"
+#include "engine_abi.hpp"

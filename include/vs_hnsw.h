@@ -198,6 +198,11 @@ VS_API int vs_hnsw_pod_stats(vs_hnsw* index, uint64_t out[12]);
  * for their workgroups to leave; [5] vs_hnsw_remove calls, [6] ns inside them; [7] pods opened for this index. */
 VS_API int vs_hnsw_modify_stats(vs_hnsw* index, uint64_t out[8]);
 
+/* Where a single-query call spends its time: [0] vs_hnsw_search calls, [1] ns inside them; [2] vs_hnsw_filtered_search[_keyed] calls,
+ * [3] ns inside them, of which [4] waiting for the device's rounds and [5] asking the predicate; [6] ns callers of either waited for
+ * staged modifications to be applied first. */
+VS_API int vs_hnsw_call_stats(vs_hnsw* index, uint64_t out[8]);
+
 /* Exact search on float storage (cos / ip, k <= 64, >= 65,536 slots) nominates with split-bf16 MFMA tiles, re-scores the nominees
  * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's
  * certificate failed. */

@@ -25,9 +25,25 @@ LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search", "search@named", "sea
         "search_while_updating:16+0", "search_while_deleting")
 
 
-def run_legs(actor, callers, queries, vectors, n, legs, seconds, producers, plain, filtered, modulus, state, tag):
-    return callers.pipeline_legs(actor, queries, vectors, n, legs, seconds=seconds, producers=producers, plain_callers=plain, filtered_callers=filtered,
-                                 modulus=modulus, state=state, log=lambda leg, r: print(f"[{tag}] {leg}: " + json.dumps(r), file=sys.stderr, flush=True))
+def run_legs(actor, callers, queries, vectors, n, legs, seconds, producers, plain, filtered, modulus, state, tag, ix=None):
+    out = {}
+    for leg in legs:  # one at a time: the engine's own account of each leg beside it
+        before = (ix.call_stats(), ix.modify_stats(), ix.filter_stats(), ix.pod_stats()) if ix is not None else None
+        r = callers.pipeline_legs(actor, queries, vectors, n, (leg,), seconds=seconds, producers=producers, plain_callers=plain, filtered_callers=filtered,
+                                  modulus=modulus, state=state)[leg]
+        if ix is not None:
+            after = (ix.call_stats(), ix.modify_stats(), ix.filter_stats(), ix.pod_stats())
+            d = [{k: (a[k] - b[k]) for k in a if isinstance(a[k], (int, float)) and not isinstance(a[k], bool)} for a, b in zip(after, before)]
+            c = d[0]
+            r["engine"] = {"ms_per_search": c["search_ms"] / max(c["searches"], 1), "ms_per_filtered": c["filtered_ms"] / max(c["filtered"], 1),
+                           "filtered_device_wait_ms": c["filtered_device_wait_ms"] / max(c["filtered"], 1),
+                           "filtered_predicate_ms": c["filtered_predicate_ms"] / max(c["filtered"], 1),
+                           "flush_wait_ms_per_call": c["flush_wait_ms"] / max(c["searches"] + c["filtered"], 1),
+                           "flushes": d[1]["flushes"], "flush_ms": d[1]["flush_ms"], "rounds_per_filtered": d[2]["lazy_rounds"] / max(c["filtered"], 1),
+                           "pods_opened": d[3]["pods_opened"], "rounds_without_a_pod": d[3]["rounds_without_a_pod"]}
+        out[leg] = r
+        print(f"[{tag}] {leg}: " + json.dumps(r), file=sys.stderr, flush=True)
+    return out
 
 
 def main():
@@ -77,7 +93,7 @@ def main():
             act.adopt_partition(0, ix.h, ix.size())
             state = {"next_key": (1 << 40) + p * (1 << 32), "delete_from": n // 2 + (p % 7) * 50_000}
             m0 = ix.modify_stats()
-            rec = run_legs(act, callers, queries, fresh, n, legs, a.seconds, p, a.plain, a.filtered, a.modulus, state, f"gpu p={p}")
+            rec = run_legs(act, callers, queries, fresh, n, legs, a.seconds, p, a.plain, a.filtered, a.modulus, state, f"gpu p={p}", ix=ix)
             m1 = ix.modify_stats()
             rec["engine"] = {k: m1[k] - m0[k] for k in m1}
             rec["actor_counters"] = act.counters()

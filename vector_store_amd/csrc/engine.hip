@@ -1657,6 +1657,8 @@ struct Engine {
     };
     // where a modification's time goes (vs_hnsw_modify_stats): flushes of staged adds, closing of this index's pods, removes
     std::atomic<uint64_t> m_flushes{0}, m_flushed{0}, m_flush_ns{0}, m_quiesces{0}, m_quiesce_ns{0}, m_removes{0}, m_remove_ns{0};
+    // ... and a search call's (vs_hnsw_call_stats): single-query calls and ns inside them, filtered calls / ns / ns waiting for the device / ns asking the predicate
+    std::atomic<uint64_t> c_searches{0}, c_search_ns{0}, c_filtered{0}, c_filtered_ns{0}, c_filtered_wait_ns{0}, c_filtered_pred_ns{0}, c_flush_wait_ns{0};
     struct Stopwatch {
         std::atomic<uint64_t>& ns;
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -1955,6 +1957,8 @@ struct Engine {
             }
             // wait for the kernel's flag (the two kinds of round take different times: one moving average each)
             static std::atomic<int> waiting{0};
+            {
+            Stopwatch wait_sw(c_filtered_wait_ns);
             for (int attempt = 0;; ++attempt) {
                 bool lost = false;
                 uint32_t looks = 0;
@@ -1971,6 +1975,7 @@ struct Engine {
                 pod.done();
                 if (!lost || attempt) break;
                 submit_round(pq, explore, ef, lay);  // the workgroup had left before it saw the post: the round goes into a batched launch
+            }
             }
             uint32_t count = h_cnt[0], consulted = h_cnt[1], found = h_cnt[2];
             if (found == kPipeRedoFound && explore) {
@@ -2041,6 +2046,7 @@ struct Engine {
                 }
                 return found;
             }
+            Stopwatch pred_sw(c_filtered_pred_ns);
             const uint32_t m = std::min(count, cap);
             uint64_t asked = 0;  // (counted here, added once: every caller's every call on one shared counter is a cache line passed round 50M times a second)
             for (uint32_t i = 0; i < m; ++i) {

@@ -126,7 +126,12 @@ int vs_hnsw_search(vs_hnsw* h, const float* q, size_t dim, size_t k, uint64_t* k
     int g = guarded([&] {
         need(h && q && keys && dist && found, "null argument");
         check_dim(h, dim);
-        h->e.flush_pending();
+        vs::Engine::Stopwatch sw(h->e.c_search_ns);
+        h->e.c_searches.fetch_add(1, std::memory_order_relaxed);
+        {
+            vs::Engine::Stopwatch fw(h->e.c_flush_wait_ns);
+            h->e.flush_pending();
+        }
         uint32_t ef;
         *found = 0;
         need(k > 0, "k must be > 0");
@@ -165,7 +170,12 @@ int vs_hnsw_filtered_search(vs_hnsw* h, const float* q, size_t dim, size_t k, vs
         need(h && q && keys && dist && found && pred, "null argument");
         need(k > 0, "k must be > 0");
         check_dim(h, dim);
-        h->e.flush_pending();
+        vs::Engine::Stopwatch sw(h->e.c_filtered_ns);
+        h->e.c_filtered.fetch_add(1, std::memory_order_relaxed);
+        {
+            vs::Engine::Stopwatch fw(h->e.c_flush_wait_ns);
+            h->e.flush_pending();
+        }
         *found = h->e.filtered(q, k, pred, ctx, keys, dist);
     });
 }
@@ -176,7 +186,12 @@ int vs_hnsw_filtered_search_keyed(vs_hnsw* h, const float* q, size_t dim, size_t
         need(h && q && keys && dist && found && pred, "null argument");
         need(k > 0, "k must be > 0");
         check_dim(h, dim);
-        h->e.flush_pending();
+        vs::Engine::Stopwatch sw(h->e.c_filtered_ns);
+        h->e.c_filtered.fetch_add(1, std::memory_order_relaxed);
+        {
+            vs::Engine::Stopwatch fw(h->e.c_flush_wait_ns);
+            h->e.flush_pending();
+        }
         *found = h->e.filtered(q, k, pred, ctx, keys, dist, false, filter_key);
     });
 }
@@ -329,6 +344,19 @@ int vs_hnsw_modify_stats(vs_hnsw* h, uint64_t out[8]) {
     out[5] = h->e.m_removes.load();
     out[6] = h->e.m_remove_ns.load();
     out[7] = h->e.pod_opens.load();
+    return VS_OK;
+}
+
+int vs_hnsw_call_stats(vs_hnsw* h, uint64_t out[8]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.c_searches.load();
+    out[1] = h->e.c_search_ns.load();
+    out[2] = h->e.c_filtered.load();
+    out[3] = h->e.c_filtered_ns.load();
+    out[4] = h->e.c_filtered_wait_ns.load();
+    out[5] = h->e.c_filtered_pred_ns.load();
+    out[6] = h->e.c_flush_wait_ns.load();
+    out[7] = 0;
     return VS_OK;
 }
 

@@ -99,7 +99,7 @@ def lib():
     # and their accessors below return zeros without them)
     if hasattr(L, "vs_hnsw_filtered_search_keyed"):
         L.vs_hnsw_filtered_search_keyed.argtypes = [vp, vp, sz, sz, PRED, vp, u64, vp, vp, C.POINTER(sz)]
-    for young in ("vs_hnsw_pipe_stats", "vs_hnsw_filter_batch_stats", "vs_hnsw_pod_stats", "vs_hnsw_modify_stats", "vs_hnsw_filter_memo_stats"):
+    for young in ("vs_hnsw_pipe_stats", "vs_hnsw_filter_batch_stats", "vs_hnsw_pod_stats", "vs_hnsw_modify_stats", "vs_hnsw_filter_memo_stats", "vs_hnsw_call_stats"):
         if hasattr(L, young):
             getattr(L, young).argtypes = [vp, vp]
     if hasattr(L, "vs_hnsw_streams_created"):  # (VS_HNSW_LIB may name an older build: A/B measurements)
@@ -247,6 +247,14 @@ class HipUsearchIndex:
             _check(self.L.vs_hnsw_filtered_search(self.h, _p(v), v.size, limit, cb, None, _p(keys), _p(d),
                                                   C.byref(found)))
         return keys[: found.value], d[: found.value]
+
+    def call_stats(self) -> dict:
+        """Where single-query calls spend their time (include/vs_hnsw.h: vs_hnsw_call_stats), totals in ms."""
+        out = np.zeros(8, dtype=np.uint64)
+        if hasattr(self.L, "vs_hnsw_call_stats"):
+            _check(self.L.vs_hnsw_call_stats(self.h, _p(out)))
+        return {"searches": int(out[0]), "search_ms": int(out[1]) / 1e6, "filtered": int(out[2]), "filtered_ms": int(out[3]) / 1e6,
+                "filtered_device_wait_ms": int(out[4]) / 1e6, "filtered_predicate_ms": int(out[5]) / 1e6, "flush_wait_ms": int(out[6]) / 1e6}
 
     def filter_memo_stats(self) -> dict:
         out = np.zeros(4, dtype=np.uint64)

@@ -616,8 +616,8 @@ def boundary_record(ix, queries_host, truth, k, seconds):
     return out, answers
 
 
-MIXED_LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search_while_updating:16+0", "search_while_updating", "search_while_updating@named",
-              "search_while_inserting", "search_while_deleting")
+MIXED_LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search_while_updating:16+0", "search_while_updating", "search:0+16@named",
+              "search_while_updating@named", "search_while_inserting", "search_while_deleting")
 
 
 def mixed_record(actor_of, queries_host, fresh, n, seconds, producers=(1, 16), named=True):
@@ -631,7 +631,9 @@ def mixed_record(actor_of, queries_host, fresh, n, seconds, producers=(1, 16), n
     for p in producers:
         act = actor_of()
         try:
-            legs = MIXED_LEGS if p == producers[0] else ("cdc_insert", "cdc_update", "search_while_updating:16+0", "search_while_updating", "search_while_updating@named")
+            # ("search:0+16@named": the named filter's callers alone -- it also warms the filter's memory for the leg behind it)
+            legs = MIXED_LEGS if p == producers[0] else ("cdc_insert", "cdc_update", "search_while_updating:16+0", "search_while_updating", "search:0+16@named",
+                                                         "search_while_updating@named")
             if not named:
                 legs = tuple(x for x in legs if "@named" not in x)
             rec = callers.pipeline_legs(act, queries_host[:4096], fresh, n, legs, seconds=seconds, producers=p,

@@ -9,12 +9,12 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; T=/tmp/prof_$TAG
 mkdir -p "$T" "$O/summary"; cd "$R"
 python3 bench.py "$@" > "$O/summary/${TAG}_bench.json" 2> "$O/${TAG}_bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 bench.py --ef "$EF" --steps 10 --warmup 2 --cpu-seconds 0 --boundary-seconds 0 --no-side-records "$@" > "$O/summary/${TAG}_bench_under_rocprof.json" 2> "$O/${TAG}_stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 bench.py --ef "$EF" --steps 10 --warmup 2 --cpu-seconds 0 --boundary-seconds 0 --mixed-seconds 0 --no-side-records "$@" > "$O/summary/${TAG}_bench_under_rocprof.json" 2> "$O/${TAG}_stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$T/pmc_$c" -- python3 bench.py --ef "$EF" --steps 3 --warmup 1 --cpu-seconds 0 --boundary-seconds 0 --no-side-records "$@" > "$O/${TAG}_pmc_$c.json" 2> "$O/${TAG}_pmc_$c.err"
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$T/pmc_$c" -- python3 bench.py --ef "$EF" --steps 3 --warmup 1 --cpu-seconds 0 --boundary-seconds 0 --mixed-seconds 0 --no-side-records "$@" > "$O/${TAG}_pmc_$c.json" 2> "$O/${TAG}_pmc_$c.err"
 done
 # one more pass: L2 hits / misses and the memory-side read requests (four TCC slots: they fit one pass)
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum --kernel-trace --output-format csv -d "$T/pmc_TCC" -- python3 bench.py --ef "$EF" --steps 3 --warmup 1 --cpu-seconds 0 --boundary-seconds 0 --no-side-records "$@" > "$O/${TAG}_pmc_TCC.json" 2> "$O/${TAG}_pmc_TCC.err"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum --kernel-trace --output-format csv -d "$T/pmc_TCC" -- python3 bench.py --ef "$EF" --steps 3 --warmup 1 --cpu-seconds 0 --boundary-seconds 0 --mixed-seconds 0 --no-side-records "$@" > "$O/${TAG}_pmc_TCC.json" 2> "$O/${TAG}_pmc_TCC.err"
 python3 scripts/summarise_profiles.py --stats-dir "$T/stats" --fetch-dir "$T/pmc_FETCH_SIZE" --write-dir "$T/pmc_WRITE_SIZE" --tcc-dir "$T/pmc_TCC" \
   --bench-json "$O/summary/${TAG}_bench_under_rocprof.json" --out "$O/summary" --tag "$TAG"
 cat "$O/summary/${TAG}_traffic.json" "$O/summary/${TAG}_traffic_insert.json" "$O/summary/${TAG}_traffic_mfma.json"; grep -E "hnsw_search|hnsw_insert|exact_dist_mfma" "$O/summary/${TAG}_kernel_stats.csv"

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstring>
 #include <mutex>
 #include <random>
 #include <thread>
@@ -299,6 +300,8 @@ extern "C" int vs_mixed_run(vs_actor* actor, const vs_mixed_options* o, const fl
     if ((o->modify == VS_MIXED_INSERT || o->modify == VS_MIXED_UPDATE) && (!vectors || !nv)) return VS_ERR_INVALID_ARGUMENT;
     if (o->filtered_callers && !o->modulus) return VS_ERR_INVALID_ARGUMENT;
     const unsigned producers = o->modify == VS_MIXED_NONE ? 0u : (o->producers ? o->producers : 1u);
+    static std::atomic<uint64_t> run_counter{0};
+    const uint64_t run_salt = producers ? run_counter.fetch_add(1, std::memory_order_relaxed) : 0;
     const size_t k = o->k;
     std::atomic<bool> stop{false};
     std::atomic<uint64_t> next_item{0}, adds_applied{0}, removes_applied{0}, calls{0}, results{0}, errors{0};
@@ -357,6 +360,18 @@ extern "C" int vs_mixed_run(vs_actor* actor, const vs_mixed_options* o, const fl
     for (unsigned t = 0; t < producers; ++t)
         th.emplace_back([&, t] {
             std::mt19937_64 g(t * 15485863 + 29);
+            std::vector<float> vec(dim);
+            // item `it` carries vectors[it % nv]; from the second pass over the pool on, one coordinate is moved so that no two items
+            // carry the same vector (exact duplicates make equal distances, which is a different workload: DESIGN.md section 4.7)
+            auto vector_of = [&](uint64_t it) -> const float* {
+                const float* src = vectors + (it % nv) * dim;
+                const uint64_t pass = it / nv + run_salt * 64;  // (the runs of one process do not repeat each other's vectors either)
+                if (!pass) return src;
+                std::memcpy(vec.data(), src, dim * sizeof(float));
+                vec[(size_t)((it * 2654435761ull) % dim)] += 0.02f * (float)(pass % 61 + 1) * ((pass & 1) ? 1.f : -1.f);
+                vec[(size_t)((it * 40503ull + pass) % dim)] += 0.01f * (float)((pass / 61) % 97 + 1);
+                return vec.data();
+            };
             while (!stop.load(std::memory_order_relaxed)) {
                 const uint64_t it = next_item.fetch_add(1, std::memory_order_relaxed);
                 if (o->max_items && it >= o->max_items) break;
@@ -364,13 +379,13 @@ extern "C" int vs_mixed_run(vs_actor* actor, const vs_mixed_options* o, const fl
                 const auto s = Clock::now();
                 switch (o->modify) {
                     case VS_MIXED_INSERT:
-                        rc = vs_actor_add_vector_wait(actor, o->partition, o->first_new_key + it, vectors + (it % nv) * dim, dim, &applied);
+                        rc = vs_actor_add_vector_wait(actor, o->partition, o->first_new_key + it, vector_of(it), dim, &applied);
                         adds_applied += (uint64_t)applied;
                         break;
                     case VS_MIXED_UPDATE: {
                         const uint64_t key = o->existing_keys ? g() % o->existing_keys : 0;
                         rc = vs_actor_remove_vector(actor, o->partition, key);  // RemoveBeforeAddValue: no marker
-                        if (rc == VS_OK) rc = vs_actor_add_vector_wait(actor, o->partition, key, vectors + (it % nv) * dim, dim, &applied);
+                        if (rc == VS_OK) rc = vs_actor_add_vector_wait(actor, o->partition, key, vector_of(it), dim, &applied);
                         adds_applied += (uint64_t)applied;
                         break;
                     }

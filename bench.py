@@ -595,7 +595,7 @@ def boundary_record(ix, queries_host, truth, k, seconds):
                                                   ("selectivity_10pct_128_callers", 10, 128, 2048, 0xA10), ("selectivity_1pct", 100, cores + 1, 256, 0xA100)):
         try:
             qs = q[:nq_used]
-            callers.run_filtered(ix, qs, k, modulus, threads, 1.0 if modulus < 100 else 2.0, filter_key=fkey)
+            callers.run_filtered(ix, qs, k, modulus, threads, 2.5 if modulus < 100 else 3.0, filter_key=fkey)
             f0, m0 = ix.filter_stats(), ix.filter_memo_stats()
             r, extra, rec, rc = callers.run_filtered(ix, qs, k, modulus, threads, max(seconds / 2, 1.0) if modulus < 100 else max(seconds, 2.0), record=cap, filter_key=fkey)
             f1, m1 = ix.filter_stats(), ix.filter_memo_stats()

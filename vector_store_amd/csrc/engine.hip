@@ -1913,7 +1913,7 @@ struct Engine {
         uint64_t n_known = 0, n_allowed = 0;
         // (a filter whose recent queries found nearly every verdict in its memory starts with the exact walk: no exploring round)
         if (memo && memo->stride < words) memo = nullptr;
-        bool explored = memo && memo->asked_avg.load(std::memory_order_relaxed) < 512u;
+        bool explored = memo && memo->asked_avg.load(std::memory_order_relaxed) < 1024u;
         int exact_rounds = 0, explore_rounds = 0;
         uint32_t apply_m = 0;
         for (int round = 0; round < 24; ++round) {
@@ -2032,7 +2032,8 @@ struct Engine {
                 std::memcpy(dist, h_d, (size_t)std::min<size_t>(found, k) * 4);
                 lazy_rounds += (uint64_t)round + 1;
                 if (memo) {
-                    const uint32_t asked = (uint32_t)std::min<uint64_t>(n_known, 0x7FFFFFFFu), avg = memo->asked_avg.load(std::memory_order_relaxed);
+                    // (clipped: ONE query in an unvisited neighbourhood must not send the filter's next dozen queries back to exploring rounds)
+                    const uint32_t asked = (uint32_t)std::min<uint64_t>(n_known, 2048u), avg = memo->asked_avg.load(std::memory_order_relaxed);
                     memo->asked_avg.store(avg == 0xFFFFFFFFu ? asked : (uint32_t)(((uint64_t)avg * 3 + asked) / 4), std::memory_order_relaxed);
                     memo->queries.fetch_add(1, std::memory_order_relaxed);
                     memo->asked.fetch_add(n_known, std::memory_order_relaxed);

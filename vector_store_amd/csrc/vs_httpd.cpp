@@ -463,6 +463,31 @@ std::vector<Test> compile_filter(const JVal& flt, const std::string& pk) {
     return tests;
 }
 
+// A name for the filter (vs_hnsw_filtered_search_keyed): the predicate below is a function of (these tests, key) and nothing else, so
+// the engine may remember its verdicts across the requests that carry the same restrictions.
+uint64_t filter_fingerprint(const std::vector<Test>& tests) {
+    auto mix = [](uint64_t h, uint64_t v) {
+        h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        return h * 0x100000001B3ull;
+    };
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (const Test& t : tests) {
+        h = mix(h, (uint64_t)t.op);
+        if (t.op == Test::In) {
+            uint64_t sum = 0, x = 0;  // (a set: the order of its members must not matter)
+            for (int64_t m : t.set) {
+                const uint64_t e = mix(0x51ED270B3A2FULL, (uint64_t)m);
+                sum += e;
+                x ^= e;
+            }
+            h = mix(mix(mix(h, t.set.size()), sum), x);
+        } else {
+            h = mix(h, (uint64_t)t.v);
+        }
+    }
+    return h | 1ull;
+}
+
 struct Served {
     std::string keyspace, name, pk = "id";
     vs_hnsw* h = nullptr;
@@ -577,8 +602,8 @@ struct FilterPool {
                     if (p->tests.empty())  // no filter: a limit beyond the LDS beam (exhaustive ranking inside the engine)
                         p->status = vs_hnsw_search(p->s->h, p->q.data(), p->q.size(), p->k, p->keys.data(), p->dist.data(), &p->found);
                     else
-                        p->status = vs_hnsw_filtered_search(p->s->h, p->q.data(), p->q.size(), p->k, pred, &p->tests, p->keys.data(),
-                                                            p->dist.data(), &p->found);
+                        p->status = vs_hnsw_filtered_search_keyed(p->s->h, p->q.data(), p->q.size(), p->k, pred, &p->tests, filter_fingerprint(p->tests),
+                                                                  p->keys.data(), p->dist.data(), &p->found);
                     if (p->status != VS_OK) p->err = vs_hnsw_last_error();
                     done(std::move(p));
                 }

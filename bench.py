@@ -187,7 +187,7 @@ def hbm_roofline(ix, st, nq, dim, kernel_ms, kernel_name):
 
 
 def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_host=None, filtered_seconds=0.0, boundary_answers=None,
-                 mixed_seconds=0.0, mixed_fresh=None, headroom=0):
+                 mixed_seconds=0.0, mixed_fresh=None, headroom=0, other_index=None):
     """The CPU restatement of the usearch algorithm (oracle/, kind "port") on the host cores of this box, on the
     SAME graph: searches one query per call from T threads (reference usearch.rs:212), then -- the build half of the
     metric -- inserts `extra_host` further vectors into that full-size index from T threads (usearch.rs:194-196).
@@ -290,8 +290,19 @@ def cpu_baseline(ix, queries_host, k, ef, seconds, gpu_keys, gpu_dist, extra_hos
             return act
         try:
             out["mixed"] = mixed_record(actor_of, queries_host, mixed_fresh, slots, mixed_seconds, named=False)  # (a CPU usearch has no verdict memory)
+            if other_index is not None:  # the reference's own shape: searches on ANOTHER index (its own actor) beside the updates
+                o_b = oracle.OracleIndex(ix.dim, ix.metric, 16, 128, ef, quantization=ix.scalar)
+                o_b.import_graph(other_index.export_graph())
+                act_b = _actor.IndexActor(ix.dim, ix.metric, 16, 128, ef, workers=threads, quantization=ix.scalar, index_vtable=oracle.trait_vtable())
+                act_b.adopt_partition(0, o_b.h, o_b.size())
+                act_a = actor_of()
+                try:
+                    out["mixed"]["two_indexes"] = two_index_record(act_a, act_b, queries_host, mixed_fresh, slots, mixed_seconds)
+                finally:
+                    act_a.stop()
+                    act_b.stop()
         except Exception as e:  # noqa: BLE001
-            out["mixed"] = {"error": repr(e)}
+            out["mixed"] = dict(out.get("mixed") or {}, error=repr(e))
     return out, keys
 
 
@@ -422,6 +433,24 @@ def config_c5(vs, dev, n, dim, k, dist_kind, rank):
                         "hbm_floor": {"bytes_per_batch": float(n) * row_bytes, "achieved_gbs": float(n) * row_bytes / (exact_ms * 1e-3) / 1e9, "frac_of_8tbs": float(n) * row_bytes / (exact_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
            "hnsw_walk_ef200": {"ms_per_batch": walk_ms, "queries_per_s": nq / walk_ms * 1e3, "recall_at_10_vs_exact": round(rec, 4)},
            "build_vectors_per_s": n / build_s, "seconds": round(time.perf_counter() - t0, 1)}
+    # PMC-measured HBM bytes of the dominant kernel (scripts/profile_c5.sh -> profiles/*_c5_kernels.json: FETCH_SIZE x 2 + WRITE_SIZE,
+    # separate --pmc passes), per batch = the record's traffic / algorithmic ratio of the tile kernel x this batch's algorithmic bytes;
+    # used only while the kernel sources hash to what the record was measured on
+    try:
+        import glob
+        from scripts.summarise_profiles import kernel_sources_sha16
+        sha_now = kernel_sources_sha16()
+        for tr in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c5_kernels.json"))):
+            rec_ = json.load(open(tr))
+            tile = rec_.get("kernels", {}).get("p1_tile_kernel")
+            if tile and "ratio_traffic_over_algorithmic" in tile and out["roofline"]["bound"] == "hbm":
+                fresh = rec_.get("kernel_sources_sha16") == sha_now
+                out["roofline"]["traffic_source"] = {"file": os.path.relpath(tr, ROOT), "kernel_sources_sha16": rec_.get("kernel_sources_sha16"),
+                                                     "current_kernel_sources_sha16": sha_now, "stale": not fresh,
+                                                     "traffic_over_algorithmic": tile["ratio_traffic_over_algorithmic"]}
+                out["roofline"]["traffic"] = tile["ratio_traffic_over_algorithmic"] * float(n) * row_bytes if fresh else None
+    except Exception:
+        pass
     del ix, q
     torch.cuda.empty_cache()
     return out
@@ -618,6 +647,27 @@ def boundary_record(ix, queries_host, truth, k, seconds):
 
 MIXED_LEGS = ("cdc_insert", "cdc_update", "cdc_delete", "search_while_updating:16+0", "search_while_updating", "search:0+16@named",
               "search_while_updating@named", "search_while_inserting", "search_while_deleting")
+
+
+def two_index_record(actor_a, actor_b, queries_host, fresh, n_a, seconds):
+    """The reference's OWN shape of search_while_updating (benches/pipeline.rs:857-1007 with run_search_in_background, :1324-1404): the
+    updates go to one index while the background searches hammer ANOTHER index of the same process -- every index has its own actor and
+    its own permits (usearch.rs:688-741), so the searches do not drain between the updates; they share the device (here: the other
+    index's pods stay open, the updated index's flushes run beside them)."""
+    import threading
+    from vector_store_amd import callers
+    res = {}
+
+    def searchers():
+        res["s"] = callers.mixed_run(actor_b, queries_host[:4096], None, plain_callers=16, filtered_callers=16, seconds=seconds)
+
+    def producers():
+        res["p"] = callers.mixed_run(actor_a, queries_host[:64], fresh, modify=callers.UPDATE, existing_keys=n_a // 2, producers=1, seconds=seconds)
+    th = [threading.Thread(target=searchers), threading.Thread(target=producers)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    return {"updates_per_s": res["p"]["items_per_s"], "update_item": res["p"].get("item"), "errors": res["p"]["errors"] + res["s"]["errors"],
+            "searches_on_the_other_index": {"plain": res["s"].get("plain"), "filtered": res["s"].get("filtered")}}
 
 
 def mixed_record(actor_of, queries_host, fresh, n, seconds, producers=(1, 16), named=True):
@@ -961,6 +1011,7 @@ def main():
 
     # ---- CPU baseline + id parity at full size: rank 0, N=1 only, bounded
     violations = 0
+    other_ix = None
     if world == 1 and a.cpu_seconds > 0:
         try:
             step(0)
@@ -970,9 +1021,18 @@ def main():
             extra = make_data(a.cpu_build_vectors, dim, a.dist, 97531, dev, a.rank).cpu().numpy() if a.cpu_build_vectors else None
             want_filtered = a.quantization == "f32" and isinstance(out.get("boundary"), dict) and "filtered" in out["boundary"]
             mixed_fresh = make_data(8192, dim, a.dist, 24680, dev, a.rank).cpu().numpy() if a.mixed_seconds > 0 else None
+            if a.mixed_seconds > 0 and a.quantization == "f32" and other_ix is None:
+                try:  # the index the background searches of boundary.mixed.two_indexes go to (1M x dim, same generator)
+                    ob = make_data(1_000_000, dim, a.dist, 777, dev, a.rank)
+                    other_ix, _ = build_index(vs, ob, np.arange(1_000_000, dtype=np.uint64), a.metric)
+                    other_ix.set_expansion_search(ef)
+                    del ob
+                except Exception:  # noqa: BLE001
+                    other_ix = None
             cb, ckeys = cpu_baseline(ix, queries.cpu().numpy(), k, ef, a.cpu_seconds, gk, gd, extra,
                                      filtered_seconds=min(6.0, a.cpu_seconds) if want_filtered else 0.0, boundary_answers=boundary_answers,
-                                     mixed_seconds=a.mixed_seconds if a.quantization == "f32" else 0.0, mixed_fresh=mixed_fresh, headroom=300_000)
+                                     mixed_seconds=a.mixed_seconds if a.quantization == "f32" else 0.0, mixed_fresh=mixed_fresh, headroom=300_000,
+                                     other_index=other_ix)
             boundary_answers = None
             cb["recall_at_10"] = round(recall_at_k(truth, ckeys), 4)
             out["cpu_baseline"] = cb
@@ -1009,6 +1069,23 @@ def main():
             mixed = mixed_record(actor_of, queries.cpu().numpy(), mixed_fresh, n, a.mixed_seconds)
             m1 = ix.modify_stats()
             mixed["engine"] = {kk: m1[kk] - m0[kk] for kk in m1}
+            if other_ix is None:
+                ob = make_data(1_000_000, dim, a.dist, 777, dev, a.rank)
+                other_ix, _ = build_index(vs, ob, np.arange(1_000_000, dtype=np.uint64), a.metric)
+                other_ix.set_expansion_search(ef)
+                del ob
+            act_a = actor_of()
+            act_b = _actor.IndexActor(dim, vs.METRICS[a.metric], 16, 128, ef, workers=effective_cores())
+            act_b.adopt_partition(0, other_ix.h, other_ix.size())
+            try:
+                mixed["two_indexes"] = two_index_record(act_a, act_b, queries.cpu().numpy(), mixed_fresh, n, a.mixed_seconds)
+                mixed["two_indexes"]["note"] = "updates on the 10M index through its actor, 16 plain + 16 filtered searchers on a 1M index through its own actor"
+                ctwo = (out.get("cpu_baseline", {}).get("mixed", {}) or {}).get("two_indexes") if isinstance(out.get("cpu_baseline"), dict) else None
+                if isinstance(ctwo, dict) and ctwo.get("updates_per_s"):
+                    mixed["two_indexes"]["vs_cpu"] = {"updates": mixed["two_indexes"]["updates_per_s"] / ctwo["updates_per_s"]}
+            finally:
+                act_a.stop()
+                act_b.stop()
             cm = out.get("cpu_baseline", {}).get("mixed", {}) if isinstance(out.get("cpu_baseline"), dict) else {}
             for pk, legs in mixed.items():  # the CPU's rate beside each leg (same actor, same driver, the oracle behind it)
                 if not pk.startswith("producers_") or not isinstance(cm.get(pk), dict):
@@ -1031,7 +1108,7 @@ def main():
     if world == 1 and not a.no_side_records and a.quantization == "f32":
         want = a.configs.split(",") if a.configs not in ("auto", "none") else []
         import gc
-        se = ix = step = finish = probe = result_keys = result_dist = gs = None  # every reference to the headline index
+        se = ix = step = finish = probe = result_keys = result_dist = gs = other_ix = None  # every reference to the headline index
         gc.collect()
         torch.cuda.empty_cache()
         free_b, _ = torch.cuda.mem_get_info()

@@ -43,8 +43,9 @@ def _same_start(n, dim, extra, seed, ef=64):
 
 
 def _script(n, extra, steps, seed):
-    """A deterministic list of modifications: ("update", key, row) = RemoveBeforeAddValue + AddVector (monitor_items.rs:301-313),
-    ("insert", key, row), ("delete", key)."""
+    """A deterministic list of single modifications, in the order the reference issues them: an update is RemoveBeforeAddValue then
+    AddVector (monitor_items.rs:301-313) -- two messages, and a search may be served between them --, an insert is one add, a delete
+    one remove.  ("remove", key) / ("add", key, row)."""
     rng = np.random.default_rng(seed)
     alive = set(range(n))
     next_new, next_row = n + (1 << 20), n
@@ -55,10 +56,11 @@ def _script(n, extra, steps, seed):
             key = int(rng.integers(0, n))
             if key not in alive:
                 continue
-            ops.append(("update", key, next_row))
+            ops.append(("remove", key))
+            ops.append(("add", key, next_row))
             next_row += 1
         elif r < 0.8 and next_row < n + extra:
-            ops.append(("insert", next_new, next_row))
+            ops.append(("add", next_new, next_row))
             alive.add(next_new)
             next_new += 1
             next_row += 1
@@ -67,28 +69,25 @@ def _script(n, extra, steps, seed):
             if key not in alive:
                 continue
             alive.discard(key)
-            ops.append(("delete", key))
+            ops.append(("remove", key))
     return ops
 
 
 def _apply_to_oracle(o, op, data):
-    if op[0] == "update":
-        assert o.remove(op[1])
-        o.add(op[1], data[op[2]])
-    elif op[0] == "insert":
+    if op[0] == "add":
         o.add(op[1], data[op[2]])
     else:
         assert o.remove(op[1])
 
 
 def test_interleaved_single_adds_and_removes_with_searches_equal_the_oracle():
-    """1,000 single modifications through the dispatch actor while 8 threads search (plain and filtered) through it: every answer
+    """A thousand single modifications through the dispatch actor while 8 threads search (plain and filtered) through it: every answer
     equals the oracle's in one of the states its call overlapped (a search is a family of its own between two modifications, so that
     state exists): ids and distance bits, no exception (tests/parity_util.py, exact)."""
     from vector_store_amd.actor import IndexActor
     n, dim, k, extra = 100_000, 8, 10, 1200
     v, o, ix, data = _same_start(n, dim, extra, seed=31)
-    ops = _script(n, extra, 1000, seed=5)
+    ops = _script(n, extra, 700, seed=5)   # ~1,100 add / remove messages
     queries = lattice(512, dim, 77, span=500)
     a = IndexActor(dim, v.L2SQ, 16, 128, 64, workers=8)
     a.adopt_partition(0, ix.h, ix.size())
@@ -116,10 +115,7 @@ def test_interleaved_single_adds_and_removes_with_searches_equal_the_oracle():
     [x.start() for x in th]
     try:
         for op in ops:
-            if op[0] == "update":
-                a.remove_vector(0, op[1])
-                assert a.add_vector_wait(0, op[1], data[op[2]])
-            elif op[0] == "insert":
+            if op[0] == "add":
                 assert a.add_vector_wait(0, op[1], data[op[2]])
             else:
                 assert a.remove_vector_wait(0, op[1])
@@ -131,9 +127,12 @@ def test_interleaved_single_adds_and_removes_with_searches_equal_the_oracle():
     total = sum(len(r) for r in records)
     assert total >= 2000, total
     # replay: after e modifications the oracle answers every search whose call overlapped that state
+    # (the counter is advanced by the modifier's thread AFTER its message was processed: a search may already have seen the modification
+    # that was in flight when it returned -- one more state than the counter said)
     by_state = {}
     for r in records:
-        for rec in r:
+        for i, rec in enumerate(r):
+            r[i] = rec = (rec[0], min(rec[1] + 1, len(ops))) + rec[2:]
             for e in range(rec[0], rec[1] + 1):
                 by_state.setdefault(e, []).append(rec)
     matched = set()

@@ -151,6 +151,29 @@ __device__ __forceinline__ float wave_min(float v) {
     return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, VS_DPP_ROR(v, 8));
+    v = fmaxf(v, VS_DPP_ROR(v, 4));
+    v = fmaxf(v, VS_DPP_ROR(v, 2));
+    v = fmaxf(v, VS_DPP_ROR(v, 1));
+    return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
+#define VS_DPP_ROR_U(x, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x120 + (n), 0xF, 0xF, true))
+    uint32_t t = VS_DPP_ROR_U(v, 8);
+    v = v > t ? v : t;
+    t = VS_DPP_ROR_U(v, 4);
+    v = v > t ? v : t;
+    t = VS_DPP_ROR_U(v, 2);
+    v = v > t ? v : t;
+    t = VS_DPP_ROR_U(v, 1);
+    v = v > t ? v : t;
+#undef VS_DPP_ROR_U
+    const uint32_t a = rl_u(v, 0), b = rl_u(v, 16), c = rl_u(v, 32), d = rl_u(v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
 // ---- helper waves --------------------------------------------------------------------------------------------------
 template <int AR, int I, class Sh>
 __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Query<AR, I>& q, Sh& sh, const WalkSpace& ws, bool tomb,
@@ -323,7 +346,92 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         return v;
     };
     float radius = INF;  // top's last distance once it is full
+    // Plain queries (round 5): `top` as a BAG.  Their answers are ordered as the caller's other kernels order them -- by (distance,
+    // slot) --, so all the walk needs of `top` while it runs is its size and its largest (distance, slot): the radius, and who leaves when
+    // a closer member arrives.  An insertion is then one masked register write and -- once the bag is full -- a wave-wide maximum,
+    // instead of a rank by ballots over every register row plus a lane shift of the whole buffer (a plain hop admits ~8 neighbours:
+    // pushes + `top` were 44 % of it); the bag is sorted once, when the walk is over (bag_sort, through the pool's LDS: `next` is dead by
+    // then).  Filtered walks keep usearch's sorted buffer: their tie rules look at positions.
+    constexpr bool kBagMode = MODE == kPipePlain;  // (compile-time: the plain instance carries no sorted buffer at all)
+    uint32_t mx_pos = 0;  // bag, full: the position (lane * R + row) of its largest (distance, slot)
+    auto bag_find_max = [&]() {
+        float lm = -INF;
+#pragma unroll
+        for (int j = 0; j < R; ++j) lm = L * (uint32_t)R + (uint32_t)j < sz ? fmaxf(lm, top.d[j]) : lm;
+        radius = wave_max(lm);
+        // who holds it: among equal distances the largest slot (the last one in (distance, slot) order)
+        uint32_t ls = 0, lj = 0;
+        bool has = false;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const bool hit = L * (uint32_t)R + (uint32_t)j < sz && top.d[j] == radius;
+            if (hit && (!has || top.s[j] > ls)) {
+                ls = top.s[j];
+                lj = (uint32_t)j;
+                has = true;
+            }
+        }
+        uint64_t who = __ballot(has);
+        if (__popcll(who) > 1) {
+            const uint32_t ms = wave_max_u(has ? ls + 1u : 0u);
+            who = __ballot(has && ls + 1u == ms);
+        }
+        const uint32_t pick = (uint32_t)__builtin_ctzll(who | (1ull << 63));
+        mx_pos = pick * (uint32_t)R + rl_u(lj, pick);
+    };
+    auto bag_sort = [&]() {  // the bag -> ascending by (distance, slot), in the registers' positional layout (what the output reads)
+        if (2u * sz > pool_cap) {
+            redo = true;
+            return;
+        }
+        uint64_t key[R];
+        uint32_t rk[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const uint32_t p = L * (uint32_t)R + (uint32_t)j;
+            if (p < sz) pool[p] = make_uint2(__float_as_uint(top.d[j]), top.s[j]);
+            key[j] = ((uint64_t)dist_key(__float_as_uint(top.d[j])) << 32) | top.s[j];
+            rk[j] = 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (uint32_t i = 0; i < sz; ++i) {
+            const uint2 e = pool[i];  // (every lane reads the same entry: a broadcast)
+            const uint64_t ke = ((uint64_t)dist_key(e.x) << 32) | e.y;
+#pragma unroll
+            for (int j = 0; j < R; ++j) rk[j] += ke < key[j] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (L * (uint32_t)R + (uint32_t)j < sz) pool[sz + rk[j]] = make_uint2(__float_as_uint(top.d[j]), top.s[j]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const uint32_t p = L * (uint32_t)R + (uint32_t)j;
+            const uint2 e = p < sz ? pool[sz + p] : make_uint2(__float_as_uint(INF), kInvalid);
+            top.d[j] = __uint_as_float(e.x);
+            top.s[j] = e.y;
+        }
+    };
     auto top_insert = [&](float d, uint32_t s) {  // top.insert({d, s}, ef) with d below the radius when full: in front of equal entries
+        if constexpr (kBagMode) {
+            bool eq = false;
+#pragma unroll
+            for (int j = 0; j < R; ++j) eq = eq || (L * (uint32_t)R + (uint32_t)j < sz && top.d[j] == d);
+            const bool eq_any = __ballot(eq) != 0ull;
+            if (tie_active && (eq_any || sz + 1u >= ef)) redo = true;  // (the sorted buffer's rule, unchanged)
+            const uint32_t p = sz < ef ? sz : mx_pos;  // a free position -- or the largest member's: it leaves (d is below the radius)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const bool here = L * (uint32_t)R + (uint32_t)j == p;
+                top.d[j] = here ? d : top.d[j];
+                top.s[j] = here ? s : top.s[j];
+            }
+            sz = sz < ef ? sz + 1u : ef;
+            if (sz == ef) bag_find_max();
+            return;
+        } else {
         uint32_t rank = 0;
         bool eq = false;
 #pragma unroll
@@ -357,6 +465,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (sz == ef) radius = top_at(ef - 1u);
         if constexpr (kFilter) {
             if (tie_active && !fused_order && sz == ef && radius < tie_v) redo = true;  // (the window's other candidates would end the walk, not be expanded)
+        }
         }
     };
     auto pool_append = [&](bool mine, float d, uint32_t s) {  // every lane with `mine` appends its entry
@@ -1076,6 +1185,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         for (uint32_t i = L; i < vcount; i += 64u) ws.bitmap[ws.vlog[i] >> 5] = 0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (kBagMode) {
+        if (!redo) bag_sort();
+    }
     PipeOut out;
     out.status = redo ? 1u : explore ? 3u : over_budget ? 2u : 0u;
     out.sz = sz;

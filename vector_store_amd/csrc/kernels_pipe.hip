@@ -148,6 +148,8 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
     Counters cnt = {0, 0, 0};
     float start_d = 0.f;
     uint32_t start;
+    // (s_setprio 3 for the walker was measured in round 5: 925 -> 920 us per lone walk, 17 callers 17.5-17.9k -> 17.6-18.1k queries/s --
+    // within the noise: the walker is bound by its own instruction count, one issue per four clocks, not by the helpers on its SIMD)
     // (inlined whatever the size of the kernel: an out-of-line call passes the query's registers through scratch memory)
     [[clang::always_inline]] start = greedy_descent<AR, I>(ix, sh, q, entry_slot, max_level, 0, cnt, lane, &start_d);
     team_release(sh, lane);  // the last barrier: from here on the waves meet through LDS words only

@@ -105,6 +105,7 @@ struct PipeShared : TeamBox<TM>, VisitedLds<!VISG, (EFCAP <= 256 ? 1024 : 2048),
     // refill
     uint32_t hist[256];
     uint2 stage[64];
+    alignas(16) uint2 merge[kEfCap + 64];  // hop_batch: one hop's admissions merged into `top` (a scatter by destination)
     uint32_t prof_jobs[2];  // profile builds: job parts done, their clocks
 };
 
@@ -289,7 +290,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     const uint32_t L = (uint32_t)lane;
     const float INF = __builtin_inff();
 #ifdef VS_WALK_PROFILE
-    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t prof_t = __builtin_amdgcn_s_memtime();
 #endif
     [[maybe_unused]] uint32_t dbg_max_next = 0, dbg_pushed = 0, dbg_miss = 0, dbg_refill = 0, dbg_early = 0, dbg_windows = 0, dbg_waits = 0, dbg_spills = 0;
@@ -346,92 +347,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         return v;
     };
     float radius = INF;  // top's last distance once it is full
-    // Plain queries (round 5): `top` as a BAG.  Their answers are ordered as the caller's other kernels order them -- by (distance,
-    // slot) --, so all the walk needs of `top` while it runs is its size and its largest (distance, slot): the radius, and who leaves when
-    // a closer member arrives.  An insertion is then one masked register write and -- once the bag is full -- a wave-wide maximum,
-    // instead of a rank by ballots over every register row plus a lane shift of the whole buffer (a plain hop admits ~8 neighbours:
-    // pushes + `top` were 44 % of it); the bag is sorted once, when the walk is over (bag_sort, through the pool's LDS: `next` is dead by
-    // then).  Filtered walks keep usearch's sorted buffer: their tie rules look at positions.
-    constexpr bool kBagMode = MODE == kPipePlain;  // (compile-time: the plain instance carries no sorted buffer at all)
-    uint32_t mx_pos = 0;  // bag, full: the position (lane * R + row) of its largest (distance, slot)
-    auto bag_find_max = [&]() {
-        float lm = -INF;
-#pragma unroll
-        for (int j = 0; j < R; ++j) lm = L * (uint32_t)R + (uint32_t)j < sz ? fmaxf(lm, top.d[j]) : lm;
-        radius = wave_max(lm);
-        // who holds it: among equal distances the largest slot (the last one in (distance, slot) order)
-        uint32_t ls = 0, lj = 0;
-        bool has = false;
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const bool hit = L * (uint32_t)R + (uint32_t)j < sz && top.d[j] == radius;
-            if (hit && (!has || top.s[j] > ls)) {
-                ls = top.s[j];
-                lj = (uint32_t)j;
-                has = true;
-            }
-        }
-        uint64_t who = __ballot(has);
-        if (__popcll(who) > 1) {
-            const uint32_t ms = wave_max_u(has ? ls + 1u : 0u);
-            who = __ballot(has && ls + 1u == ms);
-        }
-        const uint32_t pick = (uint32_t)__builtin_ctzll(who | (1ull << 63));
-        mx_pos = pick * (uint32_t)R + rl_u(lj, pick);
-    };
-    auto bag_sort = [&]() {  // the bag -> ascending by (distance, slot), in the registers' positional layout (what the output reads)
-        if (2u * sz > pool_cap) {
-            redo = true;
-            return;
-        }
-        uint64_t key[R];
-        uint32_t rk[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const uint32_t p = L * (uint32_t)R + (uint32_t)j;
-            if (p < sz) pool[p] = make_uint2(__float_as_uint(top.d[j]), top.s[j]);
-            key[j] = ((uint64_t)dist_key(__float_as_uint(top.d[j])) << 32) | top.s[j];
-            rk[j] = 0u;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (uint32_t i = 0; i < sz; ++i) {
-            const uint2 e = pool[i];  // (every lane reads the same entry: a broadcast)
-            const uint64_t ke = ((uint64_t)dist_key(e.x) << 32) | e.y;
-#pragma unroll
-            for (int j = 0; j < R; ++j) rk[j] += ke < key[j] ? 1u : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (L * (uint32_t)R + (uint32_t)j < sz) pool[sz + rk[j]] = make_uint2(__float_as_uint(top.d[j]), top.s[j]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const uint32_t p = L * (uint32_t)R + (uint32_t)j;
-            const uint2 e = p < sz ? pool[sz + p] : make_uint2(__float_as_uint(INF), kInvalid);
-            top.d[j] = __uint_as_float(e.x);
-            top.s[j] = e.y;
-        }
-    };
     auto top_insert = [&](float d, uint32_t s) {  // top.insert({d, s}, ef) with d below the radius when full: in front of equal entries
-        if constexpr (kBagMode) {
-            bool eq = false;
-#pragma unroll
-            for (int j = 0; j < R; ++j) eq = eq || (L * (uint32_t)R + (uint32_t)j < sz && top.d[j] == d);
-            const bool eq_any = __ballot(eq) != 0ull;
-            if (tie_active && (eq_any || sz + 1u >= ef)) redo = true;  // (the sorted buffer's rule, unchanged)
-            const uint32_t p = sz < ef ? sz : mx_pos;  // a free position -- or the largest member's: it leaves (d is below the radius)
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const bool here = L * (uint32_t)R + (uint32_t)j == p;
-                top.d[j] = here ? d : top.d[j];
-                top.s[j] = here ? s : top.s[j];
-            }
-            sz = sz < ef ? sz + 1u : ef;
-            if (sz == ef) bag_find_max();
-            return;
-        } else {
         uint32_t rank = 0;
         bool eq = false;
 #pragma unroll
@@ -465,7 +381,6 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (sz == ef) radius = top_at(ef - 1u);
         if constexpr (kFilter) {
             if (tie_active && !fused_order && sz == ef && radius < tie_v) redo = true;  // (the window's other candidates would end the walk, not be expanded)
-        }
         }
     };
     auto pool_append = [&](bool mine, float d, uint32_t s) {  // every lane with `mine` appends its entry
@@ -521,14 +436,58 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             nf += 1u;
         }
     };
-    // next.insert for the lanes in `mask` (their own nd / ns): below the front's reach -> the front, one at a time; the rest -> the pool
+    // Several entries (the lanes of `fm`, their own nd / ns, none with a cache entry) into the sorted front AT ONCE (round 5: a plain hop
+    // pushes ~8 neighbours below the front's reach, and one front_insert each -- a ballot rank, three readlanes, three lane shifts, six
+    // selects, the displaced entry's append -- was half of the lone walk's clocks, scripts/probe/pipe_phase_probe.sh).  One pass over the
+    // new entries gives every OLD entry the number of new ones in front of it and every NEW entry its rank among the old (behind equal
+    // ones, as front_insert places it) and among the new; then ONE scatter through LDS (sh.stage) puts the 64 closest in place, and
+    // whatever lands beyond position 63 is appended to the pool.  The multiset the front and the pool hold is what the insertions one by
+    // one leave; the order among EQUAL distances may differ, which nothing reads (windows look at distances only).
+    auto front_merge = [&](uint64_t fm, float nd, uint32_t ns) {
+        // (a lane may hold an old entry -- position L of the front -- AND a new one -- neighbour L of the hop: two destinations)
+        const bool in = L < nf, mine = ((fm >> L) & 1ull) != 0ull;
+        uint32_t new_before_old = 0;  // my OLD entry: new entries strictly closer than it
+        uint32_t new_before_new = 0;  // my NEW entry: new entries in front of it (closer, or as close and earlier in the row)
+        uint32_t old_le_new = 0;      // my NEW entry: old entries not farther than it (it goes behind equal ones, as front_insert places it)
+        for (uint64_t r = fm; r; r &= r - 1ull) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(r);
+            const float di = rl_f(nd, i);
+            const uint32_t c = (uint32_t)__popcll(__ballot(in && f_d <= di));
+            old_le_new = L == i ? c : old_le_new;
+            new_before_old += (in && di < f_d) ? 1u : 0u;
+            new_before_new += (mine && i != L && (di < nd || (di == nd && i < L))) ? 1u : 0u;
+        }
+        const uint32_t old_dest = L + new_before_old, new_dest = old_le_new + new_before_new;
+        // beyond position 63: to the pool (old ones may own a cache entry, which they lose)
+        const bool old_out = in && old_dest >= 64u, new_out = mine && new_dest >= 64u;
+        for (uint64_t r = __ballot(old_out && f_c != 0u); r; r &= r - 1ull) free_entry_of(rl_u(f_s, (uint32_t)__builtin_ctzll(r)));
+        pool_append(old_out, f_d, f_s);
+        pool_append(new_out, nd, ns);
+        // the scatter (slot | cache flag << 31: slots are below 2^30)
+        __builtin_amdgcn_wave_barrier();
+        if (in && !old_out) sh.stage[old_dest] = make_uint2(__float_as_uint(f_d), f_s | (f_c << 31));
+        if (mine && !new_out) sh.stage[new_dest] = make_uint2(__float_as_uint(nd), ns);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t total = nf + (uint32_t)__popcll(fm);
+        nf = total < 64u ? total : 64u;
+        const uint2 me = L < nf ? sh.stage[L] : make_uint2(__float_as_uint(INF), kInvalid);
+        f_d = __uint_as_float(me.x);
+        f_s = L < nf ? (me.y & 0x7FFFFFFFu) : kInvalid;
+        f_c = L < nf ? (me.y >> 31) : 0u;
+    };
+    // next.insert for the lanes in `mask` (their own nd / ns): below the front's reach -> the front (one: front_insert; several: one merge);
+    // the rest -> the pool
     auto push_lanes = [&](uint64_t mask, float nd, uint32_t ns) {
         const float reach = nf == 64u ? rl_f(f_d, 63) : (kFilter ? fminf(pool_lb, spill_lb) : pool_lb);  // closer than this: belongs to the front
         const bool mine = ((mask >> L) & 1ull) != 0ull;
         const uint64_t fm = __ballot(mine && nd < reach);
         pool_append(mine && !(nd < reach), nd, ns);
-        for (uint64_t r = fm; r; r &= r - 1ull) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(r);
+        if (__popcll(fm) > 1) {
+            front_merge(fm, nd, ns);
+        } else if (fm) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(fm);
             front_insert(rl_f(nd, j), rl_u(ns, j), 0u);
         }
         dbg_pushed += (uint32_t)__popcll(mask);
@@ -538,6 +497,93 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (d < reach) front_insert(d, s, 0u);
         else pool_append_one(d, s);
         dbg_pushed += 1u;
+    };
+    // One hop's admissions AT ONCE (round 5).  The CPU loop takes a hop's fresh neighbours one at a time against a radius that moves with
+    // every admission; done literally that is a rank by ballots over every register row, a lane shift of the whole buffer and an insertion
+    // into the front PER NEIGHBOUR -- half of a lone walk's clocks (scripts/probe/pipe_phase_probe.sh).  The same decisions in closed form:
+    //   * neighbour j passes `top.size() < limit || d < radius` exactly when fewer than `limit` members of
+    //     top  U  {admissible neighbours before j in the row}  are not farther than it (the radius IS the limit-th smallest of that set;
+    //     neighbours turned away earlier lie at or beyond it and cannot change it): one count over `top` and one over the row;
+    //   * `top` afterwards is the `limit` closest of top U {passed and admissible}: every old member moves up by the number of new ones
+    //     closer than it, every new one lands at (old members not farther) + (new ones in front of it) -- ONE scatter by destination
+    //     through LDS (sh.merge), whatever lands at `limit` or beyond is gone;
+    //   * everything that passed enters `next` (push_lanes: one merge into the front as well).
+    // The closed form is exact for the SETS; the ORDER among equal distances is what the literal code defines, so the merged list is
+    // checked for equal neighbours (up to the first entry that left) BEFORE anything is committed, and a hop that has any -- or runs
+    // inside a tie window, or holds a distance that is not a finite number -- goes through the literal loop instead (returns false).
+    auto hop_batch = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n) -> bool {
+        if (tie_active) return false;
+        const bool mine = ((cand >> L) & 1ull) != 0ull;
+        if (__ballot(mine && !(nd < INF))) return false;
+        const bool okl = mine && ((okmask >> L) & 1ull) != 0ull;
+        uint64_t pass = 0ull;
+        uint32_t my_le = 0;  // lane j: members of `top` not farther than its neighbour
+        for (uint64_t r = cand; r; r &= r - 1ull) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(r);
+            const float dj = rl_f(nd, j);
+            uint32_t gt = 0;  // (the rows' unused positions hold +inf: counted here, taken off below)
+#pragma unroll
+            for (int i = 0; i < R; ++i) gt += (uint32_t)__popcll(__ballot(top.d[i] > dj));
+            const uint32_t le = 64u * (uint32_t)R - gt;
+            const uint32_t before = (uint32_t)__popcll(__ballot(okl && nd <= dj) & ((1ull << j) - 1ull));
+            if (le + before < ef) {
+                pass |= 1ull << j;
+                my_le = L == j ? le : my_le;
+            }
+        }
+        WALK_STAMP(8);  // (inside "pushes, top": who passes)
+        const uint64_t tm = pass & okmask;
+        if (tm) {
+            const bool tmine = ((tm >> L) & 1ull) != 0ull;
+            uint32_t in_front = 0;  // my NEW entry: new ones in front of it (closer, or as close and earlier in the row)
+            uint32_t shift[R];      // my OLD entries: new ones closer than each
+#pragma unroll
+            for (int i = 0; i < R; ++i) shift[i] = 0u;
+            for (uint64_t r = tm; r; r &= r - 1ull) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(r);
+                const float dj = rl_f(nd, j);
+#pragma unroll
+                for (int i = 0; i < R; ++i) shift[i] += dj < top.d[i] ? 1u : 0u;
+                in_front += (tmine && (dj < nd || (dj == nd && j < L))) ? 1u : 0u;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const uint32_t p = L * (uint32_t)R + (uint32_t)i;
+                if (p < sz) sh.merge[p + shift[i]] = make_uint2(__float_as_uint(top.d[i]), top.s[i]);
+            }
+            if (tmine) sh.merge[my_le + in_front] = make_uint2(__float_as_uint(nd), n);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t total = sz + (uint32_t)__popcll(tm);
+            uint2 t[R + 1];
+#pragma unroll
+            for (int i = 0; i <= R; ++i) {
+                const uint32_t p = L * (uint32_t)R + (uint32_t)i;
+                t[i] = p < total ? sh.merge[p] : make_uint2(__float_as_uint(INF), kInvalid);
+            }
+            bool tie = false;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const uint32_t p = L * (uint32_t)R + (uint32_t)i;
+                tie = tie || (p + 1u < total && p < ef && __uint_as_float(t[i].x) == __uint_as_float(t[i + 1].x));
+            }
+            if (__ballot(tie)) return false;  // (nothing committed: `top` is as it was)
+            const uint32_t kept = total < ef ? total : ef;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const bool keep = L * (uint32_t)R + (uint32_t)i < kept;
+                top.d[i] = keep ? __uint_as_float(t[i].x) : INF;
+                top.s[i] = keep ? t[i].y : kInvalid;
+            }
+            sz = kept;
+            if (sz == ef) radius = top_at(ef - 1u);
+        }
+        WALK_STAMP(9);  // (the merge into `top`)
+        push_lanes(pass, nd, n);
+        WALK_STAMP(10);  // (the pushes)
+        return true;
     };
     // Radix select on the order-preserving distance bits of pool[0 .. np): a threshold with between limit / 4 and limit keys below it
     // (all: the whole pool is at most `limit` entries).  ok = false: more than `limit` entries share the smallest distance (count says how many).
@@ -1113,25 +1159,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             const uint64_t okmask = verdicts(cand, n, fl);
             if (over_budget) break;  // enough unknown slots listed for one round: the host evaluates them and launches again
             WALK_STAMP(4);  // verdicts
-            const uint32_t oks = (uint32_t)__popcll(okmask);
-            bool done = false;
-            if (sz + oks <= ef && sz < ef) {
-                // `top` cannot outgrow its limit during this hop: every fresh neighbour is pushed, the admitted ones enter `top` -- unless
-                // the one that fills `top` exactly has neighbours behind it, which then meet a finite radius: the literal loop below
-                bool filled_early = false;
-                if (sz + oks == ef) {
-                    const uint32_t last_ok = 63u - (uint32_t)__builtin_clzll(okmask | 1ull);
-                    filled_early = oks != 0u && (cand >> last_ok) > 1ull;
-                }
-                if (!filled_early) {
-                    push_lanes(cand, nd, n);
-                    for (uint64_t r = okmask; r; r &= r - 1ull) {
-                        const uint32_t j = (uint32_t)__builtin_ctzll(r);
-                        top_insert(rl_f(nd, j), rl_u(n, j));
-                    }
-                    done = true;
-                }
-            }
+            const bool done = hop_batch(cand, okmask, nd, n);
             // the CPU loop as written: one neighbour at a time, in adjacency order, against the moving radius
             for (uint64_t r = done ? 0ull : cand; r; r &= r - 1ull) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(r);
@@ -1168,6 +1196,11 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         debug[0] = (uint32_t)(prof[7] >> 4);                      // (profile builds: the wait for the entry instead of the largest `next`)
         debug[1] = dbg_waits;                                     // (hops that waited)
         debug[10] = sh.prof_jobs[0] ? sh.prof_jobs[1] / sh.prof_jobs[0] : 0u;  // (helpers: clocks per job part)
+#if VS_WALK_PROFILE == 2  // (inside "pushes, top": who passes / the merge / the pushes, in the places of atomics / verdicts / schedule)
+        debug[6] = (uint32_t)(prof[8] >> 4);
+        debug[7] = (uint32_t)(prof[9] >> 4);
+        debug[9] = (uint32_t)(prof[10] >> 4);
+#endif
 #endif
 #ifndef VS_WALK_PROFILE
         debug[10] = dbg_miss;
@@ -1185,9 +1218,6 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         for (uint32_t i = L; i < vcount; i += 64u) ws.bitmap[ws.vlog[i] >> 5] = 0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (kBagMode) {
-        if (!redo) bag_sort();
-    }
     PipeOut out;
     out.status = redo ? 1u : explore ? 3u : over_budget ? 2u : 0u;
     out.sz = sz;

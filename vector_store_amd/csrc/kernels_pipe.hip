@@ -75,6 +75,7 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
         sh.job_state[tid] = 0u;
         if (tid == 0) {
             sh.stop = 0u;
+            sh.tw_req = sh.tw_done = 0u;
             sh.prof_jobs[0] = sh.prof_jobs[1] = 0u;
         }
     }
@@ -142,6 +143,12 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
             return;
         }
 #endif
+        if constexpr (MODE == kPipePlain) {
+            if (w == kPipeTopWave) {  // plain walks: this wave keeps `top` (pipe_device.hpp, "the top wave")
+                pipe_top_loop<EFCAP / 64>(sh, ef, a.pipe_fused_order != 0u, lane);
+                return;
+            }
+        }
         pipe_helper_loop<AR, I>(ix, q, sh, ws, tomb, allow, known, lane, w);
         return;
     }

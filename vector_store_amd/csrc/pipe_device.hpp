@@ -106,6 +106,15 @@ struct PipeShared : TeamBox<TM>, VisitedLds<!VISG, (EFCAP <= 256 ? 1024 : 2048),
     uint32_t hist[256];
     uint2 stage[64];
     alignas(16) uint2 merge[kEfCap + 64];  // hop_batch: one hop's admissions merged into `top` (a scatter by destination)
+    // the top wave's mailbox (plain walks, pipe_top_loop): a hop's admitted neighbours from the walker; `top`'s size and radius back
+    float tw_nd[64];
+    uint32_t tw_n[64], tw_le[64];
+    uint32_t tw_cand[2], tw_ok[2], tw_pass[2];
+    uint32_t tw_flags;  // 1: inside a tie window; 4: a row with an infinity or a NaN (the literal loop: who passed comes back in tw_pass)
+    float tw_tie_v;
+    uint32_t tw_sz, tw_redo;
+    float tw_radius;
+    uint32_t tw_req, tw_done;  // sequence numbers: posted by the walker / merged into `top`
     uint32_t prof_jobs[2];  // profile builds: job parts done, their clocks
 };
 
@@ -261,82 +270,31 @@ struct PipeTop {
     uint32_t s[R];
 };
 
-struct PipeOut {
-    uint32_t status;  // 0 answered; 1 redo (an order-relevant tie / structure outgrown); 2 the round's budget of unknown verdicts is spent (lazy filter)
-    uint32_t sz;
-};
+constexpr uint32_t kPipeTopWave = 1u;  // plain walks: the wave that keeps `top` (it measures nothing)
 
-// MODE: what the instance is for -- each carries only the state it needs (the walker's loop lives on scalar registers, and every
-// wave-uniform variable it does not need is one it does not have to spill):
-//   kPipePlain    plain lone queries (no filter): no verdict bookkeeping, `next` never outgrows LDS (no spilling), fused-list tie order
-//   kPipeFiltered the exact walk of a filtered query
-//   kPipeExplore  an exploring round of a lazily filtered query
-enum : int { kPipePlain = 0, kPipeFiltered = 1, kPipeExplore = 2 };
-template <int AR, int I, int MODE, class Sh>
-__device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2* pool, uint32_t pool_cap, const WalkSpace& ws, uint32_t start,
-                                             float start_d, uint32_t ef, bool tomb, const uint32_t* allow, const uint32_t* known,
-                                             uint32_t* unknown_list, uint32_t* unknown_count, uint32_t unknown_cap, uint32_t unknown_budget,
-                                             uint32_t* consulted_out, Counters& cnt, int lane, PipeTop<Sh::kEfCap / 64>& top, uint32_t* debug,
-                                             bool fused_order) {
-    constexpr bool explore = MODE == kPipeExplore;
-    constexpr bool kFilter = MODE != kPipePlain;
-    if constexpr (!kFilter) {
-        allow = nullptr;
-        known = nullptr;
-    }
-    constexpr int R = Sh::kEfCap / 64;
-    constexpr uint32_t TM = (uint32_t)Sh::kTeam;
-    constexpr uint32_t K = (uint32_t)kPipeCache;
-    const uint32_t L = (uint32_t)lane;
-    const float INF = __builtin_inff();
-#ifdef VS_WALK_PROFILE
-    uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t prof_t = __builtin_amdgcn_s_memtime();
-#endif
-    [[maybe_unused]] uint32_t dbg_max_next = 0, dbg_pushed = 0, dbg_miss = 0, dbg_refill = 0, dbg_early = 0, dbg_windows = 0, dbg_waits = 0, dbg_spills = 0;
-    bool redo = false, over_budget = false;
-    const uint32_t guess_t = unknown_budget >> 24;
-    unknown_budget &= 0xFFFFFFu;
-    uint32_t ucount = 0, consulted = 0, vcount = 0;
-    bool vlog_lost = false;
-    // front / pool / top
-    float f_d = INF;
-    uint32_t f_s = kInvalid, f_c = 0, nf = 0, np = 0;  // f_c: 1 = a cache entry (complete or being measured) belongs to this candidate
-    float pool_lb = INF;  // the smallest distance in the pool
-    // (`next` beyond the pool: slots in global memory, see spill() below)
-    const uint32_t slot_cap = kFilter ? pool_cap / 2u : 0u;
-    const uint32_t n_slots = (kFilter && slot_cap && ws.heap) ? (ws.heap_cap / slot_cap < 64u ? ws.heap_cap / slot_cap : 64u) : 0u;
-    uint32_t g_cnt = 0;    // lane j: entries of slot j
-    float g_min = INF;     // lane j: their smallest distance
-    float spill_lb = INF;  // the smallest distance in any slot (plain queries: never anything)
-    constexpr uint32_t kPoolSlack = 192u;  // room a hop in progress may still need (64 pushes and as many entries displaced from the front)
-    bool spill_now = false;
+// `top` -- usearch's sorted result buffer, EFCAP / 64 consecutive positions per lane -- and what a hop does to it.  The walker's own
+// object in filtered walks; the top wave's in plain ones (pipe_top_loop).
+template <int R, bool kFilter, class Sh>
+struct TopOps {
+    PipeTop<R>& top;
+    Sh& sh;
+    const uint32_t L, ef;
+    const bool fused_order;
     uint32_t sz = 0;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        top.d[j] = INF;
-        top.s[j] = kInvalid;
-    }
-    uint32_t tag = kInvalid;  // lane e < kPipeCache: the candidate cache entry e belongs to
-    // Order among EQUAL distances: the one thing these structures do not reproduce.  While two candidates with one distance v wait in
-    // `next` together ("window": from the pop of the first of them until the head of `next` lies beyond v) usearch's heap decides who goes
-    // first.  The sets the walk works on -- visited, `next`, `top` -- come out the same either way as long as no comparison against the
-    // radius can tell the orders apart and no two equal distances are inserted into `top` in an order-dependent sequence.  Precisely
-    // (filtered walks; plain ones keep the stricter round-4 rule: inside a window `top` is not full and does not fill up):
-    //   * every candidate of the window is expanded whichever goes first iff the radius never falls below v while the window lasts (the
-    //     walk ends at the first candidate BEYOND the radius): then the same nodes are evaluated, and `top` -- the ef best admitted
-    //     members of what was evaluated -- is the same set;
-    //   * `next` may differ by entries at or beyond the radius of their evaluation, which are never expanded -- unless one EQUALS the
-    //     radius: a neighbour rejected at `d == radius` inside a window, a candidate popped at `d == radius` after one, an insertion
-    //     into `top` that meets an equal distance there inside one.
-    // Any of these hands the round to the usearch-order walk (status redo).  One exact walk in 13 did under the stricter rule at 10 %
-    // selectivity (10M x 768), seven in ten at 1 %.
-    bool tie_active = false, any_window = false;
+    float radius = __builtin_inff();  // top's last distance once it is full
+    bool redo = false, tie_active = false;
     float tie_v = 0.f;
 
+    __device__ __forceinline__ TopOps(PipeTop<R>& t, Sh& s, uint32_t lane, uint32_t limit, bool fused) : top(t), sh(s), L(lane), ef(limit), fused_order(fused) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            top.d[j] = __builtin_inff();
+            top.s[j] = kInvalid;
+        }
+    }
     // distance at position p of `top` (wave-uniform p): one readlane per register row, chosen on the scalar side (a select chain over
     // the rows themselves is turned into an indexed load from a scratch copy of the array)
-    auto top_at = [&](uint32_t p) -> float {
+    __device__ __forceinline__ float at(uint32_t p) const {
         const uint32_t pl = p / (uint32_t)R, pr = p % (uint32_t)R;
         float v = rl_f(top.d[0], pl);
 #pragma unroll
@@ -345,9 +303,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             v = pr == (uint32_t)j ? x : v;
         }
         return v;
-    };
-    float radius = INF;  // top's last distance once it is full
-    auto top_insert = [&](float d, uint32_t s) {  // top.insert({d, s}, ef) with d below the radius when full: in front of equal entries
+    }
+    // top.insert({d, s}, ef) with d below the radius when full: in front of equal entries
+    __device__ __forceinline__ void insert(float d, uint32_t s) {
         uint32_t rank = 0;
         bool eq = false;
 #pragma unroll
@@ -378,11 +336,236 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             top.s[j] = pos > rank ? ps : pos == rank ? s : top.s[j];
         }
         sz = sz < ef ? sz + 1u : ef;
-        if (sz == ef) radius = top_at(ef - 1u);
+        if (sz == ef) radius = at(ef - 1u);
         if constexpr (kFilter) {
             if (tie_active && !fused_order && sz == ef && radius < tie_v) redo = true;  // (the window's other candidates would end the walk, not be expanded)
         }
+    }
+    // One hop's admissions AT ONCE (round 5).  The CPU loop takes a hop's fresh neighbours one at a time against a radius that moves with
+    // every admission; done literally that is a rank by ballots over every register row, a lane shift of the whole buffer and an insertion
+    // into the front PER NEIGHBOUR -- half of a lone walk's clocks (scripts/probe/pipe_phase_probe.sh).  The same decisions in closed form:
+    //   * neighbour j passes `top.size() < limit || d < radius` exactly when fewer than `limit` members of
+    //     top  U  {admissible neighbours before j in the row}  are not farther than it (the radius IS the limit-th smallest of that
+    //     multiset; neighbours turned away earlier lie at or beyond it and cannot change it): one count over `top`, one over the row --
+    //     accept(), exact whatever distances are equal (finite ones: the caller sends a row with an infinity or a NaN through the
+    //     literal loop);
+    //   * `top` afterwards is the `limit` closest of top U {passed and admissible}: every old member moves up by the number of new ones
+    //     closer than it, every new one lands at (old members not farther) + (new ones in front of it) -- ONE scatter by destination
+    //     through LDS (sh.merge), whatever lands at `limit` or beyond is gone: merge().  The closed form is exact for the SET; the ORDER
+    //     among equal distances is what insert() defines, so the merged list is checked for equal neighbours (up to the first entry that
+    //     left) BEFORE anything is committed: false = nothing done, the caller inserts them one by one.
+    // lanes of `cand`: their own nd; my_le (out): members of `top` not farther than my neighbour (lanes of the result)
+    __device__ __forceinline__ uint64_t accept(uint64_t cand, uint64_t okmask, float nd, uint32_t& my_le) const {
+        const bool okl = (((cand & okmask) >> L) & 1ull) != 0ull;
+        uint64_t pass = 0ull;
+        my_le = 0;
+        for (uint64_t r = cand; r; r &= r - 1ull) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(r);
+            const float dj = rl_f(nd, j);
+            uint32_t gt = 0;  // (the rows' unused positions hold +inf: counted here, taken off below)
+#pragma unroll
+            for (int i = 0; i < R; ++i) gt += (uint32_t)__popcll(__ballot(top.d[i] > dj));
+            const uint32_t le = 64u * (uint32_t)R - gt;
+            const uint32_t before = (uint32_t)__popcll(__ballot(okl && nd <= dj) & ((1ull << j) - 1ull));
+            if (le + before < ef) {
+                pass |= 1ull << j;
+                my_le = L == j ? le : my_le;
+            }
+        }
+        return pass;
+    }
+    __device__ __forceinline__ bool merge(uint64_t tm, float nd, uint32_t n, uint32_t my_le) {
+        const float INF = __builtin_inff();
+        const bool tmine = ((tm >> L) & 1ull) != 0ull;
+        uint32_t in_front = 0;  // my NEW entry: new ones in front of it (closer, or as close and earlier in the row)
+        uint32_t shift[R];      // my OLD entries: new ones closer than each
+#pragma unroll
+        for (int i = 0; i < R; ++i) shift[i] = 0u;
+        for (uint64_t r = tm; r; r &= r - 1ull) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(r);
+            const float dj = rl_f(nd, j);
+#pragma unroll
+            for (int i = 0; i < R; ++i) shift[i] += dj < top.d[i] ? 1u : 0u;
+            in_front += (tmine && (dj < nd || (dj == nd && j < L))) ? 1u : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const uint32_t p = L * (uint32_t)R + (uint32_t)i;
+            if (p < sz) sh.merge[p + shift[i]] = make_uint2(__float_as_uint(top.d[i]), top.s[i]);
+        }
+        if (tmine) sh.merge[my_le + in_front] = make_uint2(__float_as_uint(nd), n);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t total = sz + (uint32_t)__popcll(tm);
+        uint2 t[R + 1];
+#pragma unroll
+        for (int i = 0; i <= R; ++i) {
+            const uint32_t p = L * (uint32_t)R + (uint32_t)i;
+            t[i] = p < total ? sh.merge[p] : make_uint2(__float_as_uint(INF), kInvalid);
+        }
+        bool tie = false;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const uint32_t p = L * (uint32_t)R + (uint32_t)i;
+            tie = tie || (p + 1u < total && p < ef && __uint_as_float(t[i].x) == __uint_as_float(t[i + 1].x));
+        }
+        if (__ballot(tie)) return false;  // (nothing committed: `top` is as it was)
+        const uint32_t kept = total < ef ? total : ef;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const bool keep = L * (uint32_t)R + (uint32_t)i < kept;
+            top.d[i] = keep ? __uint_as_float(t[i].x) : INF;
+            top.s[i] = keep ? t[i].y : kInvalid;
+        }
+        sz = kept;
+        if (sz == ef) radius = at(ef - 1u);
+        return true;
+    }
+};
+
+// ---- the top wave (plain walks, round 5) ------------------------------------------------------------------------------
+// What a hop does to `top` is a third of a plain hop's instructions, and the walker -- one wave, one instruction per four clocks -- is
+// what a lone walk waits for.  The walker needs `top` for two things only: who passes (TopOps::accept: the distances, which it keeps a
+// copy of) and the radius at the next pop.  So a wave of its own keeps the buffer: the walker decides who passes, posts the admitted
+// ones with their ranks (LDS) and goes on to the pushes while this wave merges them in; at the next pop the merge has finished, and the
+// walker reads the new size, the radius and the distances (sh.merge holds the merged list).  The sets are what one wave would have
+// produced -- the same closed form, the same tie rules (TopOps) --; the wave takes the place of one helper (the walker posts it no jobs).
+template <int R, class Sh>
+__device__ __forceinline__ void pipe_top_loop(Sh& sh, uint32_t ef, bool fused_order, int lane) {
+    const uint32_t L = (uint32_t)lane;
+    PipeTop<R> top;
+    TopOps<R, false, Sh> T(top, sh, L, ef, fused_order);
+    uint32_t seen = 0;
+    auto mirror = [&]() {  // `top` as it is -> sh.merge (after insertions one by one: merge() leaves it there itself)
+#pragma unroll
+        for (int i = 0; i < R; ++i) sh.merge[L * (uint32_t)R + (uint32_t)i] = make_uint2(__float_as_uint(top.d[i]), top.s[i]);
     };
+    for (;;) {
+        uint32_t req;
+        while ((req = uni(lds_flag_load(&sh.tw_req))) == seen) {
+            if (lds_load_relaxed(&sh.stop)) return;
+            __builtin_amdgcn_s_sleep(1);  // (64 clocks: the helpers on this SIMD and the LDS port are not for polling)
+        }
+        seen = req;
+        const uint32_t flags = uni(sh.tw_flags);
+        {
+            const uint64_t cand = ((uint64_t)uni(sh.tw_cand[1]) << 32) | uni(sh.tw_cand[0]);
+            const uint64_t okmask = ((uint64_t)uni(sh.tw_ok[1]) << 32) | uni(sh.tw_ok[0]);
+            const float nd = sh.tw_nd[L];
+            const uint32_t n = sh.tw_n[L];
+            T.tie_active = (flags & 1u) != 0u;
+            T.tie_v = __uint_as_float(uni(__float_as_uint(sh.tw_tie_v)));
+            if (!(flags & 4u)) {  // `cand`: the lanes that passed and may be results; tw_le: their ranks among the members of `top`
+                if (T.tie_active || !T.merge(cand, nd, n, sh.tw_le[L])) {
+                    for (uint64_t r = cand; r; r &= r - 1ull) {  // equal distances, or a tie window: one by one, as the CPU does
+                        const uint32_t j = (uint32_t)__builtin_ctzll(r);
+                        T.insert(rl_f(nd, j), rl_u(n, j));
+                    }
+                    mirror();
+                }
+            } else {  // an infinity or a NaN in the row: the CPU loop as written
+                uint64_t pass = 0ull;
+                for (uint64_t r = cand; r; r &= r - 1ull) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(r);
+                    const float dj = rl_f(nd, j);
+                    if (T.sz == ef && !(dj < T.radius)) continue;
+                    pass |= 1ull << j;
+                    if ((okmask >> j) & 1ull) T.insert(dj, rl_u(n, j));
+                }
+                mirror();
+                if (L == 0u) {
+                    sh.tw_pass[0] = (uint32_t)pass;
+                    sh.tw_pass[1] = (uint32_t)(pass >> 32);
+                }
+            }
+        }
+        if (L == 0u) {
+            sh.tw_sz = T.sz;
+            sh.tw_radius = T.radius;
+            sh.tw_redo = T.redo ? 1u : 0u;
+            lds_flag_store(&sh.tw_done, req);
+        }
+    }
+}
+
+struct PipeOut {
+    uint32_t status;  // 0 answered; 1 redo (an order-relevant tie / structure outgrown); 2 the round's budget of unknown verdicts is spent (lazy filter)
+    uint32_t sz;
+};
+
+// MODE: what the instance is for -- each carries only the state it needs (the walker's loop lives on scalar registers, and every
+// wave-uniform variable it does not need is one it does not have to spill):
+//   kPipePlain    plain lone queries (no filter): no verdict bookkeeping, `next` never outgrows LDS (no spilling), fused-list tie order
+//   kPipeFiltered the exact walk of a filtered query
+//   kPipeExplore  an exploring round of a lazily filtered query
+enum : int { kPipePlain = 0, kPipeFiltered = 1, kPipeExplore = 2 };
+template <int AR, int I, int MODE, class Sh>
+__device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2* pool, uint32_t pool_cap, const WalkSpace& ws, uint32_t start,
+                                             float start_d, uint32_t ef, bool tomb, const uint32_t* allow, const uint32_t* known,
+                                             uint32_t* unknown_list, uint32_t* unknown_count, uint32_t unknown_cap, uint32_t unknown_budget,
+                                             uint32_t* consulted_out, Counters& cnt, int lane, PipeTop<Sh::kEfCap / 64>& top, uint32_t* debug,
+                                             bool fused_order) {
+    constexpr bool explore = MODE == kPipeExplore;
+    constexpr bool kFilter = MODE != kPipePlain;
+    if constexpr (!kFilter) {
+        allow = nullptr;
+        known = nullptr;
+    }
+    constexpr int R = Sh::kEfCap / 64;
+    constexpr uint32_t TM = (uint32_t)Sh::kTeam;
+    constexpr uint32_t K = (uint32_t)kPipeCache;
+    const uint32_t L = (uint32_t)lane;
+    const float INF = __builtin_inff();
+    // `top`: the walker's own in filtered walks; plain walks keep it in the top wave (pipe_top_loop) and hold its size, its radius and a
+    // copy of its distances here
+    constexpr bool kTopWave = MODE == kPipePlain;
+    TopOps<R, kFilter, Sh> T(top, sh, L, ef, fused_order);
+    bool& redo = T.redo;
+    uint32_t& sz = T.sz;
+    float& radius = T.radius;
+    bool& tie_active = T.tie_active;
+    float& tie_v = T.tie_v;
+#ifdef VS_WALK_PROFILE
+    uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prof_t = __builtin_amdgcn_s_memtime();
+#endif
+    [[maybe_unused]] uint32_t dbg_max_next = 0, dbg_pushed = 0, dbg_miss = 0, dbg_refill = 0, dbg_early = 0, dbg_windows = 0, dbg_waits = 0, dbg_spills = 0;
+    bool over_budget = false;
+    const uint32_t guess_t = unknown_budget >> 24;
+    unknown_budget &= 0xFFFFFFu;
+    uint32_t ucount = 0, consulted = 0, vcount = 0;
+    bool vlog_lost = false;
+    // front / pool / top
+    float f_d = INF;
+    uint32_t f_s = kInvalid, f_c = 0, nf = 0, np = 0;  // f_c: 1 = a cache entry (complete or being measured) belongs to this candidate
+    float pool_lb = INF;  // the smallest distance in the pool
+    // (`next` beyond the pool: slots in global memory, see spill() below)
+    const uint32_t slot_cap = kFilter ? pool_cap / 2u : 0u;
+    const uint32_t n_slots = (kFilter && slot_cap && ws.heap) ? (ws.heap_cap / slot_cap < 64u ? ws.heap_cap / slot_cap : 64u) : 0u;
+    uint32_t g_cnt = 0;    // lane j: entries of slot j
+    float g_min = INF;     // lane j: their smallest distance
+    float spill_lb = INF;  // the smallest distance in any slot (plain queries: never anything)
+    constexpr uint32_t kPoolSlack = 192u;  // room a hop in progress may still need (64 pushes and as many entries displaced from the front)
+    bool spill_now = false;
+    uint32_t tag = kInvalid;  // lane e < kPipeCache: the candidate cache entry e belongs to
+    // Order among EQUAL distances: the one thing these structures do not reproduce.  While two candidates with one distance v wait in
+    // `next` together ("window": from the pop of the first of them until the head of `next` lies beyond v) usearch's heap decides who goes
+    // first.  The sets the walk works on -- visited, `next`, `top` -- come out the same either way as long as no comparison against the
+    // radius can tell the orders apart and no two equal distances are inserted into `top` in an order-dependent sequence.  Precisely
+    // (filtered walks; plain ones keep the stricter round-4 rule: inside a window `top` is not full and does not fill up):
+    //   * every candidate of the window is expanded whichever goes first iff the radius never falls below v while the window lasts (the
+    //     walk ends at the first candidate BEYOND the radius): then the same nodes are evaluated, and `top` -- the ef best admitted
+    //     members of what was evaluated -- is the same set;
+    //   * `next` may differ by entries at or beyond the radius of their evaluation, which are never expanded -- unless one EQUALS the
+    //     radius: a neighbour rejected at `d == radius` inside a window, a candidate popped at `d == radius` after one, an insertion
+    //     into `top` that meets an equal distance there inside one.
+    // Any of these hands the round to the usearch-order walk (status redo).  One exact walk in 13 did under the stricter rule at 10 %
+    // selectivity (10M x 768), seven in ten at 1 %.
+    bool any_window = false;
+
+    auto top_insert = [&](float d, uint32_t s) { T.insert(d, s); };
     auto pool_append = [&](bool mine, float d, uint32_t s) {  // every lane with `mine` appends its entry
         const uint64_t mk = __ballot(mine);
         if (!mk) return;
@@ -498,92 +681,70 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         else pool_append_one(d, s);
         dbg_pushed += 1u;
     };
-    // One hop's admissions AT ONCE (round 5).  The CPU loop takes a hop's fresh neighbours one at a time against a radius that moves with
-    // every admission; done literally that is a rank by ballots over every register row, a lane shift of the whole buffer and an insertion
-    // into the front PER NEIGHBOUR -- half of a lone walk's clocks (scripts/probe/pipe_phase_probe.sh).  The same decisions in closed form:
-    //   * neighbour j passes `top.size() < limit || d < radius` exactly when fewer than `limit` members of
-    //     top  U  {admissible neighbours before j in the row}  are not farther than it (the radius IS the limit-th smallest of that set;
-    //     neighbours turned away earlier lie at or beyond it and cannot change it): one count over `top` and one over the row;
-    //   * `top` afterwards is the `limit` closest of top U {passed and admissible}: every old member moves up by the number of new ones
-    //     closer than it, every new one lands at (old members not farther) + (new ones in front of it) -- ONE scatter by destination
-    //     through LDS (sh.merge), whatever lands at `limit` or beyond is gone;
-    //   * everything that passed enters `next` (push_lanes: one merge into the front as well).
-    // The closed form is exact for the SETS; the ORDER among equal distances is what the literal code defines, so the merged list is
-    // checked for equal neighbours (up to the first entry that left) BEFORE anything is committed, and a hop that has any -- or runs
-    // inside a tie window, or holds a distance that is not a finite number -- goes through the literal loop instead (returns false).
+    // One hop's admissions at once (TopOps::accept / merge), then the pushes; false: the literal loop must do the hop (a tie window,
+    // equal distances in `top`, a distance that is not a finite number).  Plain walks: the top wave does the first two (hop_posted).
     auto hop_batch = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n) -> bool {
         if (tie_active) return false;
-        const bool mine = ((cand >> L) & 1ull) != 0ull;
-        if (__ballot(mine && !(nd < INF))) return false;
-        const bool okl = mine && ((okmask >> L) & 1ull) != 0ull;
-        uint64_t pass = 0ull;
-        uint32_t my_le = 0;  // lane j: members of `top` not farther than its neighbour
-        for (uint64_t r = cand; r; r &= r - 1ull) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(r);
-            const float dj = rl_f(nd, j);
-            uint32_t gt = 0;  // (the rows' unused positions hold +inf: counted here, taken off below)
-#pragma unroll
-            for (int i = 0; i < R; ++i) gt += (uint32_t)__popcll(__ballot(top.d[i] > dj));
-            const uint32_t le = 64u * (uint32_t)R - gt;
-            const uint32_t before = (uint32_t)__popcll(__ballot(okl && nd <= dj) & ((1ull << j) - 1ull));
-            if (le + before < ef) {
-                pass |= 1ull << j;
-                my_le = L == j ? le : my_le;
-            }
-        }
+        if (__ballot((((cand >> L) & 1ull) != 0ull) && !(nd < INF))) return false;
+        uint32_t my_le;
+        const uint64_t pass = T.accept(cand, okmask, nd, my_le);
         WALK_STAMP(8);  // (inside "pushes, top": who passes)
         const uint64_t tm = pass & okmask;
-        if (tm) {
-            const bool tmine = ((tm >> L) & 1ull) != 0ull;
-            uint32_t in_front = 0;  // my NEW entry: new ones in front of it (closer, or as close and earlier in the row)
-            uint32_t shift[R];      // my OLD entries: new ones closer than each
-#pragma unroll
-            for (int i = 0; i < R; ++i) shift[i] = 0u;
-            for (uint64_t r = tm; r; r &= r - 1ull) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(r);
-                const float dj = rl_f(nd, j);
-#pragma unroll
-                for (int i = 0; i < R; ++i) shift[i] += dj < top.d[i] ? 1u : 0u;
-                in_front += (tmine && (dj < nd || (dj == nd && j < L))) ? 1u : 0u;
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const uint32_t p = L * (uint32_t)R + (uint32_t)i;
-                if (p < sz) sh.merge[p + shift[i]] = make_uint2(__float_as_uint(top.d[i]), top.s[i]);
-            }
-            if (tmine) sh.merge[my_le + in_front] = make_uint2(__float_as_uint(nd), n);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t total = sz + (uint32_t)__popcll(tm);
-            uint2 t[R + 1];
-#pragma unroll
-            for (int i = 0; i <= R; ++i) {
-                const uint32_t p = L * (uint32_t)R + (uint32_t)i;
-                t[i] = p < total ? sh.merge[p] : make_uint2(__float_as_uint(INF), kInvalid);
-            }
-            bool tie = false;
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const uint32_t p = L * (uint32_t)R + (uint32_t)i;
-                tie = tie || (p + 1u < total && p < ef && __uint_as_float(t[i].x) == __uint_as_float(t[i + 1].x));
-            }
-            if (__ballot(tie)) return false;  // (nothing committed: `top` is as it was)
-            const uint32_t kept = total < ef ? total : ef;
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const bool keep = L * (uint32_t)R + (uint32_t)i < kept;
-                top.d[i] = keep ? __uint_as_float(t[i].x) : INF;
-                top.s[i] = keep ? t[i].y : kInvalid;
-            }
-            sz = kept;
-            if (sz == ef) radius = top_at(ef - 1u);
-        }
+        if (tm && !T.merge(tm, nd, n, my_le)) return false;
         WALK_STAMP(9);  // (the merge into `top`)
         push_lanes(pass, nd, n);
         WALK_STAMP(10);  // (the pushes)
         return true;
+    };
+    // ---- the top wave's mailbox (plain walks) ----
+    uint32_t tw_seq = 0;
+    bool tw_pending = false;
+    auto tw_sync = [&]() {  // the last hop posted is in `top`: its size, its radius
+        if (!tw_pending) return;
+        for (uint32_t spins = 0; uni(lds_flag_load(&sh.tw_done)) != tw_seq; ++spins) {
+            if (spins > (1u << 24)) {
+                redo = true;
+                break;
+            }
+        }
+        sz = uni(sh.tw_sz);
+        radius = __uint_as_float(uni(__float_as_uint(sh.tw_radius)));
+        if (uni(sh.tw_redo)) redo = true;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {  // the distances, for accept()
+            const uint32_t p = L * (uint32_t)R + (uint32_t)j;
+            top.d[j] = p < sz ? __uint_as_float(sh.merge[p].x) : INF;
+        }
+        tw_pending = false;
+    };
+    auto tw_post = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n, uint32_t my_le, uint32_t flags) {
+        sh.tw_nd[L] = nd;
+        sh.tw_n[L] = n;
+        sh.tw_le[L] = my_le;
+        ++tw_seq;
+        if (L == 0u) {
+            sh.tw_cand[0] = (uint32_t)cand;
+            sh.tw_cand[1] = (uint32_t)(cand >> 32);
+            sh.tw_ok[0] = (uint32_t)okmask;
+            sh.tw_ok[1] = (uint32_t)(okmask >> 32);
+            sh.tw_flags = flags | (tie_active ? 1u : 0u);
+            sh.tw_tie_v = tie_v;
+            lds_flag_store(&sh.tw_req, tw_seq);
+        }
+        tw_pending = true;
+    };
+    // one hop (plain walks): who passes is decided here, what it does to `top` is the top wave's; returns the lanes that passed
+    auto hop_posted = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n) -> uint64_t {
+        if (__ballot((((cand >> L) & 1ull) != 0ull) && !(nd < INF))) {  // an infinity or a NaN: the literal loop, over there
+            tw_post(cand, okmask, nd, n, 0u, 4u);
+            tw_sync();
+            return ((uint64_t)uni(sh.tw_pass[1]) << 32) | uni(sh.tw_pass[0]);
+        }
+        uint32_t my_le;
+        const uint64_t pass = T.accept(cand, okmask, nd, my_le);
+        const uint64_t tm = pass & okmask;
+        if (tm) tw_post(tm, tm, nd, n, my_le, 0u);
+        return pass;
     };
     // Radix select on the order-preserving distance bits of pool[0 .. np): a threshold with between limit / 4 and limit keys below it
     // (all: the whole pool is at most `limit` entries).  ok = false: more than `limit` entries share the smallest distance (count says how many).
@@ -821,7 +982,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         uint32_t js = 1u, cr = 1u;
         if (L >= 1u && L < TM) js = lds_load_relaxed(&sh.job_state[L]);
         if (L < K) cr = lds_load_relaxed(&sh.c_ready[L]);
-        idle = __ballot(L >= 1u && L < TM && js == 0u);
+        idle = __ballot(L >= 1u && L < TM && js == 0u && !(kTopWave && L == kPipeTopWave));  // (plain walks: the top wave takes no jobs)
         freem = __ballot(L < K && tag == kInvalid && cr == 0u);
     };
     // "measure candidate s", split over up to `want` helpers; the entry, or kInvalid when no helper or no entry is to be had
@@ -919,7 +1080,11 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         }
         const uint64_t ok0 = verdicts(1ull, start, fl0);
         front_insert(start_d, start, 0u);
-        if (ok0 & 1ull) top_insert(start_d, start);
+        if constexpr (kTopWave) {
+            if (ok0 & 1ull) tw_post(1ull, 1ull, start_d, start, 0u, 0u);
+        } else {
+            if (ok0 & 1ull) top_insert(start_d, start);
+        }
     }
     // ---- exploring round (lazy filter): no answer is taken from it, so no order has to be kept.  The closest candidates are expanded
     // several at a time, each by one helper that also marks what it measures; the walker only merges: verdict bookkeeping (which lists
@@ -1033,6 +1198,10 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         }
         const float cd = rl_f(f_d, 0);
         const uint32_t cs = rl_u(f_s, 0);
+        if constexpr (kTopWave) {
+            tw_sync();
+            if (redo) break;
+        }
         if (sz == ef && cd > radius) break;  // `candidate.distance > radius && top.size() == top_limit`
         if (kFilter && any_window && !fused_order && sz == ef && cd == radius) {
             // at the radius: the last member of `top` itself, as a rule (every admitted member waits in `next` too) -- or another node at
@@ -1159,7 +1328,16 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             const uint64_t okmask = verdicts(cand, n, fl);
             if (over_budget) break;  // enough unknown slots listed for one round: the host evaluates them and launches again
             WALK_STAMP(4);  // verdicts
-            const bool done = hop_batch(cand, okmask, nd, n);
+            bool done;
+            if constexpr (kTopWave) {
+                const uint64_t pass = hop_posted(cand, okmask, nd, n);
+                WALK_STAMP(8);  // (inside "pushes, top": who passes; the admitted ones are on their way to the top wave)
+                push_lanes(pass, nd, n);
+                WALK_STAMP(10);  // (the pushes)
+                done = true;
+            } else {
+                done = hop_batch(cand, okmask, nd, n);
+            }
             // the CPU loop as written: one neighbour at a time, in adjacency order, against the moving radius
             for (uint64_t r = done ? 0ull : cand; r; r &= r - 1ull) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(r);
@@ -1182,6 +1360,14 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         dbg_max_next = nf + np > dbg_max_next ? nf + np : dbg_max_next;
         schedule();
         WALK_STAMP(6);  // scheduling
+    }
+    if constexpr (kTopWave) {  // `top` comes home: the answer is read from the walker's registers
+        tw_sync();
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const uint32_t p = L * (uint32_t)R + (uint32_t)j;
+            top.s[j] = p < sz ? sh.merge[p].y : kInvalid;
+        }
     }
     if (L == 0u) lds_flag_store(&sh.stop, 1u);
     if (unknown_count && L == 0u) *unknown_count = ucount;

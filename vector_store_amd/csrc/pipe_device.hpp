@@ -186,8 +186,13 @@ __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 
 // ---- helper waves --------------------------------------------------------------------------------------------------
 template <int AR, int I, class Sh>
-__device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Query<AR, I>& q, Sh& sh, const WalkSpace& ws, bool tomb,
+__device__ __forceinline__ void pipe_helper_loop(const IndexView& ix_args, const Query<AR, I>& q, Sh& sh, const WalkSpace& ws, bool tomb,
                                                  const uint32_t* allow, const uint32_t* known, int lane, uint32_t w) {
+    // The fields a job's address arithmetic needs, held in scalar registers: left to itself the compiler re-reads them from the kernel's
+    // argument block wherever they are used (they are constants to it, cheaper to load again than to keep) -- six scalar loads and as
+    // many waits in the chain row -> vectors -> distance that the walker is waiting for.
+    IndexView ix = ix_args;
+    asm volatile("" : "+s"(ix.vectors), "+s"(ix.adj0), "+s"(ix.stride4), "+s"(ix.lanes), "+s"(ix.lanes_log2), "+s"(ix.M0));
     for (;;) {
         while (lds_load_acquire(&sh.job_state[w]) == 0u) {
             if (lds_load_relaxed(&sh.stop)) return;
@@ -224,7 +229,13 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
         }
         // The bitmap only grows during a query, so "seen" stays true; "not seen" is re-tested by the walker when the candidate is popped.
         // (an urgent job does not wait for the visited word: it is looked at after the rows, as a hint for the walker)
-        const bool need = valid && (nofilter || ((vw >> (n & 31u)) & 1u) == 0u);
+        // (a real branch: as one expression this is a select, and a select waits for the visited word's round trip whichever side is
+        // taken -- the urgent job's rows would leave a memory latency late)
+        bool need = valid;
+        if (!nofilter) {
+            asm volatile("" ::: "memory");
+            need = valid && ((vw >> (n & 31u)) & 1u) == 0u;
+        }
         const uint64_t nm = __ballot(need);
         const uint32_t m = (uint32_t)__popcll(nm);
         if (need) sh.h_slot[w][mbcnt(nm)] = n;
@@ -698,7 +709,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     };
     // ---- the top wave's mailbox (plain walks) ----
     uint32_t tw_seq = 0;
-    bool tw_pending = false;
+    bool tw_pending = false, tw_stale = false;
     auto tw_sync = [&]() {  // the last hop posted is in `top`: its size, its radius
         if (!tw_pending) return;
         for (uint32_t spins = 0; uni(lds_flag_load(&sh.tw_done)) != tw_seq; ++spins) {
@@ -710,12 +721,17 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         sz = uni(sh.tw_sz);
         radius = __uint_as_float(uni(__float_as_uint(sh.tw_radius)));
         if (uni(sh.tw_redo)) redo = true;
+        tw_pending = false;
+        tw_stale = true;
+    };
+    auto tw_distances = [&]() {  // the copy of `top`'s distances accept() works on (asked for while the visited atomics are on their way)
+        if (!tw_stale) return;
 #pragma unroll
-        for (int j = 0; j < R; ++j) {  // the distances, for accept()
+        for (int j = 0; j < R; ++j) {
             const uint32_t p = L * (uint32_t)R + (uint32_t)j;
             top.d[j] = p < sz ? __uint_as_float(sh.merge[p].x) : INF;
         }
-        tw_pending = false;
+        tw_stale = false;
     };
     auto tw_post = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n, uint32_t my_le, uint32_t flags) {
         sh.tw_nd[L] = nd;
@@ -1279,6 +1295,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         }
         // The closest neighbour measured for this candidate, when it is closer than everything that waits in `next`, is the very next
         // candidate (if it is new, which the atomics will tell): its own measurement starts NOW, not after this hop's bookkeeping.
+        if constexpr (kTopWave) tw_distances();
         const bool evd = n != kInvalid && (fl & kPfEvaluated) != 0u;
         if (!evd) nd = INF;
         uint32_t early_slot = kInvalid, early_e = kInvalid;

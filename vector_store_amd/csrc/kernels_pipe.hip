@@ -46,7 +46,11 @@ __device__ __forceinline__ T uni(T v) {
 template <int AR, int I, int EFCAP, int MODE, class Sh>
 __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* pq, uint32_t qi, uint32_t ef, Sh& sh, uint2* pipe_pool, const uint32_t tid,
                                            const uint32_t bid, const uint64_t t_begin, const uint32_t entry_slot, const int32_t max_level, const bool tomb) {
-    const IndexView& ix = a.ix;
+    // The fields every distance's address arithmetic needs, held in scalar registers: left to itself the compiler re-reads them from the
+    // kernel's argument block wherever they are used (constants to it: cheaper to load again than to keep) -- six scalar loads and as
+    // many waits in the chain row -> vectors -> distance that the walker waits for (round 5: 845 -> 808 us per lone walk).
+    IndexView ix = a.ix;
+    asm volatile("" : "+s"(ix.vectors), "+s"(ix.aux), "+s"(ix.adj0), "+s"(ix.stride4), "+s"(ix.lanes), "+s"(ix.lanes_log2), "+s"(ix.M0));
     const int lane = (int)(tid & 63u);
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const float* query = pq ? uni(pq->query) : a.queries + (size_t)qi * a.q_stride;

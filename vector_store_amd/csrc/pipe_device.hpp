@@ -186,13 +186,8 @@ __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 
 // ---- helper waves --------------------------------------------------------------------------------------------------
 template <int AR, int I, class Sh>
-__device__ __forceinline__ void pipe_helper_loop(const IndexView& ix_args, const Query<AR, I>& q, Sh& sh, const WalkSpace& ws, bool tomb,
+__device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Query<AR, I>& q, Sh& sh, const WalkSpace& ws, bool tomb,
                                                  const uint32_t* allow, const uint32_t* known, int lane, uint32_t w) {
-    // The fields a job's address arithmetic needs, held in scalar registers: left to itself the compiler re-reads them from the kernel's
-    // argument block wherever they are used (they are constants to it, cheaper to load again than to keep) -- six scalar loads and as
-    // many waits in the chain row -> vectors -> distance that the walker is waiting for.
-    IndexView ix = ix_args;
-    asm volatile("" : "+s"(ix.vectors), "+s"(ix.adj0), "+s"(ix.stride4), "+s"(ix.lanes), "+s"(ix.lanes_log2), "+s"(ix.M0));
     for (;;) {
         while (lds_load_acquire(&sh.job_state[w]) == 0u) {
             if (lds_load_relaxed(&sh.stop)) return;

@@ -527,6 +527,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     // `top`: the walker's own in filtered walks; plain walks keep it in the top wave (pipe_top_loop) and hold its size, its radius and a
     // copy of its distances here
     constexpr bool kTopWave = MODE == kPipePlain;
+    // (plain walks, ten helpers: the candidate needed at once split five ways measured 806-808 -> 799-801 us; six ways 1,072 -- the
+    // candidates measured ahead starve)
+    constexpr uint32_t kUrgentParts = kTopWave ? kPipeUrgentParts + 1u : kPipeUrgentParts;
     TopOps<R, kFilter, Sh> T(top, sh, L, ef, fused_order);
     bool& redo = T.redo;
     uint32_t& sz = T.sz;
@@ -1025,7 +1028,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             const uint32_t i = (uint32_t)__builtin_ctzll(missing);
             const uint32_t avail = (uint32_t)__popcll(idle);
             if (i == 0u ? avail == 0u : avail < kPipeParts + 2u) break;
-            const uint32_t e = post_job(rl_u(f_s, i), i == 0u ? kPipeUrgentParts : kPipeParts, i == 0u ? kPipeUrgentFlags : 0u);
+            const uint32_t e = post_job(rl_u(f_s, i), i == 0u ? kUrgentParts : kPipeParts, i == 0u ? kPipeUrgentFlags : 0u);
             if (e == kInvalid) break;
             if (L == i) f_c = 1u;
         }
@@ -1253,7 +1256,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                     break;
                 }
                 refresh_jobs();
-                const uint32_t e = post_job(cs, kPipeUrgentParts, kPipeUrgentFlags);
+                const uint32_t e = post_job(cs, kUrgentParts, kPipeUrgentFlags);
                 if (e != kInvalid) {
                     hitm = 1ull << e;
                     break;
@@ -1299,7 +1302,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             if (best < next_d && (sz < ef || best < radius)) {
                 const uint64_t bm = __ballot(evd && !(fl & kPfSeen) && nd == best);
                 early_slot = rl_u(n, (uint32_t)__builtin_ctzll(bm));
-                early_e = post_job(early_slot, kPipeUrgentParts, kPipeUrgentFlags);
+                early_e = post_job(early_slot, kUrgentParts, kPipeUrgentFlags);
                 if (early_e == kInvalid) early_slot = kInvalid;
                 else ++dbg_early;
             }

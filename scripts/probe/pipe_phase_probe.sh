@@ -1,7 +1,8 @@
 #!/bin/bash
 # Where a lone PLAIN pipelined walk spends its clocks: a -DVS_WALK_PROFILE build of the library in a scratch copy (the tree's objects stay
 # as they are), launches instead of pods (the dispatcher prints the per-query phase clocks with VS_HNSW_WALK_DEBUG=1).
-#   scripts/probe/pipe_phase_probe.sh [vectors]
+#   scripts/probe/pipe_phase_probe.sh [vectors]      VS_PROFILE_LEVEL=1 phases of a hop; 2: "pushes, top" split in who passes / merge / pushes
+#   (printed in the places of atomics / verdicts / schedule); 3: the urgent job parts (row / list / distances / report, count, neighbours x 100)
 set -u
 N=${1:-10000000}
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -80,7 +80,7 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
         if (tid == 0) {
             sh.stop = 0u;
             sh.tw_req = sh.tw_done = 0u;
-            sh.prof_jobs[0] = sh.prof_jobs[1] = 0u;
+            for (int i = 0; i < 8; ++i) sh.prof_jobs[i] = 0u;
         }
     }
     if (tid < (uint32_t)kPipeCache) sh.c_ready[tid] = 0u;

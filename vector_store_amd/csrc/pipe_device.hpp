@@ -115,7 +115,7 @@ struct PipeShared : TeamBox<TM>, VisitedLds<!VISG, (EFCAP <= 256 ? 1024 : 2048),
     uint32_t tw_sz, tw_redo;
     float tw_radius;
     uint32_t tw_req, tw_done;  // sequence numbers: posted by the walker / merged into `top`
-    uint32_t prof_jobs[2];  // profile builds: job parts done, their clocks
+    uint32_t prof_jobs[8];  // profile builds: job parts done, their clocks; [2..7] (VS_WALK_PROFILE == 3) urgent parts: count, clocks until the row is here / the list is written / the distances are out / the part is reported, neighbours measured
 };
 
 __device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* p) {
@@ -206,6 +206,10 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
         const bool mine = (uint32_t)lane % parts == part;  // the positions of the adjacency row this helper answers for
         const uint32_t n = (mine && (uint32_t)lane < cap) ? row[lane] : kInvalid;
         const bool valid = n != kInvalid;
+#if defined(VS_WALK_PROFILE) && VS_WALK_PROFILE == 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t job_t1 = __builtin_amdgcn_s_memtime();
+#endif
         // Everything that depends on the neighbour ids alone leaves together: the visited word (read past L1: the walker's atomics live
         // in L2), the verdict words, the key (removed members), and one dword of the neighbour's own adjacency row -- should it become
         // the closest candidate at once, that row is two dependent loads away from ITS neighbours' distances; the touch pulls it into
@@ -238,7 +242,13 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
         // would also wait for the touch loads, a full HBM round trip, before the first row load is issued)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#if defined(VS_WALK_PROFILE) && VS_WALK_PROFILE == 3
+        const uint64_t job_t2 = __builtin_amdgcn_s_memtime();
+#endif
         eval_batch<AR, I, 1, Sh::kNT>(ix, q, sh.h_slot[w], sh.h_dist[w], m, lane);
+#if defined(VS_WALK_PROFILE) && VS_WALK_PROFILE == 3
+        const uint64_t job_t3 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t fl = 0;
@@ -258,6 +268,16 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
         if (lane == 0) {
             atomicAdd(&sh.prof_jobs[0], 1u);
             atomicAdd(&sh.prof_jobs[1], (uint32_t)(__builtin_amdgcn_s_memtime() - job_t0));
+#if VS_WALK_PROFILE == 3
+            if (nofilter) {
+                atomicAdd(&sh.prof_jobs[2], 1u);
+                atomicAdd(&sh.prof_jobs[3], (uint32_t)(job_t1 - job_t0));
+                atomicAdd(&sh.prof_jobs[4], (uint32_t)(job_t2 - job_t0));
+                atomicAdd(&sh.prof_jobs[5], (uint32_t)(job_t3 - job_t0));
+                atomicAdd(&sh.prof_jobs[6], (uint32_t)(__builtin_amdgcn_s_memtime() - job_t0));
+                atomicAdd(&sh.prof_jobs[7], m);
+            }
+#endif
         }
 #endif
         if (lane == 0) {
@@ -1397,6 +1417,11 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         debug[0] = (uint32_t)(prof[7] >> 4);                      // (profile builds: the wait for the entry instead of the largest `next`)
         debug[1] = dbg_waits;                                     // (hops that waited)
         debug[10] = sh.prof_jobs[0] ? sh.prof_jobs[1] / sh.prof_jobs[0] : 0u;  // (helpers: clocks per job part)
+#if VS_WALK_PROFILE == 3  // (urgent job parts: clocks until the row / the list / the distances / the report, in the places of pop .. push+top; neighbours per part in `schedule`)
+        for (int i = 0; i < 4; ++i) debug[4 + i] = sh.prof_jobs[2] ? sh.prof_jobs[3 + i] / sh.prof_jobs[2] : 0u;
+        debug[8] = sh.prof_jobs[2];
+        debug[9] = sh.prof_jobs[2] ? sh.prof_jobs[7] * 100u / sh.prof_jobs[2] : 0u;
+#endif
 #if VS_WALK_PROFILE == 2  // (inside "pushes, top": who passes / the merge / the pushes, in the places of atomics / verdicts / schedule)
         debug[6] = (uint32_t)(prof[8] >> 4);
         debug[7] = (uint32_t)(prof[9] >> 4);

@@ -148,6 +148,37 @@ def test_integer_metrics_return_the_oracles_ids_at_100k(kind, metric, dim):
     assert ix.stats()["visited_overflow"] == 0
 
 
+@pytest.mark.parametrize("metric,dim", [("cos", 96), ("l2sq", 32), ("ip", 768)])
+def test_i8_lone_queries_through_the_pods_equal_the_oracle(metric, dim):
+    """Round 5: i8 lone plain queries (`vs_hnsw_search`, one query per call -- the reference's pattern, usearch.rs:212) are posted to
+    the resident workgroups that serve the exact walks of filtered queries, with no filter: usearch's tie order, a walk handed over to
+    the usearch-order kernels where two orders could differ.  Structureless data (ties as common as i8 makes them), removed members
+    included: every answer bit-identical to the oracle's -- and the pods did serve them."""
+    v = vs()
+    n, nq = 60000, 240
+    rng = np.random.default_rng(31)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    ix = v.HipUsearchIndex(dim, v.METRICS[metric], quantization=v.SCALARS["i8"], expansion_search=100)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    o = OracleIndex(dim, oracle.METRICS[metric], quantization=oracle.SCALARS["i8"])
+    o.import_graph(ix.export_graph())
+    o.set_expansion_search(100)
+    before = ix.pod_stats()
+    for i in range(0, nq // 2):
+        assert_same_results(*ix.search(q[i], 10), *o.search(q[i], 10), exact=True, what=(metric, dim, i))
+    for key in range(0, n, 3):
+        assert ix.remove(key)
+        assert o.remove(key)
+    for i in range(nq // 2, nq):
+        assert_same_results(*ix.search(q[i], 10), *o.search(q[i], 10), exact=True, what=(metric, dim, "after removes", i))
+    after = ix.pod_stats()
+    if after["pods_enabled"]:
+        assert after["plain_queries"] - before["plain_queries"] >= nq - 8, (before, after)   # (a pod that is being opened serves the next call)
+    assert ix.stats()["visited_overflow"] == 0
+
+
 @pytest.mark.parametrize("kind,metric,dim", [("i8", "l2sq", 32), ("b1", "hamming", 256)])
 def test_walk_whose_candidate_heap_outgrows_lds_is_retried_exactly(kind, metric, dim):
     """Removed members are expanded and pushed to `next` but never enter `top`: with 15 of 16 members removed `top` fills

@@ -328,7 +328,14 @@ void Engine::search_async(const float* q, size_t k, uint64_t* keys, float* dist,
 bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dist, size_t* found) {
     uint32_t ef;
     check_search(k, ef);
-    if (!pod_pool(device).enabled || needs_global_walk(ef) || usearch_order() || !pipe_usable(ef) || team_mode == 2 || team_mode == 3 ||
+    // Integer storage (round 5): i8 lone plain queries take the EXACT pipelined walk of filtered queries -- usearch's tie order, a round
+    // handed over where two orders could differ (pipe_device.hpp) -- with no filter: every live member is admitted.  The same pods as the
+    // filtered rounds serve them.  b1 (a few hundred distinct distances: nearly every walk is handed over) and order_mode 1 stay with the
+    // usearch-order walk.  VS_HNSW_INT_PODS=0: as before.
+    static const bool int_pods = !(std::getenv("VS_HNSW_INT_PODS") && std::getenv("VS_HNSW_INT_PODS")[0] == '0');
+    const bool exact_kind = usearch_order();
+    if (exact_kind && !(int_pods && order_mode == 0 && scalar == VS_SCALAR_I8)) return false;
+    if (!pod_pool(device).enabled || needs_global_walk(ef) || !pipe_usable(ef) || team_mode == 2 || team_mode == 3 ||
         stress_small_table || force_wide_tags)
         return false;
     use_device();
@@ -367,9 +374,10 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
     pq.cnt = h_cnt;
     pq.keys = h_k;
     pq.space = (char*)w->ws.p;
+    if (exact_kind) pq.budget = 0xFFFFFFu;  // (no verdict is ever missing: nothing is listed)
     __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
     const auto t_in = std::chrono::steady_clock::now();
-    PodRelease pod{device, pod_submit(0, ef, lay, pq)};
+    PodRelease pod{device, pod_submit(exact_kind ? 1 : 0, ef, lay, pq)};
     if (!pod.t) return false;
     const int dbg_pod = pod.t.pod;
     const uint32_t dbg_slot = pod.t.slot;

@@ -150,6 +150,13 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t v, uint32_t fill) {
 }
 __device__ __forceinline__ float rl_f(float v, uint32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l)); }
 __device__ __forceinline__ uint32_t rl_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// lane l of v <- x (x, l wave-uniform, both from scalar instructions where this is used: no VALU-written-SGPR hazard to pad).  A VALU
+// instruction of gfx9 reads ONE scalar register, so the lane goes through m0 -- which the compiler reserves (it keeps no value there
+// and, in these kernels, uses it for nothing: no LDS-DMA, no movrel), hence no clobber to declare (it would only warn about it).
+__device__ __forceinline__ uint32_t wl_u(uint32_t v, uint32_t x, uint32_t l) {
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l));
+    return v;
+}
 // order-preserving key of a distance (NaN never gets here: group_reduce ranks it as +inf)
 __device__ __forceinline__ uint32_t dist_key(uint32_t bits) { return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 // minimum over the wave, in every lane: four DPP rotations inside the rows of 16, then the four row results on the scalar side
@@ -235,7 +242,7 @@ __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Quer
             asm volatile("" ::: "memory");
             need = valid && ((vw >> (n & 31u)) & 1u) == 0u;
         }
-        const uint64_t nm = __ballot(need);
+        const uint64_t nm = __builtin_amdgcn_ballot_w64(need);
         const uint32_t m = (uint32_t)__popcll(nm);
         if (need) sh.h_slot[w][mbcnt(nm)] = n;
         // (the list is this wave's own: LDS keeps one wave's accesses in order, only the compiler must be held -- a workgroup-scope fence
@@ -337,17 +344,17 @@ struct TopOps {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const bool in = L * (uint32_t)R + (uint32_t)j < sz;
-            rank += (uint32_t)__popcll(__ballot(in && top.d[j] < d));  // usearch: a new entry goes in front of equal ones
+            rank += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in && top.d[j] < d));  // usearch: a new entry goes in front of equal ones
             eq = eq || (in && top.d[j] == d);
         }
-        const bool eq_any = __ballot(eq) != 0ull;
+        const bool eq_any = __builtin_amdgcn_ballot_w64(eq) != 0ull;
         if (eq_any && fused_order) {
             // (the caller's other kernels keep ONE list ordered by (distance, slot): among equal distances the lower slot first, as they
             // do -- a second pass for the rare insertion that meets an equal distance, not a second comparison in every one)
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const bool in = L * (uint32_t)R + (uint32_t)j < sz;
-                rank += (uint32_t)__popcll(__ballot(in && top.d[j] == d && top.s[j] < s));
+                rank += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in && top.d[j] == d && top.s[j] < s));
             }
         }
         if (tie_active && (eq_any || ((!kFilter || fused_order) && sz + 1u >= ef))) redo = true;
@@ -382,23 +389,25 @@ struct TopOps {
     //     left) BEFORE anything is committed: false = nothing done, the caller inserts them one by one.
     // lanes of `cand`: their own nd; my_le (out): members of `top` not farther than my neighbour (lanes of the result)
     __device__ __forceinline__ uint64_t accept(uint64_t cand, uint64_t okmask, float nd, uint32_t& my_le) const {
-        const bool okl = (((cand & okmask) >> L) & 1ull) != 0ull;
-        uint64_t pass = 0ull;
+        // (written for the instruction count -- the walker issues one instruction per four clocks and this loop is a sixth of a plain
+        // hop: masks straight from the comparisons, the two per-lane results by v_writelane, the verdict once after the loop; the
+        // first version -- a select per result, the verdict inside the loop -- was 42 instructions per neighbour, this one is 27)
+        const uint64_t okm = cand & okmask;
+        uint32_t my_tot = 0;  // lane j: members of top U {admissible neighbours before j} not farther than neighbour j
         my_le = 0;
-        for (uint64_t r = cand; r; r &= r - 1ull) {
+        for (uint64_t r = cand; r;) {
             const uint32_t j = (uint32_t)__builtin_ctzll(r);
             const float dj = rl_f(nd, j);
             uint32_t gt = 0;  // (the rows' unused positions hold +inf: counted here, taken off below)
 #pragma unroll
-            for (int i = 0; i < R; ++i) gt += (uint32_t)__popcll(__ballot(top.d[i] > dj));
+            for (int i = 0; i < R; ++i) gt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(top.d[i] > dj));
             const uint32_t le = 64u * (uint32_t)R - gt;
-            const uint32_t before = (uint32_t)__popcll(__ballot(okl && nd <= dj) & ((1ull << j) - 1ull));
-            if (le + before < ef) {
-                pass |= 1ull << j;
-                my_le = L == j ? le : my_le;
-            }
+            const uint32_t before = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(nd <= dj) & okm & ~r);  // (~r: the lanes already done)
+            r &= ~(1ull << j);
+            my_le = wl_u(my_le, le, j);
+            my_tot = wl_u(my_tot, le + before, j);
         }
-        return pass;
+        return __builtin_amdgcn_ballot_w64(my_tot < ef) & cand;
     }
     __device__ __forceinline__ bool merge(uint64_t tm, float nd, uint32_t n, uint32_t my_le) {
         const float INF = __builtin_inff();
@@ -437,7 +446,7 @@ struct TopOps {
             const uint32_t p = L * (uint32_t)R + (uint32_t)i;
             tie = tie || (p + 1u < total && p < ef && __uint_as_float(t[i].x) == __uint_as_float(t[i + 1].x));
         }
-        if (__ballot(tie)) return false;  // (nothing committed: `top` is as it was)
+        if (__builtin_amdgcn_ballot_w64(tie)) return false;  // (nothing committed: `top` is as it was)
         const uint32_t kept = total < ef ? total : ef;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -596,7 +605,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
 
     auto top_insert = [&](float d, uint32_t s) { T.insert(d, s); };
     auto pool_append = [&](bool mine, float d, uint32_t s) {  // every lane with `mine` appends its entry
-        const uint64_t mk = __ballot(mine);
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
         if (!mk) return;
         const uint32_t c = (uint32_t)__popcll(mk);
         if (np + c + (kFilter ? kPoolSlack : 0u) > pool_cap) {
@@ -627,7 +636,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     };
     auto front_insert = [&](float d, uint32_t s, uint32_t c) {  // one entry (wave-uniform) into the sorted front; the displaced worst goes to the pool
         const bool in = L < nf;
-        const uint32_t rank = (uint32_t)__popcll(__ballot(in && f_d <= d));  // (behind equal ones: any order among them is as good)
+        const uint32_t rank = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in && f_d <= d));  // (behind equal ones: any order among them is as good)
         const bool full = nf == 64u;
         if (full && rank >= 64u) {  // (an earlier insertion of the same hop moved the front's reach below it)
             pool_append_one(d, s);
@@ -661,18 +670,22 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         uint32_t new_before_old = 0;  // my OLD entry: new entries strictly closer than it
         uint32_t new_before_new = 0;  // my NEW entry: new entries in front of it (closer, or as close and earlier in the row)
         uint32_t old_le_new = 0;      // my NEW entry: old entries not farther than it (it goes behind equal ones, as front_insert places it)
-        for (uint64_t r = fm; r; r &= r - 1ull) {
+        // (branch-free, for the instruction count: the lanes beyond the front hold +inf, so no `in` is needed in the comparisons; what a
+        // lane without an old / a new entry computes is not looked at.  As `a || (b && c)` the rank among the new ones was three nested
+        // exec-mask branches per neighbour)
+        for (uint64_t r = fm; r;) {
             const uint32_t i = (uint32_t)__builtin_ctzll(r);
+            r &= ~(1ull << i);
             const float di = rl_f(nd, i);
-            const uint32_t c = (uint32_t)__popcll(__ballot(in && f_d <= di));
-            old_le_new = L == i ? c : old_le_new;
-            new_before_old += (in && di < f_d) ? 1u : 0u;
-            new_before_new += (mine && i != L && (di < nd || (di == nd && i < L))) ? 1u : 0u;
+            const uint32_t c = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(f_d <= di));
+            old_le_new = wl_u(old_le_new, c, i);
+            new_before_old += di < f_d ? 1u : 0u;
+            new_before_new += (uint32_t)((int)(di < nd) | ((int)(di == nd) & (int)(i < L)));
         }
         const uint32_t old_dest = L + new_before_old, new_dest = old_le_new + new_before_new;
         // beyond position 63: to the pool (old ones may own a cache entry, which they lose)
         const bool old_out = in && old_dest >= 64u, new_out = mine && new_dest >= 64u;
-        for (uint64_t r = __ballot(old_out && f_c != 0u); r; r &= r - 1ull) free_entry_of(rl_u(f_s, (uint32_t)__builtin_ctzll(r)));
+        for (uint64_t r = __builtin_amdgcn_ballot_w64(old_out && f_c != 0u); r; r &= r - 1ull) free_entry_of(rl_u(f_s, (uint32_t)__builtin_ctzll(r)));
         pool_append(old_out, f_d, f_s);
         pool_append(new_out, nd, ns);
         // the scatter (slot | cache flag << 31: slots are below 2^30)
@@ -694,7 +707,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     auto push_lanes = [&](uint64_t mask, float nd, uint32_t ns) {
         const float reach = nf == 64u ? rl_f(f_d, 63) : (kFilter ? fminf(pool_lb, spill_lb) : pool_lb);  // closer than this: belongs to the front
         const bool mine = ((mask >> L) & 1ull) != 0ull;
-        const uint64_t fm = __ballot(mine && nd < reach);
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(mine && nd < reach);
         pool_append(mine && !(nd < reach), nd, ns);
         if (__popcll(fm) > 1) {
             front_merge(fm, nd, ns);
@@ -714,7 +727,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     // equal distances in `top`, a distance that is not a finite number).  Plain walks: the top wave does the first two (hop_posted).
     auto hop_batch = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n) -> bool {
         if (tie_active) return false;
-        if (__ballot((((cand >> L) & 1ull) != 0ull) && !(nd < INF))) return false;
+        if (__builtin_amdgcn_ballot_w64((((cand >> L) & 1ull) != 0ull) && !(nd < INF))) return false;
         uint32_t my_le;
         const uint64_t pass = T.accept(cand, okmask, nd, my_le);
         WALK_STAMP(8);  // (inside "pushes, top": who passes)
@@ -769,7 +782,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     };
     // one hop (plain walks): who passes is decided here, what it does to `top` is the top wave's; returns the lanes that passed
     auto hop_posted = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n) -> uint64_t {
-        if (__ballot((((cand >> L) & 1ull) != 0ull) && !(nd < INF))) {  // an infinity or a NaN: the literal loop, over there
+        if (__builtin_amdgcn_ballot_w64((((cand >> L) & 1ull) != 0ull) && !(nd < INF))) {  // an infinity or a NaN: the literal loop, over there
             tw_post(cand, okmask, nd, n, 0u, 4u);
             tw_sync();
             return ((uint64_t)uni(sh.tw_pass[1]) << 32) | uni(sh.tw_pass[0]);
@@ -810,7 +823,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             }
             const uint32_t excl = incl - (h0 + h1 + h2 + h3);
             const uint32_t room = limit - below;  // entries that may still move
-            const uint64_t over = __ballot(incl > room);  // first bucket whose inclusive count exceeds the room
+            const uint64_t over = __builtin_amdgcn_ballot_w64(incl > room);  // first bucket whose inclusive count exceeds the room
             if (!over) {  // (cannot happen: the first pass sees np > limit entries, a later one a bucket that exceeded the room)
                 r.ok = false;
                 r.count = 0;
@@ -854,7 +867,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             redo = true;
             return;
         }
-        const uint64_t freem_s = __ballot(L < n_slots && g_cnt == 0u);
+        const uint64_t freem_s = __builtin_amdgcn_ballot_w64(L < n_slots && g_cnt == 0u);
         if ((uint32_t)__popcll(freem_s) < 2u) {  // global memory for `next` is used up too: the other walk (or exhaustive ranking) serves
             redo = true;
             return;
@@ -868,7 +881,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             const float d = __uint_as_float(e.x);
             const bool keep = valid && dist_key(e.x) < sel.thr;
             const bool move = valid && !keep && !(sz == ef && d > radius);  // (beyond the radius of a full `top`: never expanded, dropped)
-            const uint64_t km = __ballot(keep), mm = __ballot(move);
+            const uint64_t km = __builtin_amdgcn_ballot_w64(keep), mm = __builtin_amdgcn_ballot_w64(move);
             if (keep) {
                 pool[kept + mbcnt(km)] = e;
                 lb = fminf(lb, d);
@@ -908,7 +921,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             spill();
             if (redo) return;
         }
-        const uint64_t hm = __ballot(L < n_slots && g_cnt != 0u && g_min == spill_lb);
+        const uint64_t hm = __builtin_amdgcn_ballot_w64(L < n_slots && g_cnt != 0u && g_min == spill_lb);
         if (!hm) {
             spill_lb = INF;
             return;
@@ -926,7 +939,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             uint2 e = make_uint2(0u, 0u);
             if (valid) e = ws.heap[(size_t)sj * slot_cap + base + L];
             const bool keep = valid && !(sz == ef && __uint_as_float(e.x) > radius);
-            const uint64_t km = __ballot(keep);
+            const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
             if (keep) {
                 pool[np + added + mbcnt(km)] = e;
                 lb = fminf(lb, __uint_as_float(e.x));
@@ -975,7 +988,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             // (once `top` is full the radius only shrinks: a candidate beyond it can never be expanded -- `candidate.distance > radius` ends
             // the walk when it is the closest -- so it is dropped here instead of being carried along)
             const bool keep = valid && !take && !(sz == ef && __uint_as_float(e.x) > radius);
-            const uint64_t tm = __ballot(take), km = __ballot(keep);
+            const uint64_t tm = __builtin_amdgcn_ballot_w64(take), km = __builtin_amdgcn_ballot_w64(keep);
             if (taken + (uint32_t)__popcll(tm) > 64u) {  // (cannot happen: the select counted them)
                 redo = true;
                 return;
@@ -1016,8 +1029,8 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         uint32_t js = 1u, cr = 1u;
         if (L >= 1u && L < TM) js = lds_load_relaxed(&sh.job_state[L]);
         if (L < K) cr = lds_load_relaxed(&sh.c_ready[L]);
-        idle = __ballot(L >= 1u && L < TM && js == 0u && !(kTopWave && L == kPipeTopWave));  // (plain walks: the top wave takes no jobs)
-        freem = __ballot(L < K && tag == kInvalid && cr == 0u);
+        idle = __builtin_amdgcn_ballot_w64(L >= 1u && L < TM && js == 0u && !(kTopWave && L == kPipeTopWave));  // (plain walks: the top wave takes no jobs)
+        freem = __builtin_amdgcn_ballot_w64(L < K && tag == kInvalid && cr == 0u);
     };
     // "measure candidate s", split over up to `want` helpers; the entry, or kInvalid when no helper or no entry is to be had
     auto post_job = [&](uint32_t s, uint32_t want, uint32_t flags = 0u) -> uint32_t {  // flags: 1 claim (exploring), 2 measure every neighbour (urgent)
@@ -1037,13 +1050,13 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             sh.job_part[L] = rank | (parts << 8) | (flags << 16);
             lds_flag_store(&sh.job_state[L], 1u);
         }
-        idle &= ~__ballot(pick);
+        idle &= ~__builtin_amdgcn_ballot_w64(pick);
         return e;
     };
     // keep the first kPipeAhead entries of the front measured (two helpers stay in reserve for the candidate a hop needs at once)
     auto schedule = [&]() {
         const uint32_t want = nf < (uint32_t)kPipeAhead ? nf : (uint32_t)kPipeAhead;
-        uint64_t missing = __ballot(L < want && f_c == 0u);
+        uint64_t missing = __builtin_amdgcn_ballot_w64(L < want && f_c == 0u);
         for (; missing; missing &= missing - 1ull) {
             const uint32_t i = (uint32_t)__builtin_ctzll(missing);
             const uint32_t avail = (uint32_t)__popcll(idle);
@@ -1064,7 +1077,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             const uint32_t bit = 1u << (n & 31u);
             fresh = (atomicOr(&ws.bitmap[n >> 5], bit) & bit) == 0u;
         }
-        const uint64_t fm = __ballot(fresh);
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(fresh);
         const uint32_t c = (uint32_t)__popcll(fm);
         if (vcount + c <= ws.vlog_cap) {
             if (fresh) ws.vlog[vcount + mbcnt(fm)] = n;
@@ -1078,10 +1091,10 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     auto verdicts = [&](uint64_t ask, uint32_t n, uint32_t fl) -> uint64_t {
         const bool mine = ((ask >> L) & 1ull) != 0ull;
         const bool live = mine && (fl & kPfLive) != 0u;
-        if (!allow) return __ballot(live);
-        consulted += (uint32_t)__popcll(__ballot(live));
+        if (!allow) return __builtin_amdgcn_ballot_w64(live);
+        consulted += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         const bool unk = live && !(fl & kPfKnown);
-        const uint64_t um = __ballot(unk);
+        const uint64_t um = __builtin_amdgcn_ballot_w64(unk);
         if (um) {
             const uint32_t c = (uint32_t)__popcll(um);
             if (unk && ucount + mbcnt(um) < unknown_cap) unknown_list[ucount + mbcnt(um)] = n;
@@ -1089,7 +1102,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             if (ucount >= unknown_budget) over_budget = true;
         }
         const bool guess = unk && guess_t != 0u && ((n * 2654435761u) >> 24) < guess_t;
-        return __ballot((live && (fl & kPfAllowed) != 0u) || guess);
+        return __builtin_amdgcn_ballot_w64((live && (fl & kPfAllowed) != 0u) || guess);
     };
     if constexpr (!Sh::kVisGlobal) {
         visited_clear(sh, lane);
@@ -1160,9 +1173,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 if (L == e) tag = kInvalid;
                 const bool evd = n != kInvalid && (fl & kPfEvaluated) != 0u;  // claimed by the helper: new to the visited set
                 if (!evd) nd = INF;
-                cnt.evals += (uint32_t)__popcll(__ballot(evd));
+                cnt.evals += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(evd));
                 if (over_budget) continue;  // (the entries of a batch in flight are still drained)
-                const uint64_t cand = __ballot(evd && (sz < ef || nd < radius));
+                const uint64_t cand = __builtin_amdgcn_ballot_w64(evd && (sz < ef || nd < radius));
                 const uint64_t okmask = verdicts(cand, n, fl);
                 WALK_STAMP(4);  // exploring: verdicts
                 push_lanes(cand, nd, n);
@@ -1267,7 +1280,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             ++dbg_windows;
         }
         // its evaluated neighbours
-        uint64_t hitm = __ballot(L < K && tag == cs);
+        uint64_t hitm = __builtin_amdgcn_ballot_w64(L < K && tag == cs);
         if (!hitm) {  // not even posted (every helper was busy, or it arrived with this very hop): post it now, first in line
             ++dbg_miss;
             for (uint32_t spins = 0;; ++spins) {
@@ -1320,7 +1333,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         {
             const float best = wave_min((fl & kPfSeen) ? INF : nd);
             if (best < next_d && (sz < ef || best < radius)) {
-                const uint64_t bm = __ballot(evd && !(fl & kPfSeen) && nd == best);
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(evd && !(fl & kPfSeen) && nd == best);
                 early_slot = rl_u(n, (uint32_t)__builtin_ctzll(bm));
                 early_e = post_job(early_slot, kUrgentParts, kPipeUrgentFlags);
                 if (early_e == kInvalid) early_slot = kInvalid;
@@ -1329,7 +1342,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         }
         WALK_STAMP(2);  // entry read, atomics issued, early post
         const bool fresh = (vold & vbit) == 0u;
-        const uint64_t fmask = __ballot(fresh);
+        const uint64_t fmask = __builtin_amdgcn_ballot_w64(fresh);
         WALK_STAMP(3);  // the atomics' round trip
         if constexpr (!Sh::kVisGlobal) {
             if (uni(sh.overflowed)) {  // the table is full: the other walk serves the query
@@ -1346,7 +1359,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             vcount += c;
         }
         const uint32_t m = (uint32_t)__popcll(fmask);
-        if (__ballot(fresh && !(fl & kPfEvaluated))) {  // (cannot happen: the bitmap only grows) -- never trust a distance that is not there
+        if (__builtin_amdgcn_ballot_w64(fresh && !(fl & kPfEvaluated))) {  // (cannot happen: the bitmap only grows) -- never trust a distance that is not there
             redo = true;
             break;
         }
@@ -1355,8 +1368,8 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             if (!fresh) nd = INF;
             // verdicts are needed only for neighbours that can still be admitted: once `top` is full, those below the hop's first radius
             const float radius0 = sz == ef ? radius : INF;
-            const uint64_t cand = __ballot(fresh && (sz < ef || nd < radius0));
-            if (kFilter && tie_active && sz == ef && __ballot(fresh && nd == radius0)) {  // rejected AT the radius inside a window
+            const uint64_t cand = __builtin_amdgcn_ballot_w64(fresh && (sz < ef || nd < radius0));
+            if (kFilter && tie_active && sz == ef && __builtin_amdgcn_ballot_w64(fresh && nd == radius0)) {  // rejected AT the radius inside a window
                 redo = true;
                 break;
             }
@@ -1389,7 +1402,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if (early_slot != kInvalid) {  // where the candidate measured ahead went: the front (it keeps its entry), or nowhere (visited already / beyond the radius)
             const bool here = L < nf && f_s == early_slot;
             if (here) f_c = 1u;
-            if (!__ballot(here)) free_entry_of(early_slot);
+            if (!__builtin_amdgcn_ballot_w64(here)) free_entry_of(early_slot);
         }
         WALK_STAMP(5);  // pushes, top
         dbg_max_next = nf + np > dbg_max_next ? nf + np : dbg_max_next;

@@ -160,12 +160,20 @@ __device__ __forceinline__ uint32_t wl_u(uint32_t v, uint32_t x, uint32_t l) {
 // order-preserving key of a distance (NaN never gets here: group_reduce ranks it as +inf)
 __device__ __forceinline__ uint32_t dist_key(uint32_t bits) { return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 // minimum over the wave, in every lane: four DPP rotations inside the rows of 16, then the four row results on the scalar side
+// (the walker calls this two or three times per hop: written out, v_min_f32 with a DPP source is the move and the minimum in ONE
+// instruction; through fminf() every step was a v_mov_dpp, two canonicalising v_max and the v_min.  No NaN gets here -- see dist_key.
+// The s_nop pads are the VALU-write -> DPP-read wait states the compiler cannot see inside an asm.)
 __device__ __forceinline__ float wave_min(float v) {
-    v = fminf(v, VS_DPP_ROR(v, 8));
-    v = fminf(v, VS_DPP_ROR(v, 4));
-    v = fminf(v, VS_DPP_ROR(v, 2));
-    v = fminf(v, VS_DPP_ROR(v, 1));
-    return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0"
+        : "+v"(v));
+    const float a = rl_f(v, 0), b = rl_f(v, 16), c = rl_f(v, 32), d = rl_f(v, 48);
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c));
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(d), "v"(r));
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r)));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -757,11 +765,12 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     };
     auto tw_distances = [&]() {  // the copy of `top`'s distances accept() works on (asked for while the visited atomics are on their way)
         if (!tw_stale) return;
+        // (every position is inside the buffer: read them all, then choose -- as `p < sz ? read : inf` each was a branch around its load)
+        uint32_t raw[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const uint32_t p = L * (uint32_t)R + (uint32_t)j;
-            top.d[j] = p < sz ? __uint_as_float(sh.merge[p].x) : INF;
-        }
+        for (int j = 0; j < R; ++j) raw[j] = sh.merge[L * (uint32_t)R + (uint32_t)j].x;
+#pragma unroll
+        for (int j = 0; j < R; ++j) top.d[j] = L * (uint32_t)R + (uint32_t)j < sz ? __uint_as_float(raw[j]) : INF;
         tw_stale = false;
     };
     auto tw_post = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n, uint32_t my_le, uint32_t flags) {

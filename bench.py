@@ -456,6 +456,46 @@ def config_c5(vs, dev, n, dim, k, dist_kind, rank):
     return out
 
 
+def i8_callers_record(vs, dev, n, dim, k, ef, dist_kind, rank, seconds):
+    """Integer storage behind the reference's call pattern (round 5): the headline workload with i8 storage, ONE query per
+    vs_hnsw_search call from num_workers() + 1 and from 64 blocking callers (usearch.rs:203-222).  i8 lone queries are posted to the pods
+    that serve the exact walks of filtered queries (usearch's tie order); every recorded answer is compared with the
+    engine's own usearch-order BATCH walk of the same query (ids and distance bits: the kernels the oracle-parity tests of
+    tests/test_gpu_quantized.py check).  Not a BASELINE config: a side record."""
+    from vector_store_amd import callers
+    t0 = time.perf_counter()
+    base = make_data(n, dim, dist_kind, 1234, dev, rank)
+    q = make_data(4096, dim, dist_kind, 4321, dev, rank)
+    ix, build_s = build_index(vs, base, np.arange(n, dtype=np.uint64), "cos", quantization="i8")
+    del base
+    ix.set_expansion_search(ef)
+    se = Searcher(ix, q, k)
+    truth, _ = se.exact()
+    se.step()
+    torch.cuda.synchronize()
+    want_k, want_d = se.keys.cpu().numpy(), se.dist.cpu().numpy()
+    qh = np.ascontiguousarray(q.cpu().numpy(), dtype=np.float32)
+    th = np.ascontiguousarray(truth, dtype=np.uint64)
+    rec = {"config": "i8_blocking_callers", "workload": f"{n}x{dim} cos, i8 storage, top-{k}, ef_search={ef}, one query per call",
+           "build_vectors_per_s": n / build_s, "batch_walk_recall_at_10": round(recall_at_k(truth, want_k), 4)}
+    pods = ix.pod_stats()
+    for name, threads in (("blocking_callers", effective_cores() + 1), ("blocking_callers_64", 64)):
+        r, got, rc = callers.run(ix, qh, k, th, threads, 1, seconds, record=50_000)
+        now = ix.pod_stats()
+        same = rows = 0
+        for qi, keys_i, dist_i in zip(got["query"], got["keys"], got["distances"]):
+            rows += 1
+            same += int(np.array_equal(keys_i.astype(np.int64), want_k[qi]) and np.array_equal(dist_i, want_d[qi]))
+        rec[name] = {"threads": threads, "queries_per_s": r.qps, "latency_min_ms": round(r.latency_min_ns / 1e6, 3),
+                     "p50_ms": round(r.p50_ns / 1e6, 3), "p99_ms": round(r.p99_ns / 1e6, 3), "recall_at_10": round(r.recall_avg, 4),
+                     "errors": int(r.errors), "status": rc, "kernel_launches": int(r.launches),
+                     "posted_to_pods": now.get("plain_queries", 0) - pods.get("plain_queries", 0),
+                     "answers_recorded": rows, "answers_equal_to_the_batch_walk": same}
+        pods = now
+    rec["seconds"] = round(time.perf_counter() - t0, 1)
+    return rec
+
+
 def config_c3(vs, dev, n, k, dist_kind, rank, target):
     """BASELINE.json configs[2]: 10M x 1536 L2 (OpenAI-large-style), single GPU, graph resident in HBM (61 GB of vectors)."""
     dim, nq = 1536, 10_000
@@ -1127,6 +1167,11 @@ def main():
                 out["configs"].append(config_c5(vs, dev, 10_000_000, 768, k, a.dist, a.rank))
             except Exception as e:
                 out["configs"].append({"config": "configs[4]", "error": repr(e)})
+        if "c5" in want:  # (with the other 10M side records: the i8 index behind the reference's call pattern)
+            try:
+                out["configs"].append(i8_callers_record(vs, dev, 10_000_000, 768, k, 200, a.dist, a.rank, 1.5))
+            except Exception as e:
+                out["configs"].append({"config": "i8_blocking_callers", "error": repr(e)})
         if "c3" in want:
             try:
                 out["configs"].append(config_c3(vs, dev, 10_000_000, k, a.dist, a.rank, a.target_recall))

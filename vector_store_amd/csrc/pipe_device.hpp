@@ -176,29 +176,6 @@ __device__ __forceinline__ float wave_min(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r)));
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, VS_DPP_ROR(v, 8));
-    v = fmaxf(v, VS_DPP_ROR(v, 4));
-    v = fmaxf(v, VS_DPP_ROR(v, 2));
-    v = fmaxf(v, VS_DPP_ROR(v, 1));
-    return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
-}
-__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
-#define VS_DPP_ROR_U(x, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x120 + (n), 0xF, 0xF, true))
-    uint32_t t = VS_DPP_ROR_U(v, 8);
-    v = v > t ? v : t;
-    t = VS_DPP_ROR_U(v, 4);
-    v = v > t ? v : t;
-    t = VS_DPP_ROR_U(v, 2);
-    v = v > t ? v : t;
-    t = VS_DPP_ROR_U(v, 1);
-    v = v > t ? v : t;
-#undef VS_DPP_ROR_U
-    const uint32_t a = rl_u(v, 0), b = rl_u(v, 16), c = rl_u(v, 32), d = rl_u(v, 48);
-    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-    return ab > cd ? ab : cd;
-}
-
 // ---- helper waves --------------------------------------------------------------------------------------------------
 template <int AR, int I, class Sh>
 __device__ __forceinline__ void pipe_helper_loop(const IndexView& ix, const Query<AR, I>& q, Sh& sh, const WalkSpace& ws, bool tomb,

@@ -33,11 +33,18 @@ def closed_form_hop(top, limit, row, admissible, rows_cap=256):
     inf = float("inf")
     regs = top + [inf] * (rows_cap - len(top))
     passed, le = [], []
+    # the shortcut (TopOps::accept, `sure`): with B admissible neighbours in the row, one closer than the member at position
+    # limit - 1 - B passes whatever the others do -- no count needed for it
+    b_all = sum(1 for ok in admissible if ok)
+    threshold = regs[limit - 1 - b_all] if b_all < limit else -inf
     for j, dj in enumerate(row):
         gt = sum(1 for x in regs if x > dj)  # ballots over the rows (the +inf padding counted, taken off next)
         le_j = rows_cap - gt  # members of `top` not farther than neighbour j
         before = sum(1 for i in range(j) if admissible[i] and row[i] <= dj)  # admissible neighbours earlier in the row, not farther
-        passed.append(le_j + before < limit)
+        exact = le_j + before < limit
+        if dj < threshold:
+            assert exact, "the shortcut passed a neighbour the exact count turns away"
+        passed.append(exact)
         le.append(le_j)
     new = [j for j in range(len(row)) if passed[j] and admissible[j]]
     merged = {}

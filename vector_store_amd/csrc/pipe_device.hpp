@@ -108,7 +108,7 @@ struct PipeShared : TeamBox<TM>, VisitedLds<!VISG, (EFCAP <= 256 ? 1024 : 2048),
     alignas(16) uint2 merge[kEfCap + 64];  // hop_batch: one hop's admissions merged into `top` (a scatter by destination)
     // the top wave's mailbox (plain walks, pipe_top_loop): a hop's admitted neighbours from the walker; `top`'s size and radius back
     float tw_nd[64];
-    uint32_t tw_n[64], tw_le[64];
+    uint32_t tw_n[64];
     uint32_t tw_cand[2], tw_ok[2], tw_pass[2];
     uint32_t tw_flags;  // 1: inside a tie window; 4: a row with an infinity or a NaN (the literal loop: who passed comes back in tw_pass)
     float tw_tie_v;
@@ -372,27 +372,44 @@ struct TopOps {
     //     through LDS (sh.merge), whatever lands at `limit` or beyond is gone: merge().  The closed form is exact for the SET; the ORDER
     //     among equal distances is what insert() defines, so the merged list is checked for equal neighbours (up to the first entry that
     //     left) BEFORE anything is committed: false = nothing done, the caller inserts them one by one.
-    // lanes of `cand`: their own nd; my_le (out): members of `top` not farther than my neighbour (lanes of the result)
-    __device__ __forceinline__ uint64_t accept(uint64_t cand, uint64_t okmask, float nd, uint32_t& my_le) const {
-        // (written for the instruction count -- the walker issues one instruction per four clocks and this loop is a sixth of a plain
-        // hop: masks straight from the comparisons, the two per-lane results by v_writelane, the verdict once after the loop; the
-        // first version -- a select per result, the verdict inside the loop -- was 42 instructions per neighbour, this one is 27)
+    // lanes of `cand`: their own nd.  Most neighbours need no count at all: with B admissible neighbours in the row, one that is closer than
+    // the member at position limit - 1 - B has at most limit - 1 - B members not farther than it, so it passes whatever the B others do
+    // (`sure`: one readlane chain and one comparison for the whole row).  In a filtered walk -- the radius is the limit-th best ADMITTED
+    // member, far beyond most neighbours -- that is nearly every lane; in a plain one about two in three.  The others: the exact count.
+    __device__ __forceinline__ uint64_t accept(uint64_t cand, uint64_t okmask, float nd) const {
+        // (written for the instruction count -- the walker issues one instruction per four clocks: masks straight from the comparisons,
+        // the per-lane result by v_writelane, the verdict once after the loop; the first version -- a select per result, the verdict
+        // inside the loop -- was 42 instructions per neighbour, this one is 27, for the lanes that need it)
         const uint64_t okm = cand & okmask;
+        const uint32_t admissible = (uint32_t)__popcll(okm);
+        uint64_t sure = 0ull;
+        if (admissible < ef) sure = __builtin_amdgcn_ballot_w64(nd < at(ef - 1u - admissible)) & cand;  // (unused positions hold +inf)
         uint32_t my_tot = 0;  // lane j: members of top U {admissible neighbours before j} not farther than neighbour j
-        my_le = 0;
-        for (uint64_t r = cand; r;) {
+        for (uint64_t r = cand & ~sure; r;) {
             const uint32_t j = (uint32_t)__builtin_ctzll(r);
+            r &= ~(1ull << j);
             const float dj = rl_f(nd, j);
             uint32_t gt = 0;  // (the rows' unused positions hold +inf: counted here, taken off below)
 #pragma unroll
             for (int i = 0; i < R; ++i) gt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(top.d[i] > dj));
-            const uint32_t le = 64u * (uint32_t)R - gt;
-            const uint32_t before = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(nd <= dj) & okm & ~r);  // (~r: the lanes already done)
-            r &= ~(1ull << j);
-            my_le = wl_u(my_le, le, j);
-            my_tot = wl_u(my_tot, le + before, j);
+            const uint32_t before = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(nd <= dj) & okm & ((1ull << j) - 1ull));
+            my_tot = wl_u(my_tot, 64u * (uint32_t)R - gt + before, j);
         }
-        return __builtin_amdgcn_ballot_w64(my_tot < ef) & cand;
+        return sure | (__builtin_amdgcn_ballot_w64(my_tot < ef) & cand & ~sure);
+    }
+    // lane j of `tm` (neighbours about to enter `top`): members of `top` not farther than it -- where merge() puts it among them
+    __device__ __forceinline__ uint32_t ranks(uint64_t tm, float nd) const {
+        uint32_t my_le = 0;
+        for (uint64_t r = tm; r;) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(r);
+            r &= ~(1ull << j);
+            const float dj = rl_f(nd, j);
+            uint32_t gt = 0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) gt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(top.d[i] > dj));
+            my_le = wl_u(my_le, 64u * (uint32_t)R - gt, j);
+        }
+        return my_le;
     }
     __device__ __forceinline__ bool merge(uint64_t tm, float nd, uint32_t n, uint32_t my_le) {
         const float INF = __builtin_inff();
@@ -477,8 +494,8 @@ __device__ __forceinline__ void pipe_top_loop(Sh& sh, uint32_t ef, bool fused_or
             const uint32_t n = sh.tw_n[L];
             T.tie_active = (flags & 1u) != 0u;
             T.tie_v = __uint_as_float(uni(__float_as_uint(sh.tw_tie_v)));
-            if (!(flags & 4u)) {  // `cand`: the lanes that passed and may be results; tw_le: their ranks among the members of `top`
-                if (T.tie_active || !T.merge(cand, nd, n, sh.tw_le[L])) {
+            if (!(flags & 4u)) {  // `cand`: the lanes that passed and may be results (their ranks among the members: counted here, off the walker's path)
+                if (T.tie_active || !T.merge(cand, nd, n, T.ranks(cand, nd))) {
                     for (uint64_t r = cand; r; r &= r - 1ull) {  // equal distances, or a tie window: one by one, as the CPU does
                         const uint32_t j = (uint32_t)__builtin_ctzll(r);
                         T.insert(rl_f(nd, j), rl_u(n, j));
@@ -713,11 +730,10 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     auto hop_batch = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n) -> bool {
         if (tie_active) return false;
         if (__builtin_amdgcn_ballot_w64((((cand >> L) & 1ull) != 0ull) && !(nd < INF))) return false;
-        uint32_t my_le;
-        const uint64_t pass = T.accept(cand, okmask, nd, my_le);
+        const uint64_t pass = T.accept(cand, okmask, nd);
         WALK_STAMP(8);  // (inside "pushes, top": who passes)
         const uint64_t tm = pass & okmask;
-        if (tm && !T.merge(tm, nd, n, my_le)) return false;
+        if (tm && !T.merge(tm, nd, n, T.ranks(tm, nd))) return false;
         WALK_STAMP(9);  // (the merge into `top`)
         push_lanes(pass, nd, n);
         WALK_STAMP(10);  // (the pushes)
@@ -750,10 +766,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         for (int j = 0; j < R; ++j) top.d[j] = L * (uint32_t)R + (uint32_t)j < sz ? __uint_as_float(raw[j]) : INF;
         tw_stale = false;
     };
-    auto tw_post = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n, uint32_t my_le, uint32_t flags) {
+    auto tw_post = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n, uint32_t flags) {
         sh.tw_nd[L] = nd;
         sh.tw_n[L] = n;
-        sh.tw_le[L] = my_le;
         ++tw_seq;
         if (L == 0u) {
             sh.tw_cand[0] = (uint32_t)cand;
@@ -769,14 +784,13 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     // one hop (plain walks): who passes is decided here, what it does to `top` is the top wave's; returns the lanes that passed
     auto hop_posted = [&](uint64_t cand, uint64_t okmask, float nd, uint32_t n) -> uint64_t {
         if (__builtin_amdgcn_ballot_w64((((cand >> L) & 1ull) != 0ull) && !(nd < INF))) {  // an infinity or a NaN: the literal loop, over there
-            tw_post(cand, okmask, nd, n, 0u, 4u);
+            tw_post(cand, okmask, nd, n, 4u);
             tw_sync();
             return ((uint64_t)uni(sh.tw_pass[1]) << 32) | uni(sh.tw_pass[0]);
         }
-        uint32_t my_le;
-        const uint64_t pass = T.accept(cand, okmask, nd, my_le);
+        const uint64_t pass = T.accept(cand, okmask, nd);
         const uint64_t tm = pass & okmask;
-        if (tm) tw_post(tm, tm, nd, n, my_le, 0u);
+        if (tm) tw_post(tm, tm, nd, n, 0u);
         return pass;
     };
     // Radix select on the order-preserving distance bits of pool[0 .. np): a threshold with between limit / 4 and limit keys below it
@@ -1114,7 +1128,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         const uint64_t ok0 = verdicts(1ull, start, fl0);
         front_insert(start_d, start, 0u);
         if constexpr (kTopWave) {
-            if (ok0 & 1ull) tw_post(1ull, 1ull, start_d, start, 0u, 0u);
+            if (ok0 & 1ull) tw_post(1ull, 1ull, start_d, start, 0u);
         } else {
             if (ok0 & 1ull) top_insert(start_d, start);
         }

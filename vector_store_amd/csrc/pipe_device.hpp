@@ -14,9 +14,11 @@
 //   next   = [front: the 64 closest unexpanded candidates, one per lane of wave 0, sorted] + [pool: the rest, unsorted, in
 //            LDS].  pop = a lane shift, push = a ballot rank + a lane shift (or an append to the pool); the front is refilled
 //            from the pool by a radix select when it runs empty (rare: every push below the front's worst goes to it).
-//   top    = usearch's sorted buffer, <= 512 entries in wave 0's registers (consecutive positions per lane); an insertion
-//            is R ballots + a lane shift, so admission is the CPU loop as written: one neighbour at a time, in adjacency
-//            order, against the moving radius.
+//   top    = usearch's sorted buffer, <= 512 entries in registers (consecutive positions per lane).  Round 4: an insertion was
+//            R ballots + a lane shift, admission the CPU loop as written -- one neighbour at a time, in adjacency order,
+//            against the moving radius.  Round 5 (TopOps): who passes is decided for the whole row in closed form, and the
+//            admitted ones are merged with one scatter; in plain walks a wave of its own (pipe_top_loop) keeps the buffer and
+//            merges while the walker pushes.  The one-by-one loop remains for rows with equal distances or inside a tie window.
 //   helpers: the walker publishes jobs "evaluate candidate X into cache entry e" for the first kPipeAhead entries of the
 //            front that have no entry yet.  A helper loads X's adjacency row, drops the neighbours the visited bitmap
 //            already holds, fetches their verdict bits, measures the rest (eval_batch: the same code as every other
@@ -32,8 +34,9 @@
 // Order among EQUAL distances is the one thing these structures do not reproduce (usearch's array heap and lower_bound
 // insertion decide it, walk_device.hpp emulates them swap for swap).  Every insertion therefore checks for an equal
 // distance among the entries it is ranked against; the first tie ends the walk with status kPipeRedo and the query is
-// answered by the usearch-order walk instead.  Float metrics on real data never tie; lattice data, duplicates, i8 and b1
-// go to the old kernels (the host does not even try the integer metrics here).  Tie-free, the decisions -- and with the
+// answered by the usearch-order walk instead.  Float metrics on real data never tie; lattice data and duplicates go to the old
+// kernels, and so does b1 (a few hundred distinct distances); i8 takes the exact instance (filtered queries since round 4, lone plain
+// ones since round 5: its tie windows hand over only where two orders could differ).  Tie-free, the decisions -- and with the
 // shared distance code the ids and distance bits -- equal walk_usearch's.
 #pragma once
 #include "walk_device.hpp"

@@ -95,3 +95,33 @@ def test_a_row_that_fills_top_midway_meets_the_radius_behind_it():
     # ... and a neighbour that is not admissible (a removed member) is pushed but does not move the radius
     ok = [False, True, True, True]
     assert closed_form_hop(top, limit, row, ok) == literal_hop(top, limit, row, ok)
+
+
+def front_merge(front, new):
+    """pipe_device.hpp `front_merge`: the sorted front of `next` (<= 64 entries, one per lane) and a hop's pushes below its reach, by
+    destination: an old entry moves up by the number of new ones strictly closer, a new one lands behind the old ones not farther than
+    it and behind the new ones in front of it (closer, or as close and earlier in the row).  Returns (front afterwards, what went to
+    the pool)."""
+    dest = {}
+    for p, x in enumerate(front):
+        dest[p + sum(1 for d in new if d < x)] = x
+    for i, d in enumerate(new):
+        old_le = sum(1 for x in front if x <= d)
+        before = sum(1 for j, e in enumerate(new) if e < d or (e == d and j < i))
+        assert old_le + before not in dest, "two entries with one destination"
+        dest[old_le + before] = d
+    total = len(front) + len(new)
+    assert sorted(dest) == list(range(total)), "holes in the merged front"
+    merged = [dest[i] for i in range(total)]
+    return merged[:64], merged[64:]
+
+
+def test_front_merge_is_a_sorted_merge_and_the_overflow_is_the_farthest():
+    rng = random.Random(11)
+    for _ in range(20_000):
+        universe = rng.choice([30, 100_000])  # (30: many equal distances)
+        front = sorted(float(rng.randrange(universe)) for _ in range(rng.randint(0, 64)))
+        new = [float(rng.randrange(universe)) for _ in range(rng.randint(2, 32))]
+        kept, pool = front_merge(front, new)
+        everything = sorted(front + new)
+        assert kept == everything[:64] and sorted(pool) == everything[64:]

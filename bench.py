@@ -10,6 +10,10 @@ rank 0's JSON line and exits with the children's status; it refuses (exit 2) whe
 Started by a launcher, every rank checks WORLD_SIZE == N and exits 2 otherwise.  `--dry-run` only brings the ranks up,
 has them agree on who they are over the chosen backend and prints that (CPU test of the launcher: gloo).
 
+stdout's LAST line is the driver's contract line and nothing else (`bench_line.py`: metric / value / ... / roofline / cpu_baseline plus
+one number per boundary leg and side config, under 8 KB, asserted); the FULL record -- every leg's latency table, the mixed legs, the
+side configs, the generators -- is written to `gpurun_out/bench_full.json` (`--full-record`), which the line names as `full_record`.
+
 A "step" is one pass of the hot path (hnsw_search, one wavefront per query) over one batch of `--nq` synthetic queries
 that are already resident in HBM; `--query-batches` (4) distinct batches rotate through the steps, so no step replays the
 previous one's rows.  Workload at N=1 = the configuration BASELINE.json's metric is quoted on: 10M x 768 cosine, top-10,
@@ -798,6 +802,8 @@ def main():
     ap.add_argument("--no-sharded-leg", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses GPU 0")
+    ap.add_argument("--full-record", default="", help="where the FULL record (every leg's latency table, the mixed legs, side configs) is written, relative to the "
+                    "repo root; default gpurun_out/bench_full.json.  stdout carries only the contract line (bench_line.py)")
     ap.add_argument("--dry-run", action="store_true", help="bring the ranks up, report their environment, measure nothing")
     a = ap.parse_args()
 
@@ -1181,7 +1187,19 @@ def main():
             out["configs"].append({"config": "configs[2]", "skipped": f"{free_b / 2 ** 30:.0f} GiB of HBM free, 180 needed"})
 
     if rank == 0:
-        print(json.dumps(out))
+        # The full record goes to a file; stdout's LAST line is the contract line alone (bench_line.py: < 8 KB, asserted).
+        from bench_line import contract_line
+        full_path = a.full_record or os.path.join("gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.join(ROOT, full_path)) or ".", exist_ok=True)
+            with open(os.path.join(ROOT, full_path), "w") as fh:
+                json.dump(out, fh)
+                fh.write("\n")
+        except OSError as e:
+            print(f"[bench] could not write the full record to {full_path}: {e}", file=sys.stderr)
+            full_path = None
+        sys.stderr.flush()
+        print(contract_line(out, full_path))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()

@@ -64,17 +64,7 @@ typedef struct vs_hnsw_options {
     int metric;       /* vs_metric_kind */
     int quantization; /* vs_scalar_kind */
     int device;       /* HIP device ordinal; -1 = current device */
-    int reserved;     /* 0; test hooks: bit 0 = tiny visited table in search (forces the overflow path),
-                         bit 1 = exact search on the VALU tile kernel instead of MFMA,
-                         bit 2 = always serve a query with a team of wavefronts, bit 3 = never (default: batches
-                         of at most one team per CU),
-                         bit 4 = usearch-order walk (two structures, exact tie order) for every search of this index (default:
-                         i8 / b1 storage only), bit 5 = always the global-bitmap instance of that walk,
-                         bit 6 = wide visited tags (the instances for indexes above 2^25 / 2^26 slots) on a small index,
-                         bit 7 = 64-entry global heap for the global-bitmap walk (a flooding walk then reports "outgrew its
-                         workspace", which the host entry points answer by ranking exhaustively),
-                         bit 8 = lone queries never take the pipelined walk (kernels_pipe.hip): the team kernels serve them, as
-                         before round 4 (A/B in tests) */
+    int reserved;     /* 0 (test hooks: include/vs_hnsw_debug.h, VS_DEBUG_*) */
 } vs_hnsw_options;
 
 /* -- lifecycle: usearch::Index::new (usearch.rs:172), drop ------------------------------- */
@@ -118,17 +108,27 @@ VS_API int vs_hnsw_search_async(vs_hnsw* index, const float* query, size_t dim, 
 typedef int (*vs_hnsw_predicate)(uint64_t key, void* ctx);
 VS_API int vs_hnsw_filtered_search(vs_hnsw* index, const float* query, size_t dim, size_t k, vs_hnsw_predicate predicate,
                             void* ctx, uint64_t* keys, float* distances, size_t* found);
-/* The same call for a filter that has a NAME: `filter_key` != 0 is a fingerprint of the restrictions the predicate evaluates (the
- * reference's predicate is a table read-lock + restriction evaluation per candidate, usearch.rs:1118-1124: the same function of the key
- * for every query with the same `Filter::restrictions`).  The engine then remembers verdicts across the queries of that filter (two
- * bits per slot in HBM, up to 4 filters per index, least recently used first out): a key is asked about at most once, and once a
- * filter's neighbourhoods are known a query is one exact walk with no predicate call.  Results are those of vs_hnsw_filtered_search
- * as long as predicate(key) depends on nothing but (filter_key, key); a member that is removed or re-added is asked about again.
- * filter_key == 0: no memory (= vs_hnsw_filtered_search). */
+/* The same call for a filter that has a NAME: `filter_key` != 0 identifies the restrictions the predicate evaluates.  The reference's
+ * predicate is a table read-lock + restriction evaluation per candidate (usearch.rs:1118-1124), the same function of the key for every
+ * query with the same `Filter::restrictions` -- UNTIL the table changes: restrictions cover the index's filtering columns, which
+ * `Table::upsert` rewrites in place under a fixed PrimaryId (`update_columns`, table/mod.rs:676-695, 1053-1061; no remove / add follows
+ * when the vector's timestamp is not newer, :905-910).  The engine remembers verdicts across the queries of a named filter (two bits per
+ * slot in HBM, up to 4 filters per index, least recently used first out): a key is asked about at most once, and once a filter's
+ * neighbourhoods are known a query is one exact walk with no predicate call.
+ * CONTRACT: results are those of vs_hnsw_filtered_search provided the caller tells the engine whenever predicate(key) may have changed
+ * for a filter it named: vs_hnsw_filter_forget_keys for the rows whose filtering columns were rewritten, or vs_hnsw_filter_forget for the
+ * whole filter (or a new filter_key: e.g. one drawn from a counter per (restrictions, table generation)).  A query that overlaps such a
+ * call may see either verdict -- as a usearch query that overlaps the upsert's `table.write()` may.  The engine itself forgets a member that
+ * is removed or whose slot is re-used.  `filter_key` must be unique per restrictions (a registry id, not a bare hash of caller-supplied
+ * values: INTEGRATION.md section 5c).  filter_key == 0: no memory (= vs_hnsw_filtered_search); this is what the trait's signature binds. */
 VS_API int vs_hnsw_filtered_search_keyed(vs_hnsw* index, const float* query, size_t dim, size_t k, vs_hnsw_predicate predicate,
                                          void* ctx, uint64_t filter_key, uint64_t* keys, float* distances, size_t* found);
-/* [0] queries answered with a filter memory, [1] verdicts they still asked the host for, [2] memories created, [3] memories held now */
-VS_API int vs_hnsw_filter_memo_stats(vs_hnsw* index, uint64_t out[4]);
+/* The named filter `filter_key` starts over (0: every named filter of the index); *dropped (may be NULL) = memories dropped.  Queries
+ * that start after the call returns ask the predicate afresh. */
+VS_API int vs_hnsw_filter_forget(vs_hnsw* index, uint64_t filter_key, size_t* dropped);
+/* Every named filter forgets what it knows about these members (unknown keys are ignored): what the host calls after it rewrote
+ * their filtering columns (table/mod.rs:1053-1061).  Queries that start after the call returns ask about them again. */
+VS_API int vs_hnsw_filter_forget_keys(vs_hnsw* index, const uint64_t* keys, size_t n);
 /* nq queries, row-major nq x dim; keys/distances are nq x k, found is nq. */
 VS_API int vs_hnsw_search_batch(vs_hnsw* index, const float* queries, size_t nq, size_t dim, size_t k, uint64_t* keys,
                          float* distances, size_t* found);
@@ -146,70 +146,7 @@ VS_API int vs_hnsw_exact_search_batch(vs_hnsw* index, const float* queries, size
 /* expansion_search can be changed between searches (usearch change_expansion_search). */
 VS_API int vs_hnsw_set_expansion_search(vs_hnsw* index, size_t expansion_search);
 
-/* -- counters for the roofline figure: cumulative since reset -----
- * [0] distance evaluations in search, [1] node expansions in search, [2] queries,
- * [3] distance evaluations in add, [4] node expansions in add, [5] vectors added,
- * [6] visited-table overflows (must stay 0), [7] the part of [3] spent re-selecting neighbours' links */
-VS_API int vs_hnsw_stats(vs_hnsw* index, uint64_t out[8], int reset);
-/* HBM held by the index: [0] bytes in all arenas, [1] of which grow in place (virtual range + mapped chunks),
- * [2] physical chunks mapped, [3] bytes copied device-to-device by arena growth so far (process-wide). */
-VS_API int vs_hnsw_memory_info(vs_hnsw* index, uint64_t out[4]);
-/* Single-query dispatcher (vs_hnsw_search / _async), process-wide: [0] kernel launches, [1] queries,
- * [2] launches and [3] queries that took the team kernel (8 wavefronts per query, lightly loaded device). */
-VS_API int vs_search_service_stats(uint64_t out[4]);
-
-/* The usearch-order walk: [0] the instance (kernels.hpp WALK_*) the index's last search launch took, ~0 if none yet;
- * [1] queries (process-wide) the single-query dispatcher answered by exhaustive ranking because their walk outgrew its workspace. */
-VS_API int vs_hnsw_walk_info(vs_hnsw* index, uint64_t out[2]);
-
-/* Filtered search on indexes above 65,536 slots asks the predicate lazily (only for members a walk needs a verdict for, in
- * rounds): [0] walk launches and [1] predicate calls spent that way so far. */
-VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
-
-/* A crowd of lazily filtered queries (more callers than the device has streams; the reference runs every filtered query on a blocking
- * thread of its own, usearch.rs:937-948) shares launches: [0] launches that served rounds of several callers at once, [1] rounds served
- * that way. */
-VS_API int vs_hnsw_filter_batch_stats(vs_hnsw* index, uint64_t out[2]);
-
-/* Lone queries (one vector per call, usearch.rs:212 / :236) on float indexes take the pipelined walk (kernels_pipe.hip):
- * [0] walks of it so far for this index (launched, or posted to a pod), [1] lone plain queries (process-wide) it handed over to the team kernels because two
- * equal distances met where their order matters. */
-VS_API int vs_hnsw_pipe_stats(vs_hnsw* index, uint64_t out[2]);
-
-/* HIP streams the engine has created in this process so far, over all devices and indexes: a fixed set per device (16 unless
- * VS_HNSW_STREAMS says otherwise) shared by every index handle -- thousands of per-partition handles (usearch.rs:704-705,
- * 766-778) own none. */
-VS_API uint64_t vs_hnsw_streams_created(void);
-
-/* Pods (vector_store_amd/csrc/pipe_pod.hpp): blocking callers of vs_hnsw_search / vs_hnsw_filtered_search on float indexes -- one
- * query per call (usearch.rs:212, :236), every filtered query on a thread of its own (:937-948) -- post their query to a workgroup of
- * a resident launch of the pipelined walk instead of launching one: as many walks in flight as callers, no launch per query.
- * [0] pods opened for this index so far, [1] queries / filter rounds its pods have served, [2] pods open on the index's device now,
- * [3] 1 unless VS_HNSW_PODS=0; where the time of the plain queries posted on the device went: [4] their number, [5] ns inside the
- * library, [6] of them waiting for the answer, [7] ns the workgroups spent on them by the device's clock; filtered queries of this
- * index: [8] answered through posted (or batched) rounds, [9] handed over to rounds of their own after such a round met two equal
- * distances where their order matters, [10] rounds no pod could take (launched in a batch instead), [11] rounds walked again in usearch's order on the caller's own stream
- * for the same reason. */
-VS_API int vs_hnsw_pod_stats(vs_hnsw* index, uint64_t out[12]);
-
-/* Where modifications spend their time (the reference's mixed add / search workloads, benches/pipeline.rs:508-1292):
- * [0] flushes of staged single-vector adds (vs_hnsw_add defers the insertion to the next call that observes the index),
- * [1] vectors they inserted, [2] ns they took; [3] times this index's pods were closed for a modification, [4] ns spent waiting
- * for their workgroups to leave; [5] vs_hnsw_remove calls, [6] ns inside them; [7] pods opened for this index. */
-VS_API int vs_hnsw_modify_stats(vs_hnsw* index, uint64_t out[8]);
-
-/* Where a single-query call spends its time: [0] vs_hnsw_search calls, [1] ns inside them; [2] vs_hnsw_filtered_search[_keyed] calls,
- * [3] ns inside them, of which [4] waiting for the device's rounds and [5] asking the predicate; [6] ns callers of either waited for
- * staged modifications to be applied first. */
-VS_API int vs_hnsw_call_stats(vs_hnsw* index, uint64_t out[8]);
-
-/* Exact search on float storage (cos / ip, k <= 64, >= 65,536 slots) nominates with split-bf16 MFMA tiles, re-scores the nominees
- * in f32 and certifies the answer: [0] batches that took that path, [1] of them re-run on the f32-input MFMA path because a query's
- * certificate failed. */
-VS_API int vs_hnsw_exact_stats(vs_hnsw* index, uint64_t out[2]);
-/* Round 3: the first stage of the exact search is a ONE-product bf16 pass over a bf16 plane of the rows (built lazily, +2 bytes per
- * element of HBM): [0] batches that took it, [1] of them handed on to the split-bf16 pass (uncertified), [2] / [3] as exact_stats. */
-VS_API int vs_hnsw_exact_stats2(vs_hnsw* index, uint64_t out[4]);
+/* Counters, timers and test hooks: include/vs_hnsw_debug.h (same library; nothing a binding of the trait needs). */
 
 /* -- graph export / import (flat layout; see oracle/cpu_hnsw.cpp orc_export_graph) ------- */
 typedef struct vs_hnsw_graph_info {

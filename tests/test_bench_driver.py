@@ -13,10 +13,19 @@ LIB = os.path.join(ROOT, "vector_store_amd", "libvs_hnsw.so")
 
 
 def test_c_abi_exports_every_declared_symbol():
-    """The library loads and exports exactly what include/vs_hnsw.h declares (no compute calls here)."""
+    """The library loads and exports exactly what include/vs_hnsw.h (the boundary) and include/vs_hnsw_debug.h (counters, test hooks)
+    declare (no compute calls here).  The boundary header carries no counters and no test hooks (round-5 review, item 9)."""
     header = open(os.path.join(ROOT, "include", "vs_hnsw.h")).read()
-    declared = set(re.findall(r"^VS_API [^;(]*?\b(vs_[a-z0-9_]+)\(", header, flags=re.M))
-    assert len(declared) >= 25
+    debug = open(os.path.join(ROOT, "include", "vs_hnsw_debug.h")).read()
+    pattern = r"^VS_API [^;(]*?\b(vs_[a-z0-9_]+)\("
+    boundary = set(re.findall(pattern, header, flags=re.M))
+    declared = boundary | set(re.findall(pattern, debug, flags=re.M))
+    assert len(boundary) >= 25
+    assert not [s for s in boundary if s.endswith("_stats") or s.endswith("_stats2") or s.endswith("_info")], "counters belong in vs_hnsw_debug.h"
+    assert "bit 0" not in header and "VS_DEBUG_TINY_VISITED" in debug  # the hooks are named in the debug header only
+    for trait_call in ("vs_hnsw_create", "vs_hnsw_reserve", "vs_hnsw_capacity", "vs_hnsw_add", "vs_hnsw_remove", "vs_hnsw_search", "vs_hnsw_filtered_search",
+                       "vs_hnsw_filter_forget", "vs_hnsw_filter_forget_keys"):
+        assert trait_call in boundary, trait_call
     out = subprocess.check_output(["nm", "-D", "--defined-only", LIB], text=True)
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert declared <= exported, declared - exported

@@ -155,3 +155,120 @@ def test_a_named_filter_remembers_verdicts_and_answers_like_the_unnamed_one():
     [x.start() for x in th]
     [x.join() for x in th]
     assert not errors, errors[:2]
+
+
+def test_a_named_filter_forgets_when_the_host_rewrites_filtering_columns():
+    """Round-5 review, weak 1 / missing 2.  The reference's predicate reads FILTERING COLUMNS, which `Table::upsert` rewrites in place
+    under a fixed PrimaryId (`update_columns`, table/mod.rs:676-695, 1053-1061) -- no remove, no add, no new key.  Two waves of the
+    same queries around such a rewrite of 5 % of the rows: without a word from the host the named filter answers with the verdicts
+    it remembered (the staleness is asserted, so that it is documented); after vs_hnsw_filter_forget_keys(the rewritten rows) -- and,
+    separately, after vs_hnsw_filter_forget(the filter) and under a NEW filter_key (a table generation) -- every answer equals the
+    oracle's under the new column values, and only what was forgotten is asked again."""
+    import vector_store_amd as v
+    n, dim, k = 100_000, 64, 10
+    data = _dataset(n + 48, dim, 67)
+    base, q = data[:n], data[n:]
+    ix = v.HipUsearchIndex(dim, v.COS, expansion_search=96)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    o = OracleIndex(dim, oracle.COS, 16, 128, 96)
+    o.import_graph(ix.export_graph())
+    column = (np.arange(n) % 10 == 3)                      # the filtering column `f`, restriction `f = true`
+    asked = {}
+
+    def pred(key):
+        asked[key] = asked.get(key, 0) + 1
+        return bool(column[key])
+
+    def wave(filter_key, what):
+        """answers of every query; rows that differ from the oracle's under the CURRENT column values"""
+        wrong = 0
+        for i in range(len(q)):
+            gk, gd = ix.filtered_search(q[i], k, pred, filter_key=filter_key)
+            wk, wd = o.filtered_search(q[i], k, lambda key: bool(column[key]))
+            try:
+                assert_same_results(gk, gd, wk, wd, lambda key, i=i: o.distance_to_slot(q[i], int(key)), what=(what, i))
+            except AssertionError:
+                wrong += 1
+        return wrong
+
+    FK = 0x51A7E
+    assert wave(FK, "first wave") == 0
+    assert wave(FK, "warm") == 0
+    # ---- the host rewrites the column of 5 % of the rows: half of the admitted ones near the queries are rejected now, others admitted
+    rng = np.random.default_rng(5)
+    near = np.unique(np.concatenate([o.filtered_search(q[i], 4, lambda key: bool(column[key]))[0] for i in range(len(q))]).astype(np.int64))
+    rewritten = np.unique(np.concatenate([near[::2], rng.choice(n, n // 20, replace=False)]))
+    column[rewritten] = ~column[rewritten]
+    asked.clear()
+    stale = wave(FK, "stale")
+    assert stale > 0 and not asked, (stale, len(asked))    # documented: nobody told the engine, it asked nothing and answers from memory
+    # ---- (1) the host names the rewritten rows
+    ix.filter_forget_keys(rewritten.astype(np.uint64))
+    asked.clear()
+    assert wave(FK, "after forget_keys") == 0
+    assert asked and set(asked) <= set(rewritten.tolist()) and max(asked.values()) == 1, (len(asked), len(set(asked) - set(rewritten.tolist())))
+    st = ix.filter_memo_stats()
+    assert st["forget_calls"] == 1 and st["members_forgotten"] == len(rewritten) and st["memories_held"] == 1
+    asked.clear()
+    assert wave(FK, "warm again") == 0 and not asked
+    # ---- (2) a second rewrite, answered by forgetting the whole filter
+    back = rewritten[: len(rewritten) // 2]
+    column[back] = ~column[back]
+    assert ix.filter_forget(FK) == 1 and ix.filter_memo_stats()["memories_held"] == 0
+    asked.clear()
+    assert wave(FK, "after forget") == 0 and len(asked) > 1000
+    # ---- (3) a third rewrite, answered by a new name (filter_key = a registry id per (restrictions, table generation))
+    column[back] = ~column[back]
+    assert wave(FK + 1, "new generation") == 0
+    assert ix.filter_forget(0) == 2 and ix.filter_memo_stats()["memories_held"] == 0
+    # unknown keys and an empty list are no-ops
+    ix.filter_forget_keys(np.array([2 ** 40, 2 ** 41], dtype=np.uint64))
+    ix.filter_forget_keys(np.zeros(0, dtype=np.uint64))
+
+
+def test_forgetting_under_concurrent_named_queries_never_leaves_a_stale_verdict():
+    """forget_keys while queries of the same filter are in flight: whatever they overlap, the queries that START after the call
+    returned answer with the new column values (copy-on-forget: verdicts evaluated before the change cannot reach the new memory)."""
+    import threading
+    import vector_store_amd as v
+    n, dim, k = 100_000, 64, 10
+    data = _dataset(n + 32, dim, 71)
+    base, q = data[:n], data[n:]
+    ix = v.HipUsearchIndex(dim, v.COS, expansion_search=96)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    o = OracleIndex(dim, oracle.COS, 16, 128, 96)
+    o.import_graph(ix.export_graph())
+    column = (np.arange(n) % 10 == 3)
+    FK = 77
+    stop = threading.Event()
+    errors = []
+
+    def crowd(t):
+        try:
+            i = t
+            while not stop.is_set():
+                ix.filtered_search(q[i % len(q)], k, lambda key: bool(column[key]), filter_key=FK)
+                i += 4
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=crowd, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    try:
+        rng = np.random.default_rng(9)
+        for rnd in range(6):
+            rewritten = rng.choice(n, n // 20, replace=False)
+            column[rewritten] = ~column[rewritten]           # `table.write()` ...
+            ix.filter_forget_keys(rewritten.astype(np.uint64))  # ... and the word to the engine, in the reference's order
+            for i in range(0, len(q), 3):
+                gk, gd = ix.filtered_search(q[i], k, lambda key: bool(column[key]), filter_key=FK)
+                wk, wd = o.filtered_search(q[i], k, lambda key: bool(column[key]))
+                assert_same_results(gk, gd, wk, wd, lambda key, i=i: o.distance_to_slot(q[i], int(key)), what=("round", rnd, i))
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert not errors, errors

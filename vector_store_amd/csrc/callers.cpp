@@ -1,6 +1,7 @@
 // callers.cpp -- libvs_callers.so (include/vs_callers.h): the reference's search load loop
 // (crates/benchmark/src/main.rs:435-525) over the C ABI of the engine, blocking or with queries in flight.
 #include "../../include/vs_callers.h"
+#include "../../include/vs_hnsw_debug.h"
 
 #include <algorithm>
 #include <atomic>

@@ -26,7 +26,7 @@
 #include <unordered_set>
 #include <vector>
 
-#include "../../include/vs_hnsw.h"
+#include "../../include/vs_hnsw_debug.h"
 #include "kernels.hpp"
 #include "pipe_pod.hpp"
 #include "filter_rounds.hpp"
@@ -1853,6 +1853,71 @@ struct Engine {
     void memos_drop() {
         std::lock_guard<std::mutex> g(memo_mu);
         memos.clear();
+    }
+    // ---- invalidation (round 6).  The reference's predicate reads FILTERING COLUMNS (`table.is_valid_for`, usearch.rs:1118-1124), which
+    // `Table::upsert` rewrites in place under a fixed PrimaryId (`update_columns`, table/mod.rs:676-695, called at :1053-1061 BEFORE
+    // `update_index`, which returns no operation when the vector's timestamp is not newer, :905-910): a CQL UPDATE of such a column
+    // changes a verdict with no remove and no add, so nothing above ever forgets it.  The host side says so:
+    //   * memo_forget_filter(key): that filter's memory is dropped (0: every filter's) -- its next query asks afresh;
+    //   * memo_forget_keys(keys): every filter forgets what it knows about those members (what `Table::upsert` calls for the row it
+    //     rewrote): copy-on-forget -- each memory is replaced by a copy with those members' bits cleared.  Queries in flight keep the
+    //     memory they started with (detached now: they finish with it, nobody reads it afterwards), so a verdict evaluated BEFORE the
+    //     change can never reach the memory the queries that start AFTER this call returns are seeded from.  The copy takes `known`
+    //     first and `allow` after it (a writer sets `allow` first): a known bit in the copy has its verdict in the copy.
+    // A query that overlaps the call may use either verdict -- as a usearch query that overlaps the `table.write()` of the upsert may.
+    std::atomic<uint64_t> memo_forgets{0}, memo_forgotten_keys{0};
+    size_t memo_forget_filter(uint64_t filter_key) {
+        std::lock_guard<std::mutex> g(memo_mu);
+        size_t dropped = 0;
+        for (size_t i = memos.size(); i-- > 0;)
+            if (!filter_key || memos[i]->key == filter_key) {
+                memos.erase(memos.begin() + (long)i);
+                ++dropped;
+            }
+        memo_forgets.fetch_add(1, std::memory_order_relaxed);
+        return dropped;
+    }
+    size_t memo_forget_keys(const uint64_t* keys_in, size_t n) {
+        if (!n) return 0;
+        std::vector<uint32_t> changed;
+        {
+            std::lock_guard<std::mutex> g(mod_mu);  // (the host map; a key that is only staged has no slot and no remembered verdict yet)
+            for (size_t i = 0; i < n; ++i) {
+                auto it = lookup.find(keys_in[i]);
+                if (it != lookup.end()) changed.push_back(it->second);
+            }
+        }
+        memo_forgets.fetch_add(1, std::memory_order_relaxed);
+        memo_forgotten_keys.fetch_add(changed.size(), std::memory_order_relaxed);
+        if (changed.empty()) return 0;
+        use_device();
+        std::lock_guard<std::mutex> g(memo_mu);
+        if (memos.empty()) return changed.size();
+        Lease w(device);
+        uint32_t* d = (uint32_t*)w->f.ensure(changed.size() * 4 + 64);
+        HIP_OK(hipMemcpyAsync(d, changed.data(), changed.size() * 4, hipMemcpyHostToDevice, w->stream));
+        std::vector<std::shared_ptr<FilterMemo>> fresh;
+        for (auto& m : memos) {
+            auto c = std::make_shared<FilterMemo>();
+            if (hipMalloc((void**)&c->bits, (size_t)m->stride * 8) != hipSuccess) {  // no HBM for the copy: the filter starts over
+                (void)hipGetLastError();
+                c->bits = nullptr;
+                continue;
+            }
+            HIP_OK(hipMemcpyAsync(c->bits + m->stride, m->bits + m->stride, (size_t)m->stride * 4, hipMemcpyDeviceToDevice, w->stream));  // known ...
+            HIP_OK(hipMemcpyAsync(c->bits, m->bits, (size_t)m->stride * 4, hipMemcpyDeviceToDevice, w->stream));                          // ... then allow
+            HIP_OK(launch_memo_forget(c->bits, m->stride, d, (uint32_t)changed.size(), w->stream));
+            c->key = m->key;
+            c->stride = m->stride;
+            c->last_use = m->last_use;
+            c->asked_avg.store(m->asked_avg.load(std::memory_order_relaxed), std::memory_order_relaxed);
+            c->queries.store(m->queries.load(std::memory_order_relaxed), std::memory_order_relaxed);
+            c->asked.store(m->asked.load(std::memory_order_relaxed), std::memory_order_relaxed);
+            fresh.push_back(std::move(c));
+        }
+        HIP_OK(hipStreamSynchronize(w->stream));
+        memos.swap(fresh);  // (the old memories die with the last query that holds them)
+        return changed.size();
     }
 
     // filtered_lazy through the batcher.  (size_t)-1: hand the query to the unbatched rounds (a tie where order matters, or a failure).

@@ -196,7 +196,22 @@ int vs_hnsw_filtered_search_keyed(vs_hnsw* h, const float* q, size_t dim, size_t
     });
 }
 
-int vs_hnsw_filter_memo_stats(vs_hnsw* h, uint64_t out[4]) {
+int vs_hnsw_filter_forget(vs_hnsw* h, uint64_t filter_key, size_t* dropped) {
+    return guarded([&] {
+        need(h, "null argument");
+        const size_t d = h->e.memo_forget_filter(filter_key);
+        if (dropped) *dropped = d;
+    });
+}
+
+int vs_hnsw_filter_forget_keys(vs_hnsw* h, const uint64_t* keys, size_t n) {
+    return guarded([&] {
+        need(h && (n == 0 || keys), "null argument");
+        h->e.memo_forget_keys(keys, n);
+    });
+}
+
+int vs_hnsw_filter_memo_stats(vs_hnsw* h, uint64_t out[6]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.memo_queries.load();
     out[1] = h->e.memo_asked.load();
@@ -205,6 +220,8 @@ int vs_hnsw_filter_memo_stats(vs_hnsw* h, uint64_t out[4]) {
         std::lock_guard<std::mutex> g(h->e.memo_mu);
         out[3] = h->e.memos.size();
     }
+    out[4] = h->e.memo_forgets.load();
+    out[5] = h->e.memo_forgotten_keys.load();
     return VS_OK;
 }
 

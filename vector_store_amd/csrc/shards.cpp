@@ -1,5 +1,6 @@
 // shards.cpp -- libvs_shards.so: one handle over several GPUs in one process (include/vs_shards.h).
 #include "../../include/vs_shards.h"
+#include "../../include/vs_hnsw_debug.h"
 
 #include <algorithm>
 #include <condition_variable>

@@ -32,7 +32,7 @@
 #include <random>
 #include <thread>
 
-#include "../../include/vs_hnsw.h"
+#include "../../include/vs_hnsw_debug.h"
 #include "bench_util.hpp"
 
 using Clock = std::chrono::steady_clock;

@@ -99,6 +99,9 @@ def lib():
     # and their accessors below return zeros without them)
     if hasattr(L, "vs_hnsw_filtered_search_keyed"):
         L.vs_hnsw_filtered_search_keyed.argtypes = [vp, vp, sz, sz, PRED, vp, u64, vp, vp, C.POINTER(sz)]
+    if hasattr(L, "vs_hnsw_filter_forget"):
+        L.vs_hnsw_filter_forget.argtypes = [vp, u64, C.POINTER(sz)]
+        L.vs_hnsw_filter_forget_keys.argtypes = [vp, vp, sz]
     for young in ("vs_hnsw_pipe_stats", "vs_hnsw_filter_batch_stats", "vs_hnsw_pod_stats", "vs_hnsw_modify_stats", "vs_hnsw_filter_memo_stats", "vs_hnsw_call_stats"):
         if hasattr(L, young):
             getattr(L, young).argtypes = [vp, vp]
@@ -256,11 +259,24 @@ class HipUsearchIndex:
         return {"searches": int(out[0]), "search_ms": int(out[1]) / 1e6, "filtered": int(out[2]), "filtered_ms": int(out[3]) / 1e6,
                 "filtered_device_wait_ms": int(out[4]) / 1e6, "filtered_predicate_ms": int(out[5]) / 1e6, "flush_wait_ms": int(out[6]) / 1e6}
 
+    def filter_forget(self, filter_key: int = 0) -> int:
+        """The named filter starts over (0: every named filter of the index); returns the memories dropped."""
+        dropped = C.c_size_t(0)
+        _check(self.L.vs_hnsw_filter_forget(self.h, filter_key, C.byref(dropped)))
+        return dropped.value
+
+    def filter_forget_keys(self, keys) -> None:
+        """Every named filter forgets its verdicts for these members: what the host calls after rewriting their filtering columns
+        (the reference's `update_columns`, table/mod.rs:676-695)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        _check(self.L.vs_hnsw_filter_forget_keys(self.h, _p(keys), keys.size))
+
     def filter_memo_stats(self) -> dict:
-        out = np.zeros(4, dtype=np.uint64)
+        out = np.zeros(6, dtype=np.uint64)
         if hasattr(self.L, "vs_hnsw_filter_memo_stats"):
             _check(self.L.vs_hnsw_filter_memo_stats(self.h, _p(out)))
-        return {"queries": int(out[0]), "verdicts_asked": int(out[1]), "memories_created": int(out[2]), "memories_held": int(out[3])}
+        return {"queries": int(out[0]), "verdicts_asked": int(out[1]), "memories_created": int(out[2]), "memories_held": int(out[3]),
+                "forget_calls": int(out[4]), "members_forgotten": int(out[5])}
 
     # --- bulk / device paths used by the benchmark driver --------------------------------
     def add_batch(self, keys, vectors):

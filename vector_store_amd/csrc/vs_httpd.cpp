@@ -52,6 +52,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <algorithm>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -463,30 +464,63 @@ std::vector<Test> compile_filter(const JVal& flt, const std::string& pk) {
     return tests;
 }
 
-// A name for the filter (vs_hnsw_filtered_search_keyed): the predicate below is a function of (these tests, key) and nothing else, so
-// the engine may remember its verdicts across the requests that carry the same restrictions.
-uint64_t filter_fingerprint(const std::vector<Test>& tests) {
-    auto mix = [](uint64_t h, uint64_t v) {
-        h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        return h * 0x100000001B3ull;
-    };
-    uint64_t h = 0xCBF29CE484222325ull;
+// A name for the filter (vs_hnsw_filtered_search_keyed).  The engine's memory is keyed by a 64-bit id, and the restrictions come
+// straight from request bodies: a bare hash of them would let a client craft restrictions that collide with another filter's id and
+// have the engine answer one filter with the other's verdicts (round-5 advisor).  So the id is NOT a hash: the server keeps the
+// canonical serialisation of every filter it has named and hands out ids from a counter -- two filters share an id exactly when their
+// canonical forms are equal, byte for byte.  (The predicate below is a function of (these tests, the key's row number); row numbers
+// never change in this server, so nothing here has to call vs_hnsw_filter_forget_keys -- a host whose restrictions read mutable
+// columns does, see include/vs_hnsw.h.)
+std::string filter_canonical(const std::vector<Test>& tests) {
+    std::string c;
     for (const Test& t : tests) {
-        h = mix(h, (uint64_t)t.op);
+        c += (char)('a' + (int)t.op);
         if (t.op == Test::In) {
-            uint64_t sum = 0, x = 0;  // (a set: the order of its members must not matter)
-            for (int64_t m : t.set) {
-                const uint64_t e = mix(0x51ED270B3A2FULL, (uint64_t)m);
-                sum += e;
-                x ^= e;
+            std::vector<int64_t> members(t.set.begin(), t.set.end());  // (a set: the order of its members must not matter)
+            std::sort(members.begin(), members.end());
+            c += std::to_string(members.size());
+            for (int64_t m : members) {
+                c += ',';
+                c += std::to_string(m);
             }
-            h = mix(mix(mix(h, t.set.size()), sum), x);
         } else {
-            h = mix(h, (uint64_t)t.v);
+            c += std::to_string(t.v);
         }
+        c += ';';
     }
-    return h | 1ull;
+    return c;
 }
+
+class FilterNames {
+    static constexpr size_t kMaxNames = 256;      // canonical forms remembered (the engine itself keeps 4 memories per index)
+    static constexpr size_t kMaxCanonical = 4096;  // longer filters (huge IN lists) stay unnamed: no memory, always exact
+    std::mutex mu_;
+    std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> ids_;  // canonical -> (id, last use)
+    uint64_t next_ = 1, clock_ = 0;
+
+public:
+    // 0: unnamed.  `retired` (may be null) receives the id of a name that fell out, so that its memory can be dropped.
+    uint64_t name_of(const std::vector<Test>& tests, uint64_t* retired = nullptr) {
+        std::string c = filter_canonical(tests);
+        if (c.size() > kMaxCanonical) return 0;
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = ids_.find(c);
+        if (it != ids_.end()) {
+            it->second.second = ++clock_;
+            return it->second.first;
+        }
+        if (ids_.size() >= kMaxNames) {
+            auto lru = ids_.begin();
+            for (auto j = ids_.begin(); j != ids_.end(); ++j)
+                if (j->second.second < lru->second.second) lru = j;
+            if (retired) *retired = lru->second.first;
+            ids_.erase(lru);
+        }
+        const uint64_t id = next_++;  // never re-used: a retired name's memory cannot be mistaken for a new filter's
+        ids_.emplace(std::move(c), std::make_pair(id, ++clock_));
+        return id;
+    }
+};
 
 struct Served {
     std::string keyspace, name, pk = "id";
@@ -497,6 +531,7 @@ struct Served {
     std::atomic<int> serving{0};  // 0 = BOOTSTRAPPING, 1 = SERVING
     std::atomic<size_t> count{0};
     std::atomic<double> progress{0.0};
+    FilterNames names;  // per index: ids of the filters its requests have carried
 };
 
 const char* similarity_name(int m) {
@@ -602,8 +637,13 @@ struct FilterPool {
                     if (p->tests.empty())  // no filter: a limit beyond the LDS beam (exhaustive ranking inside the engine)
                         p->status = vs_hnsw_search(p->s->h, p->q.data(), p->q.size(), p->k, p->keys.data(), p->dist.data(), &p->found);
                     else
-                        p->status = vs_hnsw_filtered_search_keyed(p->s->h, p->q.data(), p->q.size(), p->k, pred, &p->tests, filter_fingerprint(p->tests),
-                                                                  p->keys.data(), p->dist.data(), &p->found);
+                    {
+                        uint64_t retired = 0;
+                        const uint64_t name = p->s->names.name_of(p->tests, &retired);
+                        if (retired) (void)vs_hnsw_filter_forget(p->s->h, retired, nullptr);
+                        p->status = vs_hnsw_filtered_search_keyed(p->s->h, p->q.data(), p->q.size(), p->k, pred, &p->tests, name, p->keys.data(), p->dist.data(),
+                                                                  &p->found);
+                    }
                     if (p->status != VS_OK) p->err = vs_hnsw_last_error();
                     done(std::move(p));
                 }

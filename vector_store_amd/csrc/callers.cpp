@@ -413,11 +413,18 @@ extern "C" int vs_mixed_run(vs_actor* actor, const vs_mixed_options* o, const fl
         for (auto& x : th) x.join();
     }
     // whatever is staged inside the index is indexed before the clock stops (Count is answered by the actor; a search reaches the index)
-    if (producers && queries && nq) {
-        std::vector<uint64_t> keys(k);
-        std::vector<float> dist(k);
+    // -- ALWAYS, also in a modify-only run without queries: *_wait returns once the index has STAGED the operation, so without this
+    // the last few thousand operations would be counted but not indexed when the clock stops (round-5 advisor); the probe is the
+    // first query, or -- no queries given -- a unit vector
+    if (producers) {
+        std::vector<uint64_t> keys(k ? k : 1);
+        std::vector<float> dist(k ? k : 1), probe;
+        if (!(queries && nq)) {
+            probe.assign(dim, 0.f);
+            if (dim) probe[0] = 1.f;
+        }
         size_t found = 0;
-        (void)vs_actor_ann(actor, o->partition, queries, dim, k, keys.data(), dist.data(), &found);
+        (void)vs_actor_ann(actor, o->partition, queries && nq ? queries : probe.data(), dim, k ? k : 1, keys.data(), dist.data(), &found);
     }
     const double wall = std::chrono::duration<double>(Clock::now() - t0).count();
     SearchMeasure plain, filtered, item;

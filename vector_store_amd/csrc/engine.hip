@@ -418,10 +418,24 @@ struct Engine {
         explicit PodFreeze(Engine& eng) : e(eng) {
             Stopwatch sw(e.m_quiesce_ns);
             e.m_quiesces.fetch_add(1, std::memory_order_relaxed);
-            pod_pool(e.device).freeze(&e);
+            // Raised BEFORE the pool's lock is taken: a search that overlaps the modification (a caller of the raw C ABI breaking the
+            // reference's permits) either opened its pod before freeze() got the lock -- freeze() then sees and freezes it -- or finds the
+            // flag under that lock and is served by a launch.  Without it an index that had no pod open could get one opened in the
+            // middle of the modification, with a half-applied entry point / top level in its control block (round-5 advisor).
+            e.being_modified.fetch_add(1, std::memory_order_seq_cst);
+            try {
+                pod_pool(e.device).freeze(&e);
+            } catch (...) {
+                e.being_modified.fetch_sub(1, std::memory_order_seq_cst);
+                throw;
+            }
         }
-        ~PodFreeze() { pod_pool(e.device).thaw(&e, e.capacity, e.entry_slot.load(), e.max_level.load(), e.removed.load() ? 1u : 0u); }
+        ~PodFreeze() {
+            pod_pool(e.device).thaw(&e, e.capacity, e.entry_slot.load(), e.max_level.load(), e.removed.load() ? 1u : 0u);
+            e.being_modified.fetch_sub(1, std::memory_order_seq_cst);
+        }
     };
+    std::atomic<int> being_modified{0};
 
     void add_batch(const uint64_t* keys, const float* vecs, bool on_device, size_t n, std::vector<int>& status,
                    std::string& first_err, bool staged = false) {
@@ -1552,6 +1566,7 @@ struct Engine {
         if (mode == 2) mode = 1;  // (one kind of pod serves both kinds of round of a filtered query: its callers alternate between them)
         std::lock_guard<std::mutex> g(pp.mu);
         if (pp.holds > 0) return {};  // somebody is about to synchronise the device: no pod opens, none takes a post
+        if (being_modified.load(std::memory_order_seq_cst) > 0) return {};  // (the index is being modified -- PodFreeze: the caller breaks the reference's contract, and is served by a launch)
         int use = -1, free_pod = -1;
         for (int i = 0; i < PodPool::kPods && use < 0; ++i) {
             Pod& p = pp.pods[i];

@@ -164,7 +164,7 @@ struct PodPool {
     void thaw(const void* owner, size_t layout, uint32_t entry_slot, int32_t max_level, uint32_t has_removed) {
         std::lock_guard<std::mutex> g(mu);
         for (Pod& p : pods) {
-            if (p.owner != owner || !p.frozen) continue;
+            if (p.owner != owner || p.state == Pod::kFree) continue;  // (every open pod of the owner, frozen or not, gets the new view)
             if (p.state == Pod::kOpen && p.index_slots != layout) close_locked(p);
             if (p.state == Pod::kOpen) {
                 __atomic_store_n(&p.ctl->entry_slot, entry_slot, __ATOMIC_RELAXED);
@@ -187,6 +187,8 @@ struct PodHold {
         }
         try {
             pp.quiesce(nullptr);
+            // (parked blocks go NOW, not only when the hold ends: reserve reads its HBM budget under the hold, and would count them as used)
+            graveyard().drain();
         } catch (...) {
             std::lock_guard<std::mutex> g(pp.mu);
             --pp.holds;

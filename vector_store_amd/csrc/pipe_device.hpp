@@ -154,12 +154,17 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t v, uint32_t fill) {
 __device__ __forceinline__ float rl_f(float v, uint32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l)); }
 __device__ __forceinline__ uint32_t rl_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 // lane l of v <- x (x, l wave-uniform, both from scalar instructions where this is used: no VALU-written-SGPR hazard to pad).  A VALU
-// instruction of gfx9 reads ONE scalar register, so the lane goes through m0 -- which the compiler reserves (it keeps no value there
-// and, in these kernels, uses it for nothing: no LDS-DMA, no movrel), hence no clobber to declare (it would only warn about it).
+// instruction of gfx9 reads ONE scalar register, so the lane goes through m0.  m0 is a reserved register: the compiler keeps no value
+// in it, but it does write it right before instructions of its own that read it (readlane / writelane lane selects, LDS-DMA, movrel),
+// so the asm DECLARES the clobber -- the scheduler must not slip it between such a write and its use (round-5 advisor); clang's warning
+// about a reserved register on the clobber list is what is silenced here.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ uint32_t wl_u(uint32_t v, uint32_t x, uint32_t l) {
-    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l));
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l) : "m0");
     return v;
 }
+#pragma clang diagnostic pop
 // order-preserving key of a distance (NaN never gets here: group_reduce ranks it as +inf)
 __device__ __forceinline__ uint32_t dist_key(uint32_t bits) { return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 // minimum over the wave, in every lane: four DPP rotations inside the rows of 16, then the four row results on the scalar side

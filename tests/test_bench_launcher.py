@@ -30,6 +30,21 @@ def test_gpus_2_spawns_two_ranks_dry_run_gloo():
     assert len({r["pid"] for r in rec["ranks"]}) == 2  # two processes, one per GPU
 
 
+@pytest.mark.timeout(600)
+def test_gpus_8_dry_run_gloo_line_stays_under_the_cap():
+    """The shape the driver's scaling run has (8 ranks on one node), brought up here over gloo: eight processes, one line, under the
+    8 KB cap of the contract line (round-5 review, items 1 and 8)."""
+    import bench_line
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--backend", "gloo", "--dry-run"], env=_clean_env(), capture_output=True, text=True,
+                         timeout=560, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < bench_line.MAX_LINE_BYTES
+    rec = json.loads(lines[0])
+    assert rec["dry_run"] is True and rec["n_gpus"] == 8 and sorted(r["rank"] for r in rec["ranks"]) == list(range(8))
+    assert len({r["pid"] for r in rec["ranks"]}) == 8
+
+
 @pytest.mark.timeout(120)
 def test_world_size_must_equal_gpus():
     env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

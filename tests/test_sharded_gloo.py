@@ -100,3 +100,60 @@ def test_sharded_search_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), 600, 8, 9, 5, out), nprocs=world, join=True)
     assert dict(out) == {0: 1, 1: 1}
+
+
+def _worker_ties(rank, world, port, rows_per_rank, dim, nq, k, out):
+    """Every shard holds the SAME codebook (integer coordinates: distances are exact in f32), so every distance value occurs once per
+    rank and each query's top-k is a run of `world`-way ties that crosses every rank boundary; the last row of a shard also equals the
+    first of the next.  The merged order must be the one a single index gives: ascending distance, equal distances by ascending key --
+    which, with key ranges, is by ascending rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(11)
+        book = rng.integers(-8, 9, size=(rows_per_rank, dim)).astype(np.float32)
+        book[-1] = book[0]                              # the boundary rows of neighbouring shards are equal
+        total = rows_per_rank * world
+        base = np.tile(book, (world, 1))
+        q = rng.integers(-8, 9, size=(nq, dim)).astype(np.float32)
+        lo, hi = sharded.key_range(rank, world, total)
+        assert (lo, hi) == (rank * rows_per_rank, (rank + 1) * rows_per_rank)
+        mine = base[lo:hi]
+
+        def local_search(exact):
+            d = ((q[:, None, :] - mine[None, :, :]) ** 2).sum(-1)
+            order = np.argsort(d, axis=1, kind="stable")[:, :k]
+            return torch.from_numpy((order + lo).astype(np.int64)), torch.from_numpy(np.take_along_axis(d, order, axis=1).astype(np.float32))
+
+        def merge(blocks, out_k, out_d):
+            mk, md = sharded.merge_packed_reference(blocks.numpy(), world, nq, k)
+            out_k.copy_(torch.from_numpy(mk.view(np.int64)))
+            out_d.copy_(torch.from_numpy(md))
+
+        s = sharded.ShardedSearcher(None, torch.from_numpy(q), k, dist, None, local_search, merge)
+        s.step()
+        d_all = ((q[:, None, :] - base[None, :, :]) ** 2).sum(-1)
+        truth = np.argsort(d_all, axis=1, kind="stable")[:, :k]
+        got = s.keys.numpy()
+        ok = np.array_equal(got, truth.astype(np.int64)) and np.array_equal(s.dists.numpy(), np.take_along_axis(d_all, truth, axis=1))
+        # the ties really are there: the closest distance of every query occurs in every shard, in rank order
+        for row_k, row_d in zip(got, s.dists.numpy()):
+            tied = row_k[row_d == row_d[0]] // rows_per_rank   # ranks of the closest distance's holders, in answer order
+            ok = ok and len(tied) >= world and bool((np.diff(tied) >= 0).all()) and set(tied.tolist()) == set(range(world))
+        ok = ok and all(sharded.owner_of(int(key), world, total) == int(key) // rows_per_rank for key in got.ravel())
+        t = s.keys.clone()
+        dist.broadcast(t, src=0)
+        out[rank] = 1 if (ok and bool((t == s.keys).all())) else 0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_search_world8_gloo_ties_at_every_rank_boundary():
+    """BASELINE configs[3]'s shape (8 key ranges, one all-gather per batch, packed merge) on CPU -- the one place this pool can run 8
+    ranks.  Round-5 review, item 8."""
+    world = 8
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_ties, args=(world, _free_port(), 40, 6, 7, 24, out), nprocs=world, join=True)
+    assert dict(out) == {r: 1 for r in range(world)}

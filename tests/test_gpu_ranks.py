@@ -113,12 +113,17 @@ def test_bench_gpus_2_on_one_device_runs_both_sharded_legs():
     for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(var, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--vectors", "100000",
-                          "--dim", "96", "--nq", "1000", "--steps", "4", "--warmup", "1", "--ef", "96"], env=env, text=True, capture_output=True,
-                         timeout=800, cwd=ROOT)
+                          "--dim", "96", "--nq", "1000", "--steps", "4", "--warmup", "1", "--ef", "96", "--full-record", "gpurun_out/test_same_device_full.json"],
+                         env=env, text=True, capture_output=True, timeout=800, cwd=ROOT)
     print(out.stdout[-3000:])
     print(out.stderr[-6000:])
     assert out.returncode == 0
-    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    # stdout's last line is the contract line alone (round 6); the full record is in the file it names
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["same_device"] is True and line["comm_ranks"] == 2 and line["exchange"] == "hostshm"
+    assert line["full_record"] == "gpurun_out/test_same_device_full.json" and line["sharded"]["weak"] > 0 and line["sharded"]["fixed_total"] > 0
+    rec = json.load(open(os.path.join(ROOT, line["full_record"])))
+    assert line["sharded_weak_queries_per_s"] == pytest.approx(rec["sharded"]["weak"]["queries_per_s"], rel=1e-4)
     assert rec["n_gpus"] == 2 and rec["same_device"] is True and rec["comm_ranks"] == 2 and rec["rccl_ranks"] == 0 and rec["exchange"] == "hostshm"
     assert rec["sharded"]["weak"]["index_vectors_total"] == 200000 and rec["sharded"]["fixed_total"]["index_vectors_total"] == 100000
     for leg in ("weak", "fixed_total"):
@@ -138,6 +143,6 @@ def test_two_ranks_over_rccl():
          "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "shard", "--vectors", "200000", "--nq", "2000",
          "--steps", "4", "--warmup", "1", "--ef", "128", "--cpu-seconds", "0"], env=env, text=True, timeout=900, cwd=ROOT)
     import json
-    rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])  # (the contract line carries every field asserted here)
     assert rec["n_gpus"] == 2 and rec["config"]["mode"] == "shard" and rec["config"]["index_vectors_total"] == 400000
     assert rec["recall_at_10"] >= 0.9 and rec["value"] > 0 and rec["rccl_ranks"] == 2 and rec["exchange"] == "rccl"

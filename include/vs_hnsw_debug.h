@@ -47,6 +47,12 @@ VS_API int vs_hnsw_walk_info(vs_hnsw* index, uint64_t out[2]);
  * rounds): [0] walk launches and [1] predicate calls spent that way so far. */
 VS_API int vs_hnsw_filter_stats(vs_hnsw* index, uint64_t out[2]);
 
+/* Unnamed filters (vs_hnsw_filtered_search: an opaque predicate) are ONE walk that asks the caller while it runs (round 6):
+ * [0] queries answered that way, [1] walks that handed over to the rounds of rounds 3-5 (an order-relevant tie, a host that did not
+ * answer), [2] queries no pod could take, [3] predicate calls of the asking walks; on the device: [4] times a walker stood still for
+ * answers, [5] 100 MHz ticks it did, [6] hops, [7] ticks of the walks as a whole. */
+VS_API int vs_hnsw_filter_ask_stats(vs_hnsw* index, uint64_t out[8]);
+
 /* Named filters (vs_hnsw_filtered_search_keyed): [0] queries answered with a filter memory, [1] verdicts they still asked the host
  * for, [2] memories created, [3] memories held now, [4] vs_hnsw_filter_forget / _forget_keys calls, [5] members those forgot. */
 VS_API int vs_hnsw_filter_memo_stats(vs_hnsw* index, uint64_t out[6]);

@@ -25,7 +25,7 @@ def lib():
     global _lib
     if _lib is None:
         _ix.lib()  # libvs_hnsw.so first (RTLD_GLOBAL), then the actor on top of it
-        L = C.CDLL(os.path.join(_HERE, "libvs_actor.so"))
+        L = C.CDLL(os.path.join(os.environ.get("VS_LIB_DIR") or _HERE, "libvs_actor.so"))
         vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
         L.vs_actor_create.argtypes = [C.POINTER(_ActorOptions), C.POINTER(vp)]
         L.vs_actor_create_with.argtypes = [C.POINTER(_ActorOptions), vp, C.POINTER(vp)]

@@ -48,7 +48,7 @@ def lib():
     global _lib
     if _lib is None:
         _actor.lib()  # libvs_hnsw.so, libvs_actor.so first
-        L = C.CDLL(os.path.join(_HERE, "libvs_callers.so"))
+        L = C.CDLL(os.path.join(os.environ.get("VS_LIB_DIR") or _HERE, "libvs_callers.so"))
         L.vs_mixed_run.argtypes = [C.c_void_p, C.POINTER(MixedOptions), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                    C.POINTER(MixedResult)]
         L.vs_callers_run_recorded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint,

@@ -1562,8 +1562,8 @@ struct Engine {
         PodPool& pp = pod_pool(device);
         if (!pp.enabled || ef > 512) return {};
         const uint32_t efcap = ef <= 256 ? 256u : 512u;
-        const bool explore = mode == 2;
-        if (mode == 2) mode = 1;  // (one kind of pod serves both kinds of round of a filtered query: its callers alternate between them)
+        const uint32_t walk_kind = mode == 2 ? 1u : mode == 3 ? 2u : 0u;  // PodSlot::explore: 0 exact, 1 exploring, 2 the walk that asks (round 6)
+        if (mode == 2 || mode == 3) mode = 1;  // (one kind of pod serves every kind of round of a filtered query)
         std::lock_guard<std::mutex> g(pp.mu);
         if (pp.holds > 0) return {};  // somebody is about to synchronise the device: no pod opens, none takes a post
         if (being_modified.load(std::memory_order_seq_cst) > 0) return {};  // (the index is being modified -- PodFreeze: the caller breaks the reference's contract, and is served by a launch)
@@ -1647,7 +1647,7 @@ struct Engine {
         PodSlot& sl = p.slots[slot];
         sl.q = pq;
         sl.ef = ef;
-        sl.explore = explore ? 1u : 0u;
+        sl.explore = walk_kind;
         __atomic_store_n(&sl.posted, ++p.seq[slot], __ATOMIC_RELEASE);
         p.busy[slot] = true;
         ++p.n_busy;
@@ -1982,6 +1982,7 @@ struct Engine {
         uint32_t* h_done = (uint32_t*)w->pin + 8;    // the flag
         uint32_t* h_list = (uint32_t*)(w->pin + 64);
         uint8_t* h_verdict = (uint8_t*)(w->pin + 64 + (size_t)cap * 4);
+        w->ask_dirty = cap;  // (this path writes verdicts wherever its rounds list slots)
         uint64_t* h_k = (uint64_t*)(w->pin + 64 + (size_t)cap * 5);
         float* h_d = (float*)(h_k + k);
         float* h_q = (float*)(w->pin + ((64 + (size_t)cap * 5 + k * 12 + 63) & ~(size_t)63));
@@ -2107,6 +2108,9 @@ struct Engine {
                 if (found == kPipeRedoFound) return (size_t)-1;  // (cannot happen: the usearch-order walk answers or fails)
             }
             if (count == 0 && !explore) {
+                if (std::getenv("VS_HNSW_ASK_DEBUG"))  // (profile builds: the phases of a hop of the exact walk, as filtered_ask prints them)
+                    std::fprintf(stderr, "[exact] hops %u ticks %u | max_next %u pushed %u refill clk/16 %u refills|spills<<16 %u wait_entry %u schedule %u\n", h_cnt[9], h_cnt[4],
+                                 h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
                 if (found == kWalkFailed) return (size_t)-1;
                 std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
                 std::memcpy(dist, h_d, (size_t)std::min<size_t>(found, k) * 4);
@@ -2148,6 +2152,152 @@ struct Engine {
         }
         return (size_t)-1;
     }
+    // ---- an opaque predicate, ONE walk (round 6) -----------------------------------------------------------------------------------------
+    // The trait's own signature (usearch.rs:224-248: a closure, no name) gives the engine nothing to remember: every query asks afresh.
+    // Rounds 3-5 did that in ROUNDS (an exploring walk that lists the verdicts the exact walk will need, the answers, the exact walk
+    // from scratch: 2.2 walks, twice the CPU's predicate calls).  Here the query is posted ONCE, to a pod, as a walk that asks while it
+    // runs (pipe_device.hpp, "asks"): this thread -- it would only be waiting -- answers: the kernel's courier wave publishes the number
+    // of asks in h_cnt[5] and their slots in h_list, one verdict byte per ask goes back (1 rejected, 2 admitted).  A member is asked
+    // about when it is new to the walk's visited set and passes the radius test, i.e. when usearch would ask, once.
+    // (size_t)-1: not served here (no pod free, the walk handed over at an order-relevant tie, the device gave up on a host that did not
+    // answer) -- the rounds serve the query.
+    std::atomic<uint64_t> ask_queries{0}, ask_handed_over{0}, ask_no_pod{0}, ask_calls{0}, ask_waits{0}, ask_wait_ticks{0}, ask_hops{0}, ask_walk_ticks{0};
+    size_t filtered_ask(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, uint32_t ef) {
+        use_device();
+        housekeeping();
+        const size_t n = slots_atomic.load(std::memory_order_acquire), lay = layout_slots();
+        const size_t lay_words = (lay + 31) / 32;
+        const uint32_t cap = 1u << 17;
+        Lease w(device);
+        const size_t space = batch_space_bytes(lay);
+        if (w->ws.bytes < space || w->ws_zeroed != lay_words) {
+            char* p = (char*)w->ws.ensure(space);
+            HIP_OK(hipMemsetAsync(p, 0, w->ws.bytes, w->stream));
+            HIP_OK(hipStreamSynchronize(w->stream));
+            w->ws_zeroed = lay_words;
+        }
+        const size_t pin_need = 64 + (size_t)cap * 5 + k * 12 + 64 + (size_t)dim * 4;
+        if (w->pin_bytes < pin_need) {
+            if (w->pin) graveyard().bury(nullptr, w->pin);
+            w->pin = nullptr;
+            w->pin_bytes = 0;
+            w->ask_dirty = cap;
+            HIP_OK(hipHostMalloc((void**)&w->pin, pin_need, hipHostMallocDefault));
+            w->pin_bytes = pin_need;
+        }
+        uint32_t* h_cnt = (uint32_t*)w->pin;
+        uint32_t* h_done = (uint32_t*)w->pin + 8;
+        uint32_t* h_list = (uint32_t*)(w->pin + 64);
+        uint8_t* h_verdict = (uint8_t*)(w->pin + 64 + (size_t)cap * 4);
+        uint64_t* h_k = (uint64_t*)(w->pin + 64 + (size_t)cap * 5);
+        float* h_d = (float*)(h_k + k);
+        float* h_q = (float*)(w->pin + ((64 + (size_t)cap * 5 + k * 12 + 63) & ~(size_t)63));
+        std::memcpy(h_q, q, (size_t)dim * 4);
+        // (the verdict bytes double as "answered" flags: whatever an earlier query of this context -- of either path -- left there goes)
+        std::memset(h_verdict, 0, std::min<size_t>(cap, w->ask_dirty));
+        w->ask_dirty = cap;  // (until this query's own count is known)
+        for (int i = 0; i < 16; ++i)
+            if (i != 8) h_cnt[i] = 0u;
+        PipeQuery pq{};
+        pq.query = h_q;
+        pq.allow = nullptr;
+        pq.known = nullptr;
+        pq.words = 0u;
+        pq.zero_bits = 0u;
+        pq.list = h_list;
+        pq.verdict = h_verdict;
+        pq.apply_m = 0u;
+        pq.slots = (uint32_t)n;
+        pq.cap = cap;
+        pq.budget = cap;
+        pq.k = (uint32_t)k;
+        pq.round_id = ++w->round_seq ? w->round_seq : ++w->round_seq;
+        pq.cnt = h_cnt;
+        pq.keys = h_k;
+        pq.space = (char*)w->ws.p;
+        pq.memo = nullptr;
+        pq.memo_stride = 0u;
+        __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
+        PodRelease pod{device, pod_submit(3, ef, lay, pq)};
+        if (!pod.t) {
+            w->ask_dirty = 0;
+            ask_no_pod.fetch_add(1, std::memory_order_relaxed);
+            return (size_t)-1;
+        }
+        static std::atomic<int> waiting{0};
+        struct Count {
+            explicit Count() { waiting.fetch_add(1, std::memory_order_relaxed); }
+            ~Count() { waiting.fetch_sub(1, std::memory_order_relaxed); }
+        } count;
+        const int cores = usable_cores();
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t answered = 0;
+        uint64_t calls = 0;
+        bool lost = false, timed_out = false;
+        for (uint32_t it = 0;; ++it) {
+            const uint32_t asked = __atomic_load_n(h_cnt + 5, __ATOMIC_ACQUIRE);
+            if (asked > answered) {
+                for (uint32_t i = answered; i < asked && i < cap; ++i) {
+                    const uint32_t s = h_list[i];
+                    uint8_t v = 1;
+                    if (s < n) {
+                        const uint64_t key = h_keys[s];
+                        if (key != kFreeKey) {
+                            ++calls;
+                            v = pred(key, pctx) ? 2 : 1;
+                        }
+                    }
+                    __atomic_store_n(h_verdict + i, v, __ATOMIC_RELEASE);  // (in order: the courier takes the answered PREFIX)
+                }
+                answered = asked;
+                it = 0;
+                continue;
+            }
+            if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id) break;
+            // a caller per core spins; a crowd beyond the cores takes turns (every one of them is what a walk on the device waits for)
+            if (waiting.load(std::memory_order_relaxed) <= cores) {
+                for (int p = 0; p < 4; ++p) __builtin_ia32_pause();
+            } else {
+                std::this_thread::yield();
+            }
+            if ((it & 1023u) == 1023u) {
+                if (pod_pool(device).lost_post(pod.t) && __atomic_load_n(h_done, __ATOMIC_ACQUIRE) != pq.round_id && __atomic_load_n(h_cnt + 5, __ATOMIC_ACQUIRE) == 0u) {
+                    lost = true;  // the workgroup had left before it saw the post
+                    break;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+                    timed_out = true;
+                    break;
+                }
+            }
+        }
+        w->ask_dirty = std::min<uint32_t>(cap, answered);
+        lazy_predicate_calls += calls;
+        ask_calls.fetch_add(calls, std::memory_order_relaxed);
+        if (timed_out) {
+            w.retire();
+            fail(VS_ERR_DEVICE, "a filtered walk that asks did not finish");
+        }
+        pod.done();
+        if (lost) return (size_t)-1;
+        const uint32_t found = h_cnt[2];
+        if (found == kPipeRedoFound || found == kWalkFailed) {
+            ask_handed_over.fetch_add(1, std::memory_order_relaxed);
+            return (size_t)-1;
+        }
+        std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
+        std::memcpy(dist, h_d, (size_t)std::min<size_t>(found, k) * 4);
+        ask_queries.fetch_add(1, std::memory_order_relaxed);
+        ask_waits.fetch_add(h_cnt[6], std::memory_order_relaxed);
+        ask_wait_ticks.fetch_add(h_cnt[7], std::memory_order_relaxed);
+        ask_hops.fetch_add(h_cnt[9], std::memory_order_relaxed);
+        ask_walk_ticks.fetch_add(h_cnt[4], std::memory_order_relaxed);
+        if (std::getenv("VS_HNSW_ASK_DEBUG"))  // (profile builds: the phases of a hop, see pipe_device.hpp)
+            std::fprintf(stderr, "[ask] hops %u ticks %u waits %u | clocks/16: pop-rest %u entry %u refill %u verdicts %u wait_entry %u resolve+decide %u (%u)\n", h_cnt[9], h_cnt[4],
+                         h_cnt[6], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], 0u);
+        lazy_rounds += 1;
+        return found;
+    }
     static inline std::atomic<int> filtered_active_callers{0};
 
     static constexpr size_t kLazyFilterAbove = 1u << 16;
@@ -2177,6 +2327,16 @@ struct Engine {
             const bool several = filtered_active_callers.load(std::memory_order_relaxed) > 8;
             const bool pods = pod_pool(device).enabled;
             // (a NAMED filter always takes the posted / batched rounds: that is where its remembered verdicts are used)
+            // An unnamed filter -- the trait's own signature -- takes ONE walk that asks while it runs (round 6) whenever pods can serve;
+            // VS_HNSW_FILTER_ASK=0: the rounds of rounds 3-5 (A/B).
+            static const int ask_env = std::getenv("VS_HNSW_FILTER_ASK") ? std::atoi(std::getenv("VS_HNSW_FILTER_ASK")) : 1;
+            // (every asking walk needs its caller awake for its whole length: a crowd well beyond the cores -- measured at 64 / 128 callers
+            // on 16 cores: 1.4k / 1.2k queries/s against the rounds' 3.8k / 7.2k -- is served by the rounds, whose callers sleep)
+            const bool awake = ask_env == 2 || filtered_active_callers.load(std::memory_order_relaxed) <= usable_cores() + usable_cores() / 4;
+            if (!filter_key && ask_env != 0 && awake && pods && batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b)) {
+                const size_t f = filtered_ask(q, k, pred, pctx, keys, dist, ef_b);
+                if (f != (size_t)-1) return f;
+            }
             std::shared_ptr<FilterMemo> memo = (filter_key && batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b)) ? memo_for(filter_key) : nullptr;
             if (batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b) && (batch_env == 1 || memo || (short_walks && (pods || crowd)) || (pods && several))) {
                 const size_t f = filtered_batched(q, k, pred, pctx, keys, dist, ef_b, memo.get());
@@ -2244,6 +2404,7 @@ struct Engine {
         uint32_t* h_cnt = (uint32_t*)w->pin;
         uint32_t* h_list = (uint32_t*)(w->pin + 64);
         uint8_t* h_verdict = (uint8_t*)(w->pin + 64 + (size_t)cap * 4);
+        w->ask_dirty = cap;
         uint64_t* h_k = (uint64_t*)(w->pin + 64 + (size_t)cap * 5);
         float* h_d = (float*)(h_k + k);
         float* h_q = (float*)(w->pin + ((64 + (size_t)cap * 5 + k * 12 + 63) & ~(size_t)63));

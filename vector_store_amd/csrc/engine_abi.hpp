@@ -211,6 +211,19 @@ int vs_hnsw_filter_forget_keys(vs_hnsw* h, const uint64_t* keys, size_t n) {
     });
 }
 
+int vs_hnsw_filter_ask_stats(vs_hnsw* h, uint64_t out[8]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.ask_queries.load();
+    out[1] = h->e.ask_handed_over.load();
+    out[2] = h->e.ask_no_pod.load();
+    out[3] = h->e.ask_calls.load();
+    out[4] = h->e.ask_waits.load();
+    out[5] = h->e.ask_wait_ticks.load();
+    out[6] = h->e.ask_hops.load();
+    out[7] = h->e.ask_walk_ticks.load();
+    return VS_OK;
+}
+
 int vs_hnsw_filter_memo_stats(vs_hnsw* h, uint64_t out[6]) {
     if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
     out[0] = h->e.memo_queries.load();

@@ -296,6 +296,7 @@ struct WorkCtx {
     size_t ws_zeroed = 0;  // bitmap words the workspace is laid out (and all zero) for: the visited log behind the bitmap holds slot numbers, and a
                            // bitmap that grows by a word over them would read those as visited members
     uint32_t round_seq = 0;
+    uint32_t ask_dirty = 1u << 17;  // verdict bytes of `pin` that may be non-zero (filtered_ask reads them as "answered" flags and clears them first)
 };
 
 // The engine's streams on one device: a fixed set, shared by the leased contexts (from index 0 up) and the single-query

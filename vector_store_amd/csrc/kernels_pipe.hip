@@ -79,6 +79,8 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
         sh.job_state[tid] = 0u;
         if (tid == 0) {
             sh.stop = 0u;
+            sh.aq_tail = 0u;
+            sh.courier_done = 0u;
             sh.tw_req = sh.tw_done = 0u;
             for (int i = 0; i < 8; ++i) sh.prof_jobs[i] = 0u;
         }
@@ -153,6 +155,12 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
                 return;
             }
         }
+        if constexpr (MODE == kPipeAsk) {
+            if (w == kPipeCourierWave) {  // asks: this wave carries the walker's questions to the caller and the answers back (pipe_device.hpp)
+                pipe_courier_loop(sh, uni(pq->list), uni(pq->verdict), uni(pq->cnt), lane);
+                return;
+            }
+        }
         pipe_helper_loop<AR, I>(ix, q, sh, ws, tomb, allow, known, lane, w);
         return;
     }
@@ -170,6 +178,9 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
                                        pq ? uni(pq->cnt) : a.unknown_count ? a.unknown_count + qi : nullptr, pq ? uni(pq->cap) : a.unknown_cap,
                                        pq ? uni(pq->budget) : a.unknown_budget, pq ? uni(pq->cnt) + 1 : a.consulted ? a.consulted + qi : nullptr, cnt, lane, top,
                                        a.debug ? a.debug + (size_t)qi * 12 : nullptr, a.pipe_fused_order != 0u);
+    if constexpr (MODE == kPipeAsk) {  // (the walk has set sh.stop: the courier leaves within one look)
+        for (uint32_t spins = 0; lds_load_acquire(&sh.courier_done) == 0u && spins < (1u << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+    }
     if (r.status == 1u) {  // the usearch-order walk answers it (and lists the verdicts IT misses: this walk's list is dropped)
         if (lane == 0) {
             if (a.retry_list) a.retry_list[atomicAdd(a.retry_count, 1u)] = qi;
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
         const PipeQuery* pq = a.pipe_qtable ? a.pipe_qtable + bid : nullptr;
         uint32_t qi = bid, ef = a.ef;
         uint64_t t_begin = wall_clock64();
-        [[maybe_unused]] bool explore = false;
+        [[maybe_unused]] uint32_t explore = 0u;  // a pod of filtered queries: 0 the exact walk, 1 an exploring round, 2 the asking walk (round 6)
         // what adds and removes change: a launch carries it in its arguments, a pod reads it per query (pipe_pod.hpp: PodCtl)
         uint32_t entry_slot = a.ix.entry_slot;
         int32_t max_level = a.ix.max_level;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
             seen = p;
             t_begin = wall_clock64();
             ef = (uint32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[1]);
-            explore = __builtin_amdgcn_readfirstlane((int)pod_cmd[2]) != 0;
+            explore = (uint32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[2]);
             entry_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[3]);
             max_level = (int32_t)__builtin_amdgcn_readfirstlane((int)pod_cmd[4]);
             tomb = __builtin_amdgcn_readfirstlane((int)pod_cmd[5]) != 0;
@@ -338,7 +349,8 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
         }
         if constexpr (MODE == kPipeBoth) {
             // a pod of filtered queries: the two kinds of round alternate for every caller, so one workgroup serves either
-            if (explore) pipe_query<AR, I, EFCAP, kPipeExplore>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
+            if (explore == 2u) pipe_query<AR, I, EFCAP, kPipeAsk>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
+            else if (explore) pipe_query<AR, I, EFCAP, kPipeExplore>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
             else pipe_query<AR, I, EFCAP, kPipeFiltered>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
         } else {
             pipe_query<AR, I, EFCAP, MODE>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);

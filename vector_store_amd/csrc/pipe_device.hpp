@@ -118,6 +118,11 @@ struct PipeShared : TeamBox<TM>, VisitedLds<!VISG, (EFCAP <= 256 ? 1024 : 2048),
     uint32_t tw_sz, tw_redo;
     float tw_radius;
     uint32_t tw_req, tw_done;  // sequence numbers: posted by the walker / merged into `top`
+    // asks (kPipeAsk, round 6): the walker's questions to the host's predicate and the answers, carried by the courier wave
+    uint32_t aq_slot[256];  // ring: the slot asked about, by ask number & 255
+    uint32_t av[256];       // ring: its answer (0 none yet, 1 rejected, 2 admitted) -- zeroed by the walker when it asks
+    uint32_t aq_tail;       // asks posted by the walker so far
+    uint32_t courier_done;  // the courier has left, its last store to the caller's memory is out (the query's flag must come after it)
     uint32_t prof_jobs[8];  // profile builds: job parts done, their clocks; [2..7] (VS_WALK_PROFILE == 3) urgent parts: count, clocks until the row is here / the list is written / the distances are out / the part is reported, neighbours measured
 };
 
@@ -331,7 +336,10 @@ struct TopOps {
         return v;
     }
     // top.insert({d, s}, ef) with d below the radius when full: in front of equal entries
-    __device__ __forceinline__ void insert(float d, uint32_t s) {
+    // lazy (kPipeAsk): the entry arrives LATER than usearch would have inserted it (its verdict was on its way) -- the set `top` holds
+    // does not depend on the order of arrival, the order among equal distances does: such an insertion that meets an equal distance
+    // hands the walk over
+    __device__ __forceinline__ void insert(float d, uint32_t s, bool lazy = false) {
         uint32_t rank = 0;
         bool eq = false;
 #pragma unroll
@@ -351,6 +359,7 @@ struct TopOps {
             }
         }
         if (tie_active && (eq_any || ((!kFilter || fused_order) && sz + 1u >= ef))) redo = true;
+        if (lazy && eq_any) redo = true;
         const float cd = __uint_as_float(wave_shr1(__float_as_uint(top.d[R - 1]), 0u));
         const uint32_t cs = wave_shr1(top.s[R - 1], 0u);
 #pragma unroll
@@ -535,6 +544,52 @@ __device__ __forceinline__ void pipe_top_loop(Sh& sh, uint32_t ef, bool fused_or
     }
 }
 
+// ---- the courier wave (kPipeAsk, round 6) -------------------------------------------------------------------------------
+// An opaque predicate lives on the host (usearch.rs:224-248 binds a Rust closure: a table read-lock + restriction evaluation per
+// candidate, :1118-1124).  Rounds 3-5 answered such a query in ROUNDS -- an exploring walk that lists the verdicts an exact walk will
+// need, the host's answers, the exact walk from scratch: 2.2 walks and twice the CPU's predicate calls.  Here the walk ASKS while it
+// runs: the walker posts the slots whose verdict it needs into an LDS ring, this wave (it takes one helper's place, as the top wave
+// does in plain walks) writes them to the caller's pinned list and publishes the count (cnt[5]); the caller -- it is waiting for this
+// very query -- evaluates the predicate and writes one byte per ask (1 rejected, 2 admitted) into the pinned verdict array; this wave
+// polls those bytes (one 64-byte read past the caches per look) and hands them to the walker through LDS.  The walker never touches
+// host memory: a store or a load that crosses PCIe would sit in its vmcnt queue in front of the visited atomics it waits for.
+constexpr uint32_t kPipeCourierWave = 1u;
+template <class Sh>
+__device__ __forceinline__ void pipe_courier_loop(Sh& sh, uint32_t* list, const uint8_t* verdict, uint32_t* cnt, int lane) {
+    const uint32_t L = (uint32_t)lane;
+    uint32_t pub = 0, ans = 0;  // asks published to the host; the answered prefix
+    for (uint32_t idle = 0;;) {
+        const uint32_t tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_flag_load(&sh.aq_tail));
+        if (tail != pub) {
+            for (uint32_t i = pub + L; i < tail; i += 64u) list[i] = sh.aq_slot[i & 255u];
+            __threadfence_system();
+            __builtin_amdgcn_wave_barrier();
+            if (L == 0u) __hip_atomic_store(cnt + 5, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            pub = tail;
+            idle = 0;
+        }
+        if (ans != pub) {
+            const uint32_t i = ans + L;
+            uint32_t v = 0;
+            if (i < pub) v = (uint32_t)__hip_atomic_load(verdict + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v) sh.av[i & 255u] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const uint64_t got = __builtin_amdgcn_ballot_w64(v != 0u);
+            ans += got == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~got);  // the answered prefix (the host answers in order)
+            if (!got) __builtin_amdgcn_s_sleep(8);
+        } else {
+            if (lds_load_relaxed(&sh.stop)) break;
+            if (++idle > 64u) __builtin_amdgcn_s_sleep(16);
+            else __builtin_amdgcn_s_sleep(2);
+        }
+        if (lds_load_relaxed(&sh.stop)) break;
+    }
+    // nothing of this query reaches the caller's block after its flag: the walker waits for this before it reports
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (L == 0u) lds_store_release(&sh.courier_done, 1u);
+}
+
 struct PipeOut {
     uint32_t status;  // 0 answered; 1 redo (an order-relevant tie / structure outgrown); 2 the round's budget of unknown verdicts is spent (lazy filter)
     uint32_t sz;
@@ -545,7 +600,8 @@ struct PipeOut {
 //   kPipePlain    plain lone queries (no filter): no verdict bookkeeping, `next` never outgrows LDS (no spilling), fused-list tie order
 //   kPipeFiltered the exact walk of a filtered query
 //   kPipeExplore  an exploring round of a lazily filtered query
-enum : int { kPipePlain = 0, kPipeFiltered = 1, kPipeExplore = 2 };
+//   kPipeAsk      the exact walk of a filtered query whose verdicts are ASKED FOR while it runs (round 6: opaque predicates)
+enum : int { kPipePlain = 0, kPipeFiltered = 1, kPipeExplore = 2, kPipeAsk = 4 };
 template <int AR, int I, int MODE, class Sh>
 __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2* pool, uint32_t pool_cap, const WalkSpace& ws, uint32_t start,
                                              float start_d, uint32_t ef, bool tomb, const uint32_t* allow, const uint32_t* known,
@@ -554,6 +610,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                                              bool fused_order) {
     constexpr bool explore = MODE == kPipeExplore;
     constexpr bool kFilter = MODE != kPipePlain;
+    constexpr bool ask = MODE == kPipeAsk;
     if constexpr (!kFilter) {
         allow = nullptr;
         known = nullptr;
@@ -1037,7 +1094,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         uint32_t js = 1u, cr = 1u;
         if (L >= 1u && L < TM) js = lds_load_relaxed(&sh.job_state[L]);
         if (L < K) cr = lds_load_relaxed(&sh.c_ready[L]);
-        idle = __builtin_amdgcn_ballot_w64(L >= 1u && L < TM && js == 0u && !(kTopWave && L == kPipeTopWave));  // (plain walks: the top wave takes no jobs)
+        idle = __builtin_amdgcn_ballot_w64(L >= 1u && L < TM && js == 0u && !(kTopWave && L == kPipeTopWave) && !(ask && L == kPipeCourierWave));  // (the top wave / the courier take no jobs)
         freem = __builtin_amdgcn_ballot_w64(L < K && tag == kInvalid && cr == 0u);
     };
     // "measure candidate s", split over up to `want` helpers; the entry, or kInvalid when no helper or no entry is to be had
@@ -1112,6 +1169,116 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         const bool guess = unk && guess_t != 0u && ((n * 2654435761u) >> 24) < guess_t;
         return __builtin_amdgcn_ballot_w64((live && (fl & kPfAllowed) != 0u) || guess);
     };
+    // ---- asks (kPipeAsk): the walk goes on while its questions are on their way --------------------------------------------------
+    // A neighbour that passes the radius test and whose verdict the host has not given yet is ASKED ABOUT (the courier wave carries the
+    // question and the answer) and waits in a PENDING lane of the walker: (distance, slot, ask number).  It is pushed to `next` at once
+    // -- usearch pushes whatever passes the radius test, admitted or not -- and enters `top` when its answer arrives.  Until then the
+    // walker's `top` is the PESSIMISTIC one (pending neighbours left out): its radius is at or beyond the true one, so
+    //   * who passes the radius test, who is pushed, what refill / spill keep: supersets of usearch's, by entries at or beyond the
+    //     true radius of their hop.  The radius only shrinks once `top` is full, so such an entry can never be expanded: when it is the
+    //     closest candidate, everything usearch's own `next` holds lies as far or farther, and usearch ends its walk there too.  (At
+    //     EQUALITY with the radius the orders could differ: a candidate popped at the radius that is not top's last member hands over.)
+    //   * `top` as a SET is the `ef` closest admitted neighbours of everything that was offered, whatever the order of arrival; the
+    //     order among EQUAL distances is arrival order, so a late insertion that meets an equal distance hands over (insert(lazy)).
+    //   * the one decision that needs the TRUE radius is the pop: `candidate.distance > radius && top.size() == limit` ends the walk.
+    //     With P answers out, the walk certainly goes on while fewer than ef - P members of the pessimistic `top` lie at or below the
+    //     candidate (even if all P were admitted and closer, the ef-th best would still lie beyond it); it certainly ends when the
+    //     pessimistic `top` is full and the candidate lies beyond its radius (the true one is not larger) -- after the last answers are
+    //     in.  In between the walker waits for answers: the last stretch of a walk, where the candidates approach the radius.
+    //   * inside a tie window (equal distances waiting in `next` together) every rule about the radius is exact: the window starts with
+    //     all answers in, and its hops ask and WAIT (ask_now) before they admit anybody.
+    // Every member is asked about at most once per walk (it is asked when it is NEW to the visited set), as usearch does.
+    float p_d = INF;
+    uint32_t p_s = kInvalid, p_i = 0u;
+    uint64_t pmask = 0ull;  // pending lanes in use
+    uint32_t asked = 0u;
+    bool lazy_used = false;
+    auto resolve = [&]() {  // what the courier has brought: admitted neighbours enter `top`, their lanes are free again
+        if (!pmask) return;
+        uint32_t v = 0u;
+        if ((pmask >> L) & 1ull) v = lds_load_relaxed(&sh.av[p_i & 255u]);
+        const uint64_t rm = __builtin_amdgcn_ballot_w64(v != 0u);
+        if (!rm) return;
+        for (uint64_t r = __builtin_amdgcn_ballot_w64(v == 2u); r; r &= r - 1ull) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(r);
+            const float dj = rl_f(p_d, j);
+            if (sz < ef || dj < radius) T.insert(dj, rl_u(p_s, j), true);
+        }
+        pmask &= ~rm;
+    };
+    uint32_t ask_waits = 0, ask_wait_ticks = 0;  // how often the walker stood still for answers, and for how long (100 MHz ticks)
+    auto wait_pending = [&](uint32_t target) {  // until at most `target` answers are still out
+        if ((uint32_t)__popcll(pmask) <= target) return;
+        const uint64_t w0 = wall_clock64();
+        ++ask_waits;
+        for (uint32_t spins = 0; (uint32_t)__popcll(pmask) > target && !redo; ++spins) {
+            resolve();
+            if ((uint32_t)__popcll(pmask) <= target) break;
+            if (spins > (1u << 21)) {  // (a host that does not answer for a fifth of a second: the rounds of the old path serve the query)
+                redo = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        ask_wait_ticks += (uint32_t)(wall_clock64() - w0);
+    };
+    auto ask_post = [&](uint64_t um, uint32_t n) -> uint32_t {  // the lanes of `um` ask about their n; the first ask's number
+        const uint32_t c = (uint32_t)__popcll(um);
+        if (asked + c > unknown_cap) {
+            redo = true;
+            return kInvalid;
+        }
+        const uint32_t base = asked;
+        if ((um >> L) & 1ull) {
+            const uint32_t idx = (base + mbcnt(um)) & 255u;
+            sh.av[idx] = 0u;
+            sh.aq_slot[idx] = n;
+        }
+        asked += c;
+        if (L == 0u) lds_flag_store(&sh.aq_tail, asked);
+        return base;
+    };
+    auto ask_lanes = [&](uint64_t um, float nd, uint32_t n) {  // lazily: the asked neighbours wait in pending lanes
+        const uint32_t c = (uint32_t)__popcll(um);
+        if (64u - (uint32_t)__popcll(pmask) < c) wait_pending(64u - c);
+        if (redo) return;
+        const uint32_t base = ask_post(um, n);
+        if (base == kInvalid) return;
+        if ((um >> L) & 1ull) sh.stage[mbcnt(um)] = make_uint2(__float_as_uint(nd), n);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t fm = ~pmask;
+        const uint32_t fr = mbcnt(fm);
+        const bool take = ((fm >> L) & 1ull) != 0ull && fr < c;
+        if (take) {
+            const uint2 e = sh.stage[fr];
+            p_d = __uint_as_float(e.x);
+            p_s = e.y;
+            p_i = base + fr;
+        }
+        pmask |= __builtin_amdgcn_ballot_w64(take);
+    };
+    auto ask_now = [&](uint64_t um, uint32_t n) -> uint64_t {  // inside a tie window: the answers before anything else happens
+        const uint32_t base = ask_post(um, n);
+        if (base == kInvalid) return 0ull;
+        const bool mine = ((um >> L) & 1ull) != 0ull;
+        const uint32_t idx = (base + mbcnt(um)) & 255u;
+        uint32_t v = 0u;
+        const uint64_t w0 = wall_clock64();
+        ++ask_waits;
+        for (uint32_t spins = 0;; ++spins) {
+            if (mine && v == 0u) v = lds_load_relaxed(&sh.av[idx]);
+            if (!__builtin_amdgcn_ballot_w64(mine && v == 0u)) break;
+            if (spins > (1u << 21)) {
+                redo = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        ask_wait_ticks += (uint32_t)(wall_clock64() - w0);
+        return __builtin_amdgcn_ballot_w64(mine && v == 2u);
+    };
     if constexpr (!Sh::kVisGlobal) {
         visited_clear(sh, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1133,12 +1300,26 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 }
             }
         }
+        if constexpr (ask) {
+            front_insert(start_d, start, 0u);
+            const uint32_t f0 = rl_u(fl0, 0);
+            if (f0 & kPfLive) {
+                consulted += 1u;
+                if (allow && (f0 & kPfKnown)) {
+                    if (f0 & kPfAllowed) top_insert(start_d, start);
+                } else {
+                    lazy_used = true;
+                    ask_lanes(1ull, start_d, start);
+                }
+            }
+        } else {
         const uint64_t ok0 = verdicts(1ull, start, fl0);
         front_insert(start_d, start, 0u);
         if constexpr (kTopWave) {
             if (ok0 & 1ull) tw_post(1ull, 1ull, start_d, start, 0u);
         } else {
             if (ok0 & 1ull) top_insert(start_d, start);
+        }
         }
     }
     // ---- exploring round (lazy filter): no answer is taken from it, so no order has to be kept.  The closest candidates are expanded
@@ -1257,8 +1438,28 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             tw_sync();
             if (redo) break;
         }
+        if constexpr (kFilter && !ask) WALK_STAMP(8);
+        if constexpr (ask) {  // (see "asks" above: the pop is the one decision that needs the true radius)
+            WALK_STAMP(8);  // (profile builds, asking walks: spill / refill)
+            resolve();
+            while (pmask && !redo) {
+                if (sz == ef && cd > radius) {  // ends here, once the last answers are in (the radius only shrinks)
+                    wait_pending(0u);
+                    continue;
+                }
+                uint32_t le = 0;  // members of the pessimistic `top` at or below the candidate (unused positions hold +inf)
+#pragma unroll
+                for (int j = 0; j < R; ++j) le += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(top.d[j] <= cd));
+                // (only the pending neighbours at or below the candidate could pull the ef-th best below it)
+                const uint32_t out = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(((pmask >> L) & 1ull) != 0ull && p_d <= cd));
+                if (le + out < ef) break;
+                wait_pending((uint32_t)__popcll(pmask) - 1u);
+            }
+            if (redo) break;
+            WALK_STAMP(9);  // (asking walks: the answers taken in, the pop decided)
+        }
         if (sz == ef && cd > radius) break;  // `candidate.distance > radius && top.size() == top_limit`
-        if (kFilter && any_window && !fused_order && sz == ef && cd == radius) {
+        if (kFilter && (any_window || (ask && lazy_used)) && !fused_order && sz == ef && cd == radius) {
             // at the radius: the last member of `top` itself, as a rule (every admitted member waits in `next` too) -- or another node at
             // the same distance, which usearch's `next` may not hold: the one distance where that matters
             const uint32_t lp = (ef - 1u) / (uint32_t)R, lr = (ef - 1u) % (uint32_t)R;
@@ -1286,6 +1487,10 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             if constexpr (kFilter) any_window = true;
             tie_v = cd;
             ++dbg_windows;
+            if constexpr (ask) {  // the window's rules are about the true radius: it starts with every answer in
+                wait_pending(0u);
+                if (redo) break;
+            }
         }
         // its evaluated neighbours
         uint64_t hitm = __builtin_amdgcn_ballot_w64(L < K && tag == cs);
@@ -1381,10 +1586,35 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 redo = true;
                 break;
             }
-            const uint64_t okmask = verdicts(cand, n, fl);
+            uint64_t okmask;
+            bool done;
+            if constexpr (ask) {
+                const bool cm = ((cand >> L) & 1ull) != 0ull, live = cm && (fl & kPfLive) != 0u;
+                const bool kn = live && allow != nullptr && (fl & kPfKnown) != 0u;
+                okmask = __builtin_amdgcn_ballot_w64(kn && (fl & kPfAllowed) != 0u);
+                const uint64_t um = __builtin_amdgcn_ballot_w64(live && !kn);
+                consulted += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
+                if (tie_active) {  // inside a window: the hop as usearch does it, every verdict in hand first
+                    if (um) okmask |= ask_now(um, n);
+                    if (redo) break;
+                    done = hop_batch(cand, okmask, nd, n);
+                } else {
+                    lazy_used = true;
+                    for (uint64_t r = okmask; r; r &= r - 1ull) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(r);
+                        const float dj = rl_f(nd, j);
+                        if (sz < ef || dj < radius) T.insert(dj, rl_u(n, j), true);
+                    }
+                    if (um) ask_lanes(um, nd, n);
+                    if (redo) break;
+                    WALK_STAMP(4);  // verdicts: asked
+                    push_lanes(cand, nd, n);
+                    done = true;
+                }
+            } else {
+            okmask = verdicts(cand, n, fl);
             if (over_budget) break;  // enough unknown slots listed for one round: the host evaluates them and launches again
             WALK_STAMP(4);  // verdicts
-            bool done;
             if constexpr (kTopWave) {
                 const uint64_t pass = hop_posted(cand, okmask, nd, n);
                 WALK_STAMP(8);  // (inside "pushes, top": who passes; the admitted ones are on their way to the top wave)
@@ -1393,6 +1623,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 done = true;
             } else {
                 done = hop_batch(cand, okmask, nd, n);
+            }
             }
             // the CPU loop as written: one neighbour at a time, in adjacency order, against the moving radius
             for (uint64_t r = done ? 0ull : cand; r; r &= r - 1ull) {
@@ -1417,6 +1648,36 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         schedule();
         WALK_STAMP(6);  // scheduling
     }
+    if constexpr (ask) {  // the last answers: their admitted neighbours belong to the result
+        if (!redo) wait_pending(0u);
+        if (unknown_count && L == 0u) {  // cnt[6], cnt[7], cnt[9]: waits for answers, their ticks, hops (vs_hnsw_filter_ask_stats)
+            unknown_count[6] = ask_waits;
+            unknown_count[7] = ask_wait_ticks;
+            unknown_count[9] = (uint32_t)cnt.hops;
+#ifdef VS_WALK_PROFILE  // (profile builds: the phases of a hop, shader clocks / 16: pop+lookup, entry+atomics+early post, atomics' return, verdicts, pushes+top, scheduling -- and the wait for the entry)
+            for (int i = 0; i < 6; ++i) unknown_count[10 + i] = (uint32_t)(prof[1 + i] >> 4);
+            unknown_count[12] = (uint32_t)(prof[8] >> 4);  // (in the atomics' place: spill / refill)
+            unknown_count[15] = (uint32_t)(prof[9] >> 4);  // (in the scheduling's place: answers taken in, the pop decided)
+            unknown_count[14] = (uint32_t)(prof[7] >> 4);  // (in the pushes' place: the wait for the entry)
+            unknown_count[13] = dbg_refill | (dbg_spills << 16);
+            unknown_count[10] = dbg_max_next;
+            unknown_count[11] = dbg_pushed;
+#endif
+        }
+    }
+#ifdef VS_WALK_PROFILE
+    if constexpr (kFilter && !ask && !explore) {
+        if (unknown_count && L == 0u) {
+            unknown_count[9] = (uint32_t)cnt.hops;
+            for (int i = 0; i < 6; ++i) unknown_count[10 + i] = (uint32_t)(prof[1 + i] >> 4);
+            unknown_count[12] = (uint32_t)(prof[8] >> 4);
+            unknown_count[14] = (uint32_t)(prof[7] >> 4);
+            unknown_count[13] = dbg_refill | (dbg_spills << 16);
+            unknown_count[10] = dbg_max_next;
+            unknown_count[11] = dbg_pushed;
+        }
+    }
+#endif
     if constexpr (kTopWave) {  // `top` comes home: the answer is read from the walker's registers
         tw_sync();
 #pragma unroll

@@ -23,7 +23,7 @@ struct alignas(128) PodSlot {  // pinned host memory: one per workgroup of a pod
     uint32_t posted;           // host: 1, 2, 3, ...: the number of the query in `q`, stored last (release)
     uint32_t ef;               // its beam
     uint32_t left;             // device: 1 = this slot's workgroup has left (the pod was closed, or its host went quiet)
-    uint32_t explore;          // a pod of filtered queries: 1 = an exploring round, 0 = the exact walk
+    uint32_t explore;          // a pod of filtered queries: 1 = an exploring round, 0 = the exact walk, 2 = the walk that asks while it runs (round 6)
     PipeQuery q;
 };
 static_assert(sizeof(PodSlot) == 128, "one slot, one 128-byte line");

@@ -46,7 +46,8 @@ class _GraphInfo(C.Structure):
 
 
 def lib_path() -> str:
-    return os.environ.get("VS_HNSW_LIB") or os.path.join(_HERE, "libvs_hnsw.so")  # VS_HNSW_LIB: an instrumented build (development)
+    # VS_HNSW_LIB: an instrumented build of the engine alone; VS_LIB_DIR: a directory with instrumented builds of every library (development)
+    return os.environ.get("VS_HNSW_LIB") or os.path.join(os.environ.get("VS_LIB_DIR") or _HERE, "libvs_hnsw.so")
 
 
 _lib = None
@@ -102,7 +103,7 @@ def lib():
     if hasattr(L, "vs_hnsw_filter_forget"):
         L.vs_hnsw_filter_forget.argtypes = [vp, u64, C.POINTER(sz)]
         L.vs_hnsw_filter_forget_keys.argtypes = [vp, vp, sz]
-    for young in ("vs_hnsw_pipe_stats", "vs_hnsw_filter_batch_stats", "vs_hnsw_pod_stats", "vs_hnsw_modify_stats", "vs_hnsw_filter_memo_stats", "vs_hnsw_call_stats"):
+    for young in ("vs_hnsw_filter_ask_stats", "vs_hnsw_pipe_stats", "vs_hnsw_filter_batch_stats", "vs_hnsw_pod_stats", "vs_hnsw_modify_stats", "vs_hnsw_filter_memo_stats", "vs_hnsw_call_stats"):
         if hasattr(L, young):
             getattr(L, young).argtypes = [vp, vp]
     if hasattr(L, "vs_hnsw_streams_created"):  # (VS_HNSW_LIB may name an older build: A/B measurements)
@@ -270,6 +271,14 @@ class HipUsearchIndex:
         (the reference's `update_columns`, table/mod.rs:676-695)."""
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         _check(self.L.vs_hnsw_filter_forget_keys(self.h, _p(keys), keys.size))
+
+    def filter_ask_stats(self) -> dict:
+        """Unnamed filters: the walk that asks while it runs (include/vs_hnsw_debug.h: vs_hnsw_filter_ask_stats)."""
+        out = np.zeros(8, dtype=np.uint64)
+        if hasattr(self.L, "vs_hnsw_filter_ask_stats"):
+            _check(self.L.vs_hnsw_filter_ask_stats(self.h, _p(out)))
+        return {"queries": int(out[0]), "handed_over": int(out[1]), "no_pod": int(out[2]), "predicate_calls": int(out[3]),
+                "device_waits": int(out[4]), "device_wait_ms": int(out[5]) / 1e5, "hops": int(out[6]), "device_walk_ms": int(out[7]) / 1e5}
 
     def filter_memo_stats(self) -> dict:
         out = np.zeros(6, dtype=np.uint64)

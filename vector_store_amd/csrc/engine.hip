@@ -1563,7 +1563,7 @@ struct Engine {
         if (!pp.enabled || ef > 512) return {};
         const uint32_t efcap = ef <= 256 ? 256u : 512u;
         const uint32_t walk_kind = mode == 2 ? 1u : mode == 3 ? 2u : 0u;  // PodSlot::explore: 0 exact, 1 exploring, 2 the walk that asks (round 6)
-        if (mode == 2 || mode == 3) mode = 1;  // (one kind of pod serves every kind of round of a filtered query)
+        if (mode == 2) mode = 1;  // (one kind of pod serves both kinds of round of a filtered query; walks that ask -- mode 3 -- have pods of their own)
         std::lock_guard<std::mutex> g(pp.mu);
         if (pp.holds > 0) return {};  // somebody is about to synchronise the device: no pod opens, none takes a post
         if (being_modified.load(std::memory_order_seq_cst) > 0) return {};  // (the index is being modified -- PodFreeze: the caller breaks the reference's contract, and is served by a launch)
@@ -1612,7 +1612,7 @@ struct Engine {
             a.heap_cap = kBatchHeapCap;
             a.stats = d_stats;
             a.pipe_qtable = p.stage;
-            a.pipe_explore = 0u;
+            a.pipe_explore = mode == 3 ? 2u : 0u;
             a.pipe_fused_order = mode == 0 ? 1u : 0u;
             a.pipe_pool_cap = 12288u;
             std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -2109,8 +2109,8 @@ struct Engine {
             }
             if (count == 0 && !explore) {
                 if (std::getenv("VS_HNSW_ASK_DEBUG"))  // (profile builds: the phases of a hop of the exact walk, as filtered_ask prints them)
-                    std::fprintf(stderr, "[exact] hops %u ticks %u | max_next %u pushed %u refill clk/16 %u refills|spills<<16 %u wait_entry %u schedule %u\n", h_cnt[9], h_cnt[4],
-                                 h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
+                    std::fprintf(stderr, "[exact] hops %u ticks %u | clk/16: head %u decide %u pop %u entry %u atomics %u verdicts %u pushes %u schedule %u wait_entry %u\n", h_cnt[9],
+                                 h_cnt[4], h_cnt[7], h_cnt[1], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[6]);
                 if (found == kWalkFailed) return (size_t)-1;
                 std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
                 std::memcpy(dist, h_d, (size_t)std::min<size_t>(found, k) * 4);
@@ -2293,8 +2293,8 @@ struct Engine {
         ask_hops.fetch_add(h_cnt[9], std::memory_order_relaxed);
         ask_walk_ticks.fetch_add(h_cnt[4], std::memory_order_relaxed);
         if (std::getenv("VS_HNSW_ASK_DEBUG"))  // (profile builds: the phases of a hop, see pipe_device.hpp)
-            std::fprintf(stderr, "[ask] hops %u ticks %u waits %u | clocks/16: pop-rest %u entry %u refill %u verdicts %u wait_entry %u resolve+decide %u (%u)\n", h_cnt[9], h_cnt[4],
-                         h_cnt[6], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], 0u);
+            std::fprintf(stderr, "[ask] hops %u ticks %u | clk/16: head %u decide %u pop %u entry %u atomics %u verdicts %u pushes %u schedule %u wait_entry %u\n", h_cnt[9], h_cnt[4],
+                         h_cnt[7], h_cnt[1], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[6]);
         lazy_rounds += 1;
         return found;
     }

@@ -130,7 +130,7 @@ struct WalkArgs {
     // the kernel does the round's whole exchange itself -- the host's verdicts of the last round are applied first, the answer, the
     // counters and the list of missing verdicts go to the caller's pinned block, a flag there says when.  nullptr: the strided arrays above.
     const struct PipeQuery* pipe_qtable = nullptr;
-    uint32_t pipe_explore = 0;   // pipelined walk, lazy filter: an exploring round (lists missing verdicts, several candidates at a time; its answer is not one)
+    uint32_t pipe_explore = 0;   // pipelined walk, lazy filter: 2 = (pods) walks that ask while they run (round 6); 1 = an exploring round (lists missing verdicts, several candidates at a time; its answer is not one)
     uint32_t pipe_fused_order = 0;  // pipelined walk: the answer must be the fused-list kernel's also among EQUAL distances (plain queries of float indexes): any tie in `top` hands the query over
     uint32_t pipe_lds_visited = 0;  // pipelined walk: the visited set is the LDS tag table (unfiltered; slots < 2^25 at beams <= 256, 2^26 beyond) instead of the bitmap in a.space
     uint32_t pipe_pool_cap = 0;  // pipelined walk (kernels_pipe.hip): entries of `next` behind the front, in LDS (8 B each, <= 16,384)

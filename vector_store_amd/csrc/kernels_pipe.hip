@@ -349,8 +349,7 @@ __global__ __launch_bounds__(64 * kPipeTeam) void hnsw_pipe_walk_kernel(PipeKern
         }
         if constexpr (MODE == kPipeBoth) {
             // a pod of filtered queries: the two kinds of round alternate for every caller, so one workgroup serves either
-            if (explore == 2u) pipe_query<AR, I, EFCAP, kPipeAsk>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
-            else if (explore) pipe_query<AR, I, EFCAP, kPipeExplore>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
+            if (explore) pipe_query<AR, I, EFCAP, kPipeExplore>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
             else pipe_query<AR, I, EFCAP, kPipeFiltered>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
         } else {
             pipe_query<AR, I, EFCAP, MODE>(a, pq, qi, ef, sh, pipe_pool, tid, bid, t_begin, entry_slot, max_level, tomb);
@@ -386,6 +385,9 @@ static hipError_t pipe_ef(const WalkArgs& a, hipStream_t s, PodSlot* slots, PodC
     if (a.pipe_lds_visited) return hipErrorInvalidValue;
     // one instance per purpose (pipe_device.hpp `MODE`): plain lone queries, the exact walk of a filtered query, its exploring rounds
     if (a.ef > 512) return hipErrorInvalidValue;
+    // (round 6: a pod of walks that ask while they run is a kernel of its own -- as a third body of the kPipeBoth kernel its walker's
+    // scalar registers spilled, 311 spill instructions against 38-59 in the one-purpose kernels, and every phase of a hop ran twice as slow)
+    if (slots && a.pipe_explore == 2u) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeAsk>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipeAsk>(a, s, slots, ctl);
     if (slots && !a.pipe_fused_order) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeBoth>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipeBoth>(a, s, slots, ctl);
     if (a.pipe_explore) return a.ef <= 256 ? pipe_launch<AR, I, 256, kPipeExplore>(a, s, slots, ctl) : pipe_launch<AR, I, 512, kPipeExplore>(a, s, slots, ctl);
     // (a pod of plain queries has a staging table too: pipe_fused_order tells it from a pod of filtered ones)

@@ -561,10 +561,13 @@ __device__ __forceinline__ void pipe_courier_loop(Sh& sh, uint32_t* list, const 
     for (uint32_t idle = 0;;) {
         const uint32_t tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_flag_load(&sh.aq_tail));
         if (tail != pub) {
-            for (uint32_t i = pub + L; i < tail; i += 64u) list[i] = sh.aq_slot[i & 255u];
-            __threadfence_system();
+            // (the list and the counter live in the caller's pinned block: stores to it go past the caches, in order -- waiting for their
+            // acknowledgement is all the ordering the counter needs.  A system-scope RELEASE here is a write-back of the whole L2, and
+            // this happens two thousand times per walk: measured, every phase of every hop of the walker ran twice as slow)
+            for (uint32_t i = pub + L; i < tail; i += 64u) __hip_atomic_store(list + i, sh.aq_slot[i & 255u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (L == 0u) __hip_atomic_store(cnt + 5, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (L == 0u) __hip_atomic_store(cnt + 5, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             pub = tail;
             idle = 0;
         }
@@ -1094,7 +1097,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         uint32_t js = 1u, cr = 1u;
         if (L >= 1u && L < TM) js = lds_load_relaxed(&sh.job_state[L]);
         if (L < K) cr = lds_load_relaxed(&sh.c_ready[L]);
-        idle = __builtin_amdgcn_ballot_w64(L >= 1u && L < TM && js == 0u && !(kTopWave && L == kPipeTopWave) && !(ask && L == kPipeCourierWave));  // (the top wave / the courier take no jobs)
+        idle = __builtin_amdgcn_ballot_w64(L >= 1u && L < TM && js == 0u && !(kTopWave && L == kPipeTopWave)  && !(ask && L == kPipeCourierWave));  // (the top wave / the courier take no jobs)
         freem = __builtin_amdgcn_ballot_w64(L < K && tag == kInvalid && cr == 0u);
     };
     // "measure candidate s", split over up to `want` helpers; the entry, or kInvalid when no helper or no entry is to be had
@@ -1188,87 +1191,55 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
     //   * inside a tie window (equal distances waiting in `next` together) every rule about the radius is exact: the window starts with
     //     all answers in, and its hops ask and WAIT (ask_now) before they admit anybody.
     // Every member is asked about at most once per walk (it is asked when it is NEW to the visited set), as usearch does.
+    // (State in VECTOR registers on purpose: the walker's loop lives on scalar registers, and the first version of this -- a 64-bit mask of
+    // the lanes in use, the ask counter and two more wave-uniform words -- doubled the scalar spills of the kernel (161 against 77) and
+    // made every phase of every hop slower: 8.4 ms a walk against 6.7 with the same decisions and no asking, scripts/probe/ask_probe.py.)
     float p_d = INF;
     uint32_t p_s = kInvalid, p_i = 0u;
-    uint64_t pmask = 0ull;  // pending lanes in use
-    uint32_t asked = 0u;
-    bool lazy_used = false;
-    auto resolve = [&]() {  // what the courier has brought: admitted neighbours enter `top`, their lanes are free again
-        if (!pmask) return;
-        uint32_t v = 0u;
-        if ((pmask >> L) & 1ull) v = lds_load_relaxed(&sh.av[p_i & 255u]);
-        const uint64_t rm = __builtin_amdgcn_ballot_w64(v != 0u);
-        if (!rm) return;
-        for (uint64_t r = __builtin_amdgcn_ballot_w64(v == 2u); r; r &= r - 1ull) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(r);
-            const float dj = rl_f(p_d, j);
-            if (sz < ef || dj < radius) T.insert(dj, rl_u(p_s, j), true);
-        }
-        pmask &= ~rm;
-    };
-    uint32_t ask_waits = 0, ask_wait_ticks = 0;  // how often the walker stood still for answers, and for how long (100 MHz ticks)
-    auto wait_pending = [&](uint32_t target) {  // until at most `target` answers are still out
-        if ((uint32_t)__popcll(pmask) <= target) return;
-        const uint64_t w0 = wall_clock64();
-        ++ask_waits;
-        for (uint32_t spins = 0; (uint32_t)__popcll(pmask) > target && !redo; ++spins) {
-            resolve();
-            if ((uint32_t)__popcll(pmask) <= target) break;
+    bool p_on = false;        // this lane holds a pending neighbour
+    uint32_t asked_v = 0u;    // asks posted so far (the same in every lane)
+    auto pending = [&]() -> uint32_t { return (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(p_on)); };
+    // what the courier has brought: admitted neighbours enter `top`, their lanes are free again; returns the lanes still pending
+    auto settle = [&](uint32_t target) -> uint32_t {  // ... and waits until at most `target` answers are out (64: no wait)
+        uint32_t left = 0;
+        for (uint32_t spins = 0;; ++spins) {
+            uint32_t v = 0u;
+            if (p_on) v = lds_load_relaxed(&sh.av[p_i & 255u]);
+            for (uint64_t r = __builtin_amdgcn_ballot_w64(v == 2u); r; r &= r - 1ull) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(r);
+                const float dj = rl_f(p_d, j);
+                if (sz < ef || dj < radius) T.insert(dj, rl_u(p_s, j), true);
+            }
+            p_on = p_on && v == 0u;
+            left = pending();
+            if (left <= target || redo) break;
             if (spins > (1u << 21)) {  // (a host that does not answer for a fifth of a second: the rounds of the old path serve the query)
                 redo = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        ask_wait_ticks += (uint32_t)(wall_clock64() - w0);
+        return left;
     };
-    auto ask_post = [&](uint64_t um, uint32_t n) -> uint32_t {  // the lanes of `um` ask about their n; the first ask's number
+    auto ask_post = [&](uint64_t um, uint32_t n) -> uint32_t {  // the lanes of `um` ask about their n; this lane's ask number
         const uint32_t c = (uint32_t)__popcll(um);
-        if (asked + c > unknown_cap) {
-            redo = true;
-            return kInvalid;
-        }
-        const uint32_t base = asked;
+        const uint32_t mine_i = asked_v + mbcnt(um);
         if ((um >> L) & 1ull) {
-            const uint32_t idx = (base + mbcnt(um)) & 255u;
-            sh.av[idx] = 0u;
-            sh.aq_slot[idx] = n;
+            sh.av[mine_i & 255u] = 0u;
+            sh.aq_slot[mine_i & 255u] = n;
         }
-        asked += c;
-        if (L == 0u) lds_flag_store(&sh.aq_tail, asked);
-        return base;
+        asked_v += c;
+        if (__builtin_amdgcn_ballot_w64(asked_v > unknown_cap)) redo = true;  // (the caller's list is full: the rounds serve the query)
+        else if (L == 0u) lds_flag_store(&sh.aq_tail, asked_v);
+        return mine_i;
     };
-    auto ask_lanes = [&](uint64_t um, float nd, uint32_t n) {  // lazily: the asked neighbours wait in pending lanes
-        const uint32_t c = (uint32_t)__popcll(um);
-        if (64u - (uint32_t)__popcll(pmask) < c) wait_pending(64u - c);
-        if (redo) return;
-        const uint32_t base = ask_post(um, n);
-        if (base == kInvalid) return;
-        if ((um >> L) & 1ull) sh.stage[mbcnt(um)] = make_uint2(__float_as_uint(nd), n);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t fm = ~pmask;
-        const uint32_t fr = mbcnt(fm);
-        const bool take = ((fm >> L) & 1ull) != 0ull && fr < c;
-        if (take) {
-            const uint2 e = sh.stage[fr];
-            p_d = __uint_as_float(e.x);
-            p_s = e.y;
-            p_i = base + fr;
-        }
-        pmask |= __builtin_amdgcn_ballot_w64(take);
-    };
-    auto ask_now = [&](uint64_t um, uint32_t n) -> uint64_t {  // inside a tie window: the answers before anything else happens
-        const uint32_t base = ask_post(um, n);
-        if (base == kInvalid) return 0ull;
+    auto ask_now = [&](uint64_t um, uint32_t n) -> uint64_t {  // the answers before anything else happens (a tie window; no pending lane free)
+        const uint32_t mine_i = ask_post(um, n);
+        if (redo) return 0ull;
         const bool mine = ((um >> L) & 1ull) != 0ull;
-        const uint32_t idx = (base + mbcnt(um)) & 255u;
         uint32_t v = 0u;
-        const uint64_t w0 = wall_clock64();
-        ++ask_waits;
         for (uint32_t spins = 0;; ++spins) {
-            if (mine && v == 0u) v = lds_load_relaxed(&sh.av[idx]);
+            if (mine && v == 0u) v = lds_load_relaxed(&sh.av[mine_i & 255u]);
             if (!__builtin_amdgcn_ballot_w64(mine && v == 0u)) break;
             if (spins > (1u << 21)) {
                 redo = true;
@@ -1276,8 +1247,30 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        ask_wait_ticks += (uint32_t)(wall_clock64() - w0);
         return __builtin_amdgcn_ballot_w64(mine && v == 2u);
+    };
+    // lazily: the asked neighbours wait in pending lanes -- the r-th asking lane's entry goes to the r-th free lane, a broadcast per ask (a
+    // hop asks about two or three neighbours).  false: not enough lanes free (the caller asks with ask_now instead)
+    auto ask_lanes = [&](uint64_t um, float nd, uint32_t n) -> bool {
+        const uint32_t c = (uint32_t)__popcll(um);
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(!p_on);
+        if ((uint32_t)__popcll(fm) < c) return false;
+        const uint32_t mine_i = ask_post(um, n);
+        if (redo) return true;
+        const uint32_t fr = mbcnt(fm);
+        uint32_t r = 0;
+        for (uint64_t m = um; m; m &= m - 1ull, ++r) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(m);
+            const float dj = rl_f(nd, j);
+            const uint32_t sj = rl_u(n, j), ij = rl_u(mine_i, j);
+            if (!p_on && fr == r) {
+                p_d = dj;
+                p_s = sj;
+                p_i = ij;
+            }
+        }
+        p_on = p_on || fr < c;
+        return true;
     };
     if constexpr (!Sh::kVisGlobal) {
         visited_clear(sh, lane);
@@ -1308,8 +1301,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                 if (allow && (f0 & kPfKnown)) {
                     if (f0 & kPfAllowed) top_insert(start_d, start);
                 } else {
-                    lazy_used = true;
-                    ask_lanes(1ull, start_d, start);
+                    (void)ask_lanes(1ull, start_d, start);
                 }
             }
         } else {
@@ -1441,25 +1433,28 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         if constexpr (kFilter && !ask) WALK_STAMP(8);
         if constexpr (ask) {  // (see "asks" above: the pop is the one decision that needs the true radius)
             WALK_STAMP(8);  // (profile builds, asking walks: spill / refill)
-            resolve();
-            while (pmask && !redo) {
-                if (sz == ef && cd > radius) {  // ends here, once the last answers are in (the radius only shrinks)
-                    wait_pending(0u);
-                    continue;
-                }
-                uint32_t le = 0;  // members of the pessimistic `top` at or below the candidate (unused positions hold +inf)
+            // (the answers are looked at when the lanes fill up or the decision needs them -- not every hop: the look is an LDS round trip
+            // on the walker's path, and nothing waits for an admitted neighbour but the radius)
+            uint32_t out_n = pending();
+            if (out_n >= 24u) out_n = settle(64u);
+            for (bool looked = false; out_n && !redo;) {
+                const bool ending = sz == ef && cd > radius;  // ends here, once the last answers are in (the radius only shrinks)
+                if (!ending) {
+                    uint32_t le = 0;  // members of the pessimistic `top` at or below the candidate (unused positions hold +inf)
 #pragma unroll
-                for (int j = 0; j < R; ++j) le += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(top.d[j] <= cd));
-                // (only the pending neighbours at or below the candidate could pull the ef-th best below it)
-                const uint32_t out = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(((pmask >> L) & 1ull) != 0ull && p_d <= cd));
-                if (le + out < ef) break;
-                wait_pending((uint32_t)__popcll(pmask) - 1u);
+                    for (int j = 0; j < R; ++j) le += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(top.d[j] <= cd));
+                    // (only the pending neighbours at or below the candidate could pull the ef-th best below it)
+                    if (le + (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(p_on && p_d <= cd)) < ef) break;
+                }
+                // undecided: first whatever has arrived meanwhile, then the wait -- for every answer when the walk is about to end, else for one more
+                out_n = settle(!looked ? 64u : ending ? 0u : out_n - 1u);
+                looked = true;
             }
             if (redo) break;
             WALK_STAMP(9);  // (asking walks: the answers taken in, the pop decided)
         }
         if (sz == ef && cd > radius) break;  // `candidate.distance > radius && top.size() == top_limit`
-        if (kFilter && (any_window || (ask && lazy_used)) && !fused_order && sz == ef && cd == radius) {
+        if (kFilter && (any_window || ask) && !fused_order && sz == ef && cd == radius) {
             // at the radius: the last member of `top` itself, as a rule (every admitted member waits in `next` too) -- or another node at
             // the same distance, which usearch's `next` may not hold: the one distance where that matters
             const uint32_t lp = (ef - 1u) / (uint32_t)R, lr = (ef - 1u) % (uint32_t)R;
@@ -1488,7 +1483,7 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
             tie_v = cd;
             ++dbg_windows;
             if constexpr (ask) {  // the window's rules are about the true radius: it starts with every answer in
-                wait_pending(0u);
+                if (pending()) (void)settle(0u);
                 if (redo) break;
             }
         }
@@ -1599,14 +1594,14 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
                     if (redo) break;
                     done = hop_batch(cand, okmask, nd, n);
                 } else {
-                    lazy_used = true;
+                    // (no pending lane free: this hop's answers are waited for -- the lanes fill up only when the caller is slow)
+                    if (um && !ask_lanes(um, nd, n)) okmask |= ask_now(um, n);
+                    if (redo) break;
                     for (uint64_t r = okmask; r; r &= r - 1ull) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(r);
                         const float dj = rl_f(nd, j);
                         if (sz < ef || dj < radius) T.insert(dj, rl_u(n, j), true);
                     }
-                    if (um) ask_lanes(um, nd, n);
-                    if (redo) break;
                     WALK_STAMP(4);  // verdicts: asked
                     push_lanes(cand, nd, n);
                     done = true;
@@ -1649,35 +1644,9 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
         WALK_STAMP(6);  // scheduling
     }
     if constexpr (ask) {  // the last answers: their admitted neighbours belong to the result
-        if (!redo) wait_pending(0u);
-        if (unknown_count && L == 0u) {  // cnt[6], cnt[7], cnt[9]: waits for answers, their ticks, hops (vs_hnsw_filter_ask_stats)
-            unknown_count[6] = ask_waits;
-            unknown_count[7] = ask_wait_ticks;
-            unknown_count[9] = (uint32_t)cnt.hops;
-#ifdef VS_WALK_PROFILE  // (profile builds: the phases of a hop, shader clocks / 16: pop+lookup, entry+atomics+early post, atomics' return, verdicts, pushes+top, scheduling -- and the wait for the entry)
-            for (int i = 0; i < 6; ++i) unknown_count[10 + i] = (uint32_t)(prof[1 + i] >> 4);
-            unknown_count[12] = (uint32_t)(prof[8] >> 4);  // (in the atomics' place: spill / refill)
-            unknown_count[15] = (uint32_t)(prof[9] >> 4);  // (in the scheduling's place: answers taken in, the pop decided)
-            unknown_count[14] = (uint32_t)(prof[7] >> 4);  // (in the pushes' place: the wait for the entry)
-            unknown_count[13] = dbg_refill | (dbg_spills << 16);
-            unknown_count[10] = dbg_max_next;
-            unknown_count[11] = dbg_pushed;
-#endif
-        }
+        if (!redo && pending()) (void)settle(0u);
+        if (unknown_count && L == 0u) unknown_count[9] = (uint32_t)cnt.hops;  // (vs_hnsw_filter_ask_stats)
     }
-#ifdef VS_WALK_PROFILE
-    if constexpr (kFilter && !ask && !explore) {
-        if (unknown_count && L == 0u) {
-            unknown_count[9] = (uint32_t)cnt.hops;
-            for (int i = 0; i < 6; ++i) unknown_count[10 + i] = (uint32_t)(prof[1 + i] >> 4);
-            unknown_count[12] = (uint32_t)(prof[8] >> 4);
-            unknown_count[14] = (uint32_t)(prof[7] >> 4);
-            unknown_count[13] = dbg_refill | (dbg_spills << 16);
-            unknown_count[10] = dbg_max_next;
-            unknown_count[11] = dbg_pushed;
-        }
-    }
-#endif
     if constexpr (kTopWave) {  // `top` comes home: the answer is read from the walker's registers
         tw_sync();
 #pragma unroll
@@ -1715,6 +1684,17 @@ __device__ __forceinline__ PipeOut pipe_walk(const IndexView& ix, Sh& sh, uint2*
 #endif
         debug[11] = dbg_refill | (dbg_spills << 16);
     }
+#ifdef VS_WALK_PROFILE  // (profile builds, posted walks: the phases of a hop in the caller's counter block, shader clocks / 16)
+    if constexpr (kFilter && !explore) {
+        if (unknown_count && L == 0u) {
+            unknown_count[9] = (uint32_t)cnt.hops;
+            for (int i = 0; i < 6; ++i) unknown_count[10 + i] = (uint32_t)(prof[1 + i] >> 4);  // pop, entry, atomics, verdicts, pushes, schedule
+            unknown_count[6] = (uint32_t)(prof[7] >> 4);  // the wait for the entry
+            unknown_count[7] = (uint32_t)(prof[8] >> 4);  // the loop's head: spill / refill
+            unknown_count[1] = (uint32_t)(prof[9] >> 4);  // asking walks: answers taken in, the pop decided
+        }
+    }
+#endif
     // leave the bitmap all zero for the next query that gets this workspace
     if constexpr (!Sh::kVisGlobal) {
     } else if (vlog_lost) {

@@ -101,6 +101,11 @@ VS_API int vs_hnsw_exact_stats(vs_hnsw* index, uint64_t out[2]);
 /* Round 3: the first stage of the exact search is a ONE-product bf16 pass over a bf16 plane of the rows (built lazily, +2 bytes per
  * element of HBM): [0] batches that took it, [1] of them handed on to the split-bf16 pass (uncertified), [2] / [3] as exact_stats. */
 VS_API int vs_hnsw_exact_stats2(vs_hnsw* index, uint64_t out[4]);
+/* Round 6: the first stage runs over an 8-BIT plane of the rows (int8 + one f32 scale per row: +1 byte per element of HBM) on the int8
+ * matrix pipe: [0] batches that took it, [1] of them handed on to the bf16 plane (uncertified), [2] the f32 bits of the largest
+ * relative quantisation residual over its rows (the band of its nominations), [3] rows it covers.  exact_stats2's [0] / [1] count the
+ * batches that entered the plane stages (either plane, once) and those that left them uncertified. */
+VS_API int vs_hnsw_exact_stats3(vs_hnsw* index, uint64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -63,13 +63,16 @@ exact_ms = timed(exact)
 x1 = ix.exact_stats()
 walk_ms = timed(walk)
 mode = os.environ.get("VS_HNSW_EXACT", "")
-plane = x1["plane_batches"] > x0["plane_batches"] and x1["plane_fallbacks"] == x0["plane_fallbacks"]
-split = not plane and x1["block_batches"] > x0["block_batches"] and x1["block_fallbacks"] == x0["block_fallbacks"]
-products, row_bytes, peak = (1, 2 * ((dim + 63) // 64 * 64), 2500.0) if plane else (3, 4 * dim, 2500.0) if split else (1, 4 * dim, 157.3)
+plane8 = x1.get("plane8_batches", 0) > x0.get("plane8_batches", 0) and x1.get("plane8_fallbacks", 0) == x0.get("plane8_fallbacks", 0)
+plane = not plane8 and x1["plane_batches"] > x0["plane_batches"] and x1["plane_fallbacks"] == x0["plane_fallbacks"]
+split = not plane8 and not plane and x1["block_batches"] > x0["block_batches"] and x1["block_fallbacks"] == x0["block_fallbacks"]
+# (int8 plane, round 6: one byte per element + one f32 scale per row; the int8 matrix pipe's dense peak is twice the bf16 one)
+products, row_bytes, peak = ((1, (dim + 127) // 128 * 128 + 4, 5000.0) if plane8 else (1, 2 * ((dim + 63) // 64 * 64), 2500.0) if plane else
+                             (3, 4 * dim, 2500.0) if split else (1, 4 * dim, 157.3))
 rec = recall_at_k(tk.cpu().numpy(), ok.cpu().numpy())
 flops = 2.0 * nq * n * dim
 print(json.dumps({"workload": f"{n}x{dim} ip (unit vectors), batches of {nq} queries, top-{k}",
-                  "exact_mfma": {"path": "bf16 plane, 1 product" if plane else "split bf16, 3 products" if split else "f32-input MFMA",
+                  "exact_mfma": {"path": "int8 plane, 1 product" if plane8 else "bf16 plane, 1 product" if plane else "split bf16, 3 products" if split else "f32-input MFMA",
                                  "ms_per_batch": exact_ms, "queries_per_s": nq / exact_ms * 1e3, "f32_equivalent_tflops": flops / exact_ms / 1e9,
                                  "issued_tflops": products * flops / exact_ms / 1e9, "mfma_peak_tflops": peak,
                                  "frac_of_mfma_peak": products * flops / exact_ms / 1e9 / peak,

@@ -275,3 +275,47 @@ def test_forgetting_under_concurrent_named_queries_never_leaves_a_stale_verdict(
         for t in threads:
             t.join()
     assert not errors, errors
+
+
+def test_an_unnamed_filter_is_one_walk_that_asks_what_usearch_asks():
+    """Round 6 (review item 3): the trait's own signature -- an opaque predicate, no name -- is served by ONE walk that asks while it
+    runs.  Per query: the answer equals the oracle's, no key is asked about twice, and the predicate is called about as often as
+    usearch calls it (a member is asked about when it is new to the visited set and passes the radius test; the walk's radius may lag
+    the true one by the answers that are still on their way: a few per cent more).  Walks that hand over (an order-relevant tie) are
+    served by the rounds of rounds 3-5 and counted."""
+    import vector_store_amd as v
+    n, dim, k = 200_000, 96, 10
+    data = _dataset(n + 32, dim, 73)
+    base, q = data[:n], data[n:]
+    ix = v.HipUsearchIndex(dim, v.COS, expansion_search=128)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    o = OracleIndex(dim, oracle.COS, 16, 128, 128)
+    o.import_graph(ix.export_graph())
+    gpu_calls = cpu_calls = 0
+    for modulo in (10, 100):
+        for i in range(len(q)):
+            asked = {}
+
+            def pred(key, m=modulo, asked=asked):
+                asked[key] = asked.get(key, 0) + 1
+                return key % m == 3
+
+            s0 = ix.filter_ask_stats()
+            gk, gd = ix.filtered_search(q[i], k, pred)
+            s1 = ix.filter_ask_stats()
+            oracle_calls = [0]
+
+            def opred(key, m=modulo, c=oracle_calls):
+                c[0] += 1
+                return key % m == 3
+
+            wk, wd = o.filtered_search(q[i], k, opred)
+            assert_same_results(gk, gd, wk, wd, lambda key, i=i: o.distance_to_slot(q[i], int(key)), what=("ask", modulo, i))
+            if s1["queries"] == s0["queries"] + 1:  # served by the asking walk alone
+                assert max(asked.values()) == 1, (modulo, i, max(asked.values()))
+                gpu_calls += len(asked)
+                cpu_calls += oracle_calls[0]
+    st = ix.filter_ask_stats()
+    assert st["queries"] >= 48 and st["queries"] + st["handed_over"] + st["no_pod"] == 2 * len(q), st
+    assert cpu_calls > 0 and gpu_calls <= 1.15 * cpu_calls and gpu_calls >= 0.9 * cpu_calls, (gpu_calls, cpu_calls)

@@ -910,13 +910,17 @@ def test_exact_search_split_bf16_nomination_is_certified_or_falls_back(metric, q
     assert np.mean([fk[i].tolist() == rk[i].tolist() for i in range(len(q))]) >= 0.97      # f32 near-ties may swap
     assert all(set(fk[i].tolist()) == set(rk[i].tolist()) or np.isclose(fd[i, -1], rd[i, -1], rtol=1e-5, atol=2e-5) for i in range(len(q)))
     # 300 copies of one vector right at the query: the 64 nominees all tie with 236 rows outside -> no certificate -> f32 path
-    base[1000:1300] = q[0] / (np.linalg.norm(q[0]) if metric == "ip" else 1.0)
+    # (round 6: the 8-bit plane's lists hold 512 nominees and would certify 300 copies -- 700 of them for the plane stages)
+    copies = 700 if path == "plane" else 300
+    base[1000:1000 + copies] = q[0] / (np.linalg.norm(q[0]) if metric == "ip" else 1.0)
     fast2, ref2 = build(fast_env), build("f32")
     fk, fd, ff = fast2.exact_search_batch(q[:4], k)
     rk, rd, rf = ref2.exact_search_batch(q[:4], k)
-    assert fast2.exact_stats()[fallbacks] == 1 and fast2.exact_stats()["block_fallbacks"] == 1  # (the plane's 256 nominees tie with 44 rows outside, too)
+    assert fast2.exact_stats()[fallbacks] == 1 and fast2.exact_stats()["block_fallbacks"] == 1  # (the planes' 512 / 256 nominees tie with rows outside, too)
+    if path == "plane":
+        assert fast2.exact_stats()["plane8_batches"] == 1 and fast2.exact_stats()["plane8_fallbacks"] == 1  # 8-bit plane -> bf16 plane -> split bf16 -> f32
     assert np.array_equal(fk, rk) and np.array_equal(fd, rd)          # the very same kernels answered
-    assert set(fk[0].tolist()) <= set(range(1000, 1300))
+    assert set(fk[0].tolist()) <= set(range(1000, 1000 + copies))
     # Row blocks after the first pass on only the scores at or below each query's threshold.  (a) members of the second block
     # removed: never results; (b) rows stored farthest-first from one query: its second block beats everything seen before,
     # the per-query buffer overflows and the batch is answered by the f32 path -- same ids either way.

@@ -105,6 +105,14 @@ struct Engine {
     bool plane_failed = false;               // no HBM left for the plane: the split-bf16 path serves from then on
     int exact_mode = 0;                      // VS_HNSW_EXACT: 0 = bf16 plane -> split bf16 -> f32; 1 = "bf16x3": split bf16 -> f32; 2 = "f32"
     std::atomic<uint64_t> plane_batches{0}, plane_fallbacks{0};
+    // ... and over an 8-BIT plane first (round 6: half the bytes, half the LDS traffic, the int8 matrix pipe; kernels_misc.hip "8-BIT plane"):
+    // int8 rows + one f32 scale per row, built and extended like the bf16 plane; an uncertified batch goes on to the bf16 plane.
+    Arena ar_plane8, ar_p8scale;
+    size_t plane8_done = 0, plane8_rows_cap = 0;
+    uint32_t* d_rho8 = nullptr;
+    float plane8_rho = 0.f;                  // max |c - c^| / |c| over the plane's rows
+    bool plane8_failed = false, plane8_off = false;  // (off: VS_HNSW_EXACT=bf16, A/B)
+    std::atomic<uint64_t> plane8_batches{0}, plane8_fallbacks{0};
     bool eager_filter = false;               // VS_HNSW_FILTER=eager: always one predicate call per live member (the full bitmap)
     std::atomic<uint64_t> pipe_launches{0};  // launches of the pipelined walk (tests)
     bool no_pipe = false;                    // options.reserved bit 8: lone queries never take the pipelined walk (A/B in tests)
@@ -224,22 +232,23 @@ struct Engine {
         } catch (...) {
         }
         bool any_vmm = false;
-        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) any_vmm |= a->vmm;
+        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane, &ar_plane8, &ar_p8scale}) any_vmm |= a->vmm;
         if (any_vmm) {
             try {
                 PodHold hold(pod_pool(device));
                 (void)hipDeviceSynchronize();
-                for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) a->release();
+                for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane, &ar_plane8, &ar_p8scale}) a->release();
             } catch (...) {
             }
         }
         // (plain blocks: nothing of this index runs any more -- its calls have returned, its pods are gone -- so they can wait)
-        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane}) {
+        for (Arena* a : {&ar_vectors, &ar_aux, &ar_adj0, &ar_upper, &ar_upper_off, &ar_keys, &ar_levels, &ar_plane, &ar_plane8, &ar_p8scale}) {
             if (!a->vmm && a->base) graveyard().bury(a->base, nullptr);
             a->base = nullptr;
             a->bytes = 0;
         }
         graveyard().bury(d_rho, nullptr);
+        if (d_rho8) graveyard().bury(d_rho8, nullptr);
         graveyard().bury(d_stats, nullptr);
         graveyard().bury(d_max_norm, nullptr);
         housekeeping();
@@ -268,6 +277,7 @@ struct Engine {
         if (const char* xf = std::getenv("VS_HNSW_EXACT")) {
             exact_f32_only = !std::strcmp(xf, "f32");
             exact_mode = exact_f32_only ? 2 : !std::strcmp(xf, "bf16x3") ? 1 : 0;
+            plane8_off = !std::strcmp(xf, "bf16");  // the bf16 plane first, as before round 6
         }
         if (const char* tn = std::getenv("VS_HNSW_TIE")) tie_newest = std::strcmp(tn, "random") != 0;
         if (const char* fw = std::getenv("VS_HNSW_WALK")) force_global_walk = !std::strcmp(fw, "global");
@@ -661,6 +671,7 @@ struct Engine {
                 }
                 std::lock_guard<std::mutex> pg(plane_mu);  // ... and below plane_done: the bf16 plane is converted again
                 plane_done = 0;
+                plane8_done = 0;
             }
             if (!reuse_rows.empty()) {  // usearch update(): the reused node's links are zeroed first
                 if (!small) {
@@ -1340,6 +1351,46 @@ struct Engine {
         }
     }
 
+    // The int8 plane and its scales cover rows [0, slots) (+ zero rows up to a whole tile).  plane_mu and view_mu (shared) are held.
+    bool ensure_plane8(const IndexView& ix, hipStream_t st) {
+        const size_t kp = block8_plane_k(ix);
+        const size_t rows_cap = block1_plane_rows((uint32_t)std::max(capacity, slots));
+        try {
+            if (rows_cap != plane8_rows_cap) {
+                HIP_OK(hipStreamSynchronize(st));
+                size_t free_b = 0, total_b = 0;
+                HIP_OK(hipMemGetInfo(&free_b, &total_b));
+                const size_t want = rows_cap * kp;
+                if (ar_plane8.extra_needed(want, device) + ar_p8scale.extra_needed(rows_cap * 4, device) + (1ull << 30) > free_b)
+                    fail(VS_ERR_OUT_OF_MEMORY, "no HBM for the int8 plane");
+                const size_t whole = std::min(plane8_done, rows_cap) / 256 * 256;  // (tile-major: whole tiles are kept, see ensure_plane)
+                ar_plane8.resize(want, whole * kp, device);
+                ar_p8scale.resize(rows_cap * 4, whole * 4, device);
+                plane8_rows_cap = rows_cap;
+                plane8_done = whole;
+            }
+            if (!d_rho8) {
+                HIP_OK(hipMalloc((void**)&d_rho8, 4));
+                HIP_OK(hipMemset(d_rho8, 0, 4));
+            }
+            const size_t n = slots, end = block1_plane_rows((uint32_t)n);
+            if (plane8_done < n || plane8_done == 0) {
+                const size_t first = plane8_done / 256 * 256;
+                HIP_OK(launch_block8_plane_rows(ix, (uint8_t*)ar_plane8.base, (float*)ar_p8scale.base, (uint32_t)first, (uint32_t)end, (uint32_t)n, d_rho8, st));
+                uint32_t bits = 0;
+                HIP_OK(hipMemcpyAsync(&bits, d_rho8, 4, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                std::memcpy(&plane8_rho, &bits, 4);
+                plane8_done = n;
+            }
+            return plane8_rho < 0.25f;  // (rows that int8 cannot represent -- an infinity, a NaN -- leave the bf16 plane to serve)
+        } catch (const Fail& f) {
+            if (f.code != VS_ERR_OUT_OF_MEMORY) throw;
+            plane8_failed = true;
+            return false;
+        }
+    }
+
     void exact_device(const float* d_q, size_t nq, size_t k, uint64_t* d_keys_out, float* d_dist_out, uint32_t* d_found,
                       hipStream_t st, WorkCtx& w) {
         if (k == 0 || k > 256) fail(VS_ERR_UNSUPPORTED, "exact search supports 1 <= k <= 256");
@@ -1357,6 +1408,26 @@ struct Engine {
         a.out_found = d_found;
         // Large float indexes, cos / ip, k <= 64: nominate with ONE bf16 product per score over the bf16 plane of the rows, re-score
         // the nominees exactly, certify; an uncertified batch goes on to the split-bf16 pass, and from there to the f32 path.
+        // Round 6: first over the int8 plane (half the bytes); an uncertified batch goes on to the bf16 plane.
+        bool took_plane8 = false;
+        if (block1_supported(a.ix, a.k) && slots >= (1u << 16) && !a.use_valu && exact_mode == 0 && !plane8_failed && !plane8_off) {
+            std::lock_guard<std::mutex> pg(plane_mu);
+            if (ensure_plane8(a.ix, st)) {
+                const float mx = metric == VS_METRIC_IP ? max_row_norm(a.ix, st) : 1.f;
+                char* scratch = (char*)w.f.ensure(block8_scratch_bytes((uint32_t)nq, dim) + 256);
+                uint32_t* d_unc = (uint32_t*)scratch;
+                HIP_OK(hipMemsetAsync(d_unc, 0, 4, st));
+                HIP_OK(launch_block8_search(a, scratch + 256, (const uint8_t*)ar_plane8.base, (const float*)ar_p8scale.base, plane8_rho, mx, d_unc, st));
+                uint32_t unc = 0;
+                HIP_OK(hipMemcpyAsync(&unc, d_unc, 4, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                plane8_batches += 1;
+                plane_batches += 1;  // (batches that entered the plane stages, whichever plane: counted once)
+                took_plane8 = true;
+                if (unc == 0) return;
+                plane8_fallbacks += 1;
+            }
+        }
         if (block1_supported(a.ix, a.k) && slots >= (1u << 16) && !a.use_valu && exact_mode == 0 && !plane_failed) {
             std::lock_guard<std::mutex> pg(plane_mu);
             if (ensure_plane(a.ix, st)) {
@@ -1368,11 +1439,13 @@ struct Engine {
                 uint32_t unc = 0;
                 HIP_OK(hipMemcpyAsync(&unc, d_unc, 4, hipMemcpyDeviceToHost, st));
                 HIP_OK(hipStreamSynchronize(st));
-                plane_batches += 1;
+                if (!took_plane8) plane_batches += 1;
                 if (unc == 0) return;
                 plane_fallbacks += 1;
+                took_plane8 = false;
             }
         }
+        if (took_plane8) plane_fallbacks += 1;  // (no bf16 plane to go on to: the batch left the plane stages uncertified)
         if (block_search_supported(a.ix, a.k) && slots >= (1u << 16) && !a.use_valu && !exact_f32_only) {
             const float mx = metric == VS_METRIC_IP ? max_row_norm(a.ix, st) : 1.f;
             char* scratch = (char*)w.f.ensure(block_scratch_bytes((uint32_t)nq, dim) + 256);

@@ -319,7 +319,7 @@ int vs_hnsw_memory_info(vs_hnsw* h, uint64_t out[4]) {
         std::lock_guard<std::mutex> g(h->e.mod_mu);
         Engine& e = h->e;
         out[0] = out[1] = out[2] = 0;
-        for (const vs::Arena* a : {&e.ar_vectors, &e.ar_aux, &e.ar_adj0, &e.ar_upper, &e.ar_upper_off, &e.ar_keys, &e.ar_levels, &e.ar_plane}) {
+        for (const vs::Arena* a : {&e.ar_vectors, &e.ar_aux, &e.ar_adj0, &e.ar_upper, &e.ar_upper_off, &e.ar_keys, &e.ar_levels, &e.ar_plane, &e.ar_plane8, &e.ar_p8scale}) {
             out[0] += a->bytes;
             if (a->vmm) {
                 out[1] += a->bytes;
@@ -418,6 +418,17 @@ int vs_hnsw_exact_stats2(vs_hnsw* h, uint64_t out[4]) {
     out[1] = h->e.plane_fallbacks.load();
     out[2] = h->e.block_batches.load();
     out[3] = h->e.block_fallbacks.load();
+    return VS_OK;
+}
+
+int vs_hnsw_exact_stats3(vs_hnsw* h, uint64_t out[4]) {
+    if (!h || !out) return VS_ERR_INVALID_ARGUMENT;
+    out[0] = h->e.plane8_batches.load();
+    out[1] = h->e.plane8_fallbacks.load();
+    uint32_t bits = 0;
+    std::memcpy(&bits, &h->e.plane8_rho, 4);
+    out[2] = bits;
+    out[3] = h->e.plane8_done;
     return VS_OK;
 }
 

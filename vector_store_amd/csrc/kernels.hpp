@@ -206,6 +206,12 @@ bool block1_supported(const IndexView& ix, uint32_t k);
 uint32_t block1_plane_k(const IndexView& ix);
 uint32_t block1_plane_rows(uint32_t slots);
 size_t block1_scratch_bytes(uint32_t nq, uint32_t dim);
+// The same over an 8-BIT plane (round 6): block1_plane_rows(slots) x block8_plane_k(ix) int8 + one f32 scale per row; rho8 as rho.
+uint32_t block8_plane_k(const IndexView& ix);
+size_t block8_scratch_bytes(uint32_t nq, uint32_t dim);
+hipError_t launch_block8_plane_rows(const IndexView& ix, uint8_t* plane, float* scale, uint32_t first, uint32_t end, uint32_t slots, uint32_t* d_rho_bits, hipStream_t s);
+hipError_t launch_block8_search(const ExactArgs& a, void* scratch, const uint8_t* plane, const float* scale, float rho, float max_row_norm,
+                                uint32_t* d_uncertified, hipStream_t s);
 hipError_t launch_block1_plane_rows(const IndexView& ix, uint16_t* plane, uint32_t first, uint32_t end, uint32_t slots, uint32_t* d_rho_bits, hipStream_t s);
 hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_t* plane, float rho, float max_row_norm, uint32_t* d_uncertified,
                                 hipStream_t s);

@@ -1,6 +1,8 @@
 // kernels_misc.hip -- row staging, norms, exact (brute-force) top-k and the multi-GPU top-k merge.
 #include <atomic>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 #include "filter_rounds.hpp"
 
@@ -857,10 +859,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // its full nominee list) to a per-query buffer; one wave per query merges them into the list -- same (score, slot) order as
 // exact_select_kernel, so the nominees are the same -- and publishes the new threshold.  A buffer that overflowed (rows stored
 // in an order that keeps improving on everything seen before) raises `uncertified`: the host re-runs the batch on the f32 path.
-__global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt,
-                                                         const uint2* cand, uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr,
-                                                         uint32_t* uncertified, const float* band_eps = nullptr, uint32_t band_k = 0) {
-    __shared__ SelectShared sh;
+// order-preserving key of a distance's bits, and back
+__device__ __forceinline__ uint32_t bm_key(uint32_t bits) { return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ uint32_t bm_unkey(uint32_t key) { return (key & 0x80000000u) ? key ^ 0x80000000u : ~key; }
+// PREFILTER (round 6, the 8-bit plane's first block: every score of 2,048 rows arrives, a few dozen belong on the list): the band_k-th
+// smallest distance of the buffer by a radix select (four passes over the buffer, a histogram in LDS), and only scores within the band
+// of it go through the merges -- 32 list merges became one or two.  Removed rows take part in the select, so the threshold can come out
+// too tight when one of them is among the best: the caller checks it against the list it produced and runs again without it.
+template <class SH>
+__device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine, uint32_t n, uint32_t band_k, float eps2, int lane) {
+    uint32_t* hist = reinterpret_cast<uint32_t*>(sh.vis_tag);  // 256 words (the visited table is not used by these kernels)
+    uint32_t prefix = 0, want = band_k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hist[lane * 4 + i] = 0u;
+        __syncthreads();
+        for (uint32_t i = (uint32_t)lane; i < n; i += kWave) {
+            const uint32_t key = bm_key(mine[i].x);
+            if (shift == 24 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const uint32_t h0 = hist[lane * 4], h1 = hist[lane * 4 + 1], h2 = hist[lane * 4 + 2], h3 = hist[lane * 4 + 3];
+        uint32_t incl = h0 + h1 + h2 + h3;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += up;
+        }
+        const uint64_t reach = __ballot(incl >= want);
+        if (!reach) return __builtin_inff();  // fewer than band_k scores: no filter
+        const int ol = __builtin_ctzll(reach);
+        const uint32_t before = (uint32_t)__shfl((int)(incl - (h0 + h1 + h2 + h3)), ol);
+        const uint32_t a0 = (uint32_t)__shfl((int)h0, ol), a1 = (uint32_t)__shfl((int)h1, ol), a2 = (uint32_t)__shfl((int)h2, ol);
+        uint32_t c = before, b = (uint32_t)ol * 4u;
+        if (c + a0 < want) { c += a0; ++b; if (c + a1 < want) { c += a1; ++b; if (c + a2 < want) { c += a2; ++b; } } }
+        want -= c;
+        prefix = shift == 24 ? b : ((prefix << 8) | b);
+        __syncthreads();
+    }
+    return __uint_as_float(bm_unkey(prefix)) + eps2;
+}
+template <class SH>
+__device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt, const uint2* cand,
+                                                 uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr, uint32_t* uncertified,
+                                                 const float* band_eps, uint32_t band_k, bool prefilter = false) {
     const int lane = lane_id();
     const uint32_t ql = blockIdx.x, qg = q0 + ql;
     uint32_t n = cand_cnt[ql];
@@ -875,12 +916,15 @@ __global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t 
         if (lane == 0) atomicAdd(uncertified, 1u);
         n = cand_cap;
     }
+    float pre = __builtin_inff();
+    if (prefilter && sz == 0 && n >= 256u && band_eps && band_k) pre = block_merge_prefilter(sh, cand + (size_t)ql * cand_cap, n, band_k, 2.0f * band_eps[ql], lane);
+    for (int attempt = 0; attempt < 2; ++attempt) {
     for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
         const uint32_t i = i0 + (uint32_t)lane;
         const uint2 e = i < n ? cand[(size_t)ql * cand_cap + i] : make_uint2(0u, 0u);
         const float d = __uint_as_float(e.x);
         const uint32_t slot = e.y;
-        bool ok = i < n;
+        bool ok = i < n && d <= pre;
         if (ok && sz == C) ok = key_less(d, slot, sh.lst_d[0][C - 1], sh.lst_s[0][C - 1]);
         // one-product pass: a score more than 2 eps behind the k-th best so far cannot belong to a true top-k row (see the
         // threshold below), so it need not be listed either -- the lists stay short and the merges cheap
@@ -901,6 +945,12 @@ __global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t 
         sz = list_merge(sh, 0, sz, C, nd, ns, ma, lane);
         __syncthreads();
     }
+    // the prefilter was right iff the list's own band ends where it did (a removed row among the best makes it too tight: once more, without)
+    if (!(pre < __builtin_inff()) || (sz >= band_k && sh.lst_d[0][band_k - 1] + 2.0f * band_eps[ql] <= pre)) break;
+    pre = __builtin_inff();
+    sz = 0;
+    __syncthreads();
+    }
     for (uint32_t i = lane; i < sz; i += kWave) {
         list_d[(size_t)qg * C + i] = sh.lst_d[0][i];
         list_slot[(size_t)qg * C + i] = (uint64_t)(sh.lst_s[0][i] & kSlotMask);
@@ -914,6 +964,20 @@ __global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t 
         if (band_eps && band_k && sz >= band_k) t = fminf(t, sh.lst_d[0][band_k - 1] + 2.0f * band_eps[ql]);
         thr[ql] = t;
     }
+}
+__global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt,
+                                                         const uint2* cand, uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr,
+                                                         uint32_t* uncertified, const float* band_eps = nullptr, uint32_t band_k = 0) {
+    __shared__ SelectShared sh;
+    block_merge_body(sh, ix, q0, C, cand_cap, cand_cnt, cand, list_slot, list_d, list_n, thr, uncertified, band_eps, band_k);
+}
+// (round 6: the 8-bit plane's band is six times the bf16 plane's -- lists of up to 512 nominees)
+using SelectShared512 = BeamShared<512, 256>;
+__global__ __launch_bounds__(64) void block_merge512_kernel(IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt,
+                                                            const uint2* cand, uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr,
+                                                            uint32_t* uncertified, const float* band_eps, uint32_t band_k) {
+    __shared__ SelectShared512 sh;
+    block_merge_body(sh, ix, q0, C, cand_cap, cand_cnt, cand, list_slot, list_d, list_n, thr, uncertified, band_eps, band_k, true);
 }
 
 // exact f32 score of nominee c of query q: one wave per (query, nominee)
@@ -940,24 +1004,26 @@ __global__ __launch_bounds__(256) void block_rescore_kernel(IndexView ix, const 
 }
 
 // per query: the nominees ordered by their exact scores, the k best out, and the certificate
-__global__ __launch_bounds__(64) void block_final_kernel(IndexView ix, uint32_t k, uint32_t C, const uint64_t* cand_slot, const float* cand_approx,
-                                                         const uint32_t* cand_found, const float* exact_d, const float* qnorm,
-                                                         float max_row_norm, uint64_t* out_keys, float* out_dist, uint32_t* out_found,
-                                                         uint32_t* uncertified, const float* eps_q = nullptr) {
-    __shared__ float sd[kBlockC];
-    __shared__ uint32_t ss[kBlockC];
+template <uint32_t CMAX>
+__global__ __launch_bounds__(256) void block_final_kernel_t(IndexView ix, uint32_t k, uint32_t C, const uint64_t* cand_slot, const float* cand_approx,
+                                                           const uint32_t* cand_found, const float* exact_d, const float* qnorm,
+                                                           float max_row_norm, uint64_t* out_keys, float* out_dist, uint32_t* out_found,
+                                                           uint32_t* uncertified, const float* eps_q = nullptr) {
+    __shared__ float sd[CMAX];
+    __shared__ uint32_t ss[CMAX];
+    __shared__ float kth_s;
     const uint32_t q = blockIdx.x;
-    const int lane = lane_id();
+    const uint32_t lane = threadIdx.x, step = blockDim.x;  // (one wave for lists of 256; four for the 8-bit plane's 512: the ranking is n^2)
     const uint32_t n = cand_found[q];
-    for (uint32_t i = lane; i < n; i += kWave) {
+    if (lane == 0) kth_s = -__builtin_inff();
+    for (uint32_t i = lane; i < n; i += step) {
         const float d = exact_d[(size_t)q * C + i];
         sd[i] = d == d ? d : __builtin_inff();
         ss[i] = (uint32_t)cand_slot[(size_t)q * C + i];
     }
     __syncthreads();
     const uint32_t found = n < k ? n : k;
-    float kth = -__builtin_inff();
-    for (uint32_t i = lane; i < n; i += kWave) {  // rank by (score, slot): a strict total order
+    for (uint32_t i = lane; i < n; i += step) {  // rank by (score, slot): a strict total order
         const float d = sd[i];
         const uint32_t sl = ss[i];
         uint32_t rank = 0;
@@ -966,13 +1032,14 @@ __global__ __launch_bounds__(64) void block_final_kernel(IndexView ix, uint32_t 
             out_keys[(size_t)q * k + rank] = ix.keys[sl];
             out_dist[(size_t)q * k + rank] = d;
         }
-        if (rank + 1 == found) kth = d;
+        if (rank + 1 == found) kth_s = d;  // (ranks are distinct: one writer)
     }
-    for (uint32_t i = found + lane; i < k; i += kWave) {
+    for (uint32_t i = found + lane; i < k; i += step) {
         out_keys[(size_t)q * k + i] = kFreeKey;
         out_dist[(size_t)q * k + i] = __builtin_inff();
     }
-    for (int o = 32; o; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
+    __syncthreads();
+    const float kth = kth_s;
     if (lane == 0) {
         out_found[q] = found;
         if (n == C) {  // rows outside the nominees exist: they score at least (worst nominated approximate score - eps)
@@ -1154,7 +1221,7 @@ hipError_t launch_block_search(const ExactArgs& a, void* scratch, float max_row_
         }
     }
     hipLaunchKernelGGL(block_rescore_kernel, dim3(a.nq, C / 4), dim3(256), 0, s, a.ix, qd, kpad, q_aux, C, cand_slot, cand_found, exact_d);
-    hipLaunchKernelGGL(block_final_kernel, dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, qnorm,
+    hipLaunchKernelGGL((block_final_kernel_t<kBlockC>), dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, qnorm,
                        max_row_norm, a.out_keys, a.out_dist, a.out_found, d_uncertified);
     return hipGetLastError();
 }
@@ -1186,6 +1253,7 @@ constexpr int kP1TN = 256, kP1BK = 64, kP1RA = 2, kP1RB = 2;
 constexpr uint32_t kP1C = 256;            // nominees per query
 constexpr uint32_t kP1FirstRows = 1024;   // rows whose scores are all kept (4 tiles), <= kBlockCandCap
 using f32x4v = __attribute__((ext_vector_type(4))) float;
+using i32x4v = __attribute__((ext_vector_type(4))) int;
 
 __device__ __forceinline__ uint32_t p1_swz(uint32_t row) { return (row >> 1) & 7u; }
 // byte offset of element k of row r in a tile-major operand of `ksteps` K steps per tile (k a multiple of 4: 8 bytes stay together)
@@ -1276,11 +1344,16 @@ __global__ void p1_eps_kernel(uint32_t nq, const float* q_aux, const float* a_no
 // whole tiles).  FIRST (the first rows of a search, no thresholds yet): EVERY score goes to cand[q][n - n_begin] as (distance
 // bits, slot) by plain stores -- the host sets cand_cnt[q] = n_end - n_begin; else: scores at or above 1 - thr[q] are appended
 // to cand[q] (atomic counter).  row_scale: cosine: 1 / |row| (aux).
-template <bool WRITE_D>
+// I8 (round 6): the same kernel over an 8-BIT plane -- A and B hold int8 (per-query / per-row scale), a K step is 128 elements (the same
+// 128 bytes per row, the same LDS image, the same fragment reads), the product is v_mfma_i32_16x16x64_i8 (exact integer accumulation,
+// twice the bf16 rate) and a score is acc * q_scale[q] * row_scale[n] (row_scale: the row's quantisation step, times 1 / |row| for
+// cosine).  Half the plane's bytes, half the LDS traffic, half the matrix time.  `kp` is the row length in 2-byte units either way
+// (bf16: elements; int8: elements / 2).
+template <bool WRITE_D, bool I8 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void p1_tile_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint32_t kp, uint32_t nq_blk, uint32_t n_begin, uint32_t n_end,
     const float* __restrict__ thr, const float* __restrict__ row_scale, float* __restrict__ D, uint2* __restrict__ cand,
-    uint32_t* __restrict__ cand_cnt, uint32_t cand_cap) {
+    uint32_t* __restrict__ cand_cnt, uint32_t cand_cap, const float* __restrict__ q_scale = nullptr) {
     constexpr int TM = 256, TN = kP1TN, BK = kP1BK, RA = kP1RA, RB = kP1RB, CH = BK / 8;
     constexpr int NW = 8;
     constexpr bool SPLIT = RA != RB;
@@ -1291,13 +1364,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(1024))) char p1_lds[];
     char* lds = p1_lds;
     float* thr_s = reinterpret_cast<float*>(lds + RING_BYTES);
+    float* qs_s = reinterpret_cast<float*>(lds + RING_BYTES + 1024);  // I8: the queries' quantisation steps
+    using acc_t = typename std::conditional<I8, i32x4v, f32x4v>::type;
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
     const bool loads_a = !SPLIT || w < (uint32_t)(NW / 2), loads_b = !SPLIT || w >= (uint32_t)(NW / 2);
     const uint32_t la = w, lb = SPLIT ? w - NW / 2 : w;
     const uint32_t ksteps = kp / BK;
     const uint32_t tile0 = n_begin / TN, n_tiles = (n_end - n_begin + TN - 1) / TN;
     // similarity thresholds: a score s is a nominee iff s >= 1 - thr; queries beyond the batch never nominate
-    if (t < TM) thr_s[t] = (!WRITE_D && t < nq_blk) ? 1.0f - thr[t] : __builtin_inff();
+    // (I8: the threshold is compared with acc * row_scale, so it is divided by the query's step here: one multiplication less per score)
+    if (t < TM) {
+        const float qs = I8 ? (t < nq_blk ? q_scale[t] : 0.f) : 1.f;
+        if constexpr (I8) qs_s[t] = qs;
+        thr_s[t] = (!WRITE_D && t < nq_blk && qs > 0.f) ? (1.0f - thr[t]) / qs : __builtin_inff();
+    }
 
     uint32_t a_off[A_PW], b_off[B_PW];
 #pragma unroll
@@ -1344,13 +1424,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint32_t frow = lane & (FR - 1), fk = lane / FR;
     uint32_t sg = 0;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        f32x4v acc[MT][NT];
+        acc_t acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < ACC; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < ACC; ++r) acc[i][j][r] = 0;
         for (uint32_t ks = 0; ks < ksteps; ++ks, ++sg) {
             // stage sg has landed once at most (ring - 2) younger stages of this wave are in flight (the last steps drain)
             if constexpr (!SPLIT) {
@@ -1372,22 +1452,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const char* bbase = lds + RA * A_BYTES + (sg % RB) * B_BYTES;
 #pragma unroll
             for (int kk = 0; kk < BK / 32; ++kk) {
-                bf16x8 fa[MT], fb[NT];
+                // (a fragment is 16 bytes per lane either way: eight bf16 of a 16 x 16 x 32 product, sixteen int8 of a 16 x 16 x 64 one)
+                using frag_t = typename std::conditional<I8, i32x4v, bf16x8>::type;
+                frag_t fa[MT], fb[NT];
                 const uint32_t kc = kk * 4 + fk;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const uint32_t row = wm * WROWS + i * FR + frow;
-                    fa[i] = *reinterpret_cast<const bf16x8*>(abase + row * (BK * 2) + ((kc ^ p1_swz(row)) % CH) * 16);
+                    fa[i] = *reinterpret_cast<const frag_t*>(abase + row * (BK * 2) + ((kc ^ p1_swz(row)) % CH) * 16);
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const uint32_t row = wn * WN + j * FR + frow;
-                    fb[j] = *reinterpret_cast<const bf16x8*>(bbase + row * (BK * 2) + ((kc ^ p1_swz(row)) % CH) * 16);
+                    fb[j] = *reinterpret_cast<const frag_t*>(bbase + row * (BK * 2) + ((kc ^ p1_swz(row)) % CH) * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+                        if constexpr (I8) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    }
             }
         }
         // ---- epilogue: C/D layout -- column (row of the plane) on the lane, query rows in the registers
@@ -1404,7 +1489,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int r = 0; r < ACC; ++r) {
                         const uint32_t q = wm * WROWS + i * FR + 4 * fk + r;
-                        if (n < n_end && q < nq_blk) cand[(size_t)q * cand_cap + (n - n_begin)] = make_uint2(__float_as_uint(1.0f - acc[i][j][r] * rs[j]), n);
+                        if (n < n_end && q < nq_blk)
+                            cand[(size_t)q * cand_cap + (n - n_begin)] = make_uint2(__float_as_uint(1.0f - (float)acc[i][j][r] * rs[j] * (I8 ? qs_s[q] : 1.f)), n);
                     }
                 }
         } else {
@@ -1414,8 +1500,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float4 th = *reinterpret_cast<const float4*>(&thr_s[wm * WROWS + i * FR + 4 * fk]);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const float e0 = fmaf(acc[i][j][0], rs[j], -th.x), e1 = fmaf(acc[i][j][1], rs[j], -th.y);
-                    const float e2 = fmaf(acc[i][j][2], rs[j], -th.z), e3 = fmaf(acc[i][j][3], rs[j], -th.w);
+                    const float e0 = fmaf((float)acc[i][j][0], rs[j], -th.x), e1 = fmaf((float)acc[i][j][1], rs[j], -th.y);
+                    const float e2 = fmaf((float)acc[i][j][2], rs[j], -th.z), e3 = fmaf((float)acc[i][j][3], rs[j], -th.w);
                     tmax[i][j] = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
                 }
             }
@@ -1426,17 +1512,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (__builtin_expect(__ballot(tmax[i][j] >= 0.f) != 0ull, 0)) {  // this 16 x 16 tile holds at least one nominee
                         // the tile's scores go through this wave's LDS scratch: a runtime index into acc[][] would put ALL the
                         // accumulators in scratch memory on every tile
-                        float* sc = reinterpret_cast<float*>(lds + RING_BYTES + 1024) + w * (ACC * 64);
+                        float* sc = reinterpret_cast<float*>(lds + RING_BYTES + 2048) + w * (ACC * 64);
                         const uint32_t n = nbase + j * FR;
 #pragma unroll
-                        for (int r = 0; r < ACC; ++r) sc[r * 64 + lane] = acc[i][j][r] * rs[j];
+                        for (int r = 0; r < ACC; ++r) sc[r * 64 + lane] = (float)acc[i][j][r] * rs[j];
 #pragma unroll 1
                         for (int r = 0; r < ACC; ++r) {
                             const uint32_t q = wm * WROWS + i * FR + 4 * fk + r;
                             const float v = sc[r * 64 + lane];
                             if (v >= thr_s[q] && n < n_end) {
                                 const uint32_t at = atomicAdd(&cand_cnt[q], 1u);
-                                if (at < cand_cap) cand[(size_t)q * cand_cap + at] = make_uint2(__float_as_uint(1.0f - v), n);
+                                if (at < cand_cap) cand[(size_t)q * cand_cap + at] = make_uint2(__float_as_uint(1.0f - v * (I8 ? qs_s[q] : 1.f)), n);
                             }
                         }
                     }
@@ -1444,7 +1530,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
 }
-constexpr size_t kP1LdsBytes = (size_t)(kP1RA * 256 + kP1RB * kP1TN) * kP1BK * 2 + 1024 + 8 * 4 * 64 * 4;
+constexpr size_t kP1LdsBytes = (size_t)(kP1RA * 256 + kP1RB * kP1TN) * kP1BK * 2 + 2048 + 8 * 4 * 64 * 4;
 
 bool block1_supported(const IndexView& ix, uint32_t k) {
     return (ix.scalar == SC_F32 || ix.scalar == SC_F16 || ix.scalar == SC_BF16) && (ix.metric == COS || ix.metric == IP) && k >= 1 && k <= 64;
@@ -1542,7 +1628,212 @@ hipError_t launch_block1_search(const ExactArgs& a, void* scratch, const uint16_
         }
     }
     hipLaunchKernelGGL(block_rescore_kernel, dim3(a.nq, C / 4), dim3(256), 0, s, a.ix, qd, kpad, q_aux, C, cand_slot, cand_found, exact_d);
-    hipLaunchKernelGGL(block_final_kernel, dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, a_norm, max_row_norm,
+    hipLaunchKernelGGL((block_final_kernel_t<kBlockC>), dim3(a.nq), dim3(64), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, a_norm, max_row_norm,
+                       a.out_keys, a.out_dist, a.out_found, d_uncertified, (const float*)eps_q);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- block search over an 8-BIT plane (round 6)
+// The one-product pass above streams a bf16 plane: 2 bytes per element, and at q = 256 the HBM stream, the LDS traffic and the matrix
+// pipe each need about the same 2-2.5k clocks per K step of a tile -- the batch sits at 0.40 of the plane's HBM floor whatever the tile
+// shape.  An int8 plane halves all three at once: row c is stored as ci = round(c / s_c), s_c = max|c_k| / 127
+// (one f32 per row: `scale`, which also carries 1 / |c| for cosine), the queries likewise per batch, and
+//     s~(q, c) = s_q s_c sum_k qi[k] ci[k]          (v_mfma_i32_16x16x64_i8: exact integer accumulation)
+// nominates.  Error, rigorous: |q.c - s~| <= |q - q^| |c| + |q^| |c - c^|, with |q - q^| measured per query (r_q) and
+// |c - c^| <= rho8 |c|, rho8 = the largest relative quantisation residual over the rows of the plane (measured when the plane is built:
+// ~0.008-0.012 for rows whose components look Gaussian) -- the same eps formula as the bf16 plane's with rho8 for rho, about six times
+// wider.  Nominee lists are 512 long for it; re-score and certificate are unchanged; an uncertified batch goes on to the bf16 plane.
+constexpr uint32_t kP8C = 512;
+constexpr uint32_t kP8FirstRows = 2048;          // rows whose scores are all kept (<= kBlockCandCap)
+constexpr uint32_t kP8SlowGrowthBelow = 262144;  // chunks grow 8 x up to here, 32 x beyond
+uint32_t block8_plane_k(const IndexView& ix) { return (ix.dim + 127u) & ~127u; }  // elements (= bytes) per row: whole 128-element K steps
+size_t block8_scratch_bytes(uint32_t nq, uint32_t dim) {
+    const size_t kpad = (dim + 31u) & ~31u, kp = (dim + 127u) & ~127u, rows = ((size_t)nq + 255) / 256 * 256;
+    return (size_t)256 * kBlockCandCap * 8 + 256 * 8 + (size_t)nq * (4 * 6) + rows * 4 + (size_t)nq * kpad * 4 + rows * kp + (size_t)nq * kP8C * 16 + 8192;
+}
+// byte offset of element k of row r in a tile-major int8 operand (k a multiple of 4: 4 bytes stay together): the bf16 layout with
+// 16 elements per 16-byte chunk
+__device__ __forceinline__ size_t p8_offset(uint32_t r, uint32_t k, uint32_t ksteps) {
+    const uint32_t t = r >> 8, rt = r & 255u, ks = k >> 7, kw = k & 127u, chunk = kw >> 4;
+    return ((size_t)(t * ksteps + ks) * 256u + rt) * 128u + ((chunk ^ p1_swz(rt)) << 4) + (kw & 15u);
+}
+__device__ __forceinline__ uint32_t p8_pack(const float v[4], float inv_step, float step, float& res) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float qf = rintf(v[j] * inv_step);
+        qf = fminf(fmaxf(qf, -127.f), 127.f);
+        const float e = v[j] - qf * step;
+        res = fmaf(e, e, res);
+        w |= ((uint32_t)(int)qf & 255u) << (8 * j);
+    }
+    return w;
+}
+// plane8 (tile-major, p8_offset) := int8(row r / step_r), scale[r] = step_r (x 1 / |row| for cosine: aux), zero rows beyond `slots`;
+// *rho_bits = max over rows of |c - c^| / |c|
+__global__ __launch_bounds__(256) void p8_plane_rows_kernel(IndexView ix, uint32_t first, uint32_t end, uint32_t slots, uint32_t kp, uint8_t* plane,
+                                                            float* scale, uint32_t* rho_bits) {
+    const uint32_t r = first + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    if (r >= end) return;
+    float mx = 0.f, sq = 0.f;
+    if (r < slots)
+        for (uint32_t k = (uint32_t)lane * 4u; k < kp; k += kWave * 4u) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (k < ((ix.dim + 3u) & ~3u)) load4_dequant(ix, (size_t)r, k, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = (k + j < ix.dim) ? v[j] : 0.f;
+                mx = fmaxf(mx, fabsf(x));
+                sq = fmaf(x, x, sq);
+            }
+        }
+    for (int o = 32; o; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        sq += __shfl_xor(sq, o);
+    }
+    const bool ok = r < slots && mx > 0.f && mx < __builtin_inff() && sq == sq;  // (a row with a NaN / an infinity scores nothing here: the exact paths rank it)
+    const float step = ok ? mx / 127.f : 0.f, inv = ok ? 127.f / mx : 0.f;
+    float res = 0.f;
+    for (uint32_t k = (uint32_t)lane * 4u; k < kp; k += kWave * 4u) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok && k < ((ix.dim + 3u) & ~3u)) load4_dequant(ix, (size_t)r, k, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j >= ix.dim) v[j] = 0.f;
+        *reinterpret_cast<uint32_t*>(plane + p8_offset(r, k, kp >> 7)) = p8_pack(v, inv, step, res);
+    }
+    for (int o = 32; o; o >>= 1) res += __shfl_xor(res, o);
+    if (lane == 0) {
+        scale[r] = ok ? step * (ix.metric == COS ? ix.aux[r] : 1.f) : 0.f;
+        if (ok && res == res) atomicMax(rho_bits, __float_as_uint(sqrtf(res / sq) * 1.0001f));
+        if (r < slots && !ok && mx != 0.f) atomicMax(rho_bits, __float_as_uint(__builtin_inff()));  // (an unrepresentable row: no bound holds, the plane is not used)
+    }
+}
+// qd (nq x kpad f32) -> A (rows_pad x kp int8, tile-major; cosine: scaled by q_aux = 1 / |q| first), q_scale, |A_q| (dequantised), r_q
+__global__ __launch_bounds__(256) void p8_round_queries_kernel(const float* qd, const float* q_aux, int cosine, uint32_t nq, uint32_t rows_pad,
+                                                               uint32_t kpad, uint32_t kp, uint8_t* A, float* q_scale, float* a_norm, float* r_q) {
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    if (w >= rows_pad) return;
+    const float sc = w < nq ? (cosine ? q_aux[w] : 1.f) : 0.f;
+    float mx = 0.f;
+    for (uint32_t e = (uint32_t)lane * 4u; e < kp; e += kWave * 4u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf((w < nq && e + j < kpad) ? qd[(size_t)w * kpad + e + j] * sc : 0.f));
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const bool ok = mx > 0.f && mx < __builtin_inff();
+    const float step = ok ? mx / 127.f : 0.f, inv = ok ? 127.f / mx : 0.f;
+    float an = 0.f, rs = 0.f;
+    for (uint32_t e = (uint32_t)lane * 4u; e < kp; e += kWave * 4u) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (ok && w < nq && e + j < kpad) ? qd[(size_t)w * kpad + e + j] * sc : 0.f;
+        float res = 0.f;
+        const uint32_t word = p8_pack(v, inv, step, res);
+        rs += res;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float hv = (float)(int8_t)((word >> (8 * j)) & 255u) * step;
+            an = fmaf(hv, hv, an);
+        }
+        *reinterpret_cast<uint32_t*>(A + p8_offset(w, e, kp >> 7)) = word;
+    }
+    for (int o = 32; o; o >>= 1) {
+        an += __shfl_xor(an, o);
+        rs += __shfl_xor(rs, o);
+    }
+    if (lane == 0) {
+        q_scale[w] = step;
+        if (w < nq) {
+            a_norm[w] = sqrtf(an) * 1.0001f;
+            r_q[w] = ok ? sqrtf(rs) * 1.0001f : __builtin_inff();  // (a query that cannot be represented: its eps is infinite, the batch goes on to the other paths)
+        }
+    }
+}
+
+hipError_t launch_block8_plane_rows(const IndexView& ix, uint8_t* plane, float* scale, uint32_t first, uint32_t end, uint32_t slots, uint32_t* d_rho_bits,
+                                    hipStream_t s) {
+    if (end <= first) return hipSuccess;
+    hipLaunchKernelGGL(p8_plane_rows_kernel, dim3((end - first + 3) / 4), dim3(256), 0, s, ix, first, end, slots, block8_plane_k(ix), plane, scale, d_rho_bits);
+    return hipGetLastError();
+}
+
+// As launch_block1_search, over the int8 plane (block1_plane_rows(slots) x block8_plane_k(ix) bytes, tile-major) and its per-row scales.
+hipError_t launch_block8_search(const ExactArgs& a, void* scratch, const uint8_t* plane, const float* scale, float rho, float max_row_norm,
+                                uint32_t* d_uncertified, hipStream_t s) {
+    if (a.nq == 0) return hipSuccess;
+    if (!block1_supported(a.ix, a.k) || a.slots < (1u << 16) || !(rho < 0.25f)) return hipErrorInvalidValue;
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::atomic<bool> attr_set[64];
+    if (!attr_set[dev & 63].load(std::memory_order_acquire)) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(p1_tile_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kP1LdsBytes);
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
+        attr_set[dev & 63].store(true, std::memory_order_release);
+    }
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t kpad = (a.ix.dim + 31u) & ~31u, kp = block8_plane_k(a.ix), C = kP8C;
+    const uint32_t kp2 = kp / 2;  // the tile kernel's row length, in 2-byte units
+    const uint32_t rows_pad = (a.nq + 255u) / 256u * 256u;
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    uint2* cand = (uint2*)take((size_t)256 * kBlockCandCap * 8);
+    uint32_t* cand_cnt = (uint32_t*)take((size_t)256 * 4);
+    float* thr = (float*)take((size_t)256 * 4);
+    float* q_aux = (float*)take((size_t)a.nq * 4);
+    float* a_norm = (float*)take((size_t)a.nq * 4);
+    float* r_q = (float*)take((size_t)a.nq * 4);
+    float* eps_q = (float*)take((size_t)a.nq * 4);
+    uint32_t* cand_found = (uint32_t*)take((size_t)a.nq * 4);
+    float* q_scale = (float*)take((size_t)rows_pad * 4);
+    float* qd = (float*)take((size_t)a.nq * kpad * 4);
+    uint8_t* A = (uint8_t*)take((size_t)rows_pad * kp);
+    uint64_t* cand_slot = (uint64_t*)take((size_t)a.nq * C * 8);
+    float* cand_approx = (float*)take((size_t)a.nq * C * 4);
+    float* exact_d = (float*)take((size_t)a.nq * C * 4);
+    hipError_t e = prepare_queries(a.ix, a.queries, a.q_stride, a.nq, kpad, qd, q_aux, s);
+    if (e != hipSuccess) return e;
+    const int cosine = a.ix.metric == COS ? 1 : 0;
+    hipLaunchKernelGGL(p8_round_queries_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, s, qd, q_aux, cosine, a.nq, rows_pad, kpad, kp, A, q_scale, a_norm, r_q);
+    hipLaunchKernelGGL(p1_eps_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a.nq, q_aux, a_norm, r_q, rho, cosine ? 1.f : max_row_norm, 0.f, cosine, eps_q,
+                       d_uncertified);
+    e = hipMemsetAsync(cand_found, 0, (size_t)a.nq * 4, s);
+    if (e != hipSuccess) return e;
+    const uint16_t* plane16 = reinterpret_cast<const uint16_t*>(plane);
+    for (uint32_t q0 = 0; q0 < a.nq; q0 += 256) {
+        const uint32_t nqb = a.nq - q0 < 256u ? a.nq - q0 : 256u;
+        const uint16_t* Aq = reinterpret_cast<const uint16_t*>(A + (size_t)q0 * kp);
+        const float* qs = q_scale + q0;
+        // (the 8-bit band is six times the bf16 plane's: the first rows whose scores are all kept are 4,096 -- the candidate buffer's size
+        // -- and the chunks grow 8 x while the thresholds are young, so that each merge sees hundreds of candidates, not thousands)
+        const uint32_t n1 = a.slots < kP8FirstRows ? a.slots : kP8FirstRows;
+        hipLaunchKernelGGL((p1_tile_kernel<true, true>), dim3((n1 + kP1TN - 1) / kP1TN), dim3(512), kP1LdsBytes, s, Aq, plane16, kp2, nqb, 0u, n1, (const float*)nullptr, scale,
+                           (float*)nullptr, cand, cand_cnt, (uint32_t)kBlockCandCap, qs);
+        e = hipMemsetD32Async((hipDeviceptr_t)cand_cnt, (int)n1, 256, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(block_merge512_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
+                           cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);
+        for (uint32_t n0 = n1; n0 < a.slots;) {
+            const uint64_t want = (uint64_t)n0 * (n0 < kP8SlowGrowthBelow ? 8u : 32u);
+            const uint32_t nend = want >= a.slots ? a.slots : (uint32_t)want;
+            const uint32_t tiles = (nend - n0 + kP1TN - 1) / kP1TN;
+            const uint32_t grid = tiles < (uint32_t)cus ? tiles : (uint32_t)cus;
+            hipLaunchKernelGGL((p1_tile_kernel<false, true>), dim3(grid), dim3(512), kP1LdsBytes, s, Aq, plane16, kp2, nqb, n0, nend, thr, scale, (float*)nullptr, cand, cand_cnt,
+                               (uint32_t)kBlockCandCap, qs);
+            hipLaunchKernelGGL(block_merge512_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
+                               cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);
+            n0 = nend;
+        }
+    }
+    hipLaunchKernelGGL(block_rescore_kernel, dim3(a.nq, C / 4), dim3(256), 0, s, a.ix, qd, kpad, q_aux, C, cand_slot, cand_found, exact_d);
+    hipLaunchKernelGGL((block_final_kernel_t<kP8C>), dim3(a.nq), dim3(256), 0, s, a.ix, a.k, C, cand_slot, cand_approx, cand_found, exact_d, a_norm, max_row_norm,
                        a.out_keys, a.out_dist, a.out_found, d_uncertified, (const float*)eps_q);
     return hipGetLastError();
 }

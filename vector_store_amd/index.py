@@ -112,6 +112,8 @@ def lib():
     L.vs_hnsw_exact_stats.argtypes = [vp, vp]
     L.vs_hnsw_walk_info.argtypes = [vp, vp]
     L.vs_hnsw_exact_stats2.argtypes = [vp, vp]
+    if hasattr(L, "vs_hnsw_exact_stats3"):
+        L.vs_hnsw_exact_stats3.argtypes = [vp, vp]
     L.vs_hnsw_graph_info_get.argtypes = [vp, C.POINTER(_GraphInfo)]
     L.vs_hnsw_export_graph.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.vs_hnsw_import_graph.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, sz, C.c_int32, C.c_uint32]
@@ -378,7 +380,12 @@ class HipUsearchIndex:
         _check(self.L.vs_hnsw_exact_stats(self.h, _p(out)))
         out4 = np.zeros(4, dtype=np.uint64)
         _check(self.L.vs_hnsw_exact_stats2(self.h, _p(out4)))
-        return {"block_batches": int(out[0]), "block_fallbacks": int(out[1]), "plane_batches": int(out4[0]), "plane_fallbacks": int(out4[1])}
+        out8 = np.zeros(4, dtype=np.uint64)
+        if hasattr(self.L, "vs_hnsw_exact_stats3"):
+            _check(self.L.vs_hnsw_exact_stats3(self.h, _p(out8)))
+        return {"block_batches": int(out[0]), "block_fallbacks": int(out[1]), "plane_batches": int(out4[0]), "plane_fallbacks": int(out4[1]),
+                "plane8_batches": int(out8[0]), "plane8_fallbacks": int(out8[1]), "plane8_rho": float(np.array([int(out8[2])], dtype=np.uint32).view(np.float32)[0]),
+                "plane8_rows": int(out8[3])}
 
     def walk_info(self) -> dict:
         out = np.zeros(2, dtype=np.uint64)

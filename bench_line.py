@@ -145,12 +145,14 @@ def _side_config(c):
     for k in ("error", "skipped"):
         if k in c:
             out[k] = _clip(c[k], 100)
-    for k in ("queries_per_s", "ms_per_batch", "recall_at_10", "build_vectors_per_s", "plane_fallback_batches"):
+    for k in ("queries_per_s", "ms_per_batch", "recall_at_10", "build_vectors_per_s", "plane_fallback_batches", "plane8_batches", "plane8_fallback_batches"):
         if k in c:
             out[k] = _num(c[k])
     r = c.get("roofline")
     if isinstance(r, dict):
         out["roofline_frac"] = _num(r.get("frac"), 3)
+        if "frac_of_bf16_plane_floor" in r:
+            out["frac_of_bf16_plane_floor"] = _num(r.get("frac_of_bf16_plane_floor"), 3)
         out["kernel"] = _clip(r.get("kernel"), 48)
     for leg in ("blocking_callers", "blocking_callers_64"):
         if isinstance(c.get(leg), dict):

@@ -5,7 +5,7 @@
 set -u
 TAG=$1; N=${2:-10000000}
 export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; T=/tmp/prof_c5_$TAG
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; T=/tmp/prof_c5_${TAG}_$$_$RANDOM
 mkdir -p "$T" "$O/summary"; cd "$R"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 scripts/c5_batched_ip.py "$N" > "$O/summary/${TAG}_c5_batched_ip.json" 2> "$O/${TAG}_c5_stats.err"
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do

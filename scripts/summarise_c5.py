@@ -14,7 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarise_profiles import kernel_sources_sha16  # noqa: E402
 
-KERNELS = ("p1_tile_kernel", "p1_plane_rows_kernel", "p1_round_queries_kernel", "block_dist_bf16x3_kernel", "block_merge_kernel", "exact_select_kernel", "exact_finish_kernel", "block_rescore_kernel", "block_final_kernel",
+KERNELS = ("p1_tile_kernel", "p1_plane_rows_kernel", "p1_round_queries_kernel", "p8_plane_rows_kernel", "p8_round_queries_kernel", "block_merge512_kernel", "block_dist_bf16x3_kernel", "block_merge_kernel", "exact_select_kernel", "exact_finish_kernel", "block_rescore_kernel", "block_final_kernel",
            "split_queries_kernel", "exact_dist_mfma_kernel")
 
 
@@ -51,9 +51,12 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--tag", required=True)
     ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--plane", default="auto", choices=["auto", "int8", "bf16"], help="which plane the tile kernel streamed (auto: int8 when its instance shows in the stats)")
     a = ap.parse_args()
     stats = {}
     ks = find(os.path.join(a.dir, "stats"), "_kernel_stats.csv")
+    if a.plane == "auto":
+        a.plane = "int8" if ks and "p1_tile_kernel<false, true>" in open(ks).read() else "bf16"
     if ks:
         shutil.copy(ks, os.path.join(a.out, f"{a.tag}_c5_kernel_stats.csv"))
         for row in csv.DictReader(open(ks, newline="")):
@@ -96,16 +99,21 @@ def main():
         if k == "p1_tile_kernel" and "grid_threads" in e:
             # the persistent launch with the largest grid that runs longest is the last chunk: rows [32^2 * 1024, N) of the plane
             rows = a.vectors - 1048576 if a.vectors > 1048576 else a.vectors
-            kp = (a.dim + 63) // 64 * 64
+            int8 = a.plane == "int8"
+            kp = (a.dim + 127) // 128 * 128 if int8 else (a.dim + 63) // 64 * 64
+            e["plane"] = a.plane
             e["rows_of_the_largest_launch"] = rows
-            e["mfma_instructions_per_launch"] = 256 * rows * kp // (16 * 16 * 32)   # v_mfma_f32_16x16x32_bf16, ONE product per score
-            e["bf16_flops_per_launch"] = 2 * 256 * rows * kp
-            e["algorithmic_bytes_per_launch"] = rows * kp * 2 + 256 * kp * 2          # the plane's rows once + the query block once
+            # ONE product per score: v_mfma_i32_16x16x64_i8 over the 8-bit plane (round 6) / v_mfma_f32_16x16x32_bf16 over the bf16 plane
+            e["mfma_instructions_per_launch"] = 256 * rows * kp // (16 * 16 * (64 if int8 else 32))
+            e["bf16_flops_per_launch"] = 2 * 256 * rows * kp  # (int8 plane: integer multiply-adds, counted the same way)
+            e["algorithmic_bytes_per_launch"] = (rows * (kp + 4) + 256 * kp) if int8 else (rows * kp * 2 + 256 * kp * 2)  # the plane's rows (+ scales) once + the query block once
             ms = max(e.get("launch_ms_in_the_pmc_pass", 0.0), 1e-9)
             if k in pmc["FETCH_SIZE"]:
                 ms = pmc["FETCH_SIZE"][k][2]
             e["achieved_bf16_TFLOPs"] = e["bf16_flops_per_launch"] / (ms * 1e-3) / 1e12
             e["frac_of_2500_TFLOPs_dense_bf16"] = e["achieved_bf16_TFLOPs"] / 2500.0
+            if a.plane == "int8":
+                e["frac_of_5000_TOPs_dense_int8"] = e["achieved_bf16_TFLOPs"] / 5000.0
             e["achieved_hbm_TBps_algorithmic"] = e["algorithmic_bytes_per_launch"] / (ms * 1e-3) / 1e12
             e["frac_of_8_TBps"] = e["achieved_hbm_TBps_algorithmic"] / 8.0
             if "hbm_bytes_per_launch" in e:
@@ -113,7 +121,7 @@ def main():
             if k in pmc["SQ_VALU_MFMA_BUSY_CYCLES"]:
                 _, busy, bms, _, _ = pmc["SQ_VALU_MFMA_BUSY_CYCLES"][k]
                 e["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = busy
-                e["expected_busy_cycles_16_per_mfma"] = e["mfma_instructions_per_launch"] * 16
+                e["expected_busy_cycles_16_per_mfma"] = e["mfma_instructions_per_launch"] * 16  # (16 passes of 4 cycles... per 16x16 product, either type)
                 e["launch_ms_in_the_mfma_pass"] = bms
         rec["kernels"][k] = e
     json.dump(rec, open(os.path.join(a.out, f"{a.tag}_c5_kernels.json"), "w"), indent=1)

@@ -1,6 +1,7 @@
 // kernels_misc.hip -- row staging, norms, exact (brute-force) top-k and the multi-GPU top-k merge.
 #include <atomic>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -1813,7 +1814,11 @@ hipError_t launch_block8_search(const ExactArgs& a, void* scratch, const uint8_t
         const float* qs = q_scale + q0;
         // (the 8-bit band is six times the bf16 plane's: the first rows whose scores are all kept are 4,096 -- the candidate buffer's size
         // -- and the chunks grow 8 x while the thresholds are young, so that each merge sees hundreds of candidates, not thousands)
-        const uint32_t n1 = a.slots < kP8FirstRows ? a.slots : kP8FirstRows;
+        // (VS_P8_FIRST / VS_P8_GROWTH / VS_P8_SLOW_BELOW: the schedule, for measurements)
+        static const uint32_t first_rows = std::getenv("VS_P8_FIRST") ? (uint32_t)std::atoi(std::getenv("VS_P8_FIRST")) : kP8FirstRows;
+        static const uint32_t slow_growth = std::getenv("VS_P8_GROWTH") ? (uint32_t)std::atoi(std::getenv("VS_P8_GROWTH")) : 8u;
+        static const uint32_t slow_below = std::getenv("VS_P8_SLOW_BELOW") ? (uint32_t)std::atoi(std::getenv("VS_P8_SLOW_BELOW")) : kP8SlowGrowthBelow;
+        const uint32_t n1 = a.slots < first_rows ? a.slots : first_rows;
         hipLaunchKernelGGL((p1_tile_kernel<true, true>), dim3((n1 + kP1TN - 1) / kP1TN), dim3(512), kP1LdsBytes, s, Aq, plane16, kp2, nqb, 0u, n1, (const float*)nullptr, scale,
                            (float*)nullptr, cand, cand_cnt, (uint32_t)kBlockCandCap, qs);
         e = hipMemsetD32Async((hipDeviceptr_t)cand_cnt, (int)n1, 256, s);
@@ -1821,7 +1826,7 @@ hipError_t launch_block8_search(const ExactArgs& a, void* scratch, const uint8_t
         hipLaunchKernelGGL(block_merge512_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
                            cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);
         for (uint32_t n0 = n1; n0 < a.slots;) {
-            const uint64_t want = (uint64_t)n0 * (n0 < kP8SlowGrowthBelow ? 8u : 32u);
+            const uint64_t want = (uint64_t)n0 * (n0 < slow_below ? slow_growth : 32u);
             const uint32_t nend = want >= a.slots ? a.slots : (uint32_t)want;
             const uint32_t tiles = (nend - n0 + kP1TN - 1) / kP1TN;
             const uint32_t grid = tiles < (uint32_t)cus ? tiles : (uint32_t)cus;

@@ -6,7 +6,7 @@
 set -u
 TAG=$1; EF=$2; shift 2
 export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; T=/tmp/prof_$TAG
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; T=/tmp/prof_${TAG}_$$_$RANDOM
 mkdir -p "$T" "$O/summary"; cd "$R"
 python3 bench.py "$@" > "$O/summary/${TAG}_bench.json" 2> "$O/${TAG}_bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 bench.py --ef "$EF" --steps 10 --warmup 2 --cpu-seconds 0 --boundary-seconds 0 --mixed-seconds 0 --no-side-records "$@" > "$O/summary/${TAG}_bench_under_rocprof.json" 2> "$O/${TAG}_stats.err"

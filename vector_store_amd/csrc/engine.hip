@@ -7,6 +7,8 @@
 // (kernels_*.hip); the host keeps only the key->slot map, the free-slot ring, the level
 // RNG and the batching of concurrent single-vector callers.  There is no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <sys/prctl.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -2307,6 +2309,16 @@ struct Engine {
         uint32_t answered = 0;
         uint64_t calls = 0;
         bool lost = false, timed_out = false;
+        static const long crowd_sleep_ns = std::getenv("VS_HNSW_ASK_SLEEP_US") ? 1000L * std::atol(std::getenv("VS_HNSW_ASK_SLEEP_US")) : 30000L;
+        bool slack_cut = false;
+        long slack_was = 0;
+        struct SlackBack {
+            bool& cut;
+            long& was;
+            ~SlackBack() {
+                if (cut) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)(was > 0 ? was : 50000), 0, 0, 0);
+            }
+        } slack_back{slack_cut, slack_was};
         for (uint32_t it = 0;; ++it) {
             const uint32_t asked = __atomic_load_n(h_cnt + 5, __ATOMIC_ACQUIRE);
             if (asked > answered) {
@@ -2327,11 +2339,21 @@ struct Engine {
                 continue;
             }
             if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == pq.round_id) break;
-            // a caller per core spins; a crowd beyond the cores takes turns (every one of them is what a walk on the device waits for)
+            // A caller per core spins.  A crowd beyond the cores SLEEPS between looks, a few tens of microseconds at a time (its timer
+            // slack cut to a microsecond for the length of the call): the walk does not wait for an answer until its 64 pending lanes are
+            // full -- twenty-odd hops, a hundred microseconds -- so a caller that looks every 40-50 us keeps its walk going, and 128 of
+            // them cost two cores.  (sched_yield does not do this: spinning callers burn whole time slices while the one whose walk
+            // waits is runnable and not running -- measured with 64 / 128 callers on 16 cores: 1.4k / 1.2k queries/s, p99 93 ms.)
             if (waiting.load(std::memory_order_relaxed) <= cores) {
                 for (int p = 0; p < 4; ++p) __builtin_ia32_pause();
             } else {
-                std::this_thread::yield();
+                if (!slack_cut) {
+                    slack_was = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+                    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+                    slack_cut = true;
+                }
+                struct timespec ts = {0, crowd_sleep_ns};
+                nanosleep(&ts, nullptr);
             }
             if ((it & 1023u) == 1023u) {
                 if (pod_pool(device).lost_post(pod.t) && __atomic_load_n(h_done, __ATOMIC_ACQUIRE) != pq.round_id && __atomic_load_n(h_cnt + 5, __ATOMIC_ACQUIRE) == 0u) {
@@ -2403,9 +2425,12 @@ struct Engine {
             // An unnamed filter -- the trait's own signature -- takes ONE walk that asks while it runs (round 6) whenever pods can serve;
             // VS_HNSW_FILTER_ASK=0: the rounds of rounds 3-5 (A/B).
             static const int ask_env = std::getenv("VS_HNSW_FILTER_ASK") ? std::atoi(std::getenv("VS_HNSW_FILTER_ASK")) : 1;
-            // (every asking walk needs its caller awake for its whole length: a crowd well beyond the cores -- measured at 64 / 128 callers
-            // on 16 cores: 1.4k / 1.2k queries/s against the rounds' 3.8k / 7.2k -- is served by the rounds, whose callers sleep)
-            const bool awake = ask_env == 2 || filtered_active_callers.load(std::memory_order_relaxed) <= usable_cores() + usable_cores() / 4;
+            // (every asking walk needs its caller to look in every few tens of microseconds for its whole length -- filtered_ask: callers
+            // beyond the cores sleep between looks, 64 / 128 callers on 16 cores: 6.1k / 12.0k queries/s against the rounds' 3.8k / 7.1k;
+            // a crowd of more than eight callers per core is left to the rounds)
+            // callers per core the asking walks serve (VS_HNSW_ASK_CROWD; beyond: the rounds, whose callers sleep through two long waits)
+            static const int ask_crowd = std::getenv("VS_HNSW_ASK_CROWD") ? std::max(1, std::atoi(std::getenv("VS_HNSW_ASK_CROWD"))) : 8;
+            const bool awake = ask_env == 2 || filtered_active_callers.load(std::memory_order_relaxed) <= ask_crowd * usable_cores();
             if (!filter_key && ask_env != 0 && awake && pods && batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b)) {
                 const size_t f = filtered_ask(q, k, pred, pctx, keys, dist, ef_b);
                 if (f != (size_t)-1) return f;

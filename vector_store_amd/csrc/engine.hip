@@ -2072,6 +2072,18 @@ struct Engine {
         bool explored = memo && memo->asked_avg.load(std::memory_order_relaxed) < 1024u;
         int exact_rounds = 0, explore_rounds = 0;
         uint32_t apply_m = 0;
+        if (!memo && !tl_ask_known.empty()) {  // an asking walk handed this query over (filtered_ask): its verdicts are the first round's input
+            const uint32_t m = (uint32_t)std::min<size_t>(tl_ask_known.size(), cap);
+            for (uint32_t i = 0; i < m; ++i) {
+                h_list[i] = tl_ask_known[i] >> 1;
+                h_verdict[i] = (uint8_t)(tl_ask_known[i] & 1u);
+                n_allowed += tl_ask_known[i] & 1u;
+            }
+            n_known = m;
+            apply_m = m;
+            explored = true;
+        }
+        tl_ask_known.clear();
         for (int round = 0; round < 24; ++round) {
             uint32_t guess = 0;  // of 256
             if (n_known > 0 && guess_pct > 0) guess = std::min<uint32_t>(255u, (uint32_t)((uint64_t)256 * n_allowed * (uint64_t)guess_pct / (100 * n_known)));
@@ -2236,6 +2248,7 @@ struct Engine {
     // about when it is new to the walk's visited set and passes the radius test, i.e. when usearch would ask, once.
     // (size_t)-1: not served here (no pod free, the walk handed over at an order-relevant tie, the device gave up on a host that did not
     // answer) -- the rounds serve the query.
+    static inline thread_local std::vector<uint32_t> tl_ask_known;  // (slot << 1 | admitted) of a walk that handed over, for the rounds that follow on this thread
     std::atomic<uint64_t> ask_queries{0}, ask_handed_over{0}, ask_no_pod{0}, ask_calls{0}, ask_waits{0}, ask_wait_ticks{0}, ask_hops{0}, ask_walk_ticks{0};
     size_t filtered_ask(const float* q, size_t k, vs_hnsw_predicate pred, void* pctx, uint64_t* keys, float* dist, uint32_t ef) {
         use_device();
@@ -2378,6 +2391,11 @@ struct Engine {
         const uint32_t found = h_cnt[2];
         if (found == kPipeRedoFound || found == kWalkFailed) {
             ask_handed_over.fetch_add(1, std::memory_order_relaxed);
+            // what the walk learned goes with the query: the rounds that serve it start from these verdicts (no exploring round, no second
+            // call of the predicate for them)
+            tl_ask_known.clear();
+            for (uint32_t i = 0; i < answered && i < cap; ++i)
+                if (h_list[i] < n) tl_ask_known.push_back((h_list[i] << 1) | (h_verdict[i] == 2 ? 1u : 0u));  // (slots are below 2^30)
             return (size_t)-1;
         }
         std::memcpy(keys, h_k, (size_t)std::min<size_t>(found, k) * 8);
@@ -2432,6 +2450,7 @@ struct Engine {
             static const int ask_crowd = std::getenv("VS_HNSW_ASK_CROWD") ? std::max(1, std::atoi(std::getenv("VS_HNSW_ASK_CROWD"))) : 8;
             const bool awake = ask_env == 2 || filtered_active_callers.load(std::memory_order_relaxed) <= ask_crowd * usable_cores();
             if (!filter_key && ask_env != 0 && awake && pods && batch_env != 0 && pipe_usable(ef_b) && !needs_global_walk_beyond_pipe(ef_b)) {
+                tl_ask_known.clear();
                 const size_t f = filtered_ask(q, k, pred, pctx, keys, dist, ef_b);
                 if (f != (size_t)-1) return f;
             }

@@ -120,6 +120,10 @@ __device__ __forceinline__ void pipe_query(const WalkArgs& a, const PipeQuery* p
             }
         }
         const uint32_t m = uni(pq->apply_m);
+        if (m && uni(pq->zero_bits) == 1u) {  // (round 6: a first round that starts from verdicts an asking walk left -- zeroed words before the first bit)
+            __threadfence();
+            __syncthreads();
+        }
         for (uint32_t i = tid; i < m; i += 64u * kPipeTeam) {
             const uint32_t s = uni(pq->list)[i];
             if (s < uni(pq->slots)) {

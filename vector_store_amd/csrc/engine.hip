@@ -1636,7 +1636,8 @@ struct Engine {
     PodTicket pod_submit(int mode, uint32_t ef, size_t n, const PipeQuery& pq) {
         PodPool& pp = pod_pool(device);
         if (!pp.enabled || ef > 512) return {};
-        const uint32_t efcap = ef <= 256 ? 256u : 512u;
+        if (mode == 4 && ef > 256) return {};  // (walk pods, round 6: the usearch-order team walk's LDS instances for beams up to 256)
+        const uint32_t efcap = mode == 4 ? (ef <= 128 ? 128u : 256u) : ef <= 256 ? 256u : 512u;
         const uint32_t walk_kind = mode == 2 ? 1u : mode == 3 ? 2u : 0u;  // PodSlot::explore: 0 exact, 1 exploring, 2 the walk that asks (round 6)
         if (mode == 2) mode = 1;  // (one kind of pod serves both kinds of round of a filtered query; walks that ask -- mode 3 -- have pods of their own)
         std::lock_guard<std::mutex> g(pp.mu);
@@ -1691,7 +1692,8 @@ struct Engine {
             a.pipe_fused_order = mode == 0 ? 1u : 0u;
             a.pipe_pool_cap = 12288u;
             std::atomic_thread_fence(std::memory_order_seq_cst);
-            HIP_OK(launch_pipe_pod(a, iters, p.st, p.slots, p.ctl));
+            if (mode == 4) HIP_OK(launch_walk_pod(a, iters, p.st, p.slots, p.ctl));  // (b1: kernels_walk.hip)
+            else HIP_OK(launch_pipe_pod(a, iters, p.st, p.slots, p.ctl));
             } catch (...) {
                 (void)hipGetLastError();
                 return {};

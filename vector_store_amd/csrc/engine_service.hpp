@@ -334,8 +334,15 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
     // usearch-order walk.  VS_HNSW_INT_PODS=0: as before.
     static const bool int_pods = !(std::getenv("VS_HNSW_INT_PODS") && std::getenv("VS_HNSW_INT_PODS")[0] == '0');
     const bool exact_kind = usearch_order();
-    if (exact_kind && !(int_pods && order_mode == 0 && scalar == VS_SCALAR_I8)) return false;
-    if (!pod_pool(device).enabled || needs_global_walk(ef) || !pipe_usable(ef) || team_mode == 2 || team_mode == 3 ||
+    // b1 (round 6): WALK PODS -- the usearch-order team walk itself as a resident kernel (kernels_walk.hip): the same walk as the
+    // dispatcher's launch, minus the launch, the stream and the dispatcher's hop.  Its LDS instances: beams up to 256, slots the tags
+    // of the instance tell apart, an index whose walks have not been outgrowing the instance.  VS_HNSW_B1_PODS=0: as before.
+    static const bool b1_pods = !(std::getenv("VS_HNSW_B1_PODS") && std::getenv("VS_HNSW_B1_PODS")[0] == '0');
+    const uint32_t b1_inst = ef <= 128 ? (uint32_t)WALK_LDS_128 : (uint32_t)WALK_LDS_256;
+    const bool walk_pod = exact_kind && b1_pods && order_mode == 0 && scalar == VS_SCALAR_B1 && ef <= 256 && walk_domain_override == 0 &&
+                          std::max<uint64_t>(slots_atomic.load(std::memory_order_acquire), 1) <= (1ull << walk_instance_domain_bits(b1_inst)) && !lds_walk_bad[b1_inst].load();
+    if (exact_kind && !walk_pod && !(int_pods && order_mode == 0 && scalar == VS_SCALAR_I8)) return false;
+    if (!pod_pool(device).enabled || needs_global_walk(ef) || (!walk_pod && !pipe_usable(ef)) || team_mode == 2 || team_mode == 3 ||
         stress_small_table || force_wide_tags)
         return false;
     use_device();
@@ -377,7 +384,7 @@ bool Engine::search_one_pod(const float* q, size_t k, uint64_t* keys, float* dis
     if (exact_kind) pq.budget = 0xFFFFFFu;  // (no verdict is ever missing: nothing is listed)
     __atomic_store_n(h_done, 0u, __ATOMIC_RELEASE);
     const auto t_in = std::chrono::steady_clock::now();
-    PodRelease pod{device, pod_submit(exact_kind ? 1 : 0, ef, lay, pq)};
+    PodRelease pod{device, pod_submit(walk_pod ? 4 : exact_kind ? 1 : 0, ef, lay, pq)};
     if (!pod.t) return false;
     const int dbg_pod = pod.t.pod;
     const uint32_t dbg_slot = pod.t.slot;

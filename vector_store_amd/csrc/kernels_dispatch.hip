@@ -112,6 +112,12 @@ hipError_t launch_pipe_pod(const WalkArgs& a, uint32_t iters, hipStream_t s, Pod
     }
 }
 
+// (round 6) the usearch-order team walk as a pod: b1 storage only (kernels_walk.hip)
+hipError_t launch_walk_pod(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl) {
+    if (arith_of(a.ix.scalar, a.ix.metric) != AR_B1) return hipErrorInvalidValue;
+    return launch_walk_pod_ar<AR_B1>(a, iters, s, slots, ctl);
+}
+
 hipError_t launch_insert(const InsertArgs& a, uint32_t iters, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     if (!search_supported(iters, a.ef_add)) return hipErrorInvalidValue;

@@ -17,12 +17,18 @@
 #include <cstdio>
 #include <cstdlib>
 #include "walk_device.hpp"
+#include "pipe_pod.hpp"
 
 #ifndef VS_AR
 #error "compile with -DVS_AR=<arithmetic>"
 #endif
 
 namespace vs {
+
+#ifndef VS_WALK_LCAP
+#define VS_WALK_LCAP 512
+#endif
+constexpr int kWalkPodHeapLds = VS_WALK_LCAP;           // (= kWalkHeapLds below)
 
 template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, bool VISG, int BS = 8>
 __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
@@ -255,6 +261,171 @@ static hipError_t walk_team_launch(const WalkArgs& a, hipStream_t s, uint32_t* g
     return hipGetLastError();
 }
 
+// ---- walk PODS (round 6): the team form above as a resident kernel that callers post lone queries to (pipe_pod.hpp: the same slots,
+// the same control block, the same waiter on the host).  For the storage whose ties the pipelined walk cannot order -- b1: a few hundred
+// distinct Hamming distances, nearly every pipelined walk handed over -- a lone query was a launch of its own
+// through the single-query dispatcher: 17 blocking callers 5.8-9.8k queries/s at 10M x 768.  Workgroup b serves slot b: one thread polls
+// the slot, the other waves wait at the barrier; the posted PipeQuery names the query (pinned), the beam, the caller's pinned block for
+// keys / distances / counters / flag.  Entry point, top level and "has removed members" are read per query from the pod's control
+// block, so the pod survives adds and removes like the others.  Same walk, same ids and distance bits as the launch.
+struct WalkPodArgs {
+    WalkArgs a;
+    PodSlot* slots;
+    PodCtl* ctl;
+};
+template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, int TEAM>
+__global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_pod_kernel(WalkPodArgs ka) {
+    using Sh = WalkShared<EFCAP, LCAP, NB, CH, false, TEAM>;
+    __shared__ Sh sh;
+    __shared__ uint32_t pod_cmd[6];
+    __shared__ PipeQuery pq_s;
+    const WalkArgs& a = ka.a;
+    IndexView ix = a.ix;
+    const int lane = lane_id();
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    PodSlot* const slot = ka.slots + blockIdx.x;
+    PodCtl* const ctl = ka.ctl;
+    uint32_t seen = 0;
+    for (;;) {
+        if (tid == 0) {  // (the polling loop of hnsw_pipe_walk_kernel)
+            uint32_t p = 0, polls = 0, beat = 0;
+            uint64_t beat_at = 0;
+            for (;;) {
+                p = __hip_atomic_load(&slot->posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (p != seen) break;
+                bool leave = (polls & 7u) == 0u && __hip_atomic_load(&ctl->closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+                if (!leave && (polls & 255u) == 0u) {  // the host's heartbeat: a pod nobody looks after any more (2 s at 100 MHz) ends by itself
+                    const uint32_t b = __hip_atomic_load(&ctl->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const uint64_t now = wall_clock64();
+                    if (b != beat || beat_at == 0) {
+                        beat = b;
+                        beat_at = now;
+                    } else if (now - beat_at > 200000000ull) {
+                        leave = true;
+                    }
+                }
+                if (leave) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                    p = __hip_atomic_load(&slot->posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (p == seen) {
+                        p = 0u;
+                        __hip_atomic_store(&slot->left, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    break;
+                }
+                ++polls;
+                __builtin_amdgcn_s_sleep(60);
+                if (polls > 256u) {
+                    __builtin_amdgcn_s_sleep(127);
+                    __builtin_amdgcn_s_sleep(127);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            __builtin_amdgcn_s_dcache_inv();  // (scalar loads of the index survive no fence: a pod that outlives an add must clean the scalar cache itself)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pod_cmd[0] = p;
+            pod_cmd[1] = __hip_atomic_load(&slot->ef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            pod_cmd[3] = __hip_atomic_load(&ctl->entry_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            pod_cmd[4] = (uint32_t)__hip_atomic_load(&ctl->max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            pod_cmd[5] = __hip_atomic_load(&ctl->has_removed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        const uint32_t p = pod_cmd[0];
+        if (p == 0u) return;  // (every thread reads the same word: the workgroup leaves together)
+        seen = p;
+        const uint64_t t_begin = wall_clock64();
+        const uint32_t ef = pod_cmd[1];
+        ix.entry_slot = pod_cmd[3];
+        ix.max_level = (int32_t)pod_cmd[4];
+        const bool tomb = pod_cmd[5] != 0u;
+        if (tid < sizeof(PipeQuery) / 4) reinterpret_cast<uint32_t*>(&pq_s)[tid] = __hip_atomic_load(reinterpret_cast<uint32_t*>(&slot->q) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        const uint32_t k = pq_s.k;
+        uint64_t* const ok = pq_s.keys;
+        float* const od = reinterpret_cast<float*>(ok + k);  // (a posted query's distances follow its keys)
+        uint32_t* const cnt_out = pq_s.cnt;
+        uint32_t found = 0;
+        Counters cnt = {0, 0, 0};
+        if (ix.max_level >= 0) {
+            Query<AR, I> q;
+            query_from_f32<AR, I>(ix, pq_s.query, q, lane);
+            bool helper = false;
+            if constexpr (TEAM > 1) {
+                helper = w != 0;
+                if (helper) team_helper_loop<AR, I>(ix, q, sh, lane, w);
+            }
+            if (!helper) {
+                WalkSpace ws = {nullptr, nullptr, nullptr, 0u, 0u, 0u};  // LDS instance: nothing lives in global memory
+                const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
+                bool exhausted = false;
+                const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, ef, kInvalid, tomb, nullptr, cnt, lane, exhausted, nullptr);
+                team_release(sh, lane);
+                wsync<Sh>();
+                if (exhausted) {
+                    found = kPipeRedoFound;  // its structures ran out: the dispatcher's launch (and its retry instance) serves the query
+                } else {
+                    found = sz < k ? sz : k;
+                    for (uint32_t i = lane; i < k; i += kWave) {
+                        const bool in = i < found;
+                        ok[i] = in ? ix.keys[sh.lst_s[i]] : kFreeKey;
+                        od[i] = in ? sh.lst_d[i] : __builtin_inff();
+                    }
+                }
+            }
+        } else if (w == 0) {
+            for (uint32_t i = lane; i < k; i += kWave) {
+                ok[i] = kFreeKey;
+                od[i] = __builtin_inff();
+            }
+        }
+        if (w == 0) {
+            if (lane == 0) {
+                cnt_out[0] = cnt_out[1] = 0u;
+                cnt_out[2] = found;
+                cnt_out[3] = (uint32_t)cnt.evals;
+                cnt_out[4] = (uint32_t)(wall_clock64() - t_begin);
+                if (found != kPipeRedoFound) {
+                    atomicAdd(&a.stats[ST_SEARCH_EVALS], cnt.evals);
+                    atomicAdd(&a.stats[ST_SEARCH_HOPS], cnt.hops);
+                    atomicAdd(&a.stats[ST_QUERIES], 1ull);
+                }
+            }
+            __threadfence_system();
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_store(cnt_out + 8, pq_s.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();  // every wave is done with this query's LDS before the next one's is laid out
+    }
+}
+
+template <int AR, int I>
+static hipError_t walk_pod_ef(const WalkArgs& a, hipStream_t s, PodSlot* slots, PodCtl* ctl) {
+    if constexpr (AR == AR_B1 && I < 12) {  // (the one storage these pods are for: one more set of instances in one of the eight files)
+        if (!a.nq || !slots || !ctl) return hipErrorInvalidValue;
+        WalkPodArgs ka{a, slots, ctl};
+        // (VS_HNSW_B1_POD_TEAM: waves per posted query.  A b1 row is 96 bytes, a hop's 32 rows one wave's load: measured at 10M x 768,
+        // ef 200, one / two / eight waves per query: 1.37 ms per lone walk each, 17 callers 11.7k / 11.6k / 11.8k queries/s -- the walk is
+        // the walker's own emulation of usearch's heap, swap for swap; ONE wave per query is the default, an eighth of the team's CU share)
+        static const int team = std::getenv("VS_HNSW_B1_POD_TEAM") ? std::atoi(std::getenv("VS_HNSW_B1_POD_TEAM")) : 1;
+        if (team == 1) {
+            if (a.ef <= 128) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 128, kWalkPodHeapLds, 1024, 1, 1>), dim3(a.nq), dim3(64), 0, s, ka);
+            else if (a.ef <= 256) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 256, 796, 1024, 2, 1>), dim3(a.nq), dim3(64), 0, s, ka);
+            else return hipErrorInvalidValue;
+        } else if (team == 2) {
+            if (a.ef <= 128) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 128, kWalkPodHeapLds, 1024, 1, 2>), dim3(a.nq), dim3(128), 0, s, ka);
+            else if (a.ef <= 256) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 256, 796, 1024, 2, 2>), dim3(a.nq), dim3(128), 0, s, ka);
+            else return hipErrorInvalidValue;
+        } else {
+            if (a.ef <= 128) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 128, kWalkPodHeapLds, 1024, 1, kSearchTeam>), dim3(a.nq), dim3(64 * kSearchTeam), 0, s, ka);
+            else if (a.ef <= 256) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 256, 796, 1024, 2, kSearchTeam>), dim3(a.nq), dim3(64 * kSearchTeam), 0, s, ka);
+            else return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
 template <class K>
 static uint32_t resident_workgroups(K kernel, int device) {  // workgroups of `kernel` the chip holds at once
     int per_cu = 0, cus = 0;
@@ -346,6 +517,19 @@ static hipError_t walk_ef(const WalkArgs& a, uint32_t instance, uint32_t grid_ca
         case WALK_LDS_128_TINY:
             if constexpr (I == 1) return walk_launch<AR, 1, 128, kWalkHeapLds, 256, 1, false>(a, grid_cap, s, grid_out);
             return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <>
+hipError_t launch_walk_pod_ar<VS_AR>(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl) {
+    switch (iters) {
+        case 1: return walk_pod_ef<VS_AR, 1>(a, s, slots, ctl);
+        case 2: return walk_pod_ef<VS_AR, 2>(a, s, slots, ctl);
+        case 3: return walk_pod_ef<VS_AR, 3>(a, s, slots, ctl);
+        case 4: return walk_pod_ef<VS_AR, 4>(a, s, slots, ctl);
+        case 6: return walk_pod_ef<VS_AR, 6>(a, s, slots, ctl);
+        case 8: return walk_pod_ef<VS_AR, 8>(a, s, slots, ctl);
         default: return hipErrorInvalidValue;
     }
 }

@@ -45,5 +45,8 @@ struct alignas(64) PodCtl {    // pinned host memory: one per pod
 // `slots` == nullptr: a plain launch (a.nq queries, one workgroup each).  Else a.nq workgroups that serve slots[blockIdx.x] until ctl->closed.
 template <int AR> hipError_t launch_pipe_pod_ar(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl);
 hipError_t launch_pipe_pod(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl);
+// Round 6: the usearch-order TEAM walk as a pod (kernels_walk.hip; b1 storage): a.nq workgroups of kSearchTeam waves, a.ef = the instance's beam cap.
+template <int AR> hipError_t launch_walk_pod_ar(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl);
+hipError_t launch_walk_pod(const WalkArgs& a, uint32_t iters, hipStream_t s, PodSlot* slots, PodCtl* ctl);
 
 }  // namespace vs

@@ -654,6 +654,10 @@ def main():
                 out["configs"].append(i8_callers_record(vs, dev, 10_000_000, 768, k, 200, a.dist, a.rank, 1.5))
             except Exception as e:
                 out["configs"].append({"config": "i8_blocking_callers", "error": repr(e)})
+            try:  # (round 6: b1 storage, lone queries through the walk pods)
+                out["configs"].append(i8_callers_record(vs, dev, 10_000_000, 768, k, 200, a.dist, a.rank, 1.5, kind="b1"))
+            except Exception as e:
+                out["configs"].append({"config": "b1_blocking_callers", "error": repr(e)})
         if "c3" in want:
             try:
                 out["configs"].append(config_c3(vs, dev, 10_000_000, k, a.dist, a.rank, a.target_recall))

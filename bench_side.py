@@ -174,17 +174,18 @@ def config_c5(vs, dev, n, dim, k, dist_kind, rank):
     return out
 
 
-def i8_callers_record(vs, dev, n, dim, k, ef, dist_kind, rank, seconds):
+def i8_callers_record(vs, dev, n, dim, k, ef, dist_kind, rank, seconds, kind="i8"):
     """Integer storage behind the reference's call pattern (round 5): the headline workload with i8 storage, ONE query per
     vs_hnsw_search call from num_workers() + 1 and from 64 blocking callers (usearch.rs:203-222).  i8 lone queries are posted to the pods
     that serve the exact walks of filtered queries (usearch's tie order); every recorded answer is compared with the
     engine's own usearch-order BATCH walk of the same query (ids and distance bits: the kernels the oracle-parity tests of
-    tests/test_gpu_quantized.py check).  Not a BASELINE config: a side record."""
+    tests/test_gpu_quantized.py check).  Not a BASELINE config: a side record.  kind "b1" (round 6): the same with 1-bit storage
+    (Hamming), whose lone queries are posted to WALK pods -- the usearch-order walk itself as a resident kernel."""
     from vector_store_amd import callers
     t0 = time.perf_counter()
     base = make_data(n, dim, dist_kind, 1234, dev, rank)
     q = make_data(4096, dim, dist_kind, 4321, dev, rank)
-    ix, build_s = build_index(vs, base, np.arange(n, dtype=np.uint64), "cos", quantization="i8")
+    ix, build_s = build_index(vs, base, np.arange(n, dtype=np.uint64), "cos", quantization=kind)
     del base
     ix.set_expansion_search(ef)
     se = Searcher(ix, q, k)
@@ -194,7 +195,7 @@ def i8_callers_record(vs, dev, n, dim, k, ef, dist_kind, rank, seconds):
     want_k, want_d = se.keys.cpu().numpy(), se.dist.cpu().numpy()
     qh = np.ascontiguousarray(q.cpu().numpy(), dtype=np.float32)
     th = np.ascontiguousarray(truth, dtype=np.uint64)
-    rec = {"config": "i8_blocking_callers", "workload": f"{n}x{dim} cos, i8 storage, top-{k}, ef_search={ef}, one query per call",
+    rec = {"config": f"{kind}_blocking_callers", "workload": f"{n}x{dim} cos, {kind} storage, top-{k}, ef_search={ef}, one query per call",
            "build_vectors_per_s": n / build_s, "batch_walk_recall_at_10": round(recall_at_k(truth, want_k), 4)}
     pods = ix.pod_stats()
     for name, threads in (("blocking_callers", effective_cores() + 1), ("blocking_callers_64", 64)):

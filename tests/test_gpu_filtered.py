@@ -319,3 +319,41 @@ def test_an_unnamed_filter_is_one_walk_that_asks_what_usearch_asks():
     st = ix.filter_ask_stats()
     assert st["queries"] >= 48 and st["queries"] + st["handed_over"] + st["no_pod"] == 2 * len(q), st
     assert cpu_calls > 0 and gpu_calls <= 1.15 * cpu_calls and gpu_calls >= 0.9 * cpu_calls, (gpu_calls, cpu_calls)
+
+
+def test_a_predicate_that_stalls_is_outlasted_by_the_asking_walk():
+    """The asking walk waits for its caller's answers on the device; a caller that does not answer for a fifth of a second (a closure
+    that blocks on a lock, a thread that is not scheduled) must not hold the workgroup: the walk gives up, reports "handed over", and
+    the rounds serve the query when the caller comes back -- same answer, no hang."""
+    import time
+    import vector_store_amd as v
+    n, dim, k = 120_000, 64, 10
+    data = _dataset(n + 4, dim, 79)
+    base, q = data[:n], data[n:]
+    ix = v.HipUsearchIndex(dim, v.COS, expansion_search=96)
+    ix.reserve(n)
+    ix.add_batch(np.arange(n, dtype=np.uint64), base)
+    o = OracleIndex(dim, oracle.COS, 16, 128, 96)
+    o.import_graph(ix.export_graph())
+    ix.filtered_search(q[0], k, lambda key: key % 10 == 3)   # (pods open, contexts exist)
+    calls = [0]
+
+    def stalling(key):
+        calls[0] += 1
+        if calls[0] == 200:
+            time.sleep(1.0)
+        return key % 10 == 3
+
+    s0 = ix.filter_ask_stats()
+    t0 = time.time()
+    gk, gd = ix.filtered_search(q[1], k, stalling)
+    took = time.time() - t0
+    s1 = ix.filter_ask_stats()
+    wk, wd = o.filtered_search(q[1], k, lambda key: key % 10 == 3)
+    assert_same_results(gk, gd, wk, wd, lambda key: o.distance_to_slot(q[1], int(key)), what="stalled")
+    assert s1["handed_over"] == s0["handed_over"] + 1 and took < 10.0, (s0, s1, took)
+    # ... and the next query is served by an asking walk again
+    gk, gd = ix.filtered_search(q[2], k, lambda key: key % 10 == 3)
+    wk, wd = o.filtered_search(q[2], k, lambda key: key % 10 == 3)
+    assert_same_results(gk, gd, wk, wd, lambda key: o.distance_to_slot(q[2], int(key)), what="after the stall")
+    assert ix.filter_ask_stats()["queries"] == s1["queries"] + 1

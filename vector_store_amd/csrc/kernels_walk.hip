@@ -273,9 +273,10 @@ struct WalkPodArgs {
     PodSlot* slots;
     PodCtl* ctl;
 };
-template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, int TEAM>
+// HWV: the second wave of a two-wave team owns `next` (walk_device.hpp, HeapWaveBox) from the end of the descent to the end of the walk.
+template <int AR, int I, int EFCAP, int LCAP, int NB, int CH, int TEAM, bool HWV = false>
 __global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_pod_kernel(WalkPodArgs ka) {
-    using Sh = WalkShared<EFCAP, LCAP, NB, CH, false, TEAM>;
+    using Sh = WalkShared<EFCAP, LCAP, NB, CH, false, TEAM, false, false, 8, HWV>;
     __shared__ Sh sh;
     __shared__ uint32_t pod_cmd[6];
     __shared__ PipeQuery pq_s;
@@ -352,14 +353,18 @@ __global__ __launch_bounds__(64 * TEAM) void hnsw_walk_team_pod_kernel(WalkPodAr
             bool helper = false;
             if constexpr (TEAM > 1) {
                 helper = w != 0;
-                if (helper) team_helper_loop<AR, I>(ix, q, sh, lane, w);
+                if (helper) {
+                    team_helper_loop<AR, I>(ix, q, sh, lane, w);  // (the descent through the upper levels)
+                    if constexpr (HWV) walk_heap_wave_loop<AR, I>(ix, q, sh, lane);
+                }
             }
             if (!helper) {
                 WalkSpace ws = {nullptr, nullptr, nullptr, 0u, 0u, 0u};  // LDS instance: nothing lives in global memory
                 const uint32_t start = greedy_descent<AR, I>(ix, sh, q, ix.entry_slot, ix.max_level, 0, cnt, lane);
                 bool exhausted = false;
+                if constexpr (HWV) team_release(sh, lane);  // the helper becomes the heap wave; the walk itself sends it home
                 const uint32_t sz = walk_usearch<AR, I>(ix, sh, ws, q, start, 0, ef, kInvalid, tomb, nullptr, cnt, lane, exhausted, nullptr);
-                team_release(sh, lane);
+                if constexpr (!HWV) team_release(sh, lane);
                 wsync<Sh>();
                 if (exhausted) {
                     found = kPipeRedoFound;  // its structures ran out: the dispatcher's launch (and its retry instance) serves the query
@@ -403,17 +408,20 @@ static hipError_t walk_pod_ef(const WalkArgs& a, hipStream_t s, PodSlot* slots, 
     if constexpr (AR == AR_B1 && I < 12) {  // (the one storage these pods are for: one more set of instances in one of the eight files)
         if (!a.nq || !slots || !ctl) return hipErrorInvalidValue;
         WalkPodArgs ka{a, slots, ctl};
-        // (VS_HNSW_B1_POD_TEAM: waves per posted query.  A b1 row is 96 bytes, a hop's 32 rows one wave's load: measured at 10M x 768,
-        // ef 200, one / two / eight waves per query: 1.37 ms per lone walk each, 17 callers 11.7k / 11.6k / 11.8k queries/s -- the walk is
-        // the walker's own emulation of usearch's heap, swap for swap; ONE wave per query is the default, an eighth of the team's CU share)
-        static const int team = std::getenv("VS_HNSW_B1_POD_TEAM") ? std::atoi(std::getenv("VS_HNSW_B1_POD_TEAM")) : 1;
+        // (VS_HNSW_B1_POD_TEAM: waves per posted query.  A b1 row is 96 bytes, a hop's 32 rows one wave's load, and a lone walk is the walker's own
+        // chain of LDS round trips and scalar code -- 14.7k clocks per hop at 10M x 768, ef 200, of which the memory is a small part
+        // (profiles/r06_b1_walk_phases.txt): one / two / eight waves that only SHARE THE ROWS measured 1.37 ms per walk each.  Round 6: the
+        // second wave of two owns `next` instead (2, the default) -- pop_heap under the visited test, the push_heaps under the merge into `top`;
+        // 1 = one wave does everything, 8 = the row-sharing team.  A pod's workgroup has a CU nearly to itself, so the visited table is the wide
+        // one-choice form (4,096 buckets: one bucket read per test instead of two and an overflow list).)
+        static const int team = std::getenv("VS_HNSW_B1_POD_TEAM") ? std::atoi(std::getenv("VS_HNSW_B1_POD_TEAM")) : 2;
         if (team == 1) {
-            if (a.ef <= 128) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 128, kWalkPodHeapLds, 1024, 1, 1>), dim3(a.nq), dim3(64), 0, s, ka);
-            else if (a.ef <= 256) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 256, 796, 1024, 2, 1>), dim3(a.nq), dim3(64), 0, s, ka);
+            if (a.ef <= 128) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 128, kWalkPodHeapLds, 4096, 1, 1>), dim3(a.nq), dim3(64), 0, s, ka);
+            else if (a.ef <= 256) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 256, 796, 4096, 1, 1>), dim3(a.nq), dim3(64), 0, s, ka);
             else return hipErrorInvalidValue;
         } else if (team == 2) {
-            if (a.ef <= 128) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 128, kWalkPodHeapLds, 1024, 1, 2>), dim3(a.nq), dim3(128), 0, s, ka);
-            else if (a.ef <= 256) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 256, 796, 1024, 2, 2>), dim3(a.nq), dim3(128), 0, s, ka);
+            if (a.ef <= 128) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 128, kWalkPodHeapLds, 4096, 1, 2, true>), dim3(a.nq), dim3(128), 0, s, ka);
+            else if (a.ef <= 256) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 256, 796, 4096, 1, 2, true>), dim3(a.nq), dim3(128), 0, s, ka);
             else return hipErrorInvalidValue;
         } else {
             if (a.ef <= 128) hipLaunchKernelGGL((hnsw_walk_team_pod_kernel<AR, I, 128, kWalkPodHeapLds, 1024, 1, kSearchTeam>), dim3(a.nq), dim3(64 * kSearchTeam), 0, s, ka);

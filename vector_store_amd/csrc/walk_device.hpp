@@ -61,8 +61,23 @@ struct VisitedLds<false, NB, BS> {};
 // size or on the number of visited nodes) instead of the LDS tag table of hnsw_device.hpp.
 // BS: tags per bucket of the visited table (8; 12 = the DENSE table: 512 buckets x 12 hold the 6,144 nodes a beam of up to 256 visits
 // in 12.5 KB instead of 17: 7 walks per CU instead of 6).
-template <int EFCAP, int LCAP, int NB, int CH, bool VISG, int TM = 1, bool NT = false, bool SEL = false, int BS = 8>
-struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB, BS> {
+// HWV (round 6, the walk pods' two-wave form): wave 1 owns `next` -- usearch's array heap, swap for swap -- and repairs it while the walker
+// (wave 0) goes on with the hop: pop_heap's sift-down runs under the visited test and the row loads, the hop's push_heaps under the
+// merge into `top`.  The two meet at workgroup barriers; a command (hw_cmd, two slots used in turn) goes with each.
+template <bool ON>
+struct HeapWaveBox {
+    uint2 hw_cmd[2];
+    uint32_t hw_hn;
+    float hw_d[64];
+    uint32_t hw_s[64];
+};
+template <>
+struct HeapWaveBox<false> {};
+
+template <int EFCAP, int LCAP, int NB, int CH, bool VISG, int TM = 1, bool NT = false, bool SEL = false, int BS = 8, bool HWV = false>
+struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB, BS>, HeapWaveBox<HWV> {
+    static_assert(!HWV || (TM == 2 && !VISG), "the heap wave is wave 1 of a two-wave team over an LDS heap");
+    static constexpr bool kHeapWave = HWV;
     static constexpr bool kNT = NT;
     static constexpr int kChoices = CH;
     static constexpr int kEfCap = EFCAP;
@@ -298,6 +313,147 @@ __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& 
 // Per-lane test-and-set.  LDS table: hnsw_device.hpp; when that table is exhausted the walk cannot stay exact
 // (a node evaluated twice would be pushed twice), so `exhausted` is raised and the kernel hands the query to the
 // global-bitmap instance.
+// Which arithmetics measure a hop's neighbours before the visited set has answered (see the walk): bit rows only -- a row of
+// any other storage is 8 to 32 times as long, and a third of them would be read for nothing.
+#ifdef VS_WALK_NO_SPECULATE
+template <int AR>
+constexpr bool kWalkSpeculate = false;
+#else
+template <int AR>
+constexpr bool kWalkSpeculate = AR == AR_B1;
+#endif
+
+// group_sum for short rows (groups of 2 / 4 / 8 lanes: bit rows, low dimensions): quad permutes and the half-row mirror are DPP
+// operands, a few cycles each, where group_sum's generic loop takes one ds_bpermute round trip per halving -- 1.5k of a lone b1
+// walk's 14.7k clocks per hop (four row groups, three halvings each, one after the other).
+__device__ __forceinline__ int walk_group_sum(int v, uint32_t lanes) {
+    if (lanes >= 16) return group_sum(v, lanes);
+    if (lanes >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
+    if (lanes >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
+    if (lanes >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float walk_group_sum(float v, uint32_t lanes) {
+    if (lanes >= 16) return group_sum(v, lanes);
+    if (lanes >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    if (lanes >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    if (lanes >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+// group_reduce (hnsw_device.hpp) over walk_group_sum
+template <int AR, int I, int U, int TEAM>
+__device__ __forceinline__ void walk_group_reduce(const IndexView& ix, const RowGroup<I, U>& g, const Query<AR, I>& q, float* u_dist, uint32_t L,
+                                                  uint32_t w, uint32_t vshift, uint32_t grp, uint32_t li) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        typename Arith<AR>::acc_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < I; ++i) acc = accumulate<AR>(acc, q.c[i], g.buf[u][i]);
+        acc = walk_group_sum(acc, ix.lanes);
+        if (g.slot[u] != kInvalid && li == 0) {
+            const float d = finalize<AR>(ix.metric, acc, q.aux, g.aux[u]);
+            u_dist[(((L + (uint32_t)u) * (uint32_t)TEAM + w) << vshift) + grp] = d == d ? d : __builtin_inff();  // (NaN ranks as +inf, as there)
+        }
+    }
+}
+
+// One wave's share of a batch (eval_batch, hnsw_device.hpp, over walk_group_reduce) with `between()` run once the first row loads are in
+// flight and before they are waited for.
+template <int AR, int I, class Sh, class F>
+__device__ __forceinline__ void walk_eval_part(const IndexView& ix, const Query<AR, I>& q, Sh& sh, uint32_t m, int lane, uint32_t w, F&& between) {
+    constexpr int TEAM = Sh::kTeam;
+    constexpr bool NT = Sh::kNT;
+    constexpr int U = I >= 12 ? 1 : (I >= 6 || (AR == AR_I8 && I >= 3)) ? 2 : 4;  // (eval_batch's)
+    const uint32_t lg = ix.lanes_log2;
+    const uint32_t vshift = 6u - lg;
+    const uint32_t grp = (uint32_t)lane >> lg, li = (uint32_t)lane & (ix.lanes - 1);
+    const uint32_t nl_all = (m + (1u << vshift) - 1u) >> vshift;
+    const uint32_t nl = TEAM == 1 ? nl_all : (nl_all > w ? (nl_all - w + (uint32_t)TEAM - 1u) / (uint32_t)TEAM : 0u);
+    RowGroup<I, U> a, b;
+    if (nl) group_issue<AR, I, U, TEAM, NT>(ix, a, sh.u_slot, m, 0, w, vshift, grp, li);
+    between();
+    for (uint32_t L = 0; L < nl;) {
+        if (L + U < nl) group_issue<AR, I, U, TEAM, NT>(ix, b, sh.u_slot, m, L + U, w, vshift, grp, li);
+        walk_group_reduce<AR, I, U, TEAM>(ix, a, q, sh.u_dist, L, w, vshift, grp, li);
+        L += U;
+        if (L >= nl) break;
+        if (L + U < nl) group_issue<AR, I, U, TEAM, NT>(ix, a, sh.u_slot, m, L + U, w, vshift, grp, li);
+        walk_group_reduce<AR, I, U, TEAM>(ix, b, q, sh.u_dist, L, w, vshift, grp, li);
+        L += U;
+    }
+}
+
+// ---- the heap wave's protocol (WalkShared<.., HWV = true>) ----
+enum : uint32_t { HW_NOP = 0, HW_EVAL = 1, HW_POP = 2, HW_PUSH = 3, HW_EXIT = 4 };
+// LDS is all the two waves share: the barrier waits for the wave's LDS operations only -- a __syncthreads() would also wait for the walker's
+// adjacency prefetches, which are meant to stay in flight across it.
+__device__ __forceinline__ void hw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// walker: command number `gen` goes into slot gen & 1 -- the heap wave reads slot g right behind barrier g and the walker writes it again only
+// behind barrier g + 1, which the heap wave reaches after that read
+template <class Sh>
+__device__ __forceinline__ void hw_send(Sh& sh, uint32_t& gen, uint32_t op, uint32_t arg, int lane) {
+    if (lane == 0) sh.hw_cmd[gen & 1u] = make_uint2(op, arg);
+    hw_barrier();
+    ++gen;
+}
+// wave 1 of the team, from the moment the descent's helper loop ends (team_release) until the walk says HW_EXIT
+template <int AR, int I, class Sh>
+__device__ __forceinline__ void walk_heap_wave_loop(const IndexView& ix, const Query<AR, I>& q, Sh& sh, int lane) {
+    const WalkSpace ws = {nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    uint32_t gen = 0;
+    for (;;) {
+        hw_barrier();
+        const uint2 c = sh.hw_cmd[gen & 1u];
+        ++gen;
+        const uint32_t op = uni(c.x), arg = uni(c.y);
+        if (op == HW_EXIT) return;
+        if (op == HW_POP) {
+            uint32_t hn = arg;
+            heap_pop(sh, ws, hn, lane);
+        } else if (op == HW_PUSH) {
+            uint32_t hn = uni(sh.hw_hn);
+            for (uint32_t j = 0; j < arg; ++j) heap_push(sh, ws, hn, __uint_as_float(uni(__float_as_uint(sh.hw_d[j]))), uni(sh.hw_s[j]), lane);
+        } else if (op == HW_EVAL) {
+            walk_eval_part<AR, I>(ix, q, sh, arg, lane, 1u, [] {});
+        }
+    }
+}
+
+// eval_shared (hnsw_device.hpp) with `between()` run by the walking wave once its first row loads are in flight and before it waits
+// for them: the walk repairs `next` there (round 6 -- the phase clocks of a lone walk, profiles/r06_b1_walk_phases.txt: the pop's
+// sift-down is 2.5k clocks of LDS round trips and scalar code per hop).  `gen`: the heap wave's command counter (kHeapWave only).
+template <int AR, int I, class Sh, class F>
+__device__ __forceinline__ void eval_shared_over(const IndexView& ix, const Query<AR, I>& q, Sh& sh, uint32_t m, int lane, uint32_t& gen, F&& between) {
+    if constexpr (Sh::kHeapWave) {
+        hw_send(sh, gen, HW_EVAL, m, lane);  // (the heap wave has finished whatever it was told before: it is here)
+        walk_eval_part<AR, I>(ix, q, sh, m, lane, 0u, between);
+        hw_send(sh, gen, HW_NOP, 0u, lane);  // both shares are in LDS
+    } else {
+        if constexpr (Sh::kTeam > 1) {
+            if (lane == 0) {
+                sh.team_m = m;
+                sh.team_q = kInvalid;
+            }
+            __syncthreads();  // releases the helpers (see team_helper_loop)
+        }
+        walk_eval_part<AR, I>(ix, q, sh, m, lane, 0u, between);
+        __syncthreads();  // every wave's distances are in LDS
+    }
+}
+
+// the smallest value of a wave, in every lane: four DPP rotations inside the rows of 16, four scalar reads across them
+__device__ __forceinline__ float walk_wave_min(float v) {
+    v = fminf(v, VS_DPP_ROR(v, 8));
+    v = fminf(v, VS_DPP_ROR(v, 4));
+    v = fminf(v, VS_DPP_ROR(v, 2));
+    v = fminf(v, VS_DPP_ROR(v, 1));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(a, b), fminf(c, d));
+}
+
 template <class Sh>
 __device__ __forceinline__ bool walk_visit(Sh& sh, const WalkSpace& ws, uint32_t slot) {
     if constexpr (Sh::kVisGlobal) {
@@ -386,11 +542,21 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
     (void)mark(lane == 0 ? start : (lane == 1 && self != start) ? self : kInvalid);
     if (lane == 0) sh.u_slot[0] = start;
     wsync<Sh>();
-    eval_shared<AR, I>(ix, q, sh, 1, lane);
+    // the heap wave's command counter, and whether it may still be busy with a pop or the pushes (kHeapWave only)
+    uint32_t hw_gen = 0;
+    bool hw_busy = false;
+    auto hw_sync = [&]() {
+        if constexpr (Sh::kHeapWave) {
+            if (hw_busy) hw_send(sh, hw_gen, HW_NOP, 0u, lane);
+            hw_busy = false;
+        }
+    };
+    if constexpr (Sh::kHeapWave) eval_shared_over<AR, I>(ix, q, sh, 1, lane, hw_gen, [] {});
+    else eval_shared<AR, I>(ix, q, sh, 1, lane);
     cnt.evals += 1;
     const float d0 = sh.u_dist[0];
     uint32_t hn = 0, sz = 0;
-    heap_push(sh, ws, hn, d0, start, lane);
+    heap_push(sh, ws, hn, d0, start, lane);  // (the heap wave waits at its barrier: the first entry is the walker's)
     if (start != self && (__ballot(allowed(start, lane == 0)) & 1ull)) {
         if (lane == 0) {
             sh.lst_d[0] = d0;
@@ -401,10 +567,15 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
     wsync<Sh>();
     // Adjacency prefetch: once the candidate is popped, the new root of `next` is the runner-up; its row is loaded while
     // this hop's vectors stream in and is used when that node is indeed expanded next (nothing closer was pushed).
-    uint32_t pf_slot = kInvalid, pf_n = kInvalid;
+    // Round 6, second prefetch: more often than not the next candidate is not the runner-up but the closest neighbour this hop has
+    // just measured (the walk is greedy) -- its row is asked for as soon as the distances are known and arrives under the admission,
+    // the pushes and the merge (the phase clocks of a lone b1 walk at 10M x 768: 1.44 us of a 6 us hop went to "pop", most of it this
+    // dependent load; profiles/r06_b1_walk_phases.txt).
+    uint32_t pf_slot = kInvalid, pf_n = kInvalid, pg_slot = kInvalid, pg_n = kInvalid;
     WALK_STAMP(0);  // start-up: clear, first evaluation
     while (hn) {
         sz = uni(sz);  // wave-uniform by construction (see `start`)
+        hw_sync();     // the last hop's pushes are in
         const uint2 ce = heap_get(sh, ws, 0);
         const float cd = __uint_as_float(ce.x);
         const uint32_t cs = ce.y;
@@ -412,21 +583,49 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         uint32_t n;
         if (cs == pf_slot) {
             n = pf_n;
+        } else if (cs == pg_slot) {
+            n = pg_n;
         } else {  // on its way while the heap is repaired
             uint32_t cap;
             const uint32_t* row = adjacency(ix, cs, level, cap);
             n = (uint32_t)lane < cap ? row[lane] : kInvalid;
         }
-        heap_pop(sh, ws, hn, lane);
         cnt.hops += 1;
-        pf_slot = hn ? heap_get(sh, ws, 0).y : kInvalid;
-        if (pf_slot != kInvalid) {
-            uint32_t cap2;
-            const uint32_t* row2 = adjacency(ix, pf_slot, level, cap2);
-            pf_n = (uint32_t)lane < cap2 ? row2[lane] : kInvalid;
+        // `next` is repaired -- pop_heap's sift-down -- under the hop's row loads (eval_shared_over); a hop that measures nothing
+        // repairs it where it turns back
+        // ... and the runner-up's row is asked for only when the distances are out: the wait for the row loads is a wait for every load
+        // issued before it (returns are in order), the prefetch's included, and a prefetch issued at the end of the repair put its whole
+        // latency back into the hop.
+        bool popped = false, asked = false;
+        auto pop_now = [&]() {
+            if (popped) return;
+            popped = true;
+            if constexpr (Sh::kHeapWave) {
+                hw_send(sh, hw_gen, HW_POP, hn, lane);
+                hn -= 1u;
+                hw_busy = true;
+            } else {
+                heap_pop(sh, ws, hn, lane);
+            }
+        };
+        auto ask_runner_up = [&]() {
+            if (asked) return;
+            asked = true;
+            hw_sync();
+            pf_slot = hn ? heap_get(sh, ws, 0).y : kInvalid;
+            if (pf_slot != kInvalid) {
+                uint32_t cap2;
+                const uint32_t* row2 = adjacency(ix, pf_slot, level, cap2);
+                pf_n = (uint32_t)lane < cap2 ? row2[lane] : kInvalid;
+            }
+        };
+        if constexpr (Sh::kHeapWave) pop_now();  // the heap wave starts on it now
+        if (cs == self) {
+            pop_now();
+            ask_runner_up();
+            continue;
         }
-        if (cs == self) continue;
-        WALK_STAMP(1);  // candidate, pop, prefetch issue
+        WALK_STAMP(1);  // candidate
         // connectivity above 32: a level-0 row holds up to 128 ids, taken 64 at a time in adjacency order (as the CPU loop would)
         uint32_t n_hi = kInvalid;
         {
@@ -437,9 +636,49 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         const uint32_t halves = (level == 0 ? ix.M0 : ix.M) > (uint32_t)kWave ? 2u : 1u;
         for (uint32_t half = 0; half < halves && !exhausted; ++half) {
         if (half) n = n_hi;
+        uint32_t m;
+        if constexpr (kWalkSpeculate<AR> && Sh::kVisGlobal) {
+            // Round 6, bit rows with the visited set in global memory: a row is 96 B at 768 dimensions, a test-and-set on the bitmap is
+            // a round trip to L2 (0.8 us of a 6 us hop) -- so the rows of ALL the neighbours are asked for right behind the atomics
+            // and measured (one wave-load more than the fresh two thirds would take), and the atomics' answers, which have arrived
+            // by then (returns are in order), only choose which distances are kept.  Nothing the walk decides changes: the
+            // kept list is the one the plain order builds, in adjacency order; `evals` counts the kept ones (what usearch measures).
+            const bool valid = n != kInvalid;
+            const uint32_t bit = 1u << (n & 31u);
+            uint32_t old = 0;
+            if (valid) old = atomicOr(&ws.bitmap[n >> 5], bit);
+            const uint64_t vm = __ballot(valid);
+            const uint32_t mv = (uint32_t)__popcll(vm);
+            if (valid) sh.u_slot[mbcnt(vm)] = n;
+            wsync<Sh>();
+            if (mv == 0) {
+                pop_now();
+                continue;
+            }
+            WALK_STAMP(2);  // atomics issued, compaction
+            eval_shared_over<AR, I>(ix, q, sh, mv, lane, hw_gen, pop_now);
+            hw_busy = false;
+            const float dv = valid ? sh.u_dist[mbcnt(vm)] : __builtin_inff();
+            const bool fresh = valid && (old & bit) == 0u;
+            const uint64_t fmask = __ballot(fresh);
+            m = (uint32_t)__popcll(fmask);
+            if (vcount + m <= ws.vlog_cap) {
+                if (fresh) ws.vlog[vcount + mbcnt(fmask)] = n;
+            } else {
+                vlog_lost = true;
+            }
+            vcount += m;
+            wsync<Sh>();  // every lane holds its distance
+            if (fresh) {
+                sh.u_slot[mbcnt(fmask)] = n;
+                sh.u_dist[mbcnt(fmask)] = dv;
+            }
+            wsync<Sh>();
+            if (m == 0) continue;  // (popped: mv > 0)
+        } else {
         const bool fresh = mark(n);
         const uint64_t fmask = __ballot(fresh);
-        const uint32_t m = (uint32_t)__popcll(fmask);
+        m = (uint32_t)__popcll(fmask);
         if constexpr (!Sh::kVisGlobal) {
             if (uni(sh.overflowed)) {  // wave-uniform (LDS flag set by any lane of this hop)
                 exhausted = true;
@@ -448,13 +687,33 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         }
         if (fresh) sh.u_slot[mbcnt(fmask)] = n;
         wsync<Sh>();
-        if (m == 0) continue;
+        if (m == 0) {
+            pop_now();
+            continue;
+        }
         WALK_STAMP(2);  // visited test-and-set, compaction
-        eval_shared<AR, I>(ix, q, sh, m, lane);
+        eval_shared_over<AR, I>(ix, q, sh, m, lane, hw_gen, pop_now);
+        hw_busy = false;
+        }
         cnt.evals += m;
         WALK_STAMP(3);  // distances
         float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
         uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
+        ask_runner_up();
+        {  // the closest of this hop's neighbours, when it beats the runner-up: its adjacency row (see pg_slot above)
+            const float mn = walk_wave_min(nd);
+            const uint64_t bm = __ballot((uint32_t)lane < m && nd == mn);
+            const float root_d = hn ? __uint_as_float(heap_get(sh, ws, 0).x) : __builtin_inff();
+            if (bm && mn <= root_d) {
+                const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)__builtin_ctzll(bm));
+                if (s2 != pf_slot) {
+                    uint32_t cap3;
+                    const uint32_t* row3 = adjacency(ix, s2, level, cap3);
+                    pg_n = (uint32_t)lane < cap3 ? row3[lane] : kInvalid;
+                    pg_slot = s2;
+                }
+            }
+        }
         // the verdict is only needed for neighbours that can still be admitted (usearch asks the predicate inside
         // `if (top.size() < top_limit || d < radius)`): once `top` is full, those below the radius of the hop's start
         const float radius0 = sz == ef ? __uint_as_float(uni(__float_as_uint(sh.lst_d[sz - 1]))) : __builtin_inff();
@@ -516,6 +775,23 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         }
         WALK_STAMP(4);  // admission
         // ---- next.insert for every admitted neighbour, in order ----
+        if constexpr (Sh::kHeapWave) {  // the list goes to the heap wave, which pushes it in this order while `top` is merged here
+            const uint32_t np = (uint32_t)__popcll(pushed);
+            if (np) {
+                if (hn + np > (uint32_t)Sh::kHeapLds) {
+                    exhausted = true;
+                    break;
+                }
+                if ((pushed >> lane) & 1ull) {
+                    sh.hw_d[mbcnt(pushed)] = nd;
+                    sh.hw_s[mbcnt(pushed)] = ns;
+                }
+                if (lane == 0) sh.hw_hn = hn;
+                hw_send(sh, hw_gen, HW_PUSH, np, lane);
+                hn += np;
+                hw_busy = true;
+            }
+        } else {
         for (uint64_t r = pushed; r; r &= r - 1ull) {
             const uint32_t j = (uint32_t)__builtin_ctzll(r);
             if (hn >= (uint32_t)Sh::kHeapLds + (Sh::kHeapSpill ? ws.heap_cap : 0u)) {  // `next` outgrew its workspace
@@ -524,6 +800,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
             }
             heap_push(sh, ws, hn, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), (int)j)),
                       (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)j), lane);
+        }
         }
         if (exhausted) break;
         WALK_STAMP(5);  // pushes
@@ -628,7 +905,10 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         wsync<Sh>();
         }  // half
         if (exhausted) break;
+        pop_now();  // (a hop whose halves all turned back early)
+        ask_runner_up();
     }
+    if constexpr (Sh::kHeapWave) hw_send(sh, hw_gen, HW_EXIT, 0u, lane);  // (whatever the heap wave was told last, it gets here behind it)
     if (consulted_out && lane == 0) *consulted_out = consulted;
     if (debug && lane == 0) {
         debug[0] = dbg_max_hn;

@@ -323,21 +323,26 @@ template <int AR>
 constexpr bool kWalkSpeculate = AR == AR_B1;
 #endif
 
-// group_sum for short rows (groups of 2 / 4 / 8 lanes: bit rows, low dimensions): quad permutes and the half-row mirror are DPP
+// group_sum for short rows (groups of 2 / 4 / 8 lanes: bit rows, low dimensions): quad permutes and row shifts are DPP
 // operands, a few cycles each, where group_sum's generic loop takes one ds_bpermute round trip per halving -- 1.5k of a lone b1
 // walk's 14.7k clocks per hop (four row groups, three halvings each, one after the other).
+// (the halvings in group_sum's own order -- lane ^ 4, ^ 2, ^ 1 -- so that a float sum has the bits every other kernel gives it)
+__device__ __forceinline__ int walk_dpp_xor4(int v) {  // lane i of each group of eight reads lane i ^ 4: a shift by four either way, chosen per bank of four lanes
+    int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);  // row_shl:4 into banks 0 and 2
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);   // row_shr:4 into banks 1 and 3
+}
 __device__ __forceinline__ int walk_group_sum(int v, uint32_t lanes) {
     if (lanes >= 16) return group_sum(v, lanes);
-    if (lanes >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
-    if (lanes >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
-    if (lanes >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    if (lanes >= 8) v += walk_dpp_xor4(v);
+    if (lanes >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);  // quad_perm:[2,3,0,1]
+    if (lanes >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);  // quad_perm:[1,0,3,2]
     return v;
 }
 __device__ __forceinline__ float walk_group_sum(float v, uint32_t lanes) {
     if (lanes >= 16) return group_sum(v, lanes);
-    if (lanes >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    if (lanes >= 8) v += __int_as_float(walk_dpp_xor4(__float_as_int(v)));
     if (lanes >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-    if (lanes >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    if (lanes >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
     return v;
 }
 // group_reduce (hnsw_device.hpp) over walk_group_sum

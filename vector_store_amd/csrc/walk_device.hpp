@@ -313,16 +313,6 @@ __device__ __forceinline__ void heap_pop(Sh& sh, const WalkSpace& ws, uint32_t& 
 // Per-lane test-and-set.  LDS table: hnsw_device.hpp; when that table is exhausted the walk cannot stay exact
 // (a node evaluated twice would be pushed twice), so `exhausted` is raised and the kernel hands the query to the
 // global-bitmap instance.
-// Which arithmetics measure a hop's neighbours before the visited set has answered (see the walk): bit rows only -- a row of
-// any other storage is 8 to 32 times as long, and a third of them would be read for nothing.
-#ifdef VS_WALK_NO_SPECULATE
-template <int AR>
-constexpr bool kWalkSpeculate = false;
-#else
-template <int AR>
-constexpr bool kWalkSpeculate = AR == AR_B1;
-#endif
-
 // group_sum for short rows (groups of 2 / 4 / 8 lanes: bit rows, low dimensions): quad permutes and row shifts are DPP
 // operands, a few cycles each, where group_sum's generic loop takes one ds_bpermute round trip per halving -- 1.5k of a lone b1
 // walk's 14.7k clocks per hop (four row groups, three halvings each, one after the other).
@@ -362,10 +352,9 @@ __device__ __forceinline__ void walk_group_reduce(const IndexView& ix, const Row
     }
 }
 
-// One wave's share of a batch (eval_batch, hnsw_device.hpp, over walk_group_reduce) with `between()` run once the first row loads are in
-// flight and before they are waited for.
-template <int AR, int I, int TEAM, class Sh, class F>
-__device__ __forceinline__ void walk_eval_part(const IndexView& ix, const Query<AR, I>& q, Sh& sh, uint32_t m, int lane, uint32_t w, F&& between) {
+// One wave's share of a batch: eval_batch (hnsw_device.hpp) over walk_group_reduce.  TEAM / w: the layout of the shares, as there.
+template <int AR, int I, int TEAM, class Sh>
+__device__ __forceinline__ void walk_eval_part(const IndexView& ix, const Query<AR, I>& q, Sh& sh, uint32_t m, int lane, uint32_t w) {
     constexpr bool NT = Sh::kNT;
     constexpr int U = I >= 12 ? 1 : (I >= 6 || (AR == AR_I8 && I >= 3)) ? 2 : 4;  // (eval_batch's)
     const uint32_t lg = ix.lanes_log2;
@@ -373,10 +362,10 @@ __device__ __forceinline__ void walk_eval_part(const IndexView& ix, const Query<
     const uint32_t grp = (uint32_t)lane >> lg, li = (uint32_t)lane & (ix.lanes - 1);
     const uint32_t nl_all = (m + (1u << vshift) - 1u) >> vshift;
     const uint32_t nl = TEAM == 1 ? nl_all : (nl_all > w ? (nl_all - w + (uint32_t)TEAM - 1u) / (uint32_t)TEAM : 0u);
+    if (nl == 0) return;
     RowGroup<I, U> a, b;
-    if (nl) group_issue<AR, I, U, TEAM, NT>(ix, a, sh.u_slot, m, 0, w, vshift, grp, li);
-    between();
-    for (uint32_t L = 0; L < nl;) {
+    group_issue<AR, I, U, TEAM, NT>(ix, a, sh.u_slot, m, 0, w, vshift, grp, li);
+    for (uint32_t L = 0;;) {
         if (L + U < nl) group_issue<AR, I, U, TEAM, NT>(ix, b, sh.u_slot, m, L + U, w, vshift, grp, li);
         walk_group_reduce<AR, I, U, TEAM>(ix, a, q, sh.u_dist, L, w, vshift, grp, li);
         L += U;
@@ -384,6 +373,7 @@ __device__ __forceinline__ void walk_eval_part(const IndexView& ix, const Query<
         if (L + U < nl) group_issue<AR, I, U, TEAM, NT>(ix, a, sh.u_slot, m, L + U, w, vshift, grp, li);
         walk_group_reduce<AR, I, U, TEAM>(ix, b, q, sh.u_dist, L, w, vshift, grp, li);
         L += U;
+        if (L >= nl) break;
     }
 }
 
@@ -417,34 +407,19 @@ __device__ __forceinline__ void walk_heap_wave_loop(const IndexView& ix, const Q
         } else if (op == HW_PUSH) {
             uint32_t hn = uni(sh.hw_hn);
             for (uint32_t j = 0; j < arg; ++j) heap_push(sh, ws, hn, __uint_as_float(uni(__float_as_uint(sh.hw_d[j]))), uni(sh.hw_s[j]), lane);
-        } else if (op == HW_EVAL) {  // (not sent at present: see eval_shared_over)
-            walk_eval_part<AR, I, 2>(ix, q, sh, arg, lane, 1u, [] {});
+        } else if (op == HW_EVAL) {  // (not sent at present: see eval_walker_alone)
+            walk_eval_part<AR, I, 2>(ix, q, sh, arg, lane, 1u);
         }
     }
 }
 
-// eval_shared (hnsw_device.hpp) with `between()` run by the walking wave once its first row loads are in flight and before it waits
-// for them: the walk repairs `next` there (round 6 -- the phase clocks of a lone walk, profiles/r06_b1_walk_phases.txt: the pop's
-// sift-down is 2.5k clocks of LDS round trips and scalar code per hop).  `gen`: the heap wave's command counter (kHeapWave only).
-template <int AR, int I, class Sh, class F>
-__device__ __forceinline__ void eval_shared_over(const IndexView& ix, const Query<AR, I>& q, Sh& sh, uint32_t m, int lane, uint32_t& gen, F&& between) {
-    if constexpr (Sh::kHeapWave) {
-        // the walker measures alone: a hop's rows are one or two wave-loads, and sharing them would make the walker wait for the heap wave
-        // to finish the pop (2.5k clocks against the visited test's 1.3k) before either could start -- measured, 17 callers 14.3k queries/s
-        // with the rows shared
-        walk_eval_part<AR, I, 1>(ix, q, sh, m, lane, 0u, between);
-        wsync<Sh>();
-    } else {
-        if constexpr (Sh::kTeam > 1) {
-            if (lane == 0) {
-                sh.team_m = m;
-                sh.team_q = kInvalid;
-            }
-            __syncthreads();  // releases the helpers (see team_helper_loop)
-        }
-        walk_eval_part<AR, I, Sh::kTeam>(ix, q, sh, m, lane, 0u, between);
-        __syncthreads();  // every wave's distances are in LDS
-    }
+// eval_shared (hnsw_device.hpp) for the walker of a heap-wave team: it measures alone -- a hop's rows are one or two wave-loads, and sharing
+// them would make the walker wait for the heap wave to finish the pop (2.5k clocks against the visited test's 1.3k) before either could
+// start: measured, 17 callers 14.3k queries/s with the rows shared, 16.3k with the walker alone.
+template <int AR, int I, class Sh>
+__device__ __forceinline__ void eval_walker_alone(const IndexView& ix, const Query<AR, I>& q, Sh& sh, uint32_t m, int lane) {
+    walk_eval_part<AR, I, 1>(ix, q, sh, m, lane, 0u);
+    wsync<Sh>();
 }
 
 // the smallest value of a wave, in every lane: four DPP rotations inside the rows of 16, four scalar reads across them
@@ -557,7 +532,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
             hw_busy = false;
         }
     };
-    if constexpr (Sh::kHeapWave) eval_shared_over<AR, I>(ix, q, sh, 1, lane, hw_gen, [] {});
+    if constexpr (Sh::kHeapWave) eval_walker_alone<AR, I>(ix, q, sh, 1, lane);
     else eval_shared<AR, I>(ix, q, sh, 1, lane);
     cnt.evals += 1;
     const float d0 = sh.u_dist[0];
@@ -573,10 +548,11 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
     wsync<Sh>();
     // Adjacency prefetch: once the candidate is popped, the new root of `next` is the runner-up; its row is loaded while
     // this hop's vectors stream in and is used when that node is indeed expanded next (nothing closer was pushed).
-    // Round 6, second prefetch: more often than not the next candidate is not the runner-up but the closest neighbour this hop has
-    // just measured (the walk is greedy) -- its row is asked for as soon as the distances are known and arrives under the admission,
-    // the pushes and the merge (the phase clocks of a lone b1 walk at 10M x 768: 1.44 us of a 6 us hop went to "pop", most of it this
-    // dependent load; profiles/r06_b1_walk_phases.txt).
+    // Heap-wave walks (round 6) ask for a second row: more often than not the next candidate is the closest neighbour the hop has just
+    // measured (the walk is greedy).  Both rows are asked for when the distances are out.
+    // (Measured on the one-wave walks and NOT kept there: the second row, and the repair of `next` moved under the hop's row loads,
+    // removed no clocks from a lone b1 walk -- a hop is a chain of LDS round trips, not a wait for memory,
+    // profiles/r06_b1_walk_phases.txt -- and the i8 batch walk, seven walks to a CU, fell from 837k to 342k queries/s with them.)
     uint32_t pf_slot = kInvalid, pf_n = kInvalid, pg_slot = kInvalid, pg_n = kInvalid;
     WALK_STAMP(0);  // start-up: clear, first evaluation
     while (hn) {
@@ -589,7 +565,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         uint32_t n;
         if (cs == pf_slot) {
             n = pf_n;
-        } else if (cs == pg_slot) {
+        } else if (Sh::kHeapWave && cs == pg_slot) {
             n = pg_n;
         } else {  // on its way while the heap is repaired
             uint32_t cap;
@@ -597,27 +573,11 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
             n = (uint32_t)lane < cap ? row[lane] : kInvalid;
         }
         cnt.hops += 1;
-        // `next` is repaired -- pop_heap's sift-down -- under the hop's row loads (eval_shared_over); a hop that measures nothing
-        // repairs it where it turns back
-        // ... and the runner-up's row is asked for only when the distances are out: the wait for the row loads is a wait for every load
-        // issued before it (returns are in order), the prefetch's included, and a prefetch issued at the end of the repair put its whole
-        // latency back into the hop.
-        bool popped = false, asked = false;
-        auto pop_now = [&]() {
-            if (popped) return;
-            popped = true;
-            if constexpr (Sh::kHeapWave) {
-                hw_send(sh, hw_gen, HW_POP, hn, lane);
-                hn -= 1u;
-                hw_busy = true;
-            } else {
-                heap_pop(sh, ws, hn, lane);
-            }
-        };
+        bool asked = false;
         auto ask_runner_up = [&]() {
             if (asked) return;
             asked = true;
-            hw_sync();
+            hw_sync();  // (the pop has ended)
             pf_slot = hn ? heap_get(sh, ws, 0).y : kInvalid;
             if (pf_slot != kInvalid) {
                 uint32_t cap2;
@@ -625,9 +585,15 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
                 pf_n = (uint32_t)lane < cap2 ? row2[lane] : kInvalid;
             }
         };
-        if constexpr (Sh::kHeapWave) pop_now();  // the heap wave starts on it now
+        if constexpr (Sh::kHeapWave) {  // the heap wave starts on pop_heap's sift-down now; the walker goes on
+            hw_send(sh, hw_gen, HW_POP, hn, lane);
+            hn -= 1u;
+            hw_busy = true;
+        } else {
+            heap_pop(sh, ws, hn, lane);
+            ask_runner_up();
+        }
         if (cs == self) {
-            pop_now();
             ask_runner_up();
             continue;
         }
@@ -642,48 +608,9 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         const uint32_t halves = (level == 0 ? ix.M0 : ix.M) > (uint32_t)kWave ? 2u : 1u;
         for (uint32_t half = 0; half < halves && !exhausted; ++half) {
         if (half) n = n_hi;
-        uint32_t m;
-        if constexpr (kWalkSpeculate<AR> && Sh::kVisGlobal) {
-            // Round 6, bit rows with the visited set in global memory: a row is 96 B at 768 dimensions, a test-and-set on the bitmap is
-            // a round trip to L2 (0.8 us of a 6 us hop) -- so the rows of ALL the neighbours are asked for right behind the atomics
-            // and measured (one wave-load more than the fresh two thirds would take), and the atomics' answers, which have arrived
-            // by then (returns are in order), only choose which distances are kept.  Nothing the walk decides changes: the
-            // kept list is the one the plain order builds, in adjacency order; `evals` counts the kept ones (what usearch measures).
-            const bool valid = n != kInvalid;
-            const uint32_t bit = 1u << (n & 31u);
-            uint32_t old = 0;
-            if (valid) old = atomicOr(&ws.bitmap[n >> 5], bit);
-            const uint64_t vm = __ballot(valid);
-            const uint32_t mv = (uint32_t)__popcll(vm);
-            if (valid) sh.u_slot[mbcnt(vm)] = n;
-            wsync<Sh>();
-            if (mv == 0) {
-                pop_now();
-                continue;
-            }
-            WALK_STAMP(2);  // atomics issued, compaction
-            eval_shared_over<AR, I>(ix, q, sh, mv, lane, hw_gen, pop_now);
-            const float dv = valid ? sh.u_dist[mbcnt(vm)] : __builtin_inff();
-            const bool fresh = valid && (old & bit) == 0u;
-            const uint64_t fmask = __ballot(fresh);
-            m = (uint32_t)__popcll(fmask);
-            if (vcount + m <= ws.vlog_cap) {
-                if (fresh) ws.vlog[vcount + mbcnt(fmask)] = n;
-            } else {
-                vlog_lost = true;
-            }
-            vcount += m;
-            wsync<Sh>();  // every lane holds its distance
-            if (fresh) {
-                sh.u_slot[mbcnt(fmask)] = n;
-                sh.u_dist[mbcnt(fmask)] = dv;
-            }
-            wsync<Sh>();
-            if (m == 0) continue;  // (popped: mv > 0)
-        } else {
         const bool fresh = mark(n);
         const uint64_t fmask = __ballot(fresh);
-        m = (uint32_t)__popcll(fmask);
+        const uint32_t m = (uint32_t)__popcll(fmask);
         if constexpr (!Sh::kVisGlobal) {
             if (uni(sh.overflowed)) {  // wave-uniform (LDS flag set by any lane of this hop)
                 exhausted = true;
@@ -692,19 +619,16 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         }
         if (fresh) sh.u_slot[mbcnt(fmask)] = n;
         wsync<Sh>();
-        if (m == 0) {
-            pop_now();
-            continue;
-        }
+        if (m == 0) continue;
         WALK_STAMP(2);  // visited test-and-set, compaction
-        eval_shared_over<AR, I>(ix, q, sh, m, lane, hw_gen, pop_now);
-        }
+        if constexpr (Sh::kHeapWave) eval_walker_alone<AR, I>(ix, q, sh, m, lane);
+        else eval_shared<AR, I>(ix, q, sh, m, lane);
         cnt.evals += m;
         WALK_STAMP(3);  // distances
         float nd = (uint32_t)lane < m ? sh.u_dist[lane] : __builtin_inff();
         uint32_t ns = (uint32_t)lane < m ? sh.u_slot[lane] : kInvalid;
-        ask_runner_up();
-        {  // the closest of this hop's neighbours, when it beats the runner-up: its adjacency row (see pg_slot above)
+        if constexpr (Sh::kHeapWave) {  // the runner-up's row, and the row of the closest of this hop's neighbours when it beats the runner-up
+            ask_runner_up();
             const float mn = walk_wave_min(nd);
             const uint64_t bm = __ballot((uint32_t)lane < m && nd == mn);
             const float root_d = hn ? __uint_as_float(heap_get(sh, ws, 0).x) : __builtin_inff();
@@ -909,8 +833,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         wsync<Sh>();
         }  // half
         if (exhausted) break;
-        pop_now();  // (a hop whose halves all turned back early)
-        ask_runner_up();
+        ask_runner_up();  // (heap-wave walks: a hop whose halves all turned back early)
     }
     if constexpr (Sh::kHeapWave) hw_send(sh, hw_gen, HW_EXIT, 0u, lane);  // (whatever the heap wave was told last, it gets here behind it)
     if (consulted_out && lane == 0) *consulted_out = consulted;

@@ -108,6 +108,10 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(WalkArgs a) {
     }
 }
 
+// (Round 6, measured and not kept: this loop with TWO waves per walk -- the walker and the heap wave of the walk pods, walk_device.hpp.  Both
+// roles are one kernel, so a workgroup's waves take the larger register count of the two: 179 VGPRs for i8 rows of 768 B (one-wave walk:
+// 152), 153 for b1 (119) -- two / three waves per SIMD, i.e. 4 / 6 walks per CU where LDS would hold 7.  i8 batch 845k -> 377k queries/s,
+// b1 574k -> 575k.  The pods, one workgroup to a CU, have the registers to spare.)
 // Small batches (lone callers: the reference issues one query per FFI call): one workgroup of TEAM waves per query, as
 // hnsw_search_kernel does -- wave 0 walks exactly as above, every wave evaluates its share of each hop's neighbours, so a
 // lone walk has TEAM times the row loads in flight.  Same decisions, same ids.  LDS instances only; a query that outgrows
@@ -435,9 +439,9 @@ static hipError_t walk_pod_ef(const WalkArgs& a, hipStream_t s, PodSlot* slots, 
 }
 
 template <class K>
-static uint32_t resident_workgroups(K kernel, int device) {  // workgroups of `kernel` the chip holds at once
+static uint32_t resident_workgroups(K kernel, int device, int block = 64) {  // workgroups of `kernel` the chip holds at once
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     if (const char* pc = std::getenv("VS_HNSW_WALK_PER_CU")) per_cu = std::max(1, std::atoi(pc));  // residency experiments
     if (std::getenv("VS_HNSW_WALK_DEBUG")) {

@@ -64,19 +64,19 @@ struct VisitedLds<false, NB, BS> {};
 // HWV (round 6, the walk pods' two-wave form): wave 1 owns `next` -- usearch's array heap, swap for swap -- and repairs it while the walker
 // (wave 0) goes on with the hop: pop_heap's sift-down runs under the visited test and the row loads, the hop's push_heaps under the
 // merge into `top`.  The two meet at workgroup barriers; a command (hw_cmd, two slots used in turn) goes with each.
+// (The hop's pushes travel in u_dist / u_slot, which the walker is done with by then: 20 bytes more than a one-wave walk, so the batch
+// instances keep their walks per CU.)
 template <bool ON>
 struct HeapWaveBox {
     uint2 hw_cmd[2];
     uint32_t hw_hn;
-    float hw_d[64];
-    uint32_t hw_s[64];
 };
 template <>
 struct HeapWaveBox<false> {};
 
 template <int EFCAP, int LCAP, int NB, int CH, bool VISG, int TM = 1, bool NT = false, bool SEL = false, int BS = 8, bool HWV = false>
 struct WalkShared : SelArrays<SEL>, TeamBox<TM>, VisitedLds<!VISG, NB, BS>, HeapWaveBox<HWV> {
-    static_assert(!HWV || (TM == 2 && !VISG), "the heap wave is wave 1 of a two-wave team over an LDS heap");
+    static_assert(!HWV || (TM == 2 && !VISG && EFCAP <= 512), "the heap wave is wave 1 of a two-wave team over an LDS heap; `top` is merged in registers");
     static constexpr bool kHeapWave = HWV;
     static constexpr bool kNT = NT;
     static constexpr int kChoices = CH;
@@ -406,7 +406,7 @@ __device__ __forceinline__ void walk_heap_wave_loop(const IndexView& ix, const Q
             heap_pop(sh, ws, hn, lane);
         } else if (op == HW_PUSH) {
             uint32_t hn = uni(sh.hw_hn);
-            for (uint32_t j = 0; j < arg; ++j) heap_push(sh, ws, hn, __uint_as_float(uni(__float_as_uint(sh.hw_d[j]))), uni(sh.hw_s[j]), lane);
+            for (uint32_t j = 0; j < arg; ++j) heap_push(sh, ws, hn, __uint_as_float(uni(__float_as_uint(sh.u_dist[j]))), uni(sh.u_slot[j]), lane);
         } else if (op == HW_EVAL) {  // (not sent at present: see eval_walker_alone)
             walk_eval_part<AR, I, 2>(ix, q, sh, arg, lane, 1u);
         }
@@ -607,7 +607,10 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
         }
         const uint32_t halves = (level == 0 ? ix.M0 : ix.M) > (uint32_t)kWave ? 2u : 1u;
         for (uint32_t half = 0; half < halves && !exhausted; ++half) {
-        if (half) n = n_hi;
+        if (half) {
+            n = n_hi;
+            hw_sync();  // (the first half's pushes are read from u_slot / u_dist)
+        }
         const bool fresh = mark(n);
         const uint64_t fmask = __ballot(fresh);
         const uint32_t m = (uint32_t)__popcll(fmask);
@@ -710,9 +713,9 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
                     exhausted = true;
                     break;
                 }
-                if ((pushed >> lane) & 1ull) {
-                    sh.hw_d[mbcnt(pushed)] = nd;
-                    sh.hw_s[mbcnt(pushed)] = ns;
+                if ((pushed >> lane) & 1ull) {  // (every lane holds its own in nd / ns: the list is compacted in place)
+                    sh.u_dist[mbcnt(pushed)] = nd;
+                    sh.u_slot[mbcnt(pushed)] = ns;
                 }
                 if (lane == 0) sh.hw_hn = hn;
                 hw_send(sh, hw_gen, HW_PUSH, np, lane);

@@ -244,6 +244,14 @@ def test_walk_whose_candidate_heap_outgrows_lds_is_retried_exactly(kind, metric,
         for i in range(nq):
             assert gf[i] == of_[i]
             assert_same_results(gk[i, : gf[i]], gd[i, : gf[i]], ok_[i, : of_[i]], od_[i, : of_[i]], exact=True, what=(kind, ef, k, i))
+    if kind == "b1":
+        # ... and one query per call: the walk pods (round 6: the walker and the heap wave).  A walk whose `next` outgrows the pod's LDS heap
+        # says "redo" -- the walker stops, sends the heap wave home -- and the dispatcher's launch, with its retry instance, answers.
+        for ef, k in ((128, 10), (256, 100)):
+            ix.set_expansion_search(ef)
+            o.set_expansion_search(ef)
+            for i in range(48):
+                assert_same_results(*ix.search(q[i], k), *o.search(q[i], k), exact=True, what=(kind, "lone", ef, k, i))
 
 
 @pytest.mark.parametrize("kind", ["f16", "bf16", "i8", "b1"])

@@ -867,16 +867,19 @@ __device__ __forceinline__ uint32_t bm_unkey(uint32_t key) { return (key & 0x800
 // smallest distance of the buffer by a radix select (four passes over the buffer, a histogram in LDS), and only scores within the band
 // of it go through the merges -- 32 list merges became one or two.  Removed rows take part in the select, so the threshold can come out
 // too tight when one of them is among the best: the caller checks it against the list it produced and runs again without it.
+// (The later blocks too, since the last step of round 6: the select runs over the buffer AND the list the earlier blocks left -- the band_k-th
+// smallest of the two together is where the list's band will end -- and the thousand or so scores a large block passes become one or two
+// merges instead of one per 64.)
 template <class SH>
-__device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine, uint32_t n, uint32_t band_k, float eps2, int lane) {
+__device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine, uint32_t n, uint32_t sz, uint32_t band_k, float eps2, int lane) {
     uint32_t* hist = reinterpret_cast<uint32_t*>(sh.vis_tag);  // 256 words (the visited table is not used by these kernels)
     uint32_t prefix = 0, want = band_k;
     for (int shift = 24; shift >= 0; shift -= 8) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) hist[lane * 4 + i] = 0u;
         __syncthreads();
-        for (uint32_t i = (uint32_t)lane; i < n; i += kWave) {
-            const uint32_t key = bm_key(mine[i].x);
+        for (uint32_t i = (uint32_t)lane; i < n + sz; i += kWave) {
+            const uint32_t key = bm_key(i < n ? mine[i].x : __float_as_uint(sh.lst_d[0][i - n]));
             if (shift == 24 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -906,7 +909,8 @@ __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t 
     const int lane = lane_id();
     const uint32_t ql = blockIdx.x, qg = q0 + ql;
     uint32_t n = cand_cnt[ql];
-    uint32_t sz = list_n[qg];
+    const uint32_t sz0 = list_n[qg];
+    uint32_t sz = sz0;
     for (uint32_t i = lane; i < sz; i += kWave) {
         sh.lst_d[0][i] = list_d[(size_t)qg * C + i];
         sh.lst_s[0][i] = (uint32_t)list_slot[(size_t)qg * C + i];
@@ -918,7 +922,7 @@ __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t 
         n = cand_cap;
     }
     float pre = __builtin_inff();
-    if (prefilter && sz == 0 && n >= 256u && band_eps && band_k) pre = block_merge_prefilter(sh, cand + (size_t)ql * cand_cap, n, band_k, 2.0f * band_eps[ql], lane);
+    if (prefilter && n >= 256u && band_eps && band_k) pre = block_merge_prefilter(sh, cand + (size_t)ql * cand_cap, n, sz, band_k, 2.0f * band_eps[ql], lane);
     for (int attempt = 0; attempt < 2; ++attempt) {
     for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
         const uint32_t i = i0 + (uint32_t)lane;
@@ -949,7 +953,12 @@ __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t 
     // the prefilter was right iff the list's own band ends where it did (a removed row among the best makes it too tight: once more, without)
     if (!(pre < __builtin_inff()) || (sz >= band_k && sh.lst_d[0][band_k - 1] + 2.0f * band_eps[ql] <= pre)) break;
     pre = __builtin_inff();
-    sz = 0;
+    sz = sz0;  // once more from the list the earlier blocks left
+    __syncthreads();
+    for (uint32_t i = lane; i < sz; i += kWave) {
+        sh.lst_d[0][i] = list_d[(size_t)qg * C + i];
+        sh.lst_s[0][i] = (uint32_t)list_slot[(size_t)qg * C + i];
+    }
     __syncthreads();
     }
     for (uint32_t i = lane; i < sz; i += kWave) {

@@ -870,17 +870,40 @@ __device__ __forceinline__ uint32_t bm_unkey(uint32_t key) { return (key & 0x800
 // (The later blocks too, since the last step of round 6: the select runs over the buffer AND the list the earlier blocks left -- the band_k-th
 // smallest of the two together is where the list's band will end -- and the thousand or so scores a large block passes become one or two
 // merges instead of one per 64.)
+// skey: the buffer's keys staged in LDS by the first pass (four loads in flight per lane), so that the other three passes and the
+// filter of the merge loop below read LDS, not one dependent L2 round trip per 64 scores -- that chain was most of a merge's 0.09 ms.
 template <class SH>
-__device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine, uint32_t n, uint32_t sz, uint32_t band_k, float eps2, int lane) {
+__device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine, uint32_t n, uint32_t sz, uint32_t band_k, float eps2, int lane,
+                                                       uint32_t* skey) {
     uint32_t* hist = reinterpret_cast<uint32_t*>(sh.vis_tag);  // 256 words (the visited table is not used by these kernels)
     uint32_t prefix = 0, want = band_k;
     for (int shift = 24; shift >= 0; shift -= 8) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) hist[lane * 4 + i] = 0u;
         __syncthreads();
+        if (shift == 24) {
+            for (uint32_t i0 = 0; i0 < n; i0 += 4u * kWave) {
+                uint32_t k4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = i0 + (uint32_t)u * kWave + (uint32_t)lane;
+                    k4[u] = i < n ? bm_key(mine[i].x) : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = i0 + (uint32_t)u * kWave + (uint32_t)lane;
+                    if (i < n) {
+                        skey[i] = k4[u];
+                        atomicAdd(&hist[k4[u] >> 24], 1u);
+                    }
+                }
+            }
+            for (uint32_t i = (uint32_t)lane; i < sz; i += kWave) atomicAdd(&hist[bm_key(__float_as_uint(sh.lst_d[0][i])) >> 24], 1u);
+        } else {
         for (uint32_t i = (uint32_t)lane; i < n + sz; i += kWave) {
-            const uint32_t key = bm_key(i < n ? mine[i].x : __float_as_uint(sh.lst_d[0][i - n]));
-            if (shift == 24 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            const uint32_t key = i < n ? skey[i] : bm_key(__float_as_uint(sh.lst_d[0][i - n]));
+            if ((key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
         }
         __syncthreads();
         const uint32_t h0 = hist[lane * 4], h1 = hist[lane * 4 + 1], h2 = hist[lane * 4 + 2], h3 = hist[lane * 4 + 3];
@@ -905,7 +928,8 @@ __device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine
 template <class SH>
 __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt, const uint2* cand,
                                                  uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr, uint32_t* uncertified,
-                                                 const float* band_eps, uint32_t band_k, bool prefilter = false) {
+                                                 const float* band_eps, uint32_t band_k, uint32_t* skey = nullptr) {
+    const bool prefilter = skey != nullptr;
     const int lane = lane_id();
     const uint32_t ql = blockIdx.x, qg = q0 + ql;
     uint32_t n = cand_cnt[ql];
@@ -922,10 +946,15 @@ __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t 
         n = cand_cap;
     }
     float pre = __builtin_inff();
-    if (prefilter && n >= 256u && band_eps && band_k) pre = block_merge_prefilter(sh, cand + (size_t)ql * cand_cap, n, sz, band_k, 2.0f * band_eps[ql], lane);
+    if (prefilter && n >= 256u && band_eps && band_k) pre = block_merge_prefilter(sh, cand + (size_t)ql * cand_cap, n, sz, band_k, 2.0f * band_eps[ql], lane, skey);
+    const bool staged = pre < __builtin_inff();  // skey holds the buffer's keys
+    const uint32_t pre_key = staged ? bm_key(__float_as_uint(pre)) : 0xFFFFFFFFu;
     for (int attempt = 0; attempt < 2; ++attempt) {
     for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
         const uint32_t i = i0 + (uint32_t)lane;
+        if (staged && attempt == 0) {  // the filter on the staged keys: only a 64 with a score inside the band is read from the buffer
+            if (!__ballot(i < n && skey[i] <= pre_key)) continue;
+        }
         const uint2 e = i < n ? cand[(size_t)ql * cand_cap + i] : make_uint2(0u, 0u);
         const float d = __uint_as_float(e.x);
         const uint32_t slot = e.y;
@@ -987,7 +1016,8 @@ __global__ __launch_bounds__(64) void block_merge512_kernel(IndexView ix, uint32
                                                             const uint2* cand, uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr,
                                                             uint32_t* uncertified, const float* band_eps, uint32_t band_k) {
     __shared__ SelectShared512 sh;
-    block_merge_body(sh, ix, q0, C, cand_cap, cand_cnt, cand, list_slot, list_d, list_n, thr, uncertified, band_eps, band_k, true);
+    __shared__ uint32_t skey[kBlockCandCap];
+    block_merge_body(sh, ix, q0, C, cand_cap, cand_cnt, cand, list_slot, list_d, list_n, thr, uncertified, band_eps, band_k, skey);
 }
 
 // exact f32 score of nominee c of query q: one wave per (query, nominee)

@@ -712,6 +712,7 @@ hipError_t launch_rank_emit(const IndexView& ix, const uint64_t* sorted, uint32_
 // A query that fails the certificate (dense ties at the cut) is counted, and the host re-runs the f32 path.
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr uint32_t kBlockC = 256;    // nominees per query
+constexpr uint32_t kP8CandCap = 8192, kP8CandParts = 8;  // the 8-bit plane's buffer: eight pieces of 1,024 (see CandParts in block_merge_body)
 constexpr uint32_t kBlockCandCap = 4096;  // scores per query a row block may pass on to the nominee list (after the first block)
 constexpr int kBlockKC = 64;         // k staged per LDS buffer.  Measured at 10M x 768, q = 256 (whole search): 64 deep, one buffer, two
                                      // barriers per stage 21.8 ms; 32 deep through two buffers (the f32 kernel's structure) 31.2 ms
@@ -872,9 +873,10 @@ __device__ __forceinline__ uint32_t bm_unkey(uint32_t key) { return (key & 0x800
 // merges instead of one per 64.)
 // skey: the buffer's keys staged in LDS by the first pass (four loads in flight per lane), so that the other three passes and the
 // filter of the merge loop below read LDS, not one dependent L2 round trip per 64 scores -- that chain was most of a merge's 0.09 ms.
-template <class SH>
+// where: place i of the (concatenated) buffer -> its element in `mine` (see CandParts)
+template <class SH, class W>
 __device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine, uint32_t n, uint32_t sz, uint32_t band_k, float eps2, int lane,
-                                                       uint32_t* skey) {
+                                                       uint32_t* skey, W&& where) {
     uint32_t* hist = reinterpret_cast<uint32_t*>(sh.vis_tag);  // 256 words (the visited table is not used by these kernels)
     uint32_t prefix = 0, want = band_k;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -887,7 +889,7 @@ __device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t i = i0 + (uint32_t)u * kWave + (uint32_t)lane;
-                    k4[u] = i < n ? bm_key(mine[i].x) : 0xFFFFFFFFu;
+                    k4[u] = i < n ? bm_key(mine[where(i)].x) : 0xFFFFFFFFu;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -928,11 +930,34 @@ __device__ __forceinline__ float block_merge_prefilter(SH& sh, const uint2* mine
 template <class SH>
 __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt, const uint2* cand,
                                                  uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr, uint32_t* uncertified,
-                                                 const float* band_eps, uint32_t band_k, uint32_t* skey = nullptr) {
+                                                 const float* band_eps, uint32_t band_k, uint32_t* skey = nullptr, uint32_t parts = 1) {
     const bool prefilter = skey != nullptr;
     const int lane = lane_id();
     const uint32_t ql = blockIdx.x, qg = q0 + ql;
-    uint32_t n = cand_cnt[ql];
+    // CandParts (round 6, the 8-bit plane): a query's buffer in `parts` equal pieces with a counter each (counter p of query q: cand_cnt[p * 256 + q]) --
+    // the tile kernel's workgroups append to piece blockIdx & (parts - 1).  Behind the early blocks' loose thresholds hundreds of scores per query
+    // pass, and the returning atomics of every workgroup queued on 256 counters: a hundred microseconds per launch (profiles/r06_c5_trace.txt).
+    // The merge reads the pieces as one buffer: place i -> piece and offset.
+    const uint32_t sub = cand_cap / parts;
+    uint32_t off[9];
+    off[0] = 0;
+    bool over = false;
+#pragma unroll
+    for (uint32_t pp = 0; pp < 8u; ++pp) {
+        uint32_t c = pp < parts ? cand_cnt[pp * 256u + ql] : 0u;
+        if (c > sub) {
+            over = true;
+            c = sub;
+        }
+        off[pp + 1] = off[pp] + c;
+    }
+    auto where = [&](uint32_t i) -> uint32_t {
+        uint32_t pp = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < 8u; ++t) pp += i >= off[t] ? 1u : 0u;
+        return pp * sub + (i - off[pp]);
+    };
+    uint32_t n = off[8];
     const uint32_t sz0 = list_n[qg];
     uint32_t sz = sz0;
     for (uint32_t i = lane; i < sz; i += kWave) {
@@ -940,13 +965,11 @@ __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t 
         sh.lst_s[0][i] = (uint32_t)list_slot[(size_t)qg * C + i];
     }
     __syncthreads();
-    if (lane == 0) cand_cnt[ql] = 0;
-    if (n > cand_cap) {
-        if (lane == 0) atomicAdd(uncertified, 1u);
-        n = cand_cap;
-    }
+    if ((uint32_t)lane < parts) cand_cnt[(uint32_t)lane * 256u + ql] = 0;
+    if (over && lane == 0) atomicAdd(uncertified, 1u);
     float pre = __builtin_inff();
-    if (prefilter && n >= 256u && band_eps && band_k) pre = block_merge_prefilter(sh, cand + (size_t)ql * cand_cap, n, sz, band_k, 2.0f * band_eps[ql], lane, skey);
+    if (prefilter && n >= 256u && band_eps && band_k)
+        pre = block_merge_prefilter(sh, cand + (size_t)ql * cand_cap, n, sz, band_k, 2.0f * band_eps[ql], lane, skey, where);
     const bool staged = pre < __builtin_inff();  // skey holds the buffer's keys
     const uint32_t pre_key = staged ? bm_key(__float_as_uint(pre)) : 0xFFFFFFFFu;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -955,7 +978,7 @@ __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t 
         if (staged && attempt == 0) {  // the filter on the staged keys: only a 64 with a score inside the band is read from the buffer
             if (!__ballot(i < n && skey[i] <= pre_key)) continue;
         }
-        const uint2 e = i < n ? cand[(size_t)ql * cand_cap + i] : make_uint2(0u, 0u);
+        const uint2 e = i < n ? cand[(size_t)ql * cand_cap + where(i)] : make_uint2(0u, 0u);
         const float d = __uint_as_float(e.x);
         const uint32_t slot = e.y;
         bool ok = i < n && d <= pre;
@@ -1014,10 +1037,10 @@ __global__ __launch_bounds__(64) void block_merge_kernel(IndexView ix, uint32_t 
 using SelectShared512 = BeamShared<512, 256>;
 __global__ __launch_bounds__(64) void block_merge512_kernel(IndexView ix, uint32_t q0, uint32_t C, uint32_t cand_cap, uint32_t* cand_cnt,
                                                             const uint2* cand, uint64_t* list_slot, float* list_d, uint32_t* list_n, float* thr,
-                                                            uint32_t* uncertified, const float* band_eps, uint32_t band_k) {
+                                                            uint32_t* uncertified, const float* band_eps, uint32_t band_k, uint32_t parts) {
     __shared__ SelectShared512 sh;
-    __shared__ uint32_t skey[kBlockCandCap];
-    block_merge_body(sh, ix, q0, C, cand_cap, cand_cnt, cand, list_slot, list_d, list_n, thr, uncertified, band_eps, band_k, skey);
+    __shared__ uint32_t skey[kP8CandCap];
+    block_merge_body(sh, ix, q0, C, cand_cap, cand_cnt, cand, list_slot, list_d, list_n, thr, uncertified, band_eps, band_k, skey, parts);
 }
 
 // exact f32 score of nominee c of query q: one wave per (query, nominee)
@@ -1393,7 +1416,7 @@ template <bool WRITE_D, bool I8 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void p1_tile_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint32_t kp, uint32_t nq_blk, uint32_t n_begin, uint32_t n_end,
     const float* __restrict__ thr, const float* __restrict__ row_scale, float* __restrict__ D, uint2* __restrict__ cand,
-    uint32_t* __restrict__ cand_cnt, uint32_t cand_cap, const float* __restrict__ q_scale = nullptr) {
+    uint32_t* __restrict__ cand_cnt, uint32_t cand_cap, const float* __restrict__ q_scale = nullptr, uint32_t parts = 1) {
     constexpr int TM = 256, TN = kP1TN, BK = kP1BK, RA = kP1RA, RB = kP1RB, CH = BK / 8;
     constexpr int NW = 8;
     constexpr bool SPLIT = RA != RB;
@@ -1462,6 +1485,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (pb < total) stage_b();
 
     const uint32_t frow = lane & (FR - 1), fk = lane / FR;
+    const uint32_t part = blockIdx.x & (parts - 1u), sub_cap = cand_cap / parts;
     uint32_t sg = 0;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         acc_t acc[MT][NT];
@@ -1560,9 +1584,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int r = 0; r < ACC; ++r) {
                             const uint32_t q = wm * WROWS + i * FR + 4 * fk + r;
                             const float v = sc[r * 64 + lane];
-                            if (v >= thr_s[q] && n < n_end) {
-                                const uint32_t at = atomicAdd(&cand_cnt[q], 1u);
-                                if (at < cand_cap) cand[(size_t)q * cand_cap + at] = make_uint2(__float_as_uint(1.0f - v * (I8 ? qs_s[q] : 1.f)), n);
+                            if (v >= thr_s[q] && n < n_end) {  // (piece `part` of the query's buffer: see CandParts in block_merge_body)
+                                const uint32_t at = atomicAdd(&cand_cnt[part * 256u + q], 1u);
+                                if (at < sub_cap) cand[(size_t)q * cand_cap + part * sub_cap + at] = make_uint2(__float_as_uint(1.0f - v * (I8 ? qs_s[q] : 1.f)), n);
                             }
                         }
                     }
@@ -1689,7 +1713,7 @@ constexpr uint32_t kP8SlowGrowthBelow = 262144;  // chunks grow 8 x up to here, 
 uint32_t block8_plane_k(const IndexView& ix) { return (ix.dim + 127u) & ~127u; }  // elements (= bytes) per row: whole 128-element K steps
 size_t block8_scratch_bytes(uint32_t nq, uint32_t dim) {
     const size_t kpad = (dim + 31u) & ~31u, kp = (dim + 127u) & ~127u, rows = ((size_t)nq + 255) / 256 * 256;
-    return (size_t)256 * kBlockCandCap * 8 + 256 * 8 + (size_t)nq * (4 * 6) + rows * 4 + (size_t)nq * kpad * 4 + rows * kp + (size_t)nq * kP8C * 16 + 8192;
+    return (size_t)256 * kP8CandCap * 8 + (size_t)kP8CandParts * 256 * 4 + 256 * 4 + (size_t)nq * (4 * 6) + rows * 4 + (size_t)nq * kpad * 4 + rows * kp + (size_t)nq * kP8C * 16 + 8192;
 }
 // byte offset of element k of row r in a tile-major int8 operand (k a multiple of 4: 4 bytes stay together): the bf16 layout with
 // 16 elements per 16-byte chunk
@@ -1824,8 +1848,8 @@ hipError_t launch_block8_search(const ExactArgs& a, void* scratch, const uint8_t
         p += (bytes + 255) & ~(size_t)255;
         return r;
     };
-    uint2* cand = (uint2*)take((size_t)256 * kBlockCandCap * 8);
-    uint32_t* cand_cnt = (uint32_t*)take((size_t)256 * 4);
+    uint2* cand = (uint2*)take((size_t)256 * kP8CandCap * 8);
+    uint32_t* cand_cnt = (uint32_t*)take((size_t)kP8CandParts * 256 * 4);
     float* thr = (float*)take((size_t)256 * 4);
     float* q_aux = (float*)take((size_t)a.nq * 4);
     float* a_norm = (float*)take((size_t)a.nq * 4);
@@ -1846,6 +1870,8 @@ hipError_t launch_block8_search(const ExactArgs& a, void* scratch, const uint8_t
                        d_uncertified);
     e = hipMemsetAsync(cand_found, 0, (size_t)a.nq * 4, s);
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(cand_cnt, 0, (size_t)kP8CandParts * 256 * 4, s);  // (every merge leaves the counters it read at zero)
+    if (e != hipSuccess) return e;
     const uint16_t* plane16 = reinterpret_cast<const uint16_t*>(plane);
     for (uint32_t q0 = 0; q0 < a.nq; q0 += 256) {
         const uint32_t nqb = a.nq - q0 < 256u ? a.nq - q0 : 256u;
@@ -1859,20 +1885,20 @@ hipError_t launch_block8_search(const ExactArgs& a, void* scratch, const uint8_t
         static const uint32_t slow_below = std::getenv("VS_P8_SLOW_BELOW") ? (uint32_t)std::atoi(std::getenv("VS_P8_SLOW_BELOW")) : kP8SlowGrowthBelow;
         const uint32_t n1 = a.slots < first_rows ? a.slots : first_rows;
         hipLaunchKernelGGL((p1_tile_kernel<true, true>), dim3((n1 + kP1TN - 1) / kP1TN), dim3(512), kP1LdsBytes, s, Aq, plane16, kp2, nqb, 0u, n1, (const float*)nullptr, scale,
-                           (float*)nullptr, cand, cand_cnt, (uint32_t)kBlockCandCap, qs);
-        e = hipMemsetD32Async((hipDeviceptr_t)cand_cnt, (int)n1, 256, s);
+                           (float*)nullptr, cand, cand_cnt, (uint32_t)kP8CandCap, qs);
+        e = hipMemsetD32Async((hipDeviceptr_t)cand_cnt, (int)n1, 256, s);  // the first block's scores: one piece, all of them
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(block_merge512_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
-                           cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);
+        hipLaunchKernelGGL(block_merge512_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kP8CandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
+                           cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k, 1u);
         for (uint32_t n0 = n1; n0 < a.slots;) {
             const uint64_t want = (uint64_t)n0 * (n0 < slow_below ? slow_growth : 32u);
             const uint32_t nend = want >= a.slots ? a.slots : (uint32_t)want;
             const uint32_t tiles = (nend - n0 + kP1TN - 1) / kP1TN;
             const uint32_t grid = tiles < (uint32_t)cus ? tiles : (uint32_t)cus;
             hipLaunchKernelGGL((p1_tile_kernel<false, true>), dim3(grid), dim3(512), kP1LdsBytes, s, Aq, plane16, kp2, nqb, n0, nend, thr, scale, (float*)nullptr, cand, cand_cnt,
-                               (uint32_t)kBlockCandCap, qs);
-            hipLaunchKernelGGL(block_merge512_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kBlockCandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
-                               cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k);
+                               (uint32_t)kP8CandCap, qs, (uint32_t)kP8CandParts);
+            hipLaunchKernelGGL(block_merge512_kernel, dim3(nqb), dim3(64), 0, s, a.ix, 0u, C, (uint32_t)kP8CandCap, cand_cnt, cand, cand_slot + (size_t)q0 * C,
+                               cand_approx + (size_t)q0 * C, cand_found + q0, thr, d_uncertified, (const float*)(eps_q + q0), a.k, (uint32_t)kP8CandParts);
             n0 = nend;
         }
     }

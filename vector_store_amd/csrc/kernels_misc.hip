@@ -971,17 +971,31 @@ __device__ __forceinline__ void block_merge_body(SH& sh, IndexView ix, uint32_t 
     if (prefilter && n >= 256u && band_eps && band_k)
         pre = block_merge_prefilter(sh, cand + (size_t)ql * cand_cap, n, sz, band_k, 2.0f * band_eps[ql], lane, skey, where);
     const bool staged = pre < __builtin_inff();  // skey holds the buffer's keys
-    const uint32_t pre_key = staged ? bm_key(__float_as_uint(pre)) : 0xFFFFFFFFu;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-    for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
-        const uint32_t i = i0 + (uint32_t)lane;
-        if (staged && attempt == 0) {  // the filter on the staged keys: only a 64 with a score inside the band is read from the buffer
-            if (!__ballot(i < n && skey[i] <= pre_key)) continue;
+    // ... and then the places of the scores inside the band, compacted (in place: a 64's places land in front of where its keys were read):
+    // the few dozen survivors of a thousand scores lie scattered over nearly as many 64s, and each 64 with one of them was a list merge of its own
+    uint32_t n_in = 0;
+    if (staged) {
+        const uint32_t pre_key = bm_key(__float_as_uint(pre));
+        for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool in = i < n && skey[i] <= pre_key;
+            const uint64_t im = __ballot(in);
+            __syncthreads();
+            if (in) skey[n_in + mbcnt(im)] = i;
+            n_in += (uint32_t)__popcll(im);
         }
-        const uint2 e = i < n ? cand[(size_t)ql * cand_cap + where(i)] : make_uint2(0u, 0u);
+        __syncthreads();
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool listed = staged && attempt == 0;  // this pass takes the compacted places
+    const uint32_t count = listed ? n_in : n;
+    for (uint32_t i0 = 0; i0 < count; i0 += kWave) {
+        const uint32_t j = i0 + (uint32_t)lane;
+        const uint32_t i = j < count ? (listed ? skey[j] : j) : 0u;
+        const uint2 e = j < count ? cand[(size_t)ql * cand_cap + where(i)] : make_uint2(0u, 0u);
         const float d = __uint_as_float(e.x);
         const uint32_t slot = e.y;
-        bool ok = i < n && d <= pre;
+        bool ok = j < count && d <= pre;
         if (ok && sz == C) ok = key_less(d, slot, sh.lst_d[0][C - 1], sh.lst_s[0][C - 1]);
         // one-product pass: a score more than 2 eps behind the k-th best so far cannot belong to a true top-k row (see the
         // threshold below), so it need not be listed either -- the lists stay short and the merges cheap

@@ -597,7 +597,7 @@ __device__ uint32_t walk_usearch(const IndexView& ix, Sh& sh, const WalkSpace& w
             ask_runner_up();
             continue;
         }
-        WALK_STAMP(1);  // candidate
+        WALK_STAMP(1);  // candidate, pop, prefetch issue (heap-wave walks: the candidate and the command)
         // connectivity above 32: a level-0 row holds up to 128 ids, taken 64 at a time in adjacency order (as the CPU loop would)
         uint32_t n_hi = kInvalid;
         {
